@@ -1,0 +1,180 @@
+/*
+ * ucsa_hip.h -- C ABI of libucsa_hip.so, the MI355X (gfx950) implementation of
+ * the Semantic-NeRF volume-rendering hot path of ethz-asl/ucsa_neural_rendering.
+ *
+ * This is the drop-in boundary.  The reference's only native
+ * FFI on this path is the pybind11 module `_raymarching`
+ * (reference nr4seg/nerf/raymarching/src/bindings.cpp:5-17, signatures
+ * raymarching.h:7-18) plus the tiny-cuda-nn Python objects constructed in
+ * nr4seg/nerf/network_tcnn_semantics.py:36-100.  Every entry point below names
+ * the reference interface it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch / C++ types; pointers are DEVICE pointers unless a
+ *     parameter is documented as host;
+ *   - the caller owns every buffer; nothing is allocated, nothing syncs;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative hipError_t on a launch error, or
+ *     UCSA_ERR_ARG (-1000 - k) when argument k (0-based) is invalid;
+ *   - buffers are contiguous, fp32 unless stated, 16-byte aligned;
+ *   - re-entrant, no global state.
+ */
+#ifndef UCSA_HIP_H_
+#define UCSA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCSA_VERSION 100 /* major*10000 + minor*100 + patch */
+#define UCSA_ERR_ARG (-1000)
+#define UCSA_MAX_LEVELS 16
+
+int32_t ucsa_version(void);
+/* Human-readable text for a return code (static storage). */
+const char* ucsa_error_string(int32_t code);
+
+/* ---- hash-grid level table -------------------------------------------------
+ * Host-side description of tcnn.Encoding("HashGrid") as configured at
+ * reference network_tcnn_semantics.py:34-46.  Filled on the HOST. */
+typedef struct ucsa_grid_level {
+  float scale;      /* 2^(l*log2 s)*base - 1, float64-evaluated then cast */
+  uint32_t res;     /* ceil(scale)+1 */
+  uint32_t entries; /* min(roundup8(res^3), 2^log2_hashmap_size) */
+  uint32_t offset;  /* first entry of this level in the flat table */
+  uint32_t hashed;  /* 1: spatial hash, 0: dense x + y*res + z*res^2 */
+} ucsa_grid_level;
+
+typedef struct ucsa_grid {
+  uint32_t n_levels;   /* <= UCSA_MAX_LEVELS */
+  uint32_t n_features; /* must be 2 */
+  uint32_t total_entries;
+  float bound; /* positions are mapped (x+bound)/(2*bound) */
+  ucsa_grid_level level[UCSA_MAX_LEVELS];
+} ucsa_grid;
+
+/* HOST function.  Replaces the tcnn HashGrid constructor
+ * (reference network_tcnn_semantics.py:36-46). */
+int32_t ucsa_grid_init(ucsa_grid* grid, float bound, uint32_t n_levels,
+                       uint32_t log2_hashmap_size, uint32_t base_resolution,
+                       double per_level_scale);
+
+/* ---- rays ------------------------------------------------------------------
+ * Full-image pinhole rays, row-major pixels, pixel centres at +0.5.
+ * Replaces get_rays (reference nr4seg/dataset/ngp_utils.py:28-69) and, with
+ * `inds` != NULL, get_rays_train (reference
+ * nr4seg/lightning/joint_train_lightning_net.py:108-157).
+ *   poses [B,4,4]; intrinsics are HOST scalars (fx,fy,cx,cy);
+ *   inds [n] int64 or NULL (then n must be H*W and pixel i is ray i);
+ *   out: rays_o, rays_d [B,n,3], norms [B,n]. */
+int32_t ucsa_get_rays(const float* poses, uint32_t B, float fx, float fy,
+                      float cx, float cy, uint32_t H, uint32_t W,
+                      const int64_t* inds, uint32_t n, float* rays_o,
+                      float* rays_d, float* norms, void* stream);
+
+/* Replaces _backend.near_far_from_aabb (reference
+ * nr4seg/nerf/raymarching/src/raymarching.cu:62-126, bindings.cpp:6).
+ * aabb is 6 HOST floats (xmin,ymin,zmin,xmax,ymax,zmax). */
+int32_t ucsa_near_far_from_aabb(const float* rays_o, const float* rays_d,
+                                const float* aabb_host, uint32_t N,
+                                float min_near, float* nears, float* fars,
+                                void* stream);
+
+/* Coarse sample depths, reference renderer_semantics.py:154-168.
+ * t_rand [N,T] or NULL (perturb=False).  out z [N,T]. */
+int32_t ucsa_sample_coarse(const float* nears, const float* fars,
+                           const float* t_rand, uint32_t N, uint32_t T,
+                           float* z, void* stream);
+
+/* ---- field: hash grid + sigma MLP -----------------------------------------
+ * Encodes the positions clamp(o + d*z, aabb) of all N*T samples.
+ * Replaces tcnn.Encoding.forward as called from density()
+ * (reference network_tcnn_semantics.py:133-134) together with the position
+ * generation/clip of renderer_semantics.py:171-173.
+ *   table [total_entries,2] fp32; out feat [n_levels][N*T][2] (level-major).
+ */
+int32_t ucsa_hashgrid_encode_rays(const ucsa_grid* grid_host,
+                                  const float* table, const float* rays_o,
+                                  const float* rays_d, const float* z,
+                                  const float* aabb_host, uint32_t N,
+                                  uint32_t T, float* feat, void* stream);
+
+/* Same encoder for explicit positions x [M,3] in [-bound,bound] (the
+ * reference's network.density(x) entry, network_tcnn_semantics.py:130-135). */
+int32_t ucsa_hashgrid_encode_points(const ucsa_grid* grid_host,
+                                    const float* table, const float* x,
+                                    uint32_t M, float* feat, void* stream);
+
+/* MLP kinds: which of the three tcnn.Network objects
+ * (reference network_tcnn_semantics.py:48-58, 74-84, 90-100). */
+#define UCSA_MLP_SIGMA 0 /* 32 -> 64 -> 16        (3072 params) */
+#define UCSA_MLP_COLOR 1 /* 32 -> 64 -> 64 -> 16  (7168 params) */
+#define UCSA_MLP_SEM 2   /* 16 -> 64 -> 48        (4096 params) */
+
+/* Re-lays a tcnn-format flat weight vector (row-major [out,in] matrices back
+ * to back, padded shapes) into MFMA A-fragment order.  Must be called after
+ * every parameter update, before the kernels below.
+ *   packed: same element count as params. */
+int32_t ucsa_mlp_pack(int32_t kind, const float* params, float* packed,
+                      uint32_t n_classes, void* stream);
+
+/* sigma MLP over level-major features: h [M,16] raw outputs
+ * (h[:,0] = log-density, h[:,1:16] = geo_feat), sigma [M] = exp(h[:,0]).
+ * Replaces sigma_net + trunc_exp in density()
+ * (reference network_tcnn_semantics.py:135-139, activation.py:13). */
+int32_t ucsa_sigma_mlp_fwd(const float* feat, const float* packed_sigma,
+                           uint32_t M, uint32_t n_levels, float* h,
+                           float* sigma, void* stream);
+
+/* ---- hierarchical resampling ----------------------------------------------
+ * Coarse weights -> pdf over interior bins -> inverse CDF at u.
+ * Replaces renderer_semantics.py:182-207 and sample_pdf :10-46.
+ *   z [N,T], sigma [N,T], u [N,t] in [0,1); out new_z [N,t]. */
+int32_t ucsa_resample(const float* z, const float* sigma, const float* u,
+                      uint32_t N, uint32_t T, uint32_t t,
+                      float density_scale, float* new_z, void* stream);
+
+/* ---- merge + weights + masked colour/semantics + compositing ---------------
+ * Replaces renderer_semantics.py:220-299 and the masked color()/semantics()
+ * of network_tcnn_semantics.py:147-207.
+ *   z_c/sigma_c/h_c: coarse [N,T], [N,T], [N*T,16]
+ *   z_f/sigma_f/h_f: fine   [N,t], [N,t], [N*t,16]   (t may be 0)
+ *   out: image [N,3], depth [N], semantics [N,n_classes].
+ * Optional training outputs (NULL to skip): merged order `src` [N,S] int32
+ * (index into the concatenated [coarse|fine] sample list of the ray),
+ * `weights` [N,S] (unmasked weights), S = T+t. */
+int32_t ucsa_composite_fwd(const float* rays_d, const float* norms,
+                           const float* z_c, const float* sigma_c,
+                           const float* h_c, const float* z_f,
+                           const float* sigma_f, const float* h_f,
+                           const float* packed_color, const float* packed_sem,
+                           uint32_t N, uint32_t T, uint32_t t,
+                           uint32_t n_classes, float density_scale,
+                           float* image, float* depth, float* semantics,
+                           int32_t* src, float* weights, void* stream);
+
+/* Scratch bytes the caller must provide for ucsa_render_fwd. */
+uint64_t ucsa_render_workspace_bytes(uint32_t N, uint32_t T, uint32_t t,
+                                     uint32_t n_levels);
+
+/* Whole forward pass for N rays (the reference's SemanticNeRFRenderer.run,
+ * renderer_semantics.py:123-299): near/far, coarse sampling, density,
+ * resampling, density, merge, masked colour/semantics, compositing.
+ *   t_rand [N,T] or NULL; u [N,t]; ws: workspace of
+ *   ucsa_render_workspace_bytes(); packed_*: see ucsa_mlp_pack. */
+int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
+                        const float* packed_sigma, const float* packed_color,
+                        const float* packed_sem, const float* rays_o,
+                        const float* rays_d, const float* norms,
+                        const float* aabb_host, float min_near,
+                        const float* t_rand, const float* u, uint32_t N,
+                        uint32_t T, uint32_t t, uint32_t n_classes,
+                        float density_scale, float* image, float* depth,
+                        float* semantics, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCSA_HIP_H_ */

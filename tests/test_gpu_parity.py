@@ -1,0 +1,246 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden fixtures.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (fp32 mode): the kernels use exact-fp32 MFMA (a k-ordered fmaf
+chain) and wave scans; the oracle uses BLAS matmuls and sequential
+double-accumulated cumsum/cumprod, so agreement is at fp32 round-off, not
+bit-for-bit, wherever a sum or product is involved.  Elementwise stages are
+required to be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import field as ofield
+from oracle import rays as orays
+from oracle import renderer as oren
+from tests.util import (AABB4, hip_network_from_oracle, lively_oracle_field,
+                        load_golden, make_rays, maxabs)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ucsa_neural_rendering_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def fld():
+    return lively_oracle_field()
+
+
+@pytest.fixture(scope="module")
+def net(fld):
+    return hip_network_from_oracle(fld).eval()
+
+
+# ---------------------------------------------------------------- a1, a2, a3
+def test_get_rays_matches_oracle_and_golden(ops):
+    g = load_golden("g1_rays.npz")
+    poses = g["ngp_poses"]
+    o, d, n = ops.get_rays(poses.cuda(), g["small_intr"].numpy(), 6, 8)
+    assert torch.equal(o.cpu(), g["small_o"])
+    assert maxabs(d, g["small_d"]) <= 1.2e-7
+    assert maxabs(n, g["small_n"]) <= 2.4e-7
+    o, d, n = ops.get_rays(poses[:1].cuda(), g["big_intr"].numpy(), 480, 640)
+    pick = g["big_pick"]
+    assert maxabs(d[:, pick.cuda()], g["big_d"]) <= 1.2e-7
+    inds = torch.tensor([0, 5, 5, 47, 13])
+    o2, d2, n2 = ops.get_rays(poses.cuda(), g["small_intr"].numpy(), 6, 8,
+                              inds=inds.cuda())
+    ro, rd, rn, _ = orays.pixel_rays_train(poses, g["small_intr"].numpy(), 6, 8,
+                                           inds)
+    assert maxabs(d2, rd) <= 1.2e-7 and maxabs(n2, rn) <= 2.4e-7
+    assert torch.equal(o2.cpu(), ro.contiguous())
+
+
+def test_near_far_bit_exact(ops):
+    o, d, _ = make_rays(5000, 1, inside=False)
+    o[:10] = 0.0
+    d[10:20] = torch.tensor([0.0, 0.0, 1.0])  # axis parallel: 1/0 = inf
+    n_ref, f_ref = orays.near_far_from_aabb(o, d, AABB4)
+    n_hip, f_hip = ops.near_far_from_aabb(o.cuda(), d.cuda(), AABB4)
+    assert torch.equal(n_hip.cpu(), n_ref)
+    assert torch.equal(f_hip.cpu(), f_ref)
+    assert (n_ref == np.float32(3.4028234663852886e38)).any()  # misses covered
+
+
+@pytest.mark.parametrize("T", [3, 16, 96, 256])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_coarse_z_bit_exact(ops, T, perturb):
+    o, d, _ = make_rays(333, 2)
+    near, far = orays.near_far_from_aabb(o, d, AABB4)
+    g = torch.Generator().manual_seed(T)
+    t_rand = torch.rand(333, T, generator=g) if perturb else None
+    ref = oren.coarse_z(near[:, None], far[:, None], T, t_rand)
+    got = ops.sample_coarse(near.cuda(), far.cuda(), T,
+                            None if t_rand is None else t_rand.cuda())
+    assert torch.equal(got.cpu(), ref)
+
+
+# ---------------------------------------------------------------- a4
+def test_hashgrid_encode_matches_oracle(ops, fld, net):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(20000, 3, generator=g) * 2 - 1) * 4.0
+    x[:8] = torch.tensor([[4.0, 4, 4], [-4, -4, -4], [4, -4, 0], [0, 0, 0],
+                          [3.999, 1, 1], [-3.999, 2, 2], [0.5, 0.5, 0.5],
+                          [4, 0, -4]])
+    ref = ofield.hashgrid_encode(fld.grid, (x + 4.0) / 8.0, fld.grid_params)
+    feat = ops.hashgrid_encode_points(net.encoder.grid, net.encoder.params, x.cuda())
+    got = feat.permute(1, 0, 2).reshape(x.shape[0], 32).cpu()
+    assert maxabs(got, ref) <= 2e-6 * 3.0  # |values| <= 3
+
+
+def test_level_table_matches_oracle(net, fld):
+    for a, b in zip(net.encoder.level_table(), fld.grid.levels):
+        assert a["scale"] == b.scale and a["res"] == b.res
+        assert a["entries"] == b.entries and a["offset"] == b.offset
+        assert a["hashed"] == b.hashed
+
+
+def test_density_matches_oracle(net, fld):
+    g = torch.Generator().manual_seed(6)
+    for M in (1, 15, 16, 17, 63, 64, 65, 1000, 4099):
+        x = (torch.rand(M, 3, generator=g) * 2 - 1) * 4.0
+        ref = fld.density(x)
+        got = net.density(x.cuda())
+        assert got["sigma"].shape == (M,) and got["geo_feat"].shape == (M, 15)
+        rel = (got["sigma"].cpu() - ref["sigma"]).abs() / ref["sigma"]
+        assert float(rel.max()) <= 2e-5
+        assert maxabs(got["geo_feat"], ref["geo_feat"]) <= 2e-5
+
+
+# ---------------------------------------------------------------- a5
+@pytest.mark.parametrize("T,t", [(16, 16), (96, 96), (256, 256), (8, 40)])
+def test_resample_matches_oracle(ops, T, t):
+    g = torch.Generator().manual_seed(T + t)
+    N = 257
+    z = torch.sort(torch.rand(N, T, generator=g) * 7 + 0.2, -1)[0]
+    sigma = (torch.rand(N, T, generator=g) * 3).pow(3)
+    sigma[0] = 0.0  # degenerate: flat pdf
+    u = torch.rand(N, t, generator=g)
+    u[1, 0] = 0.0
+    deltas, w = oren.alpha_weights(z, sigma, 1.0)
+    ref = oren.inverse_cdf(z[:, :-1] + 0.5 * deltas[:, :-1], w[:, 1:-1], u)
+    got = ops.resample(z.cuda(), sigma.cuda(), u.cuda(), 1.0).cpu()
+    # Reference-inherent instability (DESIGN.md "resampling"): sample_pdf
+    # switches denom to 1 when cdf[i+1]-cdf[i] < 1e-5, and an EMPTY bin has
+    # pdf = 1e-5/sum(w+1e-5), i.e. within one fp32 cdf ulp of that threshold,
+    # so for the ~1e-5*T of the samples that land in empty bins the branch is
+    # decided by cumsum round-off (fp32 scan here, double-accumulated on the
+    # CPU, fp32 parallel scan in the reference's own CUDA path).  Those
+    # samples may move by up to one bin; everything else must be tight.
+    err = (got - ref).abs()
+    widest_bin = float((z[:, 1:] - z[:, :-1]).max())
+    loose = err > 2e-4 * 7.0
+    assert float(loose.float().mean()) <= 5e-3
+    assert float(err.max()) <= 1.5 * widest_bin
+    assert float(err.median()) <= 1e-6
+
+
+# ---------------------------------------------------------------- a3-a9
+def _hip_render(net, g, chunk=None, staged=None):
+    N = g["rays_o"].shape[0]
+    if chunk:
+        net.hip_ray_chunk = chunk
+    with torch.no_grad():
+        res = net.render(g["rays_o"][None].cuda(), g["rays_d"][None].cuda(),
+                         g["norms"][None].cuda(), staged=bool(g["staged"]),
+                         perturb=bool(g["perturb"]), num_steps=g["T"],
+                         upsample_steps=g["t"],
+                         rng_t=g["t_rand"].cuda() if g["perturb"] else None,
+                         rng_u=g["u"].cuda())
+    net.hip_ray_chunk = 32768
+    return {k: v.cpu() for k, v in res.items()}
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_render_matches_reference_fixture(net, tag):
+    """Fixtures = the REFERENCE renderer run on the restated field."""
+    g = load_golden(f"g5{tag}_run_field.npz")
+    net.train(not bool(g["staged"]))
+    res = _hip_render(net, g)
+    net.eval()
+    assert maxabs(res["image"], g["image"]) <= 1e-4
+    assert maxabs(res["semantics"], g["semantics"]) <= 1e-4
+    rel = (res["depth"] - g["depth"]).abs() / g["depth"].abs().clamp_min(1e-3)
+    assert float(rel.max()) <= 2e-4
+
+
+@pytest.mark.parametrize("N,T,t,perturb", [(1, 16, 16, False), (37, 16, 16, True),
+                                           (130, 32, 0, False), (64, 96, 96, True),
+                                           (50, 256, 256, False)])
+def test_render_matches_oracle_edge_shapes(net, fld, N, T, t, perturb):
+    o, d, norms = make_rays(N, 100 + N)
+    g = torch.Generator().manual_seed(N)
+    t_rand = torch.rand(N, T, generator=g) if perturb else None
+    u = torch.rand(N, max(t, 1), generator=g)[:, :t]
+    with torch.no_grad():
+        ref = oren.run(fld, o[None], d[None], norms[None], AABB4, num_steps=T,
+                       upsample_steps=t, t_rand=t_rand, u=u if t else None)
+        res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                         perturb=perturb, num_steps=T, upsample_steps=t,
+                         rng_t=None if t_rand is None else t_rand.cuda(),
+                         rng_u=u.cuda() if t else None)
+    assert res["image"].shape == (1, N, 3) and res["depth"].shape == (1, N)
+    assert res["semantics"].shape == (1, N, 40)
+    assert maxabs(res["image"], ref["image"]) <= 1e-4
+    assert maxabs(res["semantics"], ref["semantics"]) <= 1e-4
+    rel = (res["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-3)
+    assert float(rel.max()) <= 2e-4
+
+
+def test_render_empty_batch(net):
+    e = torch.empty(1, 0, 3, device="cuda")
+    res = net.render(e, e, torch.empty(1, 0, 1, device="cuda"), num_steps=16,
+                     upsample_steps=16)
+    assert res["image"].shape == (1, 0, 3)
+
+
+def test_chunking_and_sharding_are_bit_identical(net):
+    """Rays are independent: any chunking / ray-sharding of the batch must
+    reproduce the single-call result exactly (the multi-GPU render relies on
+    this)."""
+    N, T, t = 5000, 32, 32
+    o, d, norms = make_rays(N, 9)
+    g = torch.Generator().manual_seed(9)
+    u = torch.rand(N, t, generator=g).cuda()
+    o, d, norms = o.cuda(), d.cuda(), norms.cuda()
+    kw = dict(num_steps=T, upsample_steps=t)
+    with torch.no_grad():
+        full = net.render(o[None], d[None], norms[None], rng_u=u, **kw)
+        net.hip_ray_chunk = 777
+        chunked = net.render(o[None], d[None], norms[None], rng_u=u, **kw)
+        net.hip_ray_chunk = 32768
+        parts = [net.render(o[None, s::2], d[None, s::2], norms[None, s::2],
+                            rng_u=u[s::2], **kw) for s in (0, 1)]
+    for k in ("image", "depth", "semantics"):
+        assert torch.equal(full[k], chunked[k]), k
+        inter = torch.empty_like(full[k])
+        inter[:, 0::2] = parts[0][k]
+        inter[:, 1::2] = parts[1][k]
+        assert torch.equal(full[k], inter), k
+
+
+def test_full_size_properties(net):
+    """BASELINE cfg2 sizes (one 640x480 view would take the oracle minutes):
+    size-independent properties instead.  Weights are a sub-probability
+    distribution, so sum_c semantics <= 1, image in [0,1], depth in
+    [near, far]/norm."""
+    N, T, t = 65536, 96, 96
+    o, d, norms = make_rays(N, 21)
+    with torch.no_grad():
+        res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                         num_steps=T, upsample_steps=t)
+    img, sem, dep = res["image"][0], res["semantics"][0], res["depth"][0]
+    assert torch.isfinite(img).all() and torch.isfinite(sem).all()
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 + 1e-5
+    ssum = sem.sum(-1)
+    assert float(ssum.max()) <= 1.0 + 1e-4 and float(sem.min()) >= 0.0
+    near, far = orays.near_far_from_aabb(o, d, AABB4)
+    assert (dep.cpu() <= far / norms[:, 0] + 1e-3).all()
+    # sum of semantics == sum of weights == what the image would be for rgb==1
+    # (checked through linearity: image <= weight sum componentwise)
+    assert (img.max(-1)[0] <= ssum + 1e-4).all()

@@ -1,0 +1,52 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import field as ofield
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+AABB4 = torch.tensor([-4.0, -4, -4, 4, 4, 4])
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item())
+            for k in z.files}
+
+
+def make_rays(n, seed, inside=True):
+    g = torch.Generator().manual_seed(seed)
+    o = (torch.rand(n, 3, generator=g) * 2 - 1) * (2.5 if inside else 6.0)
+    d = torch.randn(n, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    norms = 1.0 + torch.rand(n, 1, generator=g) * 0.3
+    return o, d, norms
+
+
+def lively_oracle_field(C=40, grid_seed=77, grid_amp=3.0, seed=123):
+    """The field used by the G5 fixtures: seeded MLPs, grid ~ U(-amp, amp)."""
+    fld = ofield.OracleField(bound=4.0, num_semantic_classes=C, seed=seed)
+    gs = torch.Generator().manual_seed(grid_seed)
+    fld.grid_params = (torch.rand(fld.grid.n_params, generator=gs) * 2 - 1) * grid_amp
+    return fld
+
+
+def hip_network_from_oracle(fld, device="cuda"):
+    """A HIP SemanticNeRFNetwork carrying exactly the oracle's parameters."""
+    from ucsa_neural_rendering_amd.nerf.network_tcnn_semantics import \
+        SemanticNeRFNetwork
+    net = SemanticNeRFNetwork(encoding="hashgrid", bound=fld.bound,
+                              cuda_ray=False, density_scale=1,
+                              num_semantic_classes=fld.C)
+    with torch.no_grad():
+        net.encoder.params.copy_(fld.grid_params)
+        net.sigma_net.params.copy_(fld.sigma_params)
+        net.color_net.params.copy_(fld.color_params)
+        net.semantics_net.params.copy_(fld.sem_params)
+    return net.to(device)
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())

@@ -1,0 +1,130 @@
+"""ctypes binding of ``libucsa_hip.so`` (the C ABI declared in
+``include/ucsa_hip.h``).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the
+shared object is missing or a symbol is absent, importing/using the ops fails
+loudly with instructions to build it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+# PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and
+# must be loaded BEFORE libucsa_hip.so so that both resolve to one HIP runtime
+# instance; the other order maps a second runtime that sees no device.
+import torch  # noqa: F401  (load order matters)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libucsa_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_LEVELS = 16
+MLP_SIGMA, MLP_COLOR, MLP_SEM = 0, 1, 2
+
+
+class GridLevel(C.Structure):
+    _fields_ = [("scale", C.c_float), ("res", C.c_uint32),
+                ("entries", C.c_uint32), ("offset", C.c_uint32),
+                ("hashed", C.c_uint32)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32),
+                ("total_entries", C.c_uint32), ("bound", C.c_float),
+                ("level", GridLevel * MAX_LEVELS)]
+
+
+_p = C.c_void_p
+_u32 = C.c_uint32
+_f = C.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/ucsa_hip.h
+SIGNATURES = {
+    "ucsa_version": (C.c_int32, []),
+    "ucsa_error_string": (C.c_char_p, [C.c_int32]),
+    "ucsa_grid_init": (C.c_int32, [C.POINTER(Grid), _f, _u32, _u32, _u32,
+                                   C.c_double]),
+    "ucsa_get_rays": (C.c_int32, [_p, _u32, _f, _f, _f, _f, _u32, _u32, _p,
+                                  _u32, _p, _p, _p, _p]),
+    "ucsa_near_far_from_aabb": (C.c_int32, [_p, _p, C.POINTER(_f), _u32, _f,
+                                            _p, _p, _p]),
+    "ucsa_sample_coarse": (C.c_int32, [_p, _p, _p, _u32, _u32, _p, _p]),
+    "ucsa_hashgrid_encode_rays": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
+                                              C.POINTER(_f), _u32, _u32, _p,
+                                              _p]),
+    "ucsa_hashgrid_encode_points": (C.c_int32, [C.POINTER(Grid), _p, _p, _u32,
+                                                _p, _p]),
+    "ucsa_mlp_pack": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
+    "ucsa_sigma_mlp_fwd": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
+    "ucsa_resample": (C.c_int32, [_p, _p, _p, _u32, _u32, _u32, _f, _p, _p]),
+    "ucsa_composite_fwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                       _u32, _u32, _u32, _u32, _f, _p, _p, _p,
+                                       _p, _p, _p]),
+    "ucsa_render_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32, _u32]),
+    "ucsa_render_fwd": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p, _p,
+                                    _p, C.POINTER(_f), _f, _p, _p, _u32, _u32,
+                                    _u32, _u32, _f, _p, _p, _p, _p, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class UcsaError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libucsa_hip.so for gfx950 with hipcc (cross-compiles without a
+    GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    res = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise UcsaError("building libucsa_hip.so failed:\n" +
+                        (res.stdout or "") + (res.stderr or ""))
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UcsaError(
+            f"{LIB_PATH} is missing.  This package has no CPU/PyTorch "
+            "fallback: build the HIP library first "
+            "(`python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C {CSRC}`).")
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise UcsaError(f"libucsa_hip.so does not export {name}; "
+                            "rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ucsa_error_string(rc).decode()
+        raise UcsaError(f"{what} failed: {msg} (code {rc})")
+
+
+def make_grid(bound: float, n_levels: int = 16, log2_hashmap_size: int = 19,
+              base_resolution: int = 16,
+              per_level_scale: float = 2.0) -> Grid:
+    g = Grid()
+    check(lib().ucsa_grid_init(C.byref(g), bound, n_levels, log2_hashmap_size,
+                               base_resolution, per_level_scale),
+          "ucsa_grid_init")
+    return g
+
+
+def fvec(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])

@@ -1,0 +1,481 @@
+// Merge of coarse+fine samples, final weights, masked colour / semantics MLPs
+// and alpha compositing (SURVEY 8a rows a5 (second half), a6-a9).
+// reference nr4seg/nerf/renderer_semantics.py:220-299 and
+// nr4seg/nerf/network_tcnn_semantics.py:147-207.
+//
+// Structure (DESIGN.md "composite kernel"):
+//  * every wave owns a contiguous range of rays and is independent of the
+//    other waves of its workgroup after the weights are staged in LDS;
+//  * phase A (per ray, VALU+LDS): stable merge by rank counting, alpha /
+//    transmittance by wave scan, mask w > 1e-4, depth, ballot+popcount
+//    compaction of the surviving samples into the wave's entry list;
+//  * phase C (per 64 surviving samples, MFMA): colour and semantics nets on
+//    4 column blocks of 16 samples, fp32 MFMA, A fragments from LDS,
+//    softmax across the 4 lane groups by two xor-shuffles;
+//  * phase D: w*rgb and w*p go through a 16 x 44 LDS tile and are summed per
+//    ray in sample order by lane c = channel (deterministic, no atomics);
+//    the running sums stay in registers across groups and are stored once
+//    per ray.
+// The semantic weights are the same numbers as the colour weights in the
+// forward pass (they differ only in autograd: detached, :270).
+#include "mfma_mlp.h"
+#include "wave_ops.h"
+
+#define CMP_MAX_WAVES 8
+#define CONTRIB_STRIDE 45  // 3 rgb + up to 40.. classes, odd stride
+#define ROW_FINE 0x80000000u
+
+extern __shared__ __attribute__((aligned(16))) float cmp_smem[];
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct CmpArgs {
+  const float* rays_d;
+  const float* norms;
+  const float* z_c;
+  const float* sigma_c;
+  const float* h_c;
+  const float* z_f;
+  const float* sigma_f;
+  const float* h_f;
+  const float* packed_color;
+  const float* packed_sem;
+  uint32_t N, T, t, C;
+  float density_scale;
+  float* image;
+  float* depth;
+  float* semantics;
+  int32_t* src_out;
+  float* w_out;
+  uint32_t rays_per_wave;
+  uint32_t contrib_stride;
+};
+
+__device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
+                                           uint32_t g, float (&o)[4]) {
+  // oracle: d01 = (d + 1) / 2; x = d01 * 2 - 1   (keep the same rounding)
+  const float x = ((dx + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float y = ((dy + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float z = ((dz + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float xy = x * y, xz = x * z, yz = y * z;
+  const float x2 = x * x, y2 = y * y, z2 = z * z;
+  if (g == 0) {
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+  } else if (g == 1) {
+    o[0] = 1.0925484305920792f * xy;
+    o[1] = -1.0925484305920792f * yz;
+    o[2] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[3] = -1.0925484305920792f * xz;
+  } else if (g == 2) {
+    o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[2] = 2.8906114426405538f * xy * z;
+    o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  } else {
+    o[0] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[1] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[2] = 1.4453057213202769f * z * (x2 - y2);
+    o[3] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  }
+}
+
+template <int NRB_SEM>
+__global__ void __launch_bounds__(64 * CMP_MAX_WAVES)
+k_composite(CmpArgs a) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t nw_block = blockDim.x >> 6;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint32_t T = a.T, t = a.t, S = a.T + a.t, C = a.C;
+  const uint32_t cstride = a.contrib_stride;
+
+  // ---- LDS carve ------------------------------------------------------
+  float* w_color = cmp_smem;                       // 7168
+  float* w_sem = w_color + 7168;                   // 1024 + NRB_SEM*1024
+  float* per_wave = w_sem + 1024 + NRB_SEM * 1024;
+  const uint32_t cap = S + 64;                     // entry list capacity
+  // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
+  //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
+  const uint32_t per_wave_floats = 4 * S + 3 * cap + 16 * cstride;
+  float* base = per_wave + (size_t)wid * per_wave_floats;
+  float* zraw = base;
+  float* zm = zraw + S;
+  float* sgm = zm + S;
+  uint32_t* srcs = reinterpret_cast<uint32_t*>(sgm + S);
+  float* lw = reinterpret_cast<float*>(srcs + S);
+  uint32_t* lrow = reinterpret_cast<uint32_t*>(lw + cap);
+  uint32_t* lray = lrow + cap;
+  float* contrib = reinterpret_cast<float*>(lray + cap);
+
+  for (uint32_t i = threadIdx.x; i < 7168; i += blockDim.x)
+    w_color[i] = a.packed_color[i];
+  for (uint32_t i = threadIdx.x; i < 1024 + NRB_SEM * 1024; i += blockDim.x)
+    w_sem[i] = a.packed_sem[i];
+  __syncthreads();
+
+  const uint64_t gwave = (uint64_t)blockIdx.x * nw_block + wid;
+  const uint64_t r_begin64 = gwave * a.rays_per_wave;
+  if (r_begin64 >= a.N) return;
+  const uint32_t r_begin = (uint32_t)r_begin64;
+  const uint32_t r_end = (r_begin + a.rays_per_wave < a.N)
+                             ? r_begin + a.rays_per_wave : a.N;
+
+  uint32_t cnt = 0;            // entries waiting in the list (wave-uniform)
+  uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose sums sit in `acc`
+  float acc = 0.0f;            // lane c: running sum of channel c
+
+  auto flush_ray = [&](uint32_t ray) {
+    if (lane < 3) a.image[(size_t)ray * 3 + lane] = acc;
+    else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = acc;
+  };
+
+  // ---- phase C + D on the first `n` (<= 64) entries of the list ---------
+  auto shade = [&](uint32_t n) {
+    float ew[4], geo[4][4], sh[4][4];
+    uint32_t eray[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      uint32_t e = cb * 16 + j;
+      const bool live = e < n;
+      if (!live) e = n - 1;  // pad with the last real entry, weight 0
+      ew[cb] = live ? lw[e] : 0.0f;
+      const uint32_t row = lrow[e];
+      eray[cb] = lray[e];
+      const float* hp = ((row & ROW_FINE) ? a.h_f : a.h_c) +
+                        (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hp);
+      geo[cb][0] = (g == 0) ? 1.0f : hv[0];  // slot m==0 -> the "ones" pad
+      geo[cb][1] = hv[1];
+      geo[cb][2] = hv[2];
+      geo[cb][3] = hv[3];
+      const float* d = a.rays_d + (size_t)eray[cb] * 3;
+      sh4_select(d[0], d[1], d[2], g, sh[cb]);
+    }
+
+    // ---------------- colour net: 32 -> 64 -> 64 -> 16 -------------------
+    float rgb[4][3];
+    {
+      f32x4 acc1[4][4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const float wa = w_color[(rb * 8 + ks) * 64 + lane];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            const float x = ks < 4 ? sh[cb][ks] : geo[cb][ks - 4];
+            acc1[cb][rb] = mfma16(wa, x, acc1[cb][rb]);
+          }
+        }
+      }
+      float hid[4][16];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) chain_relu(acc1[cb], hid[cb]);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const float wa = w_color[(COLOR_L1_FRAGS + rb * 16 + ks) * 64 + lane];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            acc1[cb][rb] = mfma16(wa, hid[cb][ks], acc1[cb][rb]);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) chain_relu(acc1[cb], hid[cb]);
+      f32x4 o3[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) o3[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float wa =
+            w_color[(COLOR_L1_FRAGS + COLOR_L2_FRAGS + ks) * 64 + lane];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) o3[cb] = mfma16(wa, hid[cb][ks], o3[cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          rgb[cb][c] = 1.0f / (1.0f + expf(-o3[cb][c]));  // rows 0..2 live in g==0
+    }
+
+    // ---------------- semantics net: 16 -> 64 -> 16*NRB_SEM --------------
+    f32x4 lg[4][NRB_SEM];
+    {
+      f32x4 acc1[4][4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const float wa = w_sem[(rb * 4 + ks) * 64 + lane];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            acc1[cb][rb] = mfma16(wa, geo[cb][ks], acc1[cb][rb]);
+        }
+      }
+      float hid[4][16];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) chain_relu(acc1[cb], hid[cb]);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < NRB_SEM; ++rb) lg[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int rb = 0; rb < NRB_SEM; ++rb) {
+          const float wa = w_sem[(SEM_L1_FRAGS + rb * 16 + ks) * 64 + lane];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            lg[cb][rb] = mfma16(wa, hid[cb][ks], lg[cb][rb]);
+        }
+      }
+    }
+
+    // ---------------- softmax + contributions + per-ray sums -------------
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fmaxf(mx, lg[cb][rb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.0f;
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
+          const float ex = ok ? expf(lg[cb][rb][r] - mx) : 0.0f;
+          lg[cb][rb][r] = ex;
+          sum += ex;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float wgt = ew[cb];
+      float* crow = contrib + j * cstride;
+      if (g == 0) {
+        crow[0] = wgt * rgb[cb][0];
+        crow[1] = wgt * rgb[cb][1];
+        crow[2] = wgt * rgb[cb][2];
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t cls = rb * 16 + 4 * g + r;
+          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] / sum);
+        }
+      wave_lds_sync();
+      const uint32_t nb = (n > (uint32_t)cb * 16) ? ((n - cb * 16 < 16) ? n - cb * 16 : 16) : 0;
+      for (uint32_t e = 0; e < nb; ++e) {
+        const uint32_t ray = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)lray[cb * 16 + e]);  // wave-uniform
+        if (ray != cur_ray) {
+          if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+          cur_ray = ray;
+          acc = 0.0f;
+        }
+        if (lane < 3 + C) acc = acc + contrib[e * cstride + lane];
+      }
+      wave_lds_sync();
+    }
+  };
+
+  // ======================= per-ray loop ==================================
+  for (uint32_t r = r_begin; r < r_end; ++r) {
+    // ---- A1: load raw z (coarse then fine) ------------------------------
+    const float* zc = a.z_c + (size_t)r * T;
+    const float* zf = a.z_f + (size_t)r * t;
+    for (uint32_t e = lane; e < S; e += 64) zraw[e] = e < T ? zc[e] : zf[e - T];
+    wave_lds_sync();
+    // ---- A2: rank of every element in the stable sort of [coarse|fine] --
+    for (uint32_t e = lane; e < S; e += 64) {
+      const float ze = zraw[e];
+      uint32_t rank;
+      if (e < T) {
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < t; ++k) c += (zraw[T + k] < ze) ? 1u : 0u;
+        rank = e + c;
+      } else {
+        // coarse elements <= ze come first (coarse list is ascending)
+        uint32_t lo = 0, hi = T;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (zraw[mid] <= ze) lo = mid + 1; else hi = mid;
+        }
+        uint32_t c = 0;
+        const uint32_t kk = e - T;
+        for (uint32_t k = 0; k < t; ++k) {
+          const float zk = zraw[T + k];
+          c += (zk < ze || (zk == ze && k < kk)) ? 1u : 0u;
+        }
+        rank = lo + c;
+      }
+      const float sg = e < T ? a.sigma_c[(size_t)r * T + e]
+                             : a.sigma_f[(size_t)r * t + (e - T)];
+      zm[rank] = ze;
+      sgm[rank] = sg;
+      srcs[rank] = e;
+    }
+    wave_lds_sync();
+    // ---- A3: weights, mask, depth, compaction ---------------------------
+    float carry = 1.0f, dsum = 0.0f;
+    const uint32_t cnt0 = cnt;
+    for (uint32_t sbase = 0; sbase < S; sbase += 64) {
+      const uint32_t s = sbase + lane;
+      float alpha = 0.0f, zi = 0.0f;
+      if (s < S) {
+        zi = zm[s];
+        const float delta = (s + 1 < S) ? zm[s + 1] - zi : 1e10f;
+        alpha = 1.0f - expf(-delta * a.density_scale * sgm[s]);
+      }
+      const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
+      const float incl = wave_incl_scan_mul(fac, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.0f;
+      const float w = alpha * (carry * excl);
+      carry = carry * wave_bcast(incl, 63);
+      const bool keep = (s < S) && (w > 1e-4f);
+      if (keep) dsum += w * zi;
+      if (s < S) {
+        if (a.w_out) a.w_out[(size_t)r * S + s] = w;
+        if (a.src_out) a.src_out[(size_t)r * S + s] = (int32_t)srcs[s];
+      }
+      const unsigned long long bal = __ballot(keep);
+      if (keep) {
+        const uint32_t pos =
+            cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        const uint32_t e = srcs[s];
+        lw[pos] = w;
+        lrow[pos] = e < T ? (r * T + e) : (ROW_FINE | (r * t + (e - T)));
+        lray[pos] = r;
+      }
+      cnt += (uint32_t)__popcll(bal);
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0) a.depth[r] = dsum / a.norms[r];
+    if (cnt == cnt0) {  // nothing survived the mask: all-zero outputs
+      if (lane < 3) a.image[(size_t)r * 3 + lane] = 0.0f;
+      else if (lane < 3 + C) a.semantics[(size_t)r * C + (lane - 3)] = 0.0f;
+    }
+    wave_lds_sync();
+    // ---- C/D: shade full groups of 64 ------------------------------------
+    uint32_t head = 0;
+    while (cnt - head >= 64) {
+      // shade() reads entries [0,64): move the window down first if needed
+      if (head) {
+        for (uint32_t i = lane; i < 64; i += 64) {
+          lw[i] = lw[head + i];
+          lrow[i] = lrow[head + i];
+          lray[i] = lray[head + i];
+        }
+        wave_lds_sync();
+      }
+      shade(64);
+      head += 64;
+    }
+    if (head) {  // compact the tail [head, cnt) to the front
+      const uint32_t rem = cnt - head;  // < 64
+      float tw = 0.f;
+      uint32_t trow = 0, tray = 0;
+      if (lane < rem) {
+        tw = lw[head + lane];
+        trow = lrow[head + lane];
+        tray = lray[head + lane];
+      }
+      wave_lds_sync();
+      if (lane < rem) {
+        lw[lane] = tw;
+        lrow[lane] = trow;
+        lray[lane] = tray;
+      }
+      cnt = rem;
+      wave_lds_sync();
+    }
+  }
+  if (cnt) shade(cnt);
+  if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+}
+
+static inline uint32_t cmp_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
+
+extern "C" int32_t ucsa_composite_fwd(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const float* packed_color,
+    const float* packed_sem, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, int32_t* src, float* weights, void* stream) {
+  UCSA_CHECK_ARG(rays_d, 0);
+  UCSA_CHECK_ARG(norms, 1);
+  UCSA_CHECK_ARG(z_c && sigma_c && h_c, 2);
+  UCSA_CHECK_ARG(t == 0 || (z_f && sigma_f && h_f), 5);
+  UCSA_CHECK_ARG(packed_color && packed_sem, 8);
+  UCSA_CHECK_ARG(T >= 1 && (uint64_t)N * T < 0x80000000ull, 11);
+  UCSA_CHECK_ARG((uint64_t)N * t < 0x80000000ull && T + t <= 8192, 12);
+  UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 13);
+  UCSA_CHECK_ARG(image && depth && semantics, 15);
+  if (N == 0) return 0;
+  const uint32_t S = T + t;
+  const uint32_t nrb = cmp_pad16(n_classes) / 16;
+  uint32_t cstride = 3 + n_classes;
+  if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
+  const size_t w_floats = 7168 + 1024 + (size_t)nrb * 1024;
+  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 64) + 16 * cstride;
+  // as many waves per workgroup as fit in ~150 KiB of LDS (one WG per CU)
+  uint32_t waves = CMP_MAX_WAVES;
+  while (waves > 1 && (w_floats + waves * per_wave) * 4 > 150 * 1024) waves >>= 1;
+  const size_t smem = (w_floats + waves * per_wave) * 4;
+  UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
+  // rays per wave: spread over the chip, but at least 4 so the 64-entry
+  // groups stay dense across ray boundaries
+  const uint64_t total_waves = 256ull * waves;
+  uint32_t rpw = (uint32_t)((N + total_waves - 1) / total_waves);
+  if (rpw < 4) rpw = 4;
+  const uint32_t n_waves = ucsa_div_up(N, rpw);
+  const uint32_t blocks = ucsa_div_up(n_waves, waves);
+  CmpArgs a{rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+            packed_color, packed_sem, N, T, t, n_classes, density_scale,
+            image, depth, semantics, src, weights, rpw, cstride};
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(NRB)                                                           \
+  do {                                                                        \
+    hipError_t e = hipFuncSetAttribute(                                       \
+        reinterpret_cast<const void*>(&k_composite<NRB>),                     \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
+    if (e != hipSuccess) return -(int32_t)e;                                  \
+    UCSA_CLEAR_ERR();                                                         \
+    hipLaunchKernelGGL(k_composite<NRB>, dim3(blocks), dim3(64 * waves), smem, \
+                       s, a);                                                 \
+  } while (0)
+  switch (nrb) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    default: LAUNCH(4); break;
+  }
+#undef LAUNCH
+  return ucsa_launch_status();
+}

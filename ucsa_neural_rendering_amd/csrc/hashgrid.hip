@@ -1,0 +1,184 @@
+// Multiresolution hash-grid encoding (first half).
+//
+// Restates tiny-cuda-nn's GridEncoding (public algorithm; call site reference
+// nr4seg/nerf/network_tcnn_semantics.py:36-46,133-134).
+//
+// MI355X layout decisions (DESIGN.md "hash-grid encode"):
+//  * LEVEL-MAJOR launch: grid = (sample blocks, levels) so that all CUs work
+//    on one level at a time; one level of the table (<= 4 MiB fp32) then lives
+//    in each XCD's 4 MiB L2 instead of 52 MiB of table thrashing it.
+//  * Output is level-major too: feat[level][sample] as float2, so a wave
+//    stores 512 contiguous bytes; the sigma-MLP kernel reads the same way.
+//  * One lane per sample; lanes of a wave are consecutive samples of one ray,
+//    which share cells on the coarse levels (the TA coalesces equal lines).
+#include "ucsa_common.h"
+
+#define PRIME_Y 2654435761u
+#define PRIME_Z 805459861u
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y,
+                                               uint32_t z, uint32_t res,
+                                               uint32_t entries,
+                                               uint32_t hashed) {
+  uint32_t idx = hashed ? (x ^ (y * PRIME_Y) ^ (z * PRIME_Z))
+                        : (x + y * res + z * res * res);
+  // entries is a power of two on hashed levels
+  return hashed ? (idx & (entries - 1)) : (idx % entries);
+}
+
+// Trilinear gather of one level at x01 (already in [0,1]).
+__device__ __forceinline__ float2 encode_level(const float2* __restrict__ tab,
+                                               float x, float y, float z,
+                                               float scale, uint32_t res,
+                                               uint32_t entries,
+                                               uint32_t hashed) {
+  const float px = x * scale + 0.5f, py = y * scale + 0.5f,
+              pz = z * scale + 0.5f;
+  const float fx0 = floorf(px), fy0 = floorf(py), fz0 = floorf(pz);
+  const float wx = px - fx0, wy = py - fy0, wz = pz - fz0;
+  const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
+                 gz = (uint32_t)(int32_t)fz0;
+  float2 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint32_t ix = gx + (c & 1), iy = gy + ((c >> 1) & 1),
+                   iz = gz + ((c >> 2) & 1);
+    v[c] = tab[grid_index(ix, iy, iz, res, entries, hashed)];
+  }
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    // weight = ((1*wx')*wy')*wz' in dimension order, as the oracle does
+    float w = (c & 1) ? wx : 1.0f - wx;
+    w = w * ((c & 2) ? wy : 1.0f - wy);
+    w = w * ((c & 4) ? wz : 1.0f - wz);
+    acc.x = acc.x + w * v[c].x;
+    acc.y = acc.y + w * v[c].y;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+  // torch.min(torch.max(v, lo), hi)
+  return fminf(fmaxf(v, lo), hi);
+}
+
+template <bool FROM_RAYS>
+__global__ void __launch_bounds__(256)
+k_hashgrid_encode(GridDev g, const float2* __restrict__ table,
+                  const float* __restrict__ rays_o,
+                  const float* __restrict__ rays_d,
+                  const float* __restrict__ zs, Aabb bb, uint32_t T,
+                  uint64_t M, float2* __restrict__ feat) {
+  const uint32_t level = blockIdx.y;
+  const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float px, py, pz;
+  if (FROM_RAYS) {
+    const uint32_t r = (uint32_t)(m / T);
+    const float zz = zs[m];
+    const float* o = rays_o + (size_t)r * 3;
+    const float* d = rays_d + (size_t)r * 3;
+    px = clampf(o[0] + d[0] * zz, bb.lo[0], bb.hi[0]);
+    py = clampf(o[1] + d[1] * zz, bb.lo[1], bb.hi[1]);
+    pz = clampf(o[2] + d[2] * zz, bb.lo[2], bb.hi[2]);
+  } else {
+    const float* x = rays_o + (size_t)m * 3;  // explicit points
+    px = x[0];
+    py = x[1];
+    pz = x[2];
+  }
+  const float two_b = 2.0f * g.bound;
+  const float x01 = (px + g.bound) / two_b, y01 = (py + g.bound) / two_b,
+              z01 = (pz + g.bound) / two_b;
+  const float2 f = encode_level(table + g.offset[level], x01, y01, z01,
+                                g.scale[level], g.res[level], g.entries[level],
+                                g.hashed[level]);
+  feat[(uint64_t)level * M + m] = f;
+}
+
+extern "C" int32_t ucsa_hashgrid_encode_rays(
+    const ucsa_grid* grid, const float* table, const float* rays_o,
+    const float* rays_d, const float* z, const float* aabb_host, uint32_t N,
+    uint32_t T, float* feat, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(table, 1);
+  UCSA_CHECK_ARG(rays_o && rays_d && z, 2);
+  UCSA_CHECK_ARG(aabb_host, 5);
+  UCSA_CHECK_ARG(feat, 8);
+  const uint64_t M = (uint64_t)N * T;
+  if (M == 0) return 0;
+  dim3 grid_dim(ucsa_div_up(M, 256), grid->n_levels);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_hashgrid_encode<true>, grid_dim, dim3(256), 0,
+                     (hipStream_t)stream, ucsa_grid_dev(grid),
+                     (const float2*)table, rays_o, rays_d, z,
+                     ucsa_aabb(aabb_host), T, M, (float2*)feat);
+  return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_hashgrid_encode_points(const ucsa_grid* grid,
+                                               const float* table,
+                                               const float* x, uint32_t M,
+                                               float* feat, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(table, 1);
+  UCSA_CHECK_ARG(x, 2);
+  UCSA_CHECK_ARG(feat, 4);
+  if (M == 0) return 0;
+  Aabb bb = {};
+  dim3 grid_dim(ucsa_div_up(M, 256), grid->n_levels);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_hashgrid_encode<false>, grid_dim, dim3(256), 0,
+                     (hipStream_t)stream, ucsa_grid_dev(grid),
+                     (const float2*)table, x, (const float*)nullptr,
+                     (const float*)nullptr, bb, 1u, (uint64_t)M,
+                     (float2*)feat);
+  return ucsa_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// Host: level table.  float64 evaluation of the scale, snapped when integral
+// (SURVEY 8a caveat: levels 5/10/15 are exactly 127/1023/8191 for bound 4).
+// ---------------------------------------------------------------------------
+#include <cmath>
+extern "C" int32_t ucsa_grid_init(ucsa_grid* grid, float bound,
+                                  uint32_t n_levels,
+                                  uint32_t log2_hashmap_size,
+                                  uint32_t base_resolution,
+                                  double per_level_scale) {
+  UCSA_CHECK_ARG(grid, 0);
+  UCSA_CHECK_ARG(bound > 0.f, 1);
+  UCSA_CHECK_ARG(n_levels > 0 && n_levels <= UCSA_MAX_LEVELS, 2);
+  UCSA_CHECK_ARG(log2_hashmap_size > 0 && log2_hashmap_size < 32, 3);
+  UCSA_CHECK_ARG(per_level_scale > 0.0, 5);
+  grid->n_levels = n_levels;
+  grid->n_features = 2;
+  grid->bound = bound;
+  const double log2s = std::log2(per_level_scale);
+  const uint64_t cap = 1ull << log2_hashmap_size;
+  uint64_t offset = 0;
+  for (uint32_t l = 0; l < UCSA_MAX_LEVELS; ++l) {
+    ucsa_grid_level& lv = grid->level[l];
+    if (l >= n_levels) {
+      lv = ucsa_grid_level{0.f, 0, 0, 0, 0};
+      continue;
+    }
+    double s = std::pow(2.0, l * log2s) * base_resolution - 1.0;
+    const double r = std::round(s);
+    if (std::fabs(s - r) < 1e-9 * std::fmax(1.0, std::fabs(s))) s = r;
+    lv.scale = (float)s;
+    lv.res = (uint32_t)std::ceil((double)lv.scale) + 1;
+    uint64_t e = (uint64_t)lv.res * lv.res * lv.res;
+    e = (e + 7) / 8 * 8;
+    lv.hashed = e > cap ? 1u : 0u;
+    if (e > cap) e = cap;
+    lv.entries = (uint32_t)e;
+    lv.offset = (uint32_t)offset;
+    offset += e;
+  }
+  grid->total_entries = (uint32_t)offset;
+  return 0;
+}

@@ -1,0 +1,68 @@
+// fp32 MFMA building blocks for the three bias-free width-64 MLPs.
+//
+// Mapping (v_mfma_f32_16x16x4_f32: D[16x16] = A[16x4] * B[4x16] + C):
+//   rows    i = output neurons of the layer (16 per row block "rb"),
+//   columns j = samples (16 per MFMA),
+//   k         = input neurons (4 per k-step "ks").
+// Lane l = 16*g + j holds  A[i=j'][k=g] (j' = l&15)  and  B[k=g][j],
+// and after the MFMA   D[row = 4*g + r][col = j]   in accumulator reg r.
+//
+// Layer chaining without any cross-lane traffic: the order of the contraction
+// index is free as long as A and B agree, so k-step ks = 4*rb + r of the NEXT
+// layer is defined to be neuron 16*rb + 4*g + r -- exactly what lane (g, j)
+// already holds in acc[rb][r].  The A fragments (weights) are pre-permuted
+// accordingly by ucsa_mlp_pack, once per parameter update.
+//
+// f32 MFMA is bit-for-bit a k-ordered fmaf chain (MI355X guide), so the fp32
+// mode of this library has ordinary fp32 round-off vs the CPU oracle.
+#pragma once
+#include "ucsa_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  f32x4 r;
+  r[0] = fmaxf(v[0], 0.f);
+  r[1] = fmaxf(v[1], 0.f);
+  r[2] = fmaxf(v[2], 0.f);
+  r[3] = fmaxf(v[3], 0.f);
+  return r;
+}
+
+// Fragment counts / offsets inside a packed weight vector (in 64-float frags).
+//   sigma: L1 32->64 (4 rb x 8 ks = 32), L2 64->16 (1 x 16)            = 48
+//   color: L1 32->64 (32), L2 64->64 (4 x 16 = 64), L3 64->16 (16)     = 112
+//   sem:   L1 16->64 (4 x 4 = 16), L2 64->out_pad (nrb x 16)           = 16+16*nrb
+#define SIGMA_L1_FRAGS 32
+#define SIGMA_L2_FRAGS 16
+#define COLOR_L1_FRAGS 32
+#define COLOR_L2_FRAGS 64
+#define COLOR_L3_FRAGS 16
+#define SEM_L1_FRAGS 16
+
+// One dense layer: KS k-steps, NRB row blocks, A fragments read through `wf`
+// (a callable (rb, ks) -> float so weights may live in registers or LDS).
+template <int KS, int NRB, typename WF>
+__device__ __forceinline__ void mfma_layer(const float (&xin)[KS], WF wf,
+                                           f32x4 (&acc)[NRB]) {
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) acc[rb] = mfma16(wf(rb, ks), xin[ks], acc[rb]);
+  }
+}
+
+// acc[4] (64 neurons) -> next layer's 16 k-step operands, with ReLU.
+__device__ __forceinline__ void chain_relu(const f32x4 (&acc)[4],
+                                           float (&xin)[16]) {
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xin[rb * 4 + r] = fmaxf(acc[rb][r], 0.f);
+}

@@ -1,0 +1,169 @@
+// Weight packing and the sigma MLP (second half).
+#include "mfma_mlp.h"
+
+// ---------------------------------------------------------------------------
+// ucsa_mlp_pack: tcnn layout (row-major [out,in] per layer, back to back)
+//   -> A-fragment order packed[frag*64 + lane].
+// Column permutations per layer input (see mfma_mlp.h and DESIGN.md):
+//   chained hidden input : ks = 4*b + r  -> neuron 16*b + 4*g + r
+//   sigma L1 (features)  : ks = 2*q + c  -> feature 2*(4*q + g) + c
+//   sem   L1 (h row)     : ks = r, m = 4*g + r -> column m==0 ? 15 : m-1
+//   color L1             : ks<4: SH 4*g+ks ; ks>=4: m = 4*g+ks-4 ->
+//                          column m==0 ? 31 : 16 + m-1
+// (the h-row slot m==0 holds the log-density, which is not an input of the
+//  colour / semantics nets; the kernels put the constant 1.0 there, i.e. the
+//  tcnn "pad with ones" column.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t chain_col(uint32_t ks, uint32_t g) {
+  return 16u * (ks >> 2) + 4u * g + (ks & 3u);
+}
+
+__global__ void k_mlp_pack(int kind, const float* __restrict__ params,
+                           float* __restrict__ packed, uint32_t n_total,
+                           uint32_t sem_nrb) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_total) return;
+  uint32_t f = e >> 6;
+  const uint32_t l = e & 63u, g = l >> 4, i = l & 15u;
+  uint32_t src;
+  if (kind == UCSA_MLP_SIGMA) {
+    if (f < SIGMA_L1_FRAGS) {
+      const uint32_t rb = f / 8, ks = f % 8;
+      const uint32_t col = 2u * (4u * (ks >> 1) + g) + (ks & 1u);
+      src = (rb * 16 + i) * 32 + col;
+    } else {
+      f -= SIGMA_L1_FRAGS;
+      src = 64 * 32 + i * 64 + chain_col(f, g);
+    }
+  } else if (kind == UCSA_MLP_COLOR) {
+    if (f < COLOR_L1_FRAGS) {
+      const uint32_t rb = f / 8, ks = f % 8;
+      uint32_t col;
+      if (ks < 4) {
+        col = 4u * g + ks;
+      } else {
+        const uint32_t m = 4u * g + (ks - 4);
+        col = m == 0 ? 31u : 15u + m;
+      }
+      src = (rb * 16 + i) * 32 + col;
+    } else if (f < COLOR_L1_FRAGS + COLOR_L2_FRAGS) {
+      f -= COLOR_L1_FRAGS;
+      const uint32_t rb = f / 16, ks = f % 16;
+      src = 64 * 32 + (rb * 16 + i) * 64 + chain_col(ks, g);
+    } else {
+      f -= COLOR_L1_FRAGS + COLOR_L2_FRAGS;
+      src = 64 * 32 + 64 * 64 + i * 64 + chain_col(f, g);
+    }
+  } else {
+    if (f < SEM_L1_FRAGS) {
+      const uint32_t rb = f / 4, ks = f % 4;
+      const uint32_t m = 4u * g + ks;
+      const uint32_t col = m == 0 ? 15u : m - 1u;
+      src = (rb * 16 + i) * 16 + col;
+    } else {
+      f -= SEM_L1_FRAGS;
+      const uint32_t rb = f / 16, ks = f % 16;
+      src = 64 * 16 + (rb * 16 + i) * 64 + chain_col(ks, g);
+    }
+  }
+  packed[e] = params[src];
+}
+
+static inline uint32_t pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
+
+extern "C" int32_t ucsa_mlp_pack(int32_t kind, const float* params,
+                                 float* packed, uint32_t n_classes,
+                                 void* stream) {
+  UCSA_CHECK_ARG(kind >= 0 && kind <= 2, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed, 2);
+  uint32_t n_total, sem_nrb = 0;
+  if (kind == UCSA_MLP_SIGMA) {
+    n_total = 3072;
+  } else if (kind == UCSA_MLP_COLOR) {
+    n_total = 7168;
+  } else {
+    UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 64, 3);
+    sem_nrb = pad16(n_classes) / 16;
+    n_total = 16 * 64 + sem_nrb * 16 * 64;
+  }
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack, dim3(ucsa_div_up(n_total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (int)kind, params, packed, n_total,
+                     sem_nrb);
+  return ucsa_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// sigma MLP: 32 -> 64 (ReLU) -> 16.  One wave holds the whole net in 48 VGPRs
+// and streams 16-sample column blocks; 4 blocks in flight per iteration.
+//   in : feat[level][m] float2 (level-major)   out: h[m][16], sigma[m]
+// Roofline: f32 MFMA, 48 MFMAs (98 304 flop) per 16 samples.
+// ---------------------------------------------------------------------------
+#define SIG_UNROLL 4
+
+__global__ void __launch_bounds__(256)
+k_sigma_mlp(const float2* __restrict__ feat, const float* __restrict__ packed,
+            uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+
+  float w1[4][8], w2[16];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w1[rb][ks] = packed[(rb * 8 + ks) * 64 + lane];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) w2[ks] = packed[(SIGMA_L1_FRAGS + ks) * 64 + lane];
+
+  const uint64_t span = 16 * SIG_UNROLL;
+  for (uint64_t base = wave * span; base < M; base += nwaves * span) {
+    float xin[SIG_UNROLL][8];
+#pragma unroll
+    for (int sb = 0; sb < SIG_UNROLL; ++sb) {
+      uint64_t m = base + sb * 16 + j;
+      if (m >= M) m = M - 1;  // clamp loads, predicate stores
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 v = feat[(uint64_t)(4 * q + g) * M + m];
+        xin[sb][2 * q] = v.x;
+        xin[sb][2 * q + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < SIG_UNROLL; ++sb) {
+      f32x4 acc[4];
+      mfma_layer<8, 4>(xin[sb], [&](int rb, int ks) { return w1[rb][ks]; }, acc);
+      float hid[16];
+      chain_relu(acc, hid);
+      f32x4 out[1];
+      mfma_layer<16, 1>(hid, [&](int, int ks) { return w2[ks]; }, out);
+      const uint64_t m = base + sb * 16 + j;
+      if (m < M) {
+        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out[0];
+        if (g == 0) sigma[m] = expf(out[0][0]);
+      }
+    }
+  }
+}
+
+extern "C" int32_t ucsa_sigma_mlp_fwd(const float* feat,
+                                      const float* packed_sigma, uint32_t M,
+                                      uint32_t n_levels, float* h,
+                                      float* sigma, void* stream) {
+  UCSA_CHECK_ARG(feat, 0);
+  UCSA_CHECK_ARG(packed_sigma, 1);
+  UCSA_CHECK_ARG(n_levels == 16, 3);  // 2*16 = 32 inputs (reference config)
+  UCSA_CHECK_ARG(h && sigma, 4);
+  if (M == 0) return 0;
+  // persistent-ish: enough waves to fill 256 CUs x 8, never more than needed
+  const uint32_t need = ucsa_div_up(M, 16 * SIG_UNROLL * 4);
+  const uint32_t blocks = need < 2048u ? need : 2048u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)feat, packed_sigma,
+                     (uint64_t)M, h, sigma);
+  return ucsa_launch_status();
+}

@@ -1,0 +1,98 @@
+// ucsa_render_fwd: the reference's SemanticNeRFRenderer.run()
+// (nr4seg/nerf/renderer_semantics.py:123-299) as one enqueue of the staged
+// kernels, with every intermediate in a caller-provided workspace.
+// Also: ucsa_version / ucsa_error_string.
+#include <cstdio>
+
+#include "ucsa_common.h"
+
+namespace {
+struct Ws {
+  float *nears, *fars, *z_c, *z_f, *feat, *h_c, *sigma_c, *h_f, *sigma_f;
+  uint64_t bytes;
+};
+
+inline uint64_t align256(uint64_t b) { return (b + 255ull) & ~255ull; }
+
+Ws carve(void* base, uint32_t N, uint32_t T, uint32_t t, uint32_t L) {
+  Ws w;
+  uint64_t off = 0;
+  char* p = (char*)base;
+  auto take = [&](uint64_t n_floats) {
+    float* r = (float*)(p + off);
+    off += align256(n_floats * 4);
+    return r;
+  };
+  const uint64_t Mc = (uint64_t)N * T, Mf = (uint64_t)N * t;
+  const uint64_t Mmax = Mc > Mf ? Mc : Mf;
+  w.nears = take(N);
+  w.fars = take(N);
+  w.z_c = take(Mc);
+  w.z_f = take(Mf ? Mf : 1);
+  w.feat = take(Mmax * 2 * L);
+  w.h_c = take(Mc * 16);
+  w.sigma_c = take(Mc);
+  w.h_f = take(Mf ? Mf * 16 : 1);
+  w.sigma_f = take(Mf ? Mf : 1);
+  w.bytes = off;
+  return w;
+}
+}  // namespace
+
+extern "C" uint64_t ucsa_render_workspace_bytes(uint32_t N, uint32_t T,
+                                                uint32_t t,
+                                                uint32_t n_levels) {
+  return carve(nullptr, N, T, t, n_levels).bytes;
+}
+
+#define UCSA_TRY(expr)          \
+  do {                          \
+    int32_t rc_ = (expr);       \
+    if (rc_ != 0) return rc_;   \
+  } while (0)
+
+extern "C" int32_t ucsa_render_fwd(
+    const ucsa_grid* grid, const float* table, const float* packed_sigma,
+    const float* packed_color, const float* packed_sem, const float* rays_o,
+    const float* rays_d, const float* norms, const float* aabb_host,
+    float min_near, const float* t_rand, const float* u, uint32_t N,
+    uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
+    float* image, float* depth, float* semantics, void* ws, void* stream) {
+  UCSA_CHECK_ARG(grid, 0);
+  UCSA_CHECK_ARG(ws, 20);
+  UCSA_CHECK_ARG(t == 0 || u, 11);
+  if (N == 0) return 0;
+  const Ws w = carve(ws, N, T, t, grid->n_levels);
+  UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
+                                   w.nears, w.fars, stream));
+  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
+  UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_c,
+                                     aabb_host, N, T, w.feat, stream));
+  UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * T, grid->n_levels,
+                              w.h_c, w.sigma_c, stream));
+  if (t > 0) {
+    UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
+                           stream));
+    UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_f,
+                                       aabb_host, N, t, w.feat, stream));
+    UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * t, grid->n_levels,
+                                w.h_f, w.sigma_f, stream));
+  }
+  UCSA_TRY(ucsa_composite_fwd(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                              w.sigma_f, w.h_f, packed_color, packed_sem, N, T,
+                              t, n_classes, density_scale, image, depth,
+                              semantics, nullptr, nullptr, stream));
+  return 0;
+}
+
+extern "C" int32_t ucsa_version(void) { return UCSA_VERSION; }
+
+extern "C" const char* ucsa_error_string(int32_t code) {
+  static thread_local char buf[96];
+  if (code == 0) return "ok";
+  if (code <= UCSA_ERR_ARG) {
+    snprintf(buf, sizeof(buf), "invalid argument #%d", UCSA_ERR_ARG - code);
+    return buf;
+  }
+  return hipGetErrorString((hipError_t)(-code));
+}

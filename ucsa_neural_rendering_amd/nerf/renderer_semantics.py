@@ -1,0 +1,165 @@
+"""Mirror of reference ``nr4seg/nerf/renderer_semantics.py``.
+
+Same class, constructor, buffers and ``run`` / ``render`` signatures
+(reference :63-103, :123-135, :301-310).  ``run`` is one enqueue of the HIP
+pipeline (``ucsa_render_fwd``) instead of ~80 torch ops and three tcnn calls.
+
+Extra OPTIONAL keyword arguments: ``num_steps``,
+``upsample_steps`` (already accepted through ``**kwargs`` by the reference),
+``rng_t`` [N,T] and ``rng_u`` [N,t] to supply the uniforms the reference draws
+with ``torch.rand`` (:166 and sample_pdf :28) so results can be compared
+value-for-value.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class SemanticNeRFRenderer(nn.Module):
+
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1,
+                 num_semantic_classes=41):
+        super().__init__()
+        self.epoch = 1
+        self.weights = np.zeros([0])
+        self.weights_sum = np.zeros([0])
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.density_scale = density_scale
+        self.num_semantic_classes = num_semantic_classes
+        aabb_train = torch.FloatTensor(
+            [-bound, -bound, -bound, bound, bound, bound])
+        aabb_infer = aabb_train.clone()
+        self.register_buffer("aabb_train", aabb_train)
+        self.register_buffer("aabb_infer", aabb_infer)
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            raise NotImplementedError(
+                "cuda_ray=True (occupancy-grid marching) is dormant in the "
+                "reference (joint_train_lightning_net.py:29-35) and not built "
+                "yet (SURVEY 8f rank 1)")
+        # rays per HIP enqueue; results do not depend on it
+        self.hip_ray_chunk = 32768
+        self._ws = None
+        self._aabb_host = {}
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        return  # only meaningful with cuda_ray (reference :111-121)
+
+    # -- hooks supplied by the field (SemanticNeRFNetwork) -------------------
+    def _field(self):
+        raise NotImplementedError()
+
+    def _aabb_list(self, training: bool):
+        key = bool(training)
+        buf = self.aabb_train if training else self.aabb_infer
+        ver = buf._version
+        hit = self._aabb_host.get(key)
+        if hit is None or hit[0] != ver:
+            self._aabb_host[key] = (ver, [float(v) for v in buf.detach().cpu()])
+        return self._aabb_host[key][1]
+
+    def _workspace(self, nbytes: int, device):
+        if (self._ws is None or self._ws.numel() < nbytes or
+                self._ws.device != device):
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def run(self, rays_o, rays_d, direction_norms, num_steps=256,
+            upsample_steps=256, bg_color=None, perturb=False, epoch=None,
+            rng_t=None, rng_u=None, min_near=0.2, **kwargs):
+        """reference :123-299.  rays [B,N,3], direction_norms [B,N,1] ->
+        {"depth" [B,N], "image" [B,N,3], "semantics" [B,N,C]}.
+        ``bg_color`` is accepted and unused, exactly like the reference
+        (:288-289 assigns it, nothing reads it)."""
+        prefix = rays_o.shape[:-1]
+        device = rays_o.device
+        if device.type != "cuda":
+            raise ops._lib.UcsaError(
+                "SemanticNeRFRenderer.run needs GPU tensors: the HIP path has "
+                "no CPU fallback")
+        o = rays_o.contiguous().view(-1, 3).float()
+        d = rays_d.contiguous().view(-1, 3).float()
+        nrm = direction_norms.contiguous().view(-1).float()
+        N = o.shape[0]
+        T, t = int(num_steps), int(upsample_steps)
+        C = self.num_semantic_classes
+        if perturb and rng_t is None:
+            rng_t = torch.rand(N, T, device=device)
+        if not perturb:
+            rng_t = None
+        if t > 0 and rng_u is None:
+            rng_u = torch.rand(N, t, device=device)
+        if rng_t is not None:
+            rng_t = rng_t.reshape(N, T).float().contiguous()
+        if rng_u is not None:
+            rng_u = rng_u.reshape(N, t).float().contiguous()
+        aabb = self._aabb_list(self.training)
+
+        if N == 0:
+            return {
+                "depth": torch.empty(*prefix, device=device),
+                "image": torch.empty(*prefix, 3, device=device),
+                "semantics": torch.empty(*prefix, C, device=device),
+            }
+        if torch.is_grad_enabled() and any(
+                p.requires_grad for p in self.parameters()):
+            out = self._run_train(o, d, nrm, aabb, T, t, rng_t, rng_u, min_near)
+        else:
+            out = self._run_infer(o, d, nrm, aabb, T, t, rng_t, rng_u, min_near)
+        image, depth, sem = out
+        return {
+            "depth": depth.view(*prefix),
+            "image": image.view(*prefix, 3),
+            "semantics": sem.view(*prefix, C),
+        }
+
+    def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):
+        f = self._field()
+        N = o.shape[0]
+        C = self.num_semantic_classes
+        dev = o.device
+        image = torch.empty(N, 3, device=dev)
+        depth = torch.empty(N, device=dev)
+        sem = torch.empty(N, C, device=dev)
+        chunk = max(1, int(self.hip_ray_chunk))
+        ws = self._workspace(
+            ops.render_workspace_bytes(min(N, chunk), T, t, f["grid"].n_levels),
+            dev)
+        for head in range(0, N, chunk):
+            tail = min(head + chunk, N)
+            ops.render_fwd(
+                f["grid"], f["table"], f["packed_sigma"], f["packed_color"],
+                f["packed_sem"], o[head:tail], d[head:tail], nrm[head:tail],
+                aabb, min_near,
+                None if rng_t is None else rng_t[head:tail],
+                None if rng_u is None else rng_u[head:tail], T, t, C,
+                float(self.density_scale), image[head:tail], depth[head:tail],
+                sem[head:tail], ws)
+        return image, depth, sem
+
+    def _run_train(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):
+        raise NotImplementedError
+
+    def render(self, rays_o, rays_d, direction_norms, staged=False,
+               max_ray_batch=4096, bg_color=None, perturb=False, epoch=None,
+               **kwargs):
+        """reference :301-358.  The reference's ``staged`` loop over
+        ``max_ray_batch``-ray chunks only bounds memory; rays are independent,
+        so here ``run`` chunks internally (``hip_ray_chunk``) and one call
+        covers the whole batch.  Explicit ``rng_t`` / ``rng_u`` are [B,N,*]."""
+        return self.run(rays_o, rays_d, direction_norms=direction_norms,
+                        bg_color=bg_color, perturb=perturb, epoch=epoch,
+                        **kwargs)

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C ABI (``include/ucsa_hip.h``).
+
+PyTorch is used for device memory and streams only: every function checks its
+arguments, allocates outputs with ``torch.empty`` and enqueues the HIP kernels
+on torch's current stream.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Grid, check, fvec, lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.UcsaError(
+            f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def get_rays(poses: torch.Tensor, intrinsics, H: int, W: int,
+             inds: Optional[torch.Tensor] = None):
+    """-> rays_o, rays_d [B,n,3], direction_norms [B,n,1]."""
+    poses = _f32(poses, "poses")
+    B = poses.shape[0]
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    if inds is not None:
+        inds = inds.reshape(-1).to(torch.int64).contiguous()
+        n = inds.numel()
+    else:
+        n = H * W
+    o = torch.empty(B, n, 3, device=poses.device)
+    d = torch.empty(B, n, 3, device=poses.device)
+    nr = torch.empty(B, n, 1, device=poses.device)
+    check(lib().ucsa_get_rays(_ptr(poses), B, fx, fy, cx, cy, H, W,
+                              _ptr(inds), n, _ptr(o), _ptr(d), _ptr(nr),
+                              _stream()), "ucsa_get_rays")
+    return o, d, nr
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near: float = 0.2):
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    N = rays_o.shape[0]
+    aabb_h = fvec(aabb.detach().cpu().tolist() if torch.is_tensor(aabb) else aabb)
+    nears = torch.empty(N, device=rays_o.device)
+    fars = torch.empty(N, device=rays_o.device)
+    check(lib().ucsa_near_far_from_aabb(_ptr(rays_o), _ptr(rays_d), aabb_h, N,
+                                        float(min_near), _ptr(nears),
+                                        _ptr(fars), _stream()),
+          "ucsa_near_far_from_aabb")
+    return nears, fars
+
+
+def sample_coarse(nears, fars, T: int, t_rand=None):
+    nears = _f32(nears, "nears").view(-1)
+    fars = _f32(fars, "fars").view(-1)
+    N = nears.shape[0]
+    if t_rand is not None:
+        t_rand = _f32(t_rand, "t_rand")
+        assert t_rand.shape == (N, T)
+    z = torch.empty(N, T, device=nears.device)
+    check(lib().ucsa_sample_coarse(_ptr(nears), _ptr(fars), _ptr(t_rand), N, T,
+                                   _ptr(z), _stream()), "ucsa_sample_coarse")
+    return z
+
+
+def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb):
+    """-> feat [L, N*T, 2] (level-major)."""
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    z = _f32(z, "z")
+    N, T = z.shape
+    feat = torch.empty(grid.n_levels, N * T, 2, device=z.device)
+    check(lib().ucsa_hashgrid_encode_rays(C.byref(grid), _ptr(table),
+                                          _ptr(rays_o), _ptr(rays_d), _ptr(z),
+                                          fvec(aabb), N, T, _ptr(feat),
+                                          _stream()),
+          "ucsa_hashgrid_encode_rays")
+    return feat
+
+
+def hashgrid_encode_points(grid: Grid, table, x):
+    x = _f32(x, "x").view(-1, 3)
+    M = x.shape[0]
+    feat = torch.empty(grid.n_levels, M, 2, device=x.device)
+    check(lib().ucsa_hashgrid_encode_points(C.byref(grid), _ptr(table), _ptr(x),
+                                            M, _ptr(feat), _stream()),
+          "ucsa_hashgrid_encode_points")
+    return feat
+
+
+def mlp_pack(kind: int, params: torch.Tensor, n_classes: int = 0,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    params = _f32(params.detach(), "params")
+    if out is None:
+        out = torch.empty_like(params)
+    check(lib().ucsa_mlp_pack(kind, _ptr(params), _ptr(out), n_classes,
+                              _stream()), "ucsa_mlp_pack")
+    return out
+
+
+def sigma_mlp_fwd(feat, packed_sigma) -> Tuple[torch.Tensor, torch.Tensor]:
+    """feat [L,M,2] -> h [M,16], sigma [M]."""
+    L, M, _ = feat.shape
+    h = torch.empty(M, 16, device=feat.device)
+    sigma = torch.empty(M, device=feat.device)
+    check(lib().ucsa_sigma_mlp_fwd(_ptr(feat), _ptr(packed_sigma), M, L,
+                                   _ptr(h), _ptr(sigma), _stream()),
+          "ucsa_sigma_mlp_fwd")
+    return h, sigma
+
+
+def resample(z, sigma, u, density_scale: float = 1.0):
+    z = _f32(z, "z")
+    sigma = _f32(sigma, "sigma")
+    u = _f32(u, "u")
+    N, T = z.shape
+    t = u.shape[1]
+    new_z = torch.empty(N, t, device=z.device)
+    check(lib().ucsa_resample(_ptr(z), _ptr(sigma), _ptr(u), N, T, t,
+                              float(density_scale), _ptr(new_z), _stream()),
+          "ucsa_resample")
+    return new_z
+
+
+def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                  packed_color, packed_sem, n_classes: int,
+                  density_scale: float = 1.0, want_aux: bool = False):
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    norms = _f32(norms, "norms").view(-1)
+    N, T = z_c.shape
+    t = 0 if z_f is None else z_f.shape[1]
+    dev = z_c.device
+    image = torch.empty(N, 3, device=dev)
+    depth = torch.empty(N, device=dev)
+    sem = torch.empty(N, n_classes, device=dev)
+    src = torch.empty(N, T + t, dtype=torch.int32, device=dev) if want_aux else None
+    w = torch.empty(N, T + t, device=dev) if want_aux else None
+    check(lib().ucsa_composite_fwd(_ptr(rays_d), _ptr(norms), _ptr(z_c),
+                                   _ptr(sigma_c), _ptr(h_c), _ptr(z_f),
+                                   _ptr(sigma_f), _ptr(h_f), _ptr(packed_color),
+                                   _ptr(packed_sem), N, T, t, n_classes,
+                                   float(density_scale), _ptr(image),
+                                   _ptr(depth), _ptr(sem), _ptr(src), _ptr(w),
+                                   _stream()), "ucsa_composite_fwd")
+    if want_aux:
+        return image, depth, sem, src, w
+    return image, depth, sem
+
+
+def render_workspace_bytes(N: int, T: int, t: int, n_levels: int) -> int:
+    return int(lib().ucsa_render_workspace_bytes(N, T, t, n_levels))
+
+
+def render_fwd(grid: Grid, table, packed_sigma, packed_color, packed_sem,
+               rays_o, rays_d, norms, aabb, min_near: float, t_rand, u, T: int,
+               t: int, n_classes: int, density_scale: float, image, depth,
+               semantics, ws: torch.Tensor):
+    """All tensors already validated/contiguous; outputs written in place."""
+    N = rays_o.shape[0]
+    check(lib().ucsa_render_fwd(C.byref(grid), _ptr(table), _ptr(packed_sigma),
+                                _ptr(packed_color), _ptr(packed_sem),
+                                _ptr(rays_o), _ptr(rays_d), _ptr(norms),
+                                fvec(aabb), float(min_near), _ptr(t_rand),
+                                _ptr(u), N, T, t, n_classes,
+                                float(density_scale), _ptr(image), _ptr(depth),
+                                _ptr(semantics), _ptr(ws), _stream()),
+          "ucsa_render_fwd")
