@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd sqlite database (kernel-trace / --pmc) as a
+small text table: per-kernel calls, total/avg/min/max duration, share, and
+(when counters were collected) per-kernel counter sums per dispatch.
+
+    python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/x.txt
+"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = c.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = defaultdict(list)
+    for n, s, e in rows:
+        agg[n].append(e - s)
+    tot = sum(sum(v) for v in agg.values()) or 1
+    print(f"# rocprofv3 kernel-trace summary of {path}")
+    print(f"# {'kernel':60s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} "
+          f"{'min_us':>10s} {'max_us':>10s} {'share%':>7s}")
+    for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        short = n if len(n) <= 60 else n[:57] + "..."
+        print(f"  {short:60s} {len(v):7d} {sum(v)/1e6:10.3f} "
+              f"{sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} "
+              f"{max(v)/1e3:10.2f} {100*sum(v)/tot:7.2f}")
+    try:
+        pm = c.execute("select * from counters_collection limit 1").fetchall()
+        ccols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    except sqlite3.Error:
+        pm, ccols = [], []
+    if pm:
+        kn = "kernel_name" if "kernel_name" in ccols else "name"
+        q = (f"select {kn}, counter_name, sum(value), count(distinct dispatch_id) "
+             f"from counters_collection group by {kn}, counter_name")
+        print("\n# counters: kernel, counter, sum over dispatches, dispatches, per dispatch")
+        for n, cn, v, nd in c.execute(q):
+            short = n if len(n) <= 50 else n[:47] + "..."
+            print(f"  {short:50s} {cn:24s} {v:18.0f} {nd:6d} {v/max(nd,1):18.1f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
