@@ -174,6 +174,66 @@ int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
                         float density_scale, float* image, float* depth,
                         float* semantics, void* ws, void* stream);
 
+/* ======================= training (backward) ============================== */
+
+/* A fragments of W^T for the dX = W^T dY passes (layout: DESIGN.md).
+ * ucsa_mlp_pack_t_size() elements; call after every parameter update. */
+uint32_t ucsa_mlp_pack_t_size(int32_t kind, uint32_t n_classes);
+int32_t ucsa_mlp_pack_t(int32_t kind, const float* params, float* packed_t,
+                        uint32_t n_classes, void* stream);
+
+/* grad[p] = (accumulate ? grad[p] : 0) + sum_w partial[w][p], summed in a
+ * fixed order (deterministic alternative to float atomics for dW). */
+int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,
+                             uint32_t n_params, int32_t accumulate,
+                             float* grad, void* stream);
+
+/* Backward of ucsa_sigma_mlp_fwd (autograd of tcnn.Network in density(),
+ * reference network_tcnn_semantics.py:135).  d_h [M,16] is the gradient wrt
+ * the RAW outputs (slot 0 already multiplied by the trunc_exp backward,
+ * reference activation.py:17-21).  Out: d_feat [n_levels][M][2] and per-wave
+ * dW partials [ucsa_sigma_mlp_bwd_parts(M)][3072] (tcnn layout). */
+uint32_t ucsa_sigma_mlp_bwd_parts(uint32_t M);
+int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
+                           const float* packed_sigma,
+                           const float* packed_sigma_t, uint32_t M,
+                           uint32_t n_levels, float* d_feat, float* partial,
+                           void* stream);
+
+/* Backward of ucsa_hashgrid_encode_rays: atomically adds into grad_table
+ * [total_entries,2] (caller zeroes it).  Autograd of tcnn.Encoding. */
+int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid_host, const float* rays_o,
+                               const float* rays_d, const float* z,
+                               const float* aabb_host, uint32_t N, uint32_t T,
+                               const float* d_feat, float* grad_table,
+                               void* stream);
+
+/* Backward of ucsa_composite_fwd (autograd of renderer_semantics.py:238-299
+ * and the masked color()/semantics()).  Needs the forward's `src` and
+ * `weights`.  Out: d_h_c [N*T,16], d_h_f [N*t,16] (all 16 slots; slot 0 is
+ * d/d(log-density)), scratch G [N,S], per-wave partials
+ * [ucsa_composite_bwd_parts(N)][7168] and [..][1024 + 1024*ceil(C/16)]. */
+uint32_t ucsa_composite_bwd_parts(uint32_t N);
+int32_t ucsa_composite_bwd(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const float* packed_color, const float* packed_sem,
+    const float* packed_color_t, const float* packed_sem_t,
+    const float* d_image, const float* d_depth, const float* d_sem, uint32_t N,
+    uint32_t T, uint32_t t, uint32_t n_classes, float density_scale, float* G,
+    float* d_h_c, float* d_h_f, float* partial_color, float* partial_sem,
+    void* stream);
+
+/* torch.optim.Adam step as configured at reference
+ * joint_train_lightning_net.py:897-919 (L2 weight decay in the gradient,
+ * non-AMSGrad).  `step` is 1-based; grads are multiplied by inv_grad_scale
+ * first (GradScaler unscale, :509-513). */
+int32_t ucsa_adam_step(float* params, const float* grads, float* exp_avg,
+                       float* exp_avg_sq, uint64_t n, uint32_t step, float lr,
+                       float beta1, float beta2, float eps, float weight_decay,
+                       float inv_grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,78 @@
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports exactly
+the symbols include/ucsa_hip.h declares; the ctypes table covers all of them.
+No kernel is launched (there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ucsa_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ucsa_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from ucsa_neural_rendering_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib
+
+
+def test_header_symbols_are_exported(built_lib):
+    syms = declared_symbols()
+    assert "ucsa_render_fwd" in syms and "ucsa_near_far_from_aabb" in syms
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH],
+                         capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ucsa_[a-z0-9_]+)", out))
+    missing = [s for s in syms if s not in exported]
+    assert not missing, f"declared but not exported: {missing}"
+    extra = sorted(exported - set(syms))
+    assert not extra, f"exported but not declared in the header: {extra}"
+
+
+def test_ctypes_table_covers_header(built_lib):
+    assert sorted(built_lib.SIGNATURES) == declared_symbols()
+    l = built_lib.lib()  # resolves every symbol, raises otherwise
+    assert l.ucsa_version() == 100
+    assert l.ucsa_error_string(0) == b"ok"
+    assert b"argument #3" in l.ucsa_error_string(-1003)
+
+
+def test_grid_init_host_function_matches_survey_table(built_lib):
+    g = built_lib.make_grid(4.0, 16, 19, 16, 2.0**0.6)
+    res = [g.level[i].res for i in range(16)]
+    assert res == [16, 25, 37, 56, 85, 128, 195, 295, 446, 676, 1024, 1553,
+                   2353, 3566, 5405, 8192]
+    assert g.total_entries == 6537456
+    assert [g.level[i].hashed for i in range(16)] == [0] * 4 + [1] * 12
+    assert g.level[5].scale == 127.0 and g.level[15].scale == 8191.0
+    # argument validation returns UCSA_ERR_ARG - index, never crashes
+    bad = built_lib.Grid()
+    rc = built_lib.lib().ucsa_grid_init(ctypes.byref(bad), -1.0, 16, 19, 16, 1.5)
+    assert rc == -1001
+
+
+def test_null_arguments_are_rejected_before_any_launch(built_lib):
+    l = built_lib.lib()
+    assert l.ucsa_near_far_from_aabb(None, None, None, 8, 0.2, None, None, None) == -1000
+    assert l.ucsa_sample_coarse(None, None, None, 8, 16, None, None) == -1000
+    assert l.ucsa_mlp_pack(7, None, None, 40, None) == -1000
+    assert l.ucsa_resample(None, None, None, 8, 16, 16, 1.0, None, None) == -1000
+
+
+def test_product_has_no_oracle_import():
+    """The shipped package must never route through the CPU oracle."""
+    pkg = os.path.join(ROOT, "ucsa_neural_rendering_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f

@@ -1,0 +1,552 @@
+// Backward of merge/weights/masked MLPs/compositing (the autograd of
+// reference nr4seg/nerf/renderer_semantics.py:238-299 and
+// nr4seg/nerf/network_tcnn_semantics.py:147-207).
+//
+// Two kernels:
+//  k_shade_bwd   : for every sample that passed the w > 1e-4 mask, recompute
+//                  the colour / semantics nets (fp32 MFMA), push d_image and
+//                  d_semantics back through them, write d(geo_feat) into the
+//                  sample's d_h row, the colour/depth gradient wrt its weight
+//                  into G[N,S], and accumulate dW for both nets in registers
+//                  (per-wave partials, reduced deterministically afterwards).
+//                  The semantic weights are detached (:270): no d_w from them.
+//  k_weights_bwd : per ray, d_sigma from G by a forward transmittance scan and
+//                  a reverse suffix scan, times the trunc_exp backward
+//                  (reference nr4seg/nerf/activation.py:17-21), into d_h[:,0].
+#include "mfma_mlp.h"
+#include "wave_ops.h"
+
+#define CB_WAVES 4
+#define CB_CAP 80  // 15 pending + one 64-sample chunk
+#define ROW_FINE 0x80000000u
+
+extern __shared__ __attribute__((aligned(16))) float cb_smem[];
+
+__device__ __forceinline__ void cb_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct ShadeBwdArgs {
+  const float* rays_d;
+  const float* norms;
+  const float* z_c;
+  const float* z_f;
+  const float* h_c;
+  const float* h_f;
+  const int32_t* src;
+  const float* weights;
+  const float* d_image;
+  const float* d_depth;
+  const float* d_sem;
+  const float* packed_color;
+  const float* packed_sem;
+  const float* packed_color_t;
+  const float* packed_sem_t;
+  uint32_t N, T, t, C;
+  float* G;
+  float* d_h_c;
+  float* d_h_f;
+  float* partial_color;
+  float* partial_sem;
+  uint32_t rays_per_wave;
+};
+
+__device__ __forceinline__ void sh4_select_b(float dx, float dy, float dz,
+                                             uint32_t g, f32x4& o) {
+  const float x = ((dx + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float y = ((dy + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float z = ((dz + 1.0f) / 2.0f) * 2.0f - 1.0f;
+  const float xy = x * y, xz = x * z, yz = y * z;
+  const float x2 = x * x, y2 = y * y, z2 = z * z;
+  if (g == 0) {
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+  } else if (g == 1) {
+    o[0] = 1.0925484305920792f * xy;
+    o[1] = -1.0925484305920792f * yz;
+    o[2] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[3] = -1.0925484305920792f * xz;
+  } else if (g == 2) {
+    o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[2] = 2.8906114426405538f * xy * z;
+    o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  } else {
+    o[0] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[1] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[2] = 1.4453057213202769f * z * (x2 - y2);
+    o[3] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  }
+}
+
+__device__ __forceinline__ f32x4 gate4(f32x4 pre, f32x4 v) {
+  f32x4 r;
+  r[0] = pre[0] > 0.f ? v[0] : 0.f;
+  r[1] = pre[1] > 0.f ? v[1] : 0.f;
+  r[2] = pre[2] > 0.f ? v[2] : 0.f;
+  r[3] = pre[3] > 0.f ? v[3] : 0.f;
+  return r;
+}
+
+template <int NRB>
+__global__ void __launch_bounds__(64 * CB_WAVES)
+k_shade_bwd(ShadeBwdArgs a) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint32_t T = a.T, t = a.t, S = a.T + a.t, C = a.C;
+
+  float* w_color = cb_smem;                    // 7168
+  float* w_sem = w_color + 7168;               // 1024 + NRB*1024
+  float* wt_color = w_sem + 1024 + NRB * 1024; // 6144
+  float* wt_sem = wt_color + 6144;             // (16*NRB + 16) * 64
+  float* per_wave = wt_sem + (16 * NRB + 16) * 64;
+  const uint32_t per_wave_floats = 5 * CB_CAP + 2 * 16 * TILE_LD;
+  float* base = per_wave + (size_t)wid * per_wave_floats;
+  float* lw = base;
+  uint32_t* lrow = reinterpret_cast<uint32_t*>(lw + CB_CAP);
+  uint32_t* lray = lrow + CB_CAP;
+  uint32_t* lsmp = lray + CB_CAP;
+  float* lz = reinterpret_cast<float*>(lsmp + CB_CAP);
+  float* dy_tile = lz + CB_CAP;
+  float* x_tile = dy_tile + 16 * TILE_LD;
+
+  for (uint32_t i = threadIdx.x; i < 7168; i += blockDim.x) w_color[i] = a.packed_color[i];
+  for (uint32_t i = threadIdx.x; i < 1024 + NRB * 1024; i += blockDim.x) w_sem[i] = a.packed_sem[i];
+  for (uint32_t i = threadIdx.x; i < 6144; i += blockDim.x) wt_color[i] = a.packed_color_t[i];
+  for (uint32_t i = threadIdx.x; i < (16 * NRB + 16) * 64; i += blockDim.x) wt_sem[i] = a.packed_sem_t[i];
+  __syncthreads();
+
+  const uint64_t gwave = (uint64_t)blockIdx.x * CB_WAVES + wid;
+  f32x4 dwc1[4][2], dwc2[4][4], dwc3[1][4], dws1[4][1], dws2[NRB][4];
+  dw_zero(dwc1);
+  dw_zero(dwc2);
+  dw_zero(dwc3);
+  dw_zero(dws1);
+  dw_zero(dws2);
+
+  uint32_t cnt = 0;
+
+  // ---- one block of up to 16 surviving samples ---------------------------
+  auto shade16 = [&](uint32_t n) {
+    uint32_t e = j;
+    const bool live = e < n;
+    if (!live) e = n - 1;
+    const float wgt = live ? lw[e] : 0.0f;
+    const uint32_t row = lrow[e], ray = lray[e], smp = lsmp[e];
+    const float zz = lz[e];
+    const bool fine = (row & ROW_FINE) != 0;
+    const size_t hoff = (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
+    f32x4 geo = *reinterpret_cast<const f32x4*>((fine ? a.h_f : a.h_c) + hoff);
+    if (g == 0) geo[0] = 1.0f;
+    const float* dptr = a.rays_d + (size_t)ray * 3;
+    f32x4 sh;
+    sh4_select_b(dptr[0], dptr[1], dptr[2], g, sh);
+
+    // ------------------------- forward (recompute) ------------------------
+    f32x4 a1c[4], a2c[4], o3[1], a1s[4], lg[NRB];
+    {
+      float xin[8] = {sh[0], sh[1], sh[2], sh[3], geo[0], geo[1], geo[2], geo[3]};
+      mfma_layer<8, 4>(xin, [&](int rb, int ks) { return w_color[(rb * 8 + ks) * 64 + lane]; }, a1c);
+      float hid[16];
+      chain_relu(a1c, hid);
+      mfma_layer<16, 4>(hid, [&](int rb, int ks) { return w_color[(COLOR_L1_FRAGS + rb * 16 + ks) * 64 + lane]; }, a2c);
+      chain_relu(a2c, hid);
+      mfma_layer<16, 1>(hid, [&](int, int ks) { return w_color[(COLOR_L1_FRAGS + COLOR_L2_FRAGS + ks) * 64 + lane]; }, o3);
+      float xs[4] = {geo[0], geo[1], geo[2], geo[3]};
+      mfma_layer<4, 4>(xs, [&](int rb, int ks) { return w_sem[(rb * 4 + ks) * 64 + lane]; }, a1s);
+      chain_relu(a1s, hid);
+      mfma_layer<16, NRB>(hid, [&](int rb, int ks) { return w_sem[(SEM_L1_FRAGS + rb * 16 + ks) * 64 + lane]; }, lg);
+    }
+    // softmax
+    float mx = -INFINITY;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fmaxf(mx, lg[rb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
+        const float ex = ok ? expf(lg[rb][r] - mx) : 0.0f;
+        lg[rb][r] = ex;
+        sum += ex;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    // ------------------------- upstream gradients -------------------------
+    const float* di = a.d_image + (size_t)ray * 3;
+    f32x4 dy3 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g == 0) {
+      float dwsum = a.d_depth[ray] * zz / a.norms[ray];
+      // image = sum_s w*rgb  ->  d_rgb = w*d_image, d_w += d_image . rgb
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float rgb = 1.0f / (1.0f + expf(-o3[0][c]));
+        dwsum += di[c] * rgb;
+        dy3[c] = wgt * di[c] * rgb * (1.0f - rgb);
+      }
+      if (live) a.G[(size_t)ray * S + smp] = dwsum;
+    }
+    // semantics = sum_s w_detached * p ; p = softmax(logits)
+    float dot = 0.0f;
+    f32x4 dlg[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t cls = rb * 16 + 4 * g + r;
+        const float p = lg[rb][r] / sum;
+        const float dp = cls < C ? wgt * a.d_sem[(size_t)ray * C + cls] : 0.0f;
+        lg[rb][r] = p;
+        dlg[rb][r] = dp;
+        dot += p * dp;
+      }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dlg[rb][r] = lg[rb][r] * (dlg[rb][r] - dot);
+
+    // ------------------------- colour net backward ------------------------
+    // L3: dW3 += dy3 (x) relu(a2c);  d_hid2 = W3^T dy3
+    tile_store(dy_tile, g, j, 0, dy3);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(x_tile, g, j, rb, relu4(a2c[rb]));
+    cb_sync();
+    dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
+    cb_sync();
+    f32x4 dh2[4];
+    {
+      float b[4] = {dy3[0], dy3[1], dy3[2], dy3[3]};
+      mfma_layer<4, 4>(b, [&](int rb, int ks) { return wt_color[(rb * 4 + ks) * 64 + lane]; }, dh2);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) dh2[rb] = gate4(a2c[rb], dh2[rb]);
+    // L2: dW2 += d_hid2 (x) relu(a1c);  d_hid1 = W2^T d_hid2
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      tile_store(dy_tile, g, j, rb, dh2[rb]);
+      tile_store(x_tile, g, j, rb, relu4(a1c[rb]));
+    }
+    cb_sync();
+    dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
+    cb_sync();
+    f32x4 dh1[4];
+    {
+      float b[16];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dh2[rb][r];
+      mfma_layer<16, 4>(b, [&](int rb, int ks) { return wt_color[(16 + rb * 16 + ks) * 64 + lane]; }, dh1);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) dh1[rb] = gate4(a1c[rb], dh1[rb]);
+    // L1: dW1 += d_hid1 (x) [SH16 | geo15 | 1];  d_slot = W1^T(slot rows) d_hid1
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(dy_tile, g, j, rb, dh1[rb]);
+    tile_store(x_tile, g, j, 0, sh);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t m = 4 * g + r;
+      x_tile[j * TILE_LD + (m == 0 ? 31u : 15u + m)] = geo[r];
+    }
+    cb_sync();
+    dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
+    cb_sync();
+    f32x4 dslot[1];
+    {
+      float b[16];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dh1[rb][r];
+      mfma_layer<16, 1>(b, [&](int, int ks) { return wt_color[(80 + ks) * 64 + lane]; }, dslot);
+    }
+
+    // ------------------------- semantics net backward ---------------------
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) tile_store(dy_tile, g, j, rb, dlg[rb]);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(x_tile, g, j, rb, relu4(a1s[rb]));
+    cb_sync();
+    dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
+    cb_sync();
+    f32x4 dhs[4];
+    {
+      float b[4 * NRB];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dlg[rb][r];
+      mfma_layer<4 * NRB, 4>(b, [&](int rb, int ks) { return wt_sem[(rb * 4 * NRB + ks) * 64 + lane]; }, dhs);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      dhs[rb] = gate4(a1s[rb], dhs[rb]);
+      tile_store(dy_tile, g, j, rb, dhs[rb]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t m = 4 * g + r;
+      x_tile[j * TILE_LD + (m == 0 ? 15u : m - 1u)] = geo[r];
+    }
+    cb_sync();
+    dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
+    cb_sync();
+    f32x4 dslot_s[1];
+    {
+      float b[16];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dhs[rb][r];
+      mfma_layer<16, 1>(b, [&](int, int ks) { return wt_sem[(16 * NRB + ks) * 64 + lane]; }, dslot_s);
+    }
+    if (live) {
+      f32x4 out;
+      out[0] = (g == 0) ? 0.0f : dslot[0][0] + dslot_s[0][0];  // slot 0: k_weights_bwd
+      out[1] = dslot[0][1] + dslot_s[0][1];
+      out[2] = dslot[0][2] + dslot_s[0][2];
+      out[3] = dslot[0][3] + dslot_s[0][3];
+      *reinterpret_cast<f32x4*>((fine ? a.d_h_f : a.d_h_c) + hoff) = out;
+    }
+  };
+
+  const uint64_t r_begin64 = gwave * a.rays_per_wave;
+  if (r_begin64 < a.N) {
+    const uint32_t r_begin = (uint32_t)r_begin64;
+    const uint32_t r_end = (r_begin + a.rays_per_wave < a.N) ? r_begin + a.rays_per_wave : a.N;
+    for (uint32_t r = r_begin; r < r_end; ++r) {
+      for (uint32_t sbase = 0; sbase < S; sbase += 64) {
+        const uint32_t s = sbase + lane;
+        float w = 0.0f;
+        bool keep = false;
+        if (s < S) {
+          w = a.weights[(size_t)r * S + s];
+          keep = w > 1e-4f;
+          if (!keep) a.G[(size_t)r * S + s] = 0.0f;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+          const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          const uint32_t e = (uint32_t)a.src[(size_t)r * S + s];
+          lw[pos] = w;
+          lrow[pos] = e < T ? (r * T + e) : (ROW_FINE | (r * t + (e - T)));
+          lray[pos] = r;
+          lsmp[pos] = s;
+          lz[pos] = e < T ? a.z_c[(size_t)r * T + e] : a.z_f[(size_t)r * t + (e - T)];
+        }
+        cnt += (uint32_t)__popcll(bal);
+        cb_sync();
+        uint32_t head = 0;
+        while (cnt - head >= 16) {
+          if (head) {
+            float tw = 0.f, tz = 0.f;
+            uint32_t tr = 0, ty = 0, ts = 0;
+            if (lane < 16) {
+              tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
+              ts = lsmp[head + lane]; tz = lz[head + lane];
+            }
+            cb_sync();
+            if (lane < 16) {
+              lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
+            }
+            cb_sync();
+          }
+          shade16(16);
+          head += 16;
+        }
+        if (head) {
+          const uint32_t rem = cnt - head;  // < 16
+          float tw = 0.f, tz = 0.f;
+          uint32_t tr = 0, ty = 0, ts = 0;
+          if (lane < rem) {
+            tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
+            ts = lsmp[head + lane]; tz = lz[head + lane];
+          }
+          cb_sync();
+          if (lane < rem) {
+            lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
+          }
+          cnt = rem;
+          cb_sync();
+        }
+      }
+    }
+    if (cnt) shade16(cnt);
+  }
+  // per-wave partial gradients, tcnn layout
+  float* pc = a.partial_color + (size_t)gwave * 7168;
+  dw_store<4, 2>(pc, 32, lane, dwc1);
+  dw_store<4, 4>(pc + 2048, 64, lane, dwc2);
+  dw_store<1, 4>(pc + 6144, 64, lane, dwc3);
+  float* ps = a.partial_sem + (size_t)gwave * (1024 + NRB * 1024);
+  dw_store<4, 1>(ps, 16, lane, dws1);
+  dw_store<NRB, 4>(ps + 1024, 64, lane, dws2);
+}
+
+static inline uint32_t cb_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
+
+static void shade_bwd_geometry(uint32_t N, uint32_t& rpw, uint32_t& blocks) {
+  const uint64_t total_waves = 256ull * CB_WAVES;
+  rpw = (uint32_t)((N + total_waves - 1) / total_waves);
+  if (rpw < 2) rpw = 2;
+  const uint32_t n_waves = ucsa_div_up(N, rpw);
+  blocks = ucsa_div_up(n_waves, CB_WAVES);
+}
+
+// number of per-wave partial slots the caller must provide
+extern "C" uint32_t ucsa_composite_bwd_parts(uint32_t N) {
+  uint32_t rpw, blocks;
+  shade_bwd_geometry(N ? N : 1, rpw, blocks);
+  return blocks * CB_WAVES;
+}
+
+// ---------------------------------------------------------------------------
+// k_weights_bwd: one wave per ray.
+// ---------------------------------------------------------------------------
+#define WB_WAVES 4
+extern __shared__ __attribute__((aligned(16))) float wb_smem[];
+
+__global__ void __launch_bounds__(64 * WB_WAVES)
+k_weights_bwd(const float* __restrict__ z_c, const float* __restrict__ z_f,
+              const float* __restrict__ sigma_c,
+              const float* __restrict__ sigma_f,
+              const int32_t* __restrict__ src, const float* __restrict__ weights,
+              const float* __restrict__ G, uint32_t N, uint32_t T, uint32_t t,
+              float density_scale, float* __restrict__ d_h_c,
+              float* __restrict__ d_h_f) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t r = blockIdx.x * WB_WAVES + wid;
+  if (r >= N) return;
+  const uint32_t S = T + t;
+  float* zm = wb_smem + (size_t)wid * 3 * S;
+  float* sg = zm + S;
+  float* suf = sg + S;
+  for (uint32_t s = lane; s < S; s += 64) {
+    const uint32_t e = (uint32_t)src[(size_t)r * S + s];
+    zm[s] = e < T ? z_c[(size_t)r * T + e] : z_f[(size_t)r * t + (e - T)];
+    sg[s] = e < T ? sigma_c[(size_t)r * T + e] : sigma_f[(size_t)r * t + (e - T)];
+  }
+  cb_sync();
+  // reverse exclusive suffix sums of q_k = G_k * w_k
+  float carry = 0.0f;
+  for (uint32_t rb = 0; rb < S; rb += 64) {
+    const uint32_t k = rb + lane;
+    const bool ok = k < S;
+    const uint32_t i = ok ? S - 1 - k : 0;
+    const float q = ok ? G[(size_t)r * S + i] * weights[(size_t)r * S + i] : 0.0f;
+    const float incl = wave_incl_scan_add(q, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0f;
+    if (ok) suf[i] = carry + excl;
+    carry = carry + wave_bcast(incl, 63);
+  }
+  cb_sync();
+  float tcarry = 1.0f;
+  const float lo = expf(-15.0f), hi = expf(15.0f);
+  for (uint32_t sb = 0; sb < S; sb += 64) {
+    const uint32_t s = sb + lane;
+    float ex = 1.0f, alpha = 0.0f, delta = 0.0f;
+    if (s < S) {
+      delta = (s + 1 < S) ? zm[s + 1] - zm[s] : 1e10f;
+      ex = expf(-delta * density_scale * sg[s]);
+      alpha = 1.0f - ex;
+    }
+    const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
+    const float incl = wave_incl_scan_mul(fac, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float Ti = tcarry * excl;
+    tcarry = tcarry * wave_bcast(incl, 63);
+    if (s < S) {
+      const float Gi = G[(size_t)r * S + s];
+      const float dalpha = Gi * Ti - suf[s] / fac;
+      const float dsigma = dalpha * (ex * delta * density_scale);
+      const float sig = sg[s];
+      const float dh0 = dsigma * fminf(fmaxf(sig, lo), hi);
+      const uint32_t e = (uint32_t)src[(size_t)r * S + s];
+      if (e < T) d_h_c[((size_t)r * T + e) * 16] = dh0;
+      else d_h_f[((size_t)r * t + (e - T)) * 16] = dh0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int32_t ucsa_composite_bwd(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const float* packed_color, const float* packed_sem,
+    const float* packed_color_t, const float* packed_sem_t,
+    const float* d_image, const float* d_depth, const float* d_sem, uint32_t N,
+    uint32_t T, uint32_t t, uint32_t n_classes, float density_scale, float* G,
+    float* d_h_c, float* d_h_f, float* partial_color, float* partial_sem,
+    void* stream) {
+  UCSA_CHECK_ARG(rays_d && norms, 0);
+  UCSA_CHECK_ARG(z_c && sigma_c && h_c, 2);
+  UCSA_CHECK_ARG(t == 0 || (z_f && sigma_f && h_f), 5);
+  UCSA_CHECK_ARG(src && weights, 8);
+  UCSA_CHECK_ARG(packed_color && packed_sem && packed_color_t && packed_sem_t, 10);
+  UCSA_CHECK_ARG(d_image && d_depth && d_sem, 14);
+  UCSA_CHECK_ARG(T >= 1 && (uint64_t)N * T < 0x80000000ull, 18);
+  UCSA_CHECK_ARG((uint64_t)N * t < 0x80000000ull && T + t <= 8192, 19);
+  UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 20);
+  UCSA_CHECK_ARG(G && d_h_c && (t == 0 || d_h_f), 22);
+  UCSA_CHECK_ARG(partial_color && partial_sem, 25);
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t nrb = cb_pad16(n_classes) / 16;
+  uint32_t rpw, blocks;
+  shade_bwd_geometry(N, rpw, blocks);
+  // d_h rows of samples outside the mask get no geo gradient
+  hipError_t e = hipMemsetAsync(d_h_c, 0, (size_t)N * T * 16 * sizeof(float), s);
+  if (e != hipSuccess) return -(int32_t)e;
+  if (t) {
+    e = hipMemsetAsync(d_h_f, 0, (size_t)N * t * 16 * sizeof(float), s);
+    if (e != hipSuccess) return -(int32_t)e;
+  }
+  ShadeBwdArgs a{rays_d, norms, z_c, z_f, h_c, h_f, src, weights, d_image,
+                 d_depth, d_sem, packed_color, packed_sem, packed_color_t,
+                 packed_sem_t, N, T, t, n_classes, G, d_h_c, d_h_f,
+                 partial_color, partial_sem, rpw};
+  const size_t smem = (7168 + 1024 + (size_t)nrb * 1024 + 6144 +
+                       (16 * (size_t)nrb + 16) * 64 +
+                       (size_t)CB_WAVES * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
+#define LAUNCH(NRB)                                                           \
+  do {                                                                        \
+    hipError_t e2 = hipFuncSetAttribute(                                      \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB>),                     \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
+    if (e2 != hipSuccess) return -(int32_t)e2;                                \
+    UCSA_CLEAR_ERR();                                                         \
+    hipLaunchKernelGGL(k_shade_bwd<NRB>, dim3(blocks), dim3(64 * CB_WAVES),   \
+                       smem, s, a);                                           \
+  } while (0)
+  switch (nrb) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    default: LAUNCH(4); break;
+  }
+#undef LAUNCH
+  int32_t rc = ucsa_launch_status();
+  if (rc) return rc;
+  const size_t smem2 = (size_t)WB_WAVES * 3 * (T + t) * sizeof(float);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_weights_bwd, dim3(ucsa_div_up(N, WB_WAVES)),
+                     dim3(64 * WB_WAVES), smem2, s, z_c, z_f, sigma_c, sigma_f,
+                     src, weights, G, N, T, t, density_scale, d_h_c, d_h_f);
+  return ucsa_launch_status();
+}

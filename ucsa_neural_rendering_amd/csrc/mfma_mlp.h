@@ -66,3 +66,71 @@ __device__ __forceinline__ void chain_relu(const f32x4 (&acc)[4],
 #pragma unroll
     for (int r = 0; r < 4; ++r) xin[rb * 4 + r] = fmaxf(acc[rb][r], 0.f);
 }
+
+// ---------------------------------------------------------------------------
+// Backward helpers.
+//
+// dX = W^T dY uses "transposed" A fragments (ucsa_mlp_pack_t): rows = input
+// neurons of the layer, k-steps follow dY's accumulator layout, so dY's
+// registers are the B operands directly and dX comes out in the layout of the
+// forward activations it belongs to.
+//
+// dW = dY X^T contracts over SAMPLES, which sit on the column index of every
+// activation register, so both operands are transposed through a small LDS
+// tile [16 samples][neurons] (row stride TILE_LD floats):
+//     A[i = o][k = s]  <- dY_tile[s][16*ob + i]
+//     B[k = s][j = c]  <- X_tile [s][16*ib + j]
+// and accumulated in registers for the whole kernel (one 16x16 tile = 4 regs).
+// ---------------------------------------------------------------------------
+#define TILE_LD 68
+
+// store lane (g,j)'s accumulator block rb (neurons 16*rb+4g..+3 of sample j)
+__device__ __forceinline__ void tile_store(float* tile, uint32_t g, uint32_t j,
+                                           int rb, f32x4 v) {
+  *reinterpret_cast<f32x4*>(tile + j * TILE_LD + 16 * rb + 4 * g) = v;
+}
+
+// dW[ob][ib] += dY_tile^T X_tile over the 16 samples of the tile
+template <int OB, int IB>
+__device__ __forceinline__ void dw_accumulate(const float* dy_tile,
+                                              const float* x_tile,
+                                              uint32_t lane,
+                                              f32x4 (&dw)[OB][IB]) {
+  const uint32_t i = lane & 15u, k = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    float a[OB], b[IB];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) a[ob] = dy_tile[(4 * ks + k) * TILE_LD + 16 * ob + i];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) b[ib] = x_tile[(4 * ks + k) * TILE_LD + 16 * ib + i];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) dw[ob][ib] = mfma16(a[ob], b[ib], dw[ob][ib]);
+  }
+}
+
+// write one wave's dW tiles into its slot of the partial buffer, tcnn layout
+// (row-major [out, in_cols]); lane (g', j') holds rows 4g'+r, column j'.
+template <int OB, int IB>
+__device__ __forceinline__ void dw_store(float* dst, uint32_t in_cols,
+                                         uint32_t lane,
+                                         const f32x4 (&dw)[OB][IB]) {
+  const uint32_t gq = lane >> 4, jq = lane & 15u;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dst[(16 * ob + 4 * gq + r) * in_cols + 16 * ib + jq] = dw[ob][ib][r];
+}
+
+template <int OB, int IB>
+__device__ __forceinline__ void dw_zero(f32x4 (&dw)[OB][IB]) {
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) dw[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+}

@@ -1,0 +1,254 @@
+// Backward of the sigma MLP (+ trunc_exp is applied upstream), transposed
+// weight packing, and the deterministic reduction of per-wave dW partials.
+// Restates the autograd of tcnn.Network as used by density()
+// (reference nr4seg/nerf/network_tcnn_semantics.py:130-144).
+#include "mfma_mlp.h"
+
+__device__ __forceinline__ void wave_lds_sync_b() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t chain_col_b(uint32_t ks, uint32_t g) {
+  return 16u * (ks >> 2) + 4u * g + (ks & 3u);
+}
+
+// ---------------------------------------------------------------------------
+// ucsa_mlp_pack_t: A fragments of W^T for dX = W^T dY (see mfma_mlp.h).
+//   sigma: [L2^T 16 frags | L1^T 32 frags]
+//   color: [L3^T 16 | L2^T 64 | L1^T (h-slot rows only) 16]
+//   sem  : [L2^T 16*nrb | L1^T (h-slot rows) 16]
+// ---------------------------------------------------------------------------
+__global__ void k_mlp_pack_t(int kind, const float* __restrict__ params,
+                             float* __restrict__ packed, uint32_t n_total,
+                             uint32_t nrb) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_total) return;
+  uint32_t f = e >> 6;
+  const uint32_t l = e & 63u, g = l >> 4, i = l & 15u;
+  uint32_t src;
+  if (kind == UCSA_MLP_SIGMA) {
+    if (f < 16) {
+      const uint32_t rb = f / 4, ks = f % 4;
+      src = 64 * 32 + (4 * g + ks) * 64 + 16 * rb + i;
+    } else {
+      f -= 16;
+      const uint32_t rb = f / 16, ks = f % 16;
+      src = chain_col_b(ks, g) * 32 + 16 * rb + i;
+    }
+  } else if (kind == UCSA_MLP_COLOR) {
+    if (f < 16) {
+      const uint32_t rb = f / 4, ks = f % 4;
+      src = 64 * 32 + 64 * 64 + (4 * g + ks) * 64 + 16 * rb + i;
+    } else if (f < 80) {
+      f -= 16;
+      const uint32_t rb = f / 16, ks = f % 16;
+      src = 64 * 32 + chain_col_b(ks, g) * 64 + 16 * rb + i;
+    } else {
+      f -= 80;
+      const uint32_t col = i == 0 ? 31u : 15u + i;
+      src = chain_col_b(f, g) * 32 + col;
+    }
+  } else {
+    if (f < 16 * nrb) {
+      const uint32_t rb = f / (4 * nrb), ks = f % (4 * nrb);
+      src = 64 * 16 + chain_col_b(ks, g) * 64 + 16 * rb + i;
+    } else {
+      f -= 16 * nrb;
+      const uint32_t col = i == 0 ? 15u : i - 1u;
+      src = chain_col_b(f, g) * 16 + col;
+    }
+  }
+  packed[e] = params[src];
+}
+
+static inline uint32_t pad16b(uint32_t n) { return (n + 15u) / 16u * 16u; }
+
+extern "C" uint32_t ucsa_mlp_pack_t_size(int32_t kind, uint32_t n_classes) {
+  if (kind == UCSA_MLP_SIGMA) return 48 * 64;
+  if (kind == UCSA_MLP_COLOR) return 96 * 64;
+  return (16 * (pad16b(n_classes) / 16) + 16) * 64;
+}
+
+extern "C" int32_t ucsa_mlp_pack_t(int32_t kind, const float* params,
+                                   float* packed_t, uint32_t n_classes,
+                                   void* stream) {
+  UCSA_CHECK_ARG(kind >= 0 && kind <= 2, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed_t, 2);
+  UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
+  const uint32_t n_total = ucsa_mlp_pack_t_size(kind, n_classes);
+  const uint32_t nrb = pad16b(n_classes ? n_classes : 1) / 16;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack_t, dim3(ucsa_div_up(n_total, 256)), dim3(256),
+                     0, (hipStream_t)stream, (int)kind, params, packed_t,
+                     n_total, nrb);
+  return ucsa_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// Deterministic reduction of per-wave partial gradients:
+//   grad[p] = (accumulate ? grad[p] : 0) + sum_{w < n_parts} partial[w][p]
+// summed in wave order (fixed), one thread per parameter.
+// ---------------------------------------------------------------------------
+__global__ void k_reduce_partials(const float* __restrict__ partial,
+                                  uint32_t n_parts, uint32_t n_params,
+                                  int accumulate, float* __restrict__ grad) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_params) return;
+  float s = accumulate ? grad[p] : 0.0f;
+  for (uint32_t w = 0; w < n_parts; ++w) s += partial[(size_t)w * n_params + p];
+  grad[p] = s;
+}
+
+extern "C" int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,
+                                        uint32_t n_params, int32_t accumulate,
+                                        float* grad, void* stream) {
+  UCSA_CHECK_ARG(partial, 0);
+  UCSA_CHECK_ARG(grad, 4);
+  if (n_params == 0) return 0;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ucsa_div_up(n_params, 256)),
+                     dim3(256), 0, (hipStream_t)stream, partial, n_parts,
+                     n_params, (int)accumulate, grad);
+  return ucsa_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// sigma MLP backward.
+//   in : feat[level][m] (saved), d_h[m][16] (grad wrt the RAW outputs: slot 0
+//        already carries the trunc_exp backward), packed fwd + transposed W
+//   out: d_feat[level][m] float2, per-wave dW partials [n_waves][3072]
+// Per 16 samples: 32 (fwd L1) + 16 + 32 (dX) + 16 + 32 (dW) MFMAs.
+// ---------------------------------------------------------------------------
+#define SIGB_WAVES 4
+
+extern __shared__ __attribute__((aligned(16))) float sigb_smem[];
+
+__global__ void __launch_bounds__(64 * SIGB_WAVES)
+k_sigma_mlp_bwd(const float2* __restrict__ feat, const float* __restrict__ d_h,
+                const float* __restrict__ packed,
+                const float* __restrict__ packed_t, uint64_t M,
+                float2* __restrict__ d_feat, float* __restrict__ partial) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint64_t wave = (uint64_t)blockIdx.x * SIGB_WAVES + wid;
+  const uint64_t nwaves = (uint64_t)gridDim.x * SIGB_WAVES;
+  float* dy_tile = sigb_smem + (size_t)wid * 2 * 16 * TILE_LD;
+  float* x_tile = dy_tile + 16 * TILE_LD;
+
+  float w1[4][8], w2t[4][4], w1t[2][16];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w1[rb][ks] = packed[(rb * 8 + ks) * 64 + lane];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w2t[rb][ks] = packed_t[(rb * 4 + ks) * 64 + lane];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      w1t[rb][ks] = packed_t[(16 + rb * 16 + ks) * 64 + lane];
+
+  f32x4 dw1[4][2], dw2[1][4];
+  dw_zero(dw1);
+  dw_zero(dw2);
+
+  for (uint64_t base = wave * 16; base < M; base += nwaves * 16) {
+    uint64_t m = base + j;
+    const bool live = m < M;
+    if (!live) m = M - 1;
+    float xin[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float2 v = feat[(uint64_t)(4 * q + g) * M + m];
+      xin[2 * q] = v.x;
+      xin[2 * q + 1] = v.y;
+    }
+    f32x4 dh = *reinterpret_cast<const f32x4*>(d_h + m * 16 + 4 * g);
+    if (!live) dh = f32x4{0.f, 0.f, 0.f, 0.f};  // padded columns add nothing
+
+    f32x4 acc1[4];
+    mfma_layer<8, 4>(xin, [&](int rb, int ks) { return w1[rb][ks]; }, acc1);
+
+    // dW2 += dh (x) relu(acc1)
+    tile_store(dy_tile, g, j, 0, dh);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(x_tile, g, j, rb, relu4(acc1[rb]));
+    wave_lds_sync_b();
+    dw_accumulate<1, 4>(dy_tile, x_tile, lane, dw2);
+    wave_lds_sync_b();
+
+    // d_hid = W2^T dh, gated by ReLU
+    f32x4 dhid[4];
+    {
+      float b[4] = {dh[0], dh[1], dh[2], dh[3]};
+      mfma_layer<4, 4>(b, [&](int rb, int ks) { return w2t[rb][ks]; }, dhid);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dhid[rb][r] = acc1[rb][r] > 0.f ? dhid[rb][r] : 0.f;
+
+    // dW1 += d_hid (x) x   (x tile in natural feature order 2*level + c)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(dy_tile, g, j, rb, dhid[rb]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float2*>(x_tile + j * TILE_LD + 8 * q + 2 * g) =
+          make_float2(live ? xin[2 * q] : 0.f, live ? xin[2 * q + 1] : 0.f);
+    wave_lds_sync_b();
+    dw_accumulate<4, 2>(dy_tile, x_tile, lane, dw1);
+    wave_lds_sync_b();
+
+    // d_feat = W1^T d_hid
+    float bh[16];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bh[rb * 4 + r] = dhid[rb][r];
+    f32x4 dx[2];
+    mfma_layer<16, 2>(bh, [&](int rb, int ks) { return w1t[rb][ks]; }, dx);
+    if (live) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const uint32_t lv = 8 * rb + 2 * g;
+        d_feat[(uint64_t)lv * M + m] = make_float2(dx[rb][0], dx[rb][1]);
+        d_feat[(uint64_t)(lv + 1) * M + m] = make_float2(dx[rb][2], dx[rb][3]);
+      }
+    }
+  }
+  float* dst = partial + (size_t)wave * 3072;
+  dw_store<4, 2>(dst, 32, lane, dw1);
+  dw_store<1, 4>(dst + 2048, 64, lane, dw2);
+}
+
+extern "C" uint32_t ucsa_sigma_mlp_bwd_parts(uint32_t M) {
+  const uint32_t need = ucsa_div_up(M, 16 * SIGB_WAVES * 4);
+  const uint32_t blocks = need < 512u ? (need ? need : 1u) : 512u;
+  return blocks * SIGB_WAVES;
+}
+
+extern "C" int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
+                                      const float* packed_sigma,
+                                      const float* packed_sigma_t, uint32_t M,
+                                      uint32_t n_levels, float* d_feat,
+                                      float* partial, void* stream) {
+  UCSA_CHECK_ARG(feat, 0);
+  UCSA_CHECK_ARG(d_h, 1);
+  UCSA_CHECK_ARG(packed_sigma && packed_sigma_t, 2);
+  UCSA_CHECK_ARG(n_levels == 16, 5);
+  UCSA_CHECK_ARG(d_feat && partial, 6);
+  if (M == 0) return 0;
+  const uint32_t blocks = ucsa_sigma_mlp_bwd_parts(M) / SIGB_WAVES;
+  const size_t smem = (size_t)SIGB_WAVES * 2 * 16 * TILE_LD * sizeof(float);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp_bwd, dim3(blocks), dim3(64 * SIGB_WAVES), smem,
+                     (hipStream_t)stream, (const float2*)feat, d_h,
+                     packed_sigma, packed_sigma_t, (uint64_t)M,
+                     (float2*)d_feat, partial);
+  return ucsa_launch_status();
+}

@@ -16,6 +16,71 @@ from .encoding import FullyFusedMLP, HashGridEncoding, SHEncoding
 from .renderer_semantics import SemanticNeRFRenderer
 
 
+class _RenderFn(torch.autograd.Function):
+    """Autograd boundary of the HIP renderer.  Differentiable inputs are the
+    four flat parameter tensors only (rays, depths and the resampled depths
+    carry no gradient in the reference either: new_z_vals is detached,
+    renderer_semantics.py:203-207)."""
+
+    @staticmethod
+    def forward(ctx, grid_p, sigma_p, color_p, sem_p, net, o, d, nrm, aabb, T,
+                t, rng_t, rng_u, min_near):
+        f = net._field(transposed=True)
+        N = o.shape[0]
+        C = net.num_semantic_classes
+        ds = float(net.density_scale)
+        near, far = ops.near_far_from_aabb(o, d, aabb, min_near)
+        z_c = ops.sample_coarse(near, far, T, rng_t)
+        feat_c = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z_c, aabb)
+        h_c, s_c = ops.sigma_mlp_fwd(feat_c, f["packed_sigma"])
+        s_c = s_c.view(N, T)
+        if t > 0:
+            z_f = ops.resample(z_c, s_c, rng_u, ds)
+            feat_f = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z_f,
+                                              aabb)
+            h_f, s_f = ops.sigma_mlp_fwd(feat_f, f["packed_sigma"])
+            s_f = s_f.view(N, t)
+        else:
+            z_f = feat_f = h_f = s_f = None
+        image, depth, sem, src, w = ops.composite_fwd(
+            d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, f["packed_color"],
+            f["packed_sem"], C, ds, want_aux=True)
+        ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t = net, f, aabb, T, t
+        ctx.saved = (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f,
+                     src, w)
+        return image, depth, sem
+
+    @staticmethod
+    def backward(ctx, d_image, d_depth, d_sem):
+        net, f, aabb, T, t = ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t
+        (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f, src,
+         w) = ctx.saved
+        C = net.num_semantic_classes
+        ds = float(net.density_scale)
+        d_h_c, d_h_f, pc, ps = ops.composite_bwd(
+            d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, src, w, f["packed_color"],
+            f["packed_sem"], f["packed_color_t"], f["packed_sem_t"],
+            d_image.contiguous(), d_depth.contiguous(), d_sem.contiguous(), C,
+            ds)
+        g_color = torch.empty_like(net.color_net.params)
+        g_sem = torch.empty_like(net.semantics_net.params)
+        ops.reduce_partials(pc, g_color, False)
+        ops.reduce_partials(ps, g_sem, False)
+        g_sigma = torch.empty_like(net.sigma_net.params)
+        g_grid = torch.zeros_like(net.encoder.params)
+        d_feat, part = ops.sigma_mlp_bwd(feat_c, d_h_c, f["packed_sigma"],
+                                         f["packed_sigma_t"])
+        ops.reduce_partials(part, g_sigma, False)
+        ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid)
+        if t > 0:
+            d_feat, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
+                                             f["packed_sigma_t"])
+            ops.reduce_partials(part, g_sigma, True)
+            ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat, g_grid)
+        ctx.saved = None
+        return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
+
+
 class SemanticNeRFNetwork(SemanticNeRFRenderer):
 
     def __init__(self, encoding="HashGrid", encoding_dir="SphericalHarmonics",
@@ -69,11 +134,35 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             self._packed[name] = (key, packed)
         return self._packed[name][1]
 
-    def _field(self):
-        return dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
-                    packed_sigma=self._pack("sigma", self.sigma_net),
-                    packed_color=self._pack("color", self.color_net),
-                    packed_sem=self._pack("sem", self.semantics_net))
+    def _pack_t(self, name: str, net: FullyFusedMLP):
+        p = net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get(name + "_t")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            packed = ops.mlp_pack_t(net.kind, p, self.num_semantic_classes,
+                                    out=out)
+            self._packed[name + "_t"] = (key, packed)
+        return self._packed[name + "_t"][1]
+
+    def _field(self, transposed: bool = False):
+        f = dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
+                 packed_sigma=self._pack("sigma", self.sigma_net),
+                 packed_color=self._pack("color", self.color_net),
+                 packed_sem=self._pack("sem", self.semantics_net))
+        if transposed:
+            f.update(packed_sigma_t=self._pack_t("sigma", self.sigma_net),
+                     packed_color_t=self._pack_t("color", self.color_net),
+                     packed_sem_t=self._pack_t("sem", self.semantics_net))
+        return f
+
+    def _render_fn(self):
+        def call(net, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):
+            return _RenderFn.apply(net.encoder.params, net.sigma_net.params,
+                                   net.color_net.params,
+                                   net.semantics_net.params, net, o, d, nrm,
+                                   aabb, T, t, rng_t, rng_u, min_near)
+        return call
 
     # -- pointwise API (reference :102-207) -----------------------------------
     def density(self, x):

@@ -151,6 +151,12 @@ class SemanticNeRFRenderer(nn.Module):
         return image, depth, sem
 
     def _run_train(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):
+        """Differentiable pass: the same staged kernels with their
+        intermediates kept for the backward (see _RenderFn)."""
+        return self._render_fn()(self, o, d, nrm, aabb, T, t, rng_t, rng_u,
+                                 min_near)
+
+    def _render_fn(self):
         raise NotImplementedError
 
     def render(self, rays_o, rays_d, direction_norms, staged=False,

@@ -181,3 +181,83 @@ def render_fwd(grid: Grid, table, packed_sigma, packed_color, packed_sem,
                                 float(density_scale), _ptr(image), _ptr(depth),
                                 _ptr(semantics), _ptr(ws), _stream()),
           "ucsa_render_fwd")
+
+
+# ============================ training (backward) ===========================
+def mlp_pack_t(kind: int, params: torch.Tensor, n_classes: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    params = _f32(params.detach(), "params")
+    n = int(lib().ucsa_mlp_pack_t_size(kind, n_classes))
+    if out is None:
+        out = torch.empty(n, device=params.device)
+    check(lib().ucsa_mlp_pack_t(kind, _ptr(params), _ptr(out), n_classes,
+                                _stream()), "ucsa_mlp_pack_t")
+    return out
+
+
+def reduce_partials(partial: torch.Tensor, grad: torch.Tensor,
+                    accumulate: bool):
+    n_parts, n_params = partial.shape
+    check(lib().ucsa_reduce_partials(_ptr(partial), n_parts, n_params,
+                                     1 if accumulate else 0, _ptr(grad),
+                                     _stream()), "ucsa_reduce_partials")
+
+
+def sigma_mlp_bwd(feat, d_h, packed_sigma, packed_sigma_t):
+    """-> d_feat [L,M,2], dW partials [parts, 3072]."""
+    L, M, _ = feat.shape
+    d_feat = torch.empty_like(feat)
+    parts = int(lib().ucsa_sigma_mlp_bwd_parts(M))
+    partial = torch.empty(parts, 3072, device=feat.device)
+    check(lib().ucsa_sigma_mlp_bwd(_ptr(feat), _ptr(d_h), _ptr(packed_sigma),
+                                   _ptr(packed_sigma_t), M, L, _ptr(d_feat),
+                                   _ptr(partial), _stream()),
+          "ucsa_sigma_mlp_bwd")
+    return d_feat, partial
+
+
+def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table):
+    N, T = z.shape
+    check(lib().ucsa_hashgrid_bwd_rays(C.byref(grid), _ptr(rays_o),
+                                       _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
+                                       _ptr(d_feat), _ptr(grad_table),
+                                       _stream()), "ucsa_hashgrid_bwd_rays")
+
+
+def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
+                  weights, packed_color, packed_sem, packed_color_t,
+                  packed_sem_t, d_image, d_depth, d_sem, n_classes: int,
+                  density_scale: float = 1.0):
+    """-> d_h_c [N*T,16], d_h_f [N*t,16] | None, partial_color, partial_sem."""
+    N, T = z_c.shape
+    t = 0 if z_f is None else z_f.shape[1]
+    dev = z_c.device
+    d_image = _f32(d_image, "d_image").view(N, 3)
+    d_depth = _f32(d_depth, "d_depth").view(N)
+    d_sem = _f32(d_sem, "d_sem").view(N, n_classes)
+    G = torch.empty(N, T + t, device=dev)
+    d_h_c = torch.empty(N * T, 16, device=dev)
+    d_h_f = torch.empty(N * t, 16, device=dev) if t else None
+    parts = int(lib().ucsa_composite_bwd_parts(N))
+    nrb = (n_classes + 15) // 16
+    pc = torch.empty(parts, 7168, device=dev)
+    ps = torch.empty(parts, 1024 + 1024 * nrb, device=dev)
+    check(lib().ucsa_composite_bwd(
+        _ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
+        _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(src), _ptr(weights),
+        _ptr(packed_color), _ptr(packed_sem), _ptr(packed_color_t),
+        _ptr(packed_sem_t), _ptr(d_image), _ptr(d_depth), _ptr(d_sem), N, T, t,
+        n_classes, float(density_scale), _ptr(G), _ptr(d_h_c), _ptr(d_h_f),
+        _ptr(pc), _ptr(ps), _stream()), "ucsa_composite_bwd")
+    return d_h_c, d_h_f, pc, ps
+
+
+def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float,
+              eps: float, weight_decay: float, inv_grad_scale: float = 1.0):
+    for x in (p, g, m, v):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    check(lib().ucsa_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(),
+                               int(step), float(lr), float(beta1), float(beta2),
+                               float(eps), float(weight_decay),
+                               float(inv_grad_scale), _stream()),
+          "ucsa_adam_step")
