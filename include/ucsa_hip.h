@@ -234,6 +234,48 @@ int32_t ucsa_adam_step(float* params, const float* grads, float* exp_avg,
                        float beta1, float beta2, float eps, float weight_decay,
                        float inv_grad_scale, void* stream);
 
+/* ======================= losses / post-processing / metric ================ */
+
+/* Scratch floats needed by the reductions below for n rays / pixels. */
+uint32_t ucsa_loss_partial_floats(uint32_t n);
+
+/* NeRF losses of reference joint_train_lightning_net.py:180-223 with the
+ * weighting of :44-45,:503-507, and (when d_* != NULL) the gradient of
+ * grad_scale * total wrt the rendered outputs.
+ *   rgb,gt_rgb [N,3]; sem [N,C] composited probabilities; depth, gt_depth [N];
+ *   labels [N] int64 (-1 ignored).  stats[6] (device) = {loss_color,
+ *   loss_semantics (NaN = the reference's None), loss_depth, n_invalid_sem,
+ *   n_valid_depth, total}. */
+int32_t ucsa_nerf_loss(const float* rgb, const float* sem, const float* depth,
+                       const float* gt_rgb, const int64_t* labels,
+                       const float* gt_depth, uint32_t N, uint32_t C,
+                       float one_m_to_scene_uom, float w_sem, float w_depth,
+                       float grad_scale, float* stats, float* d_rgb,
+                       float* d_sem, float* d_depth, float* partial,
+                       void* stream);
+
+/* reference joint_train_lightning_net.py:246-251: rows summing to 0 become
+ * uniform, normalise, argmax.  normalised may be NULL. */
+int32_t ucsa_semantic_postproc(const float* sem, uint32_t N, uint32_t C,
+                               float* normalised, int64_t* argmax,
+                               void* stream);
+
+/* Segmentation tail on NCHW logits [B,C,P]: softmax (prob, may be NULL),
+ * argmax (may be NULL) and, when labels != NULL, the reference's
+ * CrossEntropyLoss(ignore_index=-1, reduction="none")(softmax(out), label)
+ * .mean() (double softmax; :37-38,:163,:456-458) plus grad_scale * dLoss/dlogits
+ * (d_logits may be NULL). */
+int32_t ucsa_seg_tail(const float* logits, const int64_t* labels, uint32_t B,
+                      uint32_t C, uint32_t P, float grad_scale, float* prob,
+                      int64_t* argmax, float* loss, float* d_logits,
+                      float* partial, void* stream);
+
+/* Confusion matrix, rows = truth, truth == -1 dropped (reference
+ * nr4seg/utils/metrics.py:31-46); adds into cm [C,C] int64. */
+int32_t ucsa_confusion_matrix(const int64_t* preds, const int64_t* truths,
+                              uint64_t n, uint32_t C, int64_t* cm,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,14 @@ SIGNATURES = {
                            [_p] * 6),
     "ucsa_adam_step": (C.c_int32, [_p, _p, _p, _p, C.c_uint64, _u32, _f, _f,
                                    _f, _f, _f, _f, _p]),
+    # ---- losses / post-processing / metric ----
+    "ucsa_loss_partial_floats": (C.c_uint32, [_u32]),
+    "ucsa_nerf_loss": (C.c_int32, [_p] * 6 + [_u32, _u32, _f, _f, _f, _f] +
+                       [_p] * 6),
+    "ucsa_semantic_postproc": (C.c_int32, [_p, _u32, _u32, _p, _p, _p]),
+    "ucsa_seg_tail": (C.c_int32, [_p, _p, _u32, _u32, _u32, _f, _p, _p, _p, _p,
+                                  _p, _p]),
+    "ucsa_confusion_matrix": (C.c_int32, [_p, _p, C.c_uint64, _u32, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,424 @@
+"""Mirror of reference ``nr4seg/lightning/joint_train_lightning_net.py``.
+
+The four hot-path methods keep their names, arguments and return values:
+``get_rays_train`` (:108-157), ``forward_seg`` (:159-165),
+``forward_nerf_train`` (:167-223), ``forward_nerf_test`` (:225-257); so do
+``training_step_nerf`` (:473-513), ``training_step_joint`` (:363-471) and
+``configure_optimizers`` (:876-921).  What they call is the HIP path:
+
+* rays            -> ``ucsa_get_rays`` (pixel indices drawn with torch.randint
+                     exactly like :141)
+* NeRF render     -> ``SemanticNeRFNetwork.render`` (HIP pipeline + backward)
+* NeRF losses     -> ``ucsa_nerf_loss`` (fused forward+gradient)
+* softmax/argmax, CE-on-softmax -> ``ucsa_seg_tail``
+* post-processing -> ``ucsa_semantic_postproc``
+* mIoU            -> ``ucsa_confusion_matrix`` + reference formula
+* NeRF optimizer  -> ``HipAdam`` (``ucsa_adam_step``), same two param groups.
+
+Out of scope and therefore reduced: PNG dumps of
+``predict_step`` (returns tensors instead), the Visualizer, WandB logging
+(``self.log`` goes to the JSONL logger of the thin Trainer), and colour-jitter
+hue in ``data_aug``.  PyTorch-Lightning itself is not required: the class is a
+plain ``nn.Module`` with the few LightningModule members the code uses.
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import dist as udist
+from .. import losses as ulosses
+from .. import ops
+from ..nerf.network_tcnn_semantics import SemanticNeRFNetwork
+from ..nerf.optim import HipAdam
+from ..network import DeepLabV3
+from ..utils.metrics import SemanticsMeter
+
+
+class JointTrainLightningNet(nn.Module):
+
+    def __init__(self, exp, env):
+        super().__init__()
+        self.num_classes = exp["model"]["num_classes"]
+        self.seg_model = DeepLabV3(exp["model"])
+        self.nerf_model = SemanticNeRFNetwork(
+            encoding="hashgrid", bound=4, cuda_ray=False, density_scale=1,
+            num_semantic_classes=self.num_classes,
+            seed=exp.get("nerf_seed"))
+        nerf_cfg = exp.get("nerf", {})  # optional block, defaults = reference
+        self.n_rays_train = int(nerf_cfg.get("n_rays", 4096))
+        self.num_steps = int(nerf_cfg.get("num_steps", 256))
+        self.upsample_steps = int(nerf_cfg.get("upsample_steps", 256))
+
+        self.weight_depth = ulosses.WEIGHT_DEPTH
+        self.weight_semantics = ulosses.WEIGHT_SEMANTICS
+        self.nerf_scaler = torch.amp.GradScaler("cuda", enabled=True)
+        self.automatic_optimization = False
+        self.joint_train = False
+        self.fix_nerf = exp.get("fix_nerf", False)
+        self.root_new_scene = os.path.join(
+            env.get("scannet", "."), str(exp["scenes"][-1]),
+            str(exp.get("exp_name", "debug")))
+        self.prev_scene_name = None
+        names = ["train_nerf", "train_seg", "train_nerf_seg", "train_seg_nerf",
+                 "val_seg", "train_val_seg", "test_nerf", "test_25k"]
+        self._meter = {n: SemanticsMeter(number_classes=self.num_classes)
+                       for n in names}
+        self._exp, self._env = exp, env
+        self._mode = "train"
+        self._output_size = (240, 320)
+        self._flip_p = 0.5
+        self._degrees = 10
+        self._jitter = dict(brightness=0.3, contrast=0.3, saturation=0.3)
+        self._default_H = None
+        self._default_W = None
+        # thin-Trainer plumbing
+        self.trainer = None
+        self._optimizers = None
+        self.logged = {}
+
+    # ---- LightningModule members used by the code --------------------------
+    @property
+    def current_epoch(self):
+        return self.trainer.current_epoch if self.trainer else 0
+
+    def log(self, name, value, **kw):
+        self.logged[name] = float(value)
+        if self.trainer is not None and udist.world()[0] == 0:
+            self.trainer.logger.log(name, value, self.trainer.global_step)
+
+    def optimizers(self, use_pl_optimizer=False):
+        if self._optimizers is None:
+            self._optimizers = self.configure_optimizers()
+        return self._optimizers
+
+    def manual_backward(self, loss):
+        loss.backward()
+
+    def on_train_epoch_start(self):
+        self._mode = "train"
+
+    # ---- a1 ------------------------------------------------------------------
+    @torch.no_grad()
+    def get_rays_train(self, batch, bs, N=None):
+        """reference :108-157 -> rays_o, rays_d [1,N,3], direction_norms
+        [1,N,1], inds [1,N]."""
+        N = self.n_rays_train if N is None else N
+        poses = batch["pose"][[bs], ...]
+        device = poses.device
+        fx, fy, cx, cy = [float(v) for v in batch["intrinsics"][bs]]
+        H, W = int(batch["H"][bs]), int(batch["W"][bs])
+        N = min(N, H * W)
+        inds = torch.randint(0, H * W, size=[N], device=device)  # may duplicate
+        o, d, n = ops.get_rays(poses, (fx, fy, cx, cy), H, W, inds=inds)
+        return o, d, n, inds.expand([1, N])
+
+    # ---- a14 / a15 -------------------------------------------------------------
+    def forward_seg(self, batch, image=None):
+        """reference :159-165 -> {"seg_semantics" argmax, "seg_semantics_raw"
+        softmax probabilities, "seg_logits" (extra: lets seg_loss fuse the
+        double softmax with its backward)}."""
+        if image is None:
+            image = batch["img"]
+        output = self.seg_model(image)
+        logits = output["out"]
+        with torch.no_grad():
+            tail = ops.seg_tail(logits.detach().contiguous(), None,
+                                want_prob=True)
+        return {"seg_semantics": tail["argmax"],
+                "seg_semantics_raw": tail["prob"], "seg_logits": logits}
+
+    # ---- a3-a12 ----------------------------------------------------------------
+    def forward_nerf_train(self, batch, output_seg, bs):
+        """reference :167-223 -> (loss_color, loss_semantics | None,
+        loss_depth)."""
+        rays_o, rays_d, direction_norms, inds = self.get_rays_train(batch, bs)
+        images = batch["img_fp16"][[bs], ...]
+        label_nerf = output_seg["seg_semantics"][[bs], ...]
+        depths = batch["depth"][[bs], ...]
+        uom = batch["one_m_to_scene_uom"][bs]
+        uom = float(uom)
+        B, C, H, W = images.shape
+        self._default_H, self._default_W = H, W
+        # the reference gathers from the fp16 image / depth (:180-189)
+        gt_rgb = torch.gather(images.reshape(B, C, -1).permute(0, 2, 1), 1,
+                              torch.stack(C * [inds], -1))
+        labels = torch.gather(label_nerf.reshape(B, -1), 1, inds)
+        gt_depth = torch.gather(depths.reshape(B, -1), 1, inds)
+        outputs = self.nerf_model.render(
+            rays_o, rays_d, direction_norms=direction_norms, staged=False,
+            bg_color=None, perturb=True, epoch=self.current_epoch,
+            num_steps=self.num_steps, upsample_steps=self.upsample_steps)
+        return ulosses.nerf_losses(outputs["image"], outputs["semantics"],
+                                   outputs["depth"], gt_rgb.float(), labels,
+                                   gt_depth.float(), uom)
+
+    @torch.no_grad()
+    def forward_nerf_test(self, batch):
+        """reference :225-257."""
+        rays_o, rays_d = batch["rays_o"], batch["rays_d"]
+        direction_norms = batch["direction_norms"]
+        if batch["viewpoint_is_novel"][0]:
+            B = len(batch["viewpoint_is_novel"])
+            H, W = self._default_H, self._default_W
+        else:
+            B, C, H, W = batch["img"].shape
+        outputs = self.nerf_model.render(
+            rays_o, rays_d, direction_norms=direction_norms, staged=True,
+            bg_color=1, perturb=False, num_steps=self.num_steps,
+            upsample_steps=self.upsample_steps)
+        pred_rgb = outputs["image"].reshape(B, H, W, 3)
+        sem = outputs["semantics"].reshape(B, H, W, self.num_classes)
+        sem_norm, pred_sem = ops.semantic_postproc(sem)
+        return {"nerf_rgb": pred_rgb.permute(0, 3, 1, 2),
+                "nerf_semantics": pred_sem, "nerf_semantics_raw": sem_norm}
+
+    # ---- rendered-image augmentation (reference :259-302; 8f rank 2) --------
+    @torch.no_grad()
+    def data_aug(self, img, label):
+        """img [3,H,W] in [0,1], label [H,W] -> jitter, rotate +-10 deg
+        (bilinear / nearest, fill 0 resp. -1), flip.  Crop to the image's own
+        size and centre crop are identities at 240x320, as in the reference."""
+        label = label[None].float() + 1  # unknown -> 0 so the fill is "unknown"
+        b = 1 + random.uniform(-self._jitter["brightness"], self._jitter["brightness"])
+        c = 1 + random.uniform(-self._jitter["contrast"], self._jitter["contrast"])
+        s = 1 + random.uniform(-self._jitter["saturation"], self._jitter["saturation"])
+        img = (img * b).clamp(0, 1)
+        grey = (0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2])
+        img = ((img - grey.mean()) * c + grey.mean()).clamp(0, 1)
+        grey = (0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2])[None]
+        img = ((img - grey) * s + grey).clamp(0, 1)
+        angle = math.radians(random.uniform(-self._degrees, self._degrees))
+        H, W = img.shape[-2:]
+        cos, sin = math.cos(angle), math.sin(angle)
+        theta = torch.tensor([[cos, -sin * H / W, 0.0], [sin * W / H, cos, 0.0]],
+                             device=img.device)[None]
+        grid = F.affine_grid(theta, (1, 1, H, W), align_corners=False)
+        img = F.grid_sample(img[None], grid, mode="bilinear",
+                            padding_mode="zeros", align_corners=False)[0]
+        label = F.grid_sample(label[None], grid, mode="nearest",
+                              padding_mode="zeros", align_corners=False)[0]
+        if random.random() < self._flip_p:
+            img, label = img.flip(-1), label.flip(-1)
+        return img, (label[0] - 1).long()
+
+    # ---- training ------------------------------------------------------------
+    def training_step(self, batch, batch_idx):
+        if self.joint_train:
+            self.training_step_joint(batch)
+        else:
+            self.training_step_nerf(batch)
+
+    def _nerf_update(self, optimizer_nerf, loss_color, loss_semantics,
+                     loss_depth):
+        """reference :497-513 (+ RCCL sum of the ray-sharded gradients)."""
+        for nm, v in (("loss_nerf_rgb", loss_color), ("loss_depth", loss_depth),
+                      ("loss_nerf_semantics", loss_semantics)):
+            if v is not None:
+                self.log(f"{self._mode}/{nm}", v.detach())
+        total = ulosses.nerf_total_loss(loss_color, loss_semantics, loss_depth)
+        optimizer_nerf.zero_grad()
+        total = self.nerf_scaler.scale(total)
+        self.manual_backward(total)
+        if udist.world()[1] > 1:
+            ps = list(self.nerf_model.parameters())
+            udist.allreduce_grads_(ps)
+            w = udist.world()[1]
+            for p in ps:
+                if p.grad is not None:
+                    p.grad.div_(w)
+        self.nerf_scaler.step(optimizer_nerf)
+        self.nerf_scaler.update()
+
+    def training_step_nerf(self, batch):
+        """reference :473-513."""
+        optimizer_seg, optimizer_nerf = self.optimizers()
+        with torch.no_grad():
+            self.seg_model.eval()
+            output_seg = self.forward_seg(batch)
+            self.seg_model.train()
+        for bs in range(batch["img"].shape[0]):
+            lc, ls, ld = self.forward_nerf_train(batch, output_seg, bs)
+            self._nerf_update(optimizer_nerf, lc, ls, ld)
+
+    def training_step_joint(self, batch):
+        """reference :363-471."""
+        optimizer_seg, optimizer_nerf = self.optimizers()
+        batch_old, batch_new, batch_cl = batch
+        if batch_new is not None:
+            with torch.no_grad():
+                self.nerf_model.eval()
+                output_nerf = self.forward_nerf_test(batch_new)
+                self.nerf_model.train()
+        if not self.fix_nerf and batch_new is not None:
+            self.seg_model.eval()
+            if batch_new["img"].shape[0] > 1:  # BN trains only when B > 1
+                for m in self.seg_model.modules():
+                    if m.__class__.__name__.startswith("BatchNorm"):
+                        m.train()
+            with torch.no_grad():
+                output_seg = self.forward_seg(batch_new)
+            self.seg_model.train()
+            for bs in range(batch_new["img"].shape[0]):
+                lc, ls, ld = self.forward_nerf_train(batch_new, output_seg, bs)
+                self._nerf_update(optimizer_nerf, lc, ls, ld)
+        with torch.no_grad():
+            rgb_seg = label_seg = None
+            if batch_new is not None:
+                aug = [self.data_aug(output_nerf["nerf_rgb"][bs],
+                                     output_nerf["nerf_semantics"][bs])
+                       for bs in range(batch_new["img"].shape[0])]
+                rgb_seg = torch.stack([a[0] for a in aug], dim=0)
+                label_seg = torch.stack([a[1] for a in aug], dim=0)
+            if batch_old is not None:
+                o_rgb, o_lab = batch_old["img"], batch_old["nerf_label"]
+                rgb_seg = o_rgb if rgb_seg is None else torch.cat([rgb_seg, o_rgb], 0)
+                label_seg = o_lab if label_seg is None else torch.cat([label_seg, o_lab], 0)
+            if batch_cl is not None:
+                rimg = batch_cl["replay_img"]
+                _, _, C, H, W = rimg.shape
+                rgb_seg = torch.cat([rgb_seg, rimg.reshape(-1, C, H, W)], 0)
+                label_seg = torch.cat(
+                    [label_seg, batch_cl["replay_label"].reshape(-1, H, W)], 0)
+        logits = self.seg_model(rgb_seg)["out"]
+        loss = ulosses.seg_loss(logits, label_seg)  # CE on softmax (:456-458)
+        optimizer_seg.zero_grad()
+        self.manual_backward(loss)
+        if udist.world()[1] > 1:
+            ps = list(self.seg_model.parameters())
+            udist.allreduce_grads_(ps)
+            for p in ps:
+                if p.grad is not None:
+                    p.grad.div_(udist.world()[1])
+        optimizer_seg.step()
+        self.log(f"{self._mode}/loss_seg", loss.detach())
+
+    def on_train_epoch_end(self):
+        for net_name in ["seg", "nerf", "nerf_seg", "seg_nerf"]:
+            m = self._meter[f"train_{net_name}"]
+            if m.conf_mat is not None:
+                m_iou, total_acc, m_acc = m.measure()
+                self.log(f"train/{net_name}_total_accuracy", total_acc)
+                self.log(f"train/{net_name}_mean_accuracy", m_acc)
+                self.log(f"train/{net_name}_mean_IoU", m_iou)
+                m.clear()
+
+    # ---- validation (:541-646) ------------------------------------------------
+    def on_validation_epoch_start(self):
+        self._mode = "val"
+        self._meter["val_seg"].clear()
+        self._meter["train_val_seg"].clear()
+
+    def validation_step(self, batch, batch_idx, dataloader_idx=0):
+        output_seg = self.forward_seg(batch)
+        mode = "val" if dataloader_idx == 0 else "train_val"
+        self.prev_scene_name = batch["current_scene_name"][0]
+        self._meter[f"{mode}_seg"].update(output_seg["seg_semantics"],
+                                          batch["label"])
+        loss = ops.seg_tail(output_seg["seg_logits"].contiguous(),
+                            batch["label"], want_prob=False)["loss"]
+        self.log(f"{self._mode}/loss", loss)
+        return loss
+
+    def on_validation_epoch_end(self):
+        out = {}
+        for mode in ("val", "train_val"):
+            m = self._meter[f"{mode}_seg"]
+            if m.conf_mat is None:
+                continue
+            m_iou, total_acc, m_acc = m.measure()
+            tag = self.prev_scene_name
+            self.log(f"{mode}/seg_total_accuracy_{tag}", total_acc)
+            self.log(f"{mode}/seg_mean_accuracy_{tag}", m_acc)
+            self.log(f"{mode}/seg_mean_IoU_{tag}", m_iou)
+            out[f"{mode}_mIoU"] = m_iou
+            m.clear()
+        self.prev_scene_name = None
+        return out
+
+    # ---- test (:648-693) --------------------------------------------------------
+    def on_test_epoch_start(self):
+        self._mode = "test"
+        self._meter["test_nerf"].clear()
+        self._meter["test_25k"].clear()
+        self._psnr = []
+
+    def test_step(self, batch, batch_idx, dataloader_idx=0):
+        if dataloader_idx == 0:
+            out = self.forward_nerf_test(batch)
+            self._meter["test_nerf"].update(out["nerf_semantics"], batch["label"])
+            mse = torch.mean((out["nerf_rgb"] - batch["img"]) ** 2)
+            self._psnr.append(float(-10.0 * torch.log10(mse)))
+        else:
+            tail = ops.seg_tail(self.seg_model(batch["img"])["out"].contiguous(),
+                                None, want_prob=False)
+            self._meter["test_25k"].update(tail["argmax"], batch["label"])
+
+    def on_test_epoch_end(self):
+        out = {}
+        for net_name in ["nerf", "25k"]:
+            m = self._meter[f"test_{net_name}"]
+            if m.conf_mat is not None:
+                if udist.world()[1] > 1:  # sum the 40x40 matrix, not label maps
+                    cm = torch.from_numpy(m.conf_mat).cuda()
+                    m.conf_mat = udist.allreduce_confusion_(cm).cpu().numpy()
+                m_iou, total_acc, m_acc = m.measure()
+                self.log(f"test/{net_name}_total_accuracy", total_acc)
+                self.log(f"test/{net_name}_mean_accuracy", m_acc)
+                self.log(f"test/{net_name}_mean_IoU", m_iou)
+                out[f"test_{net_name}_mIoU"] = m_iou
+                m.clear()
+        if self._psnr:
+            out["test_nerf_PSNR"] = sum(self._psnr) / len(self._psnr)
+            self.log("test/nerf_PSNR", out["test_nerf_PSNR"])
+        return out
+
+    # ---- predict (:695-782, tensors instead of PNG files) ----------------------
+    def on_predict_epoch_start(self):
+        self._mode = "predict"
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=0):
+        out = self.forward_nerf_test(batch)
+        seg = self.forward_seg(batch, out["nerf_rgb"].contiguous())
+        return {"nerf_image": out["nerf_rgb"],
+                "nerf_label": out["nerf_semantics"] + 1,  # +1 when saved (:763)
+                "seg_label": seg["seg_semantics"] + 1,
+                "index": batch["current_index"]}
+
+    def on_predict_epoch_end(self):
+        return None
+
+    # ---- optimizers (:876-921) ---------------------------------------------------
+    def configure_optimizers(self):
+        name = self._exp["optimizer"]["name"]
+        lr_seg = self._exp["optimizer"]["lr_seg"]
+        params = self.seg_model.parameters()
+        if name == "Adam":
+            optimizer_seg = torch.optim.Adam(params, lr=lr_seg)
+        elif name == "SGD":
+            cfg = self._exp["optimizer"]["sgd_cfg"]
+            optimizer_seg = torch.optim.SGD(params, lr=lr_seg,
+                                            momentum=cfg["momentum"],
+                                            weight_decay=cfg["weight_decay"])
+        elif name == "Adadelta":
+            optimizer_seg = torch.optim.Adadelta(params, lr=lr_seg)
+        elif name == "RMSprop":
+            optimizer_seg = torch.optim.RMSprop(params, momentum=0.9, lr=lr_seg)
+        else:
+            raise ValueError(name)
+        lr_nerf = self._exp["optimizer"]["lr_nerf"]
+        optimizer_nerf = HipAdam(
+            [{"name": "encoding",
+              "params": list(self.nerf_model.encoder.parameters())},
+             {"name": "net",
+              "params": list(self.nerf_model.sigma_net.parameters()) +
+              list(self.nerf_model.color_net.parameters()) +
+              list(self.nerf_model.semantics_net.parameters()),
+              "weight_decay": 1e-6}],
+            lr=lr_nerf, betas=(0.9, 0.99), eps=1e-15)
+        return optimizer_seg, optimizer_nerf

@@ -1,0 +1,124 @@
+"""A thin stand-in for the PyTorch-Lightning 1.6 pieces the reference's entry
+point uses (scripts/train_joint.py:146-181): ``Trainer(max_epochs=...)`` with
+``fit / test / validate / predict`` and ``seed_everything``.  PyTorch-Lightning
+is not installed on the MI355X image; Trainer internals are out of
+scope, only the call order and hook names the LightningModule relies on are
+kept.  One process per GPU; under ``torch.distributed`` the NeRF gradient
+all-reduce lives in the module (``dist.allreduce_grads_``), not here.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+
+def seed_everything(seed: int):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return seed
+
+
+class JsonlLogger:
+    """Plain JSONL metrics logger (same metric names as the reference's
+    self.log calls; WandB is out of scope)."""
+
+    def __init__(self, save_dir=None):
+        self.path = os.path.join(save_dir, "metrics.jsonl") if save_dir else None
+        self.history = []
+
+    def log(self, name, value, step=None):
+        rec = {"name": name, "value": float(value), "step": step,
+               "time": time.time()}
+        self.history.append(rec)
+        if self.path:
+            with open(self.path, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+
+    def log_hyperparams(self, params):
+        pass
+
+
+class Trainer:
+
+    def __init__(self, max_epochs=1, default_root_dir=None, logger=None,
+                 callbacks=None, check_val_every_n_epoch=1, device=None,
+                 limit_batches=None, **unused):
+        self.max_epochs = int(max_epochs)
+        self.root = default_root_dir
+        self.logger = logger or JsonlLogger(default_root_dir)
+        self.check_val_every_n_epoch = check_val_every_n_epoch
+        self.device = torch.device(device or (
+            "cuda" if torch.cuda.is_available() else "cpu"))
+        self.limit_batches = limit_batches
+        self.current_epoch = 0
+        self.global_step = 0
+
+    # -- helpers -------------------------------------------------------------
+    def _attach(self, model):
+        model.trainer = self
+        model.to(self.device)
+        if not getattr(model, "_optimizers", None):
+            model._optimizers = model.configure_optimizers()
+
+    def _to_device(self, obj):
+        if torch.is_tensor(obj):
+            return obj.to(self.device, non_blocking=True)
+        if isinstance(obj, dict):
+            return {k: self._to_device(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._to_device(v) for v in obj)
+        return obj
+
+    def _loaders(self, dl):
+        return dl if isinstance(dl, (list, tuple)) else [dl]
+
+    def _batches(self, loader):
+        for i, b in enumerate(loader):
+            if self.limit_batches is not None and i >= self.limit_batches:
+                break
+            yield i, self._to_device(b)
+
+    # -- loops ---------------------------------------------------------------
+    def fit(self, model, train_dataloaders=None, val_dataloaders=None):
+        self._attach(model)
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            model.train()
+            model.on_train_epoch_start()
+            for i, batch in self._batches(train_dataloaders):
+                model.training_step(batch, i)
+                self.global_step += 1
+            model.on_train_epoch_end()
+            if val_dataloaders is not None and (
+                    epoch + 1) % self.check_val_every_n_epoch == 0:
+                self.validate(model, dataloaders=val_dataloaders)
+
+    def _eval_loop(self, model, dataloaders, kind):
+        self._attach(model)
+        model.eval()
+        getattr(model, f"on_{kind}_epoch_start")()
+        outs = []
+        with torch.no_grad():
+            for li, loader in enumerate(self._loaders(dataloaders)):
+                for i, batch in self._batches(loader):
+                    outs.append(getattr(model, f"{kind}_step")(batch, i, li))
+        res = getattr(model, f"on_{kind}_epoch_end")()
+        model.train()
+        return res if res is not None else outs
+
+    def validate(self, model, dataloaders=None):
+        return self._eval_loop(model, dataloaders, "validation")
+
+    def test(self, model, dataloaders=None):
+        return self._eval_loop(model, dataloaders, "test")
+
+    def predict(self, model, dataloaders=None):
+        return self._eval_loop(model, dataloaders, "predict")

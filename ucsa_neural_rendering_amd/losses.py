@@ -1,0 +1,82 @@
+"""Autograd wrappers of the fused loss kernels.
+
+``nerf_losses`` returns what reference ``forward_nerf_train`` returns
+(joint_train_lightning_net.py:208-223): ``(loss_color, loss_semantics | None,
+loss_depth)``; the three scalars share one fused forward+backward kernel
+(``ucsa_nerf_loss``): the gradient of ``color + 0.04 sem + 0.1 depth`` wrt the
+rendered outputs is produced in the same pass, and the returned scalars carry
+an autograd node that hands those gradients back, so
+``total = lc + ls*0.04 + ld*0.1; total.backward()`` works exactly like in the
+reference (:497-513), including under ``GradScaler``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+WEIGHT_DEPTH = 0.1  # reference :44
+WEIGHT_SEMANTICS = 0.04  # reference :45
+
+
+class _NerfLossFn(torch.autograd.Function):
+    """Outputs the three loss terms.  Each term depends on one rendered output
+    only (colour on rgb, semantics on the probabilities, depth on depth), so
+    the kernel's unit-weight gradients computed in the forward launch are
+    simply scaled by the three cotangents on the way back (no extra launch,
+    no host sync)."""
+
+    @staticmethod
+    def forward(ctx, rgb, sem, depth, gt_rgb, labels, gt_depth, uom):
+        stats, g = ops.nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom,
+                                 w_sem=1.0, w_depth=1.0, grad_scale=1.0,
+                                 want_grad=True)
+        ctx.save_for_backward(*g)
+        ctx.shapes = (rgb.shape, sem.shape, depth.shape)
+        return stats[0].clone(), stats[1].clone(), stats[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_c, g_s, g_d):
+        d_rgb, d_sem, d_depth = ctx.saved_tensors
+        sr, ss, sd = ctx.shapes
+        return ((d_rgb * g_c).view(sr), (d_sem * g_s).view(ss),
+                (d_depth * g_d).view(sd), None, None, None, None)
+
+
+def nerf_losses(pred_rgb, pred_sem, pred_depth, gt_rgb, labels, gt_depth,
+                one_m_to_scene_uom):
+    """-> (loss_color, loss_semantics | None, loss_depth) like the reference."""
+    lc, ls, ld = _NerfLossFn.apply(pred_rgb, pred_sem, pred_depth, gt_rgb,
+                                   labels, gt_depth, float(one_m_to_scene_uom))
+    if bool(torch.isnan(ls.detach())):
+        ls = None  # every ray invalid: "no gradient flow" branch (:212-213)
+    return lc, ls, ld
+
+
+def nerf_total_loss(lc, ls, ld):
+    total = lc
+    if ls is not None:
+        total = total + ls * WEIGHT_SEMANTICS
+    if ld is not None:
+        total = total + ld * WEIGHT_DEPTH
+    return total
+
+
+class _SegLossFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        r = ops.seg_tail(logits, labels, want_prob=False, want_grad=True)
+        ctx.save_for_backward(r["d_logits"])
+        return r["loss"].view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g, None
+
+
+def seg_loss(logits, labels):
+    """CrossEntropyLoss(ignore_index=-1, reduction="none")(softmax(out),
+    label).mean()  -- reference :37-38, :456-458."""
+    return _SegLossFn.apply(logits, labels)

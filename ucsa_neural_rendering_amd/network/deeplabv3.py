@@ -1,0 +1,194 @@
+"""Mirror of reference ``nr4seg/network/deeplabv3.py``.
+
+The reference wraps ``torchvision.models.segmentation.deeplabv3_resnet101``
+(torchvision 0.12, ``aux_loss=None``).  torchvision is not a dependency here:
+the same architecture is defined below with **torchvision-compatible module
+names**, so reference checkpoints (keys ``_model.backbone.*``,
+``_model.classifier.*``; rewrite at scripts/train_joint.py:116-128) load with
+``strict=True``.
+
+Convolutions / batch-norm run through PyTorch-ROCm (MIOpen) -- dense,
+library-shaped work; the hand-written HIP part of the
+segmentation path is the fused tail (softmax / argmax / CE-on-softmax fwd+bwd,
+``ucsa_seg_tail``).  ``cfg_model["backbone"]`` ("resnet101" default,
+"resnet50" for BASELINE cfg3's ResNet-50 wording) is an optional extra key.
+Pretrained weights cannot be downloaded here (no network): the flags are
+accepted and ignored with a warning unless ``cfg_model["weights_path"]`` points
+to a local state_dict.
+"""
+from __future__ import annotations
+
+import warnings
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ["DeepLabV3"]
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        # torchvision "v1.5": the stride sits on the 3x3 convolution
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride,
+                               padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNetBackbone(nn.Module):
+    """ResNet-50/101 trunk with replace_stride_with_dilation=[False, True,
+    True] (output stride 8), truncated after layer4 -- what torchvision's
+    IntermediateLayerGetter(return_layers={"layer4": "out"}) keeps."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.inplanes = 64
+        self.dilation = 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2, dilate=True)
+        self.layer4 = self._make_layer(512, layers[3], stride=2, dilate=True)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out",
+                                        nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1, dilate=False):
+        downsample = None
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride,
+                          bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample,
+                             previous_dilation)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes,
+                                     dilation=self.dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return OrderedDict(out=x)
+
+
+class ASPPConv(nn.Sequential):
+
+    def __init__(self, cin, cout, dilation):
+        super().__init__(
+            nn.Conv2d(cin, cout, 3, padding=dilation, dilation=dilation,
+                      bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+
+
+class ASPPPooling(nn.Sequential):
+
+    def __init__(self, cin, cout):
+        super().__init__(nn.AdaptiveAvgPool2d(1),
+                         nn.Conv2d(cin, cout, 1, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU())
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        for mod in self:
+            x = mod(x)
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+class ASPP(nn.Module):
+
+    def __init__(self, cin, rates, cout=256):
+        super().__init__()
+        mods = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False),
+                              nn.BatchNorm2d(cout), nn.ReLU())]
+        mods += [ASPPConv(cin, cout, r) for r in rates]
+        mods.append(ASPPPooling(cin, cout))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(
+            nn.Conv2d(len(self.convs) * cout, cout, 1, bias=False),
+            nn.BatchNorm2d(cout), nn.ReLU(), nn.Dropout(0.5))
+
+    def forward(self, x):
+        return self.project(torch.cat([c(x) for c in self.convs], dim=1))
+
+
+class DeepLabHead(nn.Sequential):
+
+    def __init__(self, cin, num_classes):
+        super().__init__(ASPP(cin, [12, 24, 36]),
+                         nn.Conv2d(256, 256, 3, padding=1, bias=False),
+                         nn.BatchNorm2d(256), nn.ReLU(),
+                         nn.Conv2d(256, num_classes, 1))
+
+
+class _DeepLabV3Model(nn.Module):
+    """torchvision.models.segmentation.DeepLabV3 with aux_classifier=None."""
+
+    def __init__(self, backbone, classifier):
+        super().__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        feats = self.backbone(x)
+        out = self.classifier(feats["out"])
+        out = F.interpolate(out, size=size, mode="bilinear",
+                            align_corners=False)
+        return OrderedDict(out=out)
+
+
+_LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}
+
+
+class DeepLabV3(nn.Module):
+    """reference nr4seg/network/deeplabv3.py:6-19: ``DeepLabV3(cfg_model)``,
+    ``forward(img) -> {"out": logits [B,num_classes,H,W]}``."""
+
+    def __init__(self, cfg_model):
+        super().__init__()
+        name = cfg_model.get("backbone", "resnet101")
+        self._model = _DeepLabV3Model(ResNetBackbone(_LAYERS[name]),
+                                      DeepLabHead(2048, cfg_model["num_classes"]))
+        path = cfg_model.get("weights_path")
+        if path:
+            sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            self.load_state_dict(sd, strict=False)
+        elif cfg_model.get("pretrained") or cfg_model.get("pretrained_backbone"):
+            warnings.warn(
+                "pretrained / pretrained_backbone requested but no network "
+                "access and no cfg_model['weights_path']: random initialisation")
+
+    def forward(self, data):
+        return self._model(data)

@@ -261,3 +261,83 @@ def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float,
                                float(eps), float(weight_decay),
                                float(inv_grad_scale), _stream()),
           "ucsa_adam_step")
+
+
+# ===================== losses / post-processing / metric ====================
+def nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom: float,
+              w_sem: float = 0.04, w_depth: float = 0.1,
+              grad_scale: float = 1.0, want_grad: bool = True):
+    """-> stats[6] (device), (d_rgb, d_sem, d_depth) | None."""
+    rgb = _f32(rgb, "rgb").view(-1, 3)
+    N = rgb.shape[0]
+    sem = _f32(sem, "sem").view(N, -1)
+    Cn = sem.shape[1]
+    depth = _f32(depth, "depth").view(N)
+    gt_rgb = _f32(gt_rgb, "gt_rgb").view(N, 3)
+    gt_depth = _f32(gt_depth, "gt_depth").view(N)
+    labels = labels.reshape(N).to(torch.int64).contiguous()
+    dev = rgb.device
+    stats = torch.empty(6, device=dev)
+    partial = torch.empty(int(lib().ucsa_loss_partial_floats(N)), device=dev)
+    grads = None
+    if want_grad:
+        grads = (torch.empty_like(rgb), torch.empty_like(sem),
+                 torch.empty_like(depth))
+    check(lib().ucsa_nerf_loss(
+        _ptr(rgb), _ptr(sem), _ptr(depth), _ptr(gt_rgb), _ptr(labels),
+        _ptr(gt_depth), N, Cn, float(uom), float(w_sem), float(w_depth),
+        float(grad_scale), _ptr(stats),
+        _ptr(grads[0]) if grads else None, _ptr(grads[1]) if grads else None,
+        _ptr(grads[2]) if grads else None, _ptr(partial), _stream()),
+        "ucsa_nerf_loss")
+    return stats, grads
+
+
+def semantic_postproc(sem, want_normalised: bool = True):
+    """[..., C] -> (normalised [..., C] | None, argmax [...] int64)."""
+    shape = sem.shape
+    s = _f32(sem, "sem").view(-1, shape[-1])
+    N, Cn = s.shape
+    norm = torch.empty_like(s) if want_normalised else None
+    arg = torch.empty(N, dtype=torch.int64, device=s.device)
+    check(lib().ucsa_semantic_postproc(_ptr(s), N, Cn, _ptr(norm), _ptr(arg),
+                                       _stream()), "ucsa_semantic_postproc")
+    return (None if norm is None else norm.view(shape)), arg.view(shape[:-1])
+
+
+def seg_tail(logits, labels=None, grad_scale: float = 1.0,
+             want_prob: bool = True, want_grad: bool = False):
+    """logits [B,C,H,W] -> dict(prob, argmax, loss, d_logits)."""
+    x = _f32(logits, "logits")
+    B, Cn, H, W = x.shape
+    P = H * W
+    dev = x.device
+    prob = torch.empty_like(x) if want_prob else None
+    arg = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+    loss = d_logits = partial = None
+    if labels is not None:
+        labels = labels.reshape(B, P).to(torch.int64).contiguous()
+        loss = torch.empty(1, device=dev)
+        partial = torch.empty(int(lib().ucsa_loss_partial_floats(B * P)),
+                              device=dev)
+        if want_grad:
+            d_logits = torch.empty_like(x)
+    check(lib().ucsa_seg_tail(_ptr(x), _ptr(labels), B, Cn, P,
+                              float(grad_scale), _ptr(prob), _ptr(arg),
+                              _ptr(loss), _ptr(d_logits), _ptr(partial),
+                              _stream()), "ucsa_seg_tail")
+    return dict(prob=prob, argmax=arg, loss=loss, d_logits=d_logits)
+
+
+def confusion_matrix(preds, truths, n_classes: int, cm=None):
+    p = preds.reshape(-1).to(torch.int64).contiguous()
+    t = truths.reshape(-1).to(torch.int64).contiguous()
+    if not p.is_cuda:
+        raise _lib.UcsaError("confusion_matrix needs GPU tensors")
+    if cm is None:
+        cm = torch.zeros(n_classes, n_classes, dtype=torch.int64,
+                         device=p.device)
+    check(lib().ucsa_confusion_matrix(_ptr(p), _ptr(t), p.numel(), n_classes,
+                                      _ptr(cm), _stream()),
+          "ucsa_confusion_matrix")
+    return cm

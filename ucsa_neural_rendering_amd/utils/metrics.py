@@ -1,0 +1,51 @@
+"""Mirror of reference ``nr4seg/utils/metrics.py`` (``SemanticsMeter``).
+
+GPU label maps are counted by the HIP kernel ``ucsa_confusion_matrix``
+(integer atomics: exact); CPU inputs (numpy / CPU tensors, as the reference's
+callers sometimes pass) are counted with numpy.  ``measure`` follows :48-65:
+mIoU over classes with at least one ground-truth pixel, total accuracy,
+class-average accuracy ignoring absent classes.  The 40x40 matrix can be
+summed across ranks (``dist.allreduce_confusion_``)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class SemanticsMeter:
+
+    def __init__(self, number_classes):
+        self.conf_mat = None
+        self.number_classes = number_classes
+
+    def clear(self):
+        self.conf_mat = None
+
+    def update(self, preds, truths):
+        C = self.number_classes
+        if torch.is_tensor(preds) and preds.is_cuda:
+            from .. import ops
+            cm = ops.confusion_matrix(preds, truths.to(preds.device), C)
+            cm = cm.cpu().numpy()
+        else:
+            p = preds.detach().cpu().numpy() if torch.is_tensor(preds) else np.asarray(preds)
+            t = truths.detach().cpu().numpy() if torch.is_tensor(truths) else np.asarray(truths)
+            p, t = p.reshape(-1), t.reshape(-1)
+            ok = (t >= 0) & (t < C) & (p >= 0) & (p < C)
+            cm = np.zeros((C, C), dtype=np.int64)
+            np.add.at(cm, (t[ok].astype(np.int64), p[ok].astype(np.int64)), 1)
+        self.conf_mat = cm if self.conf_mat is None else self.conf_mat + cm
+
+    def measure(self):
+        cm = self.conf_mat.astype(np.int64)
+        rows = cm.sum(axis=1).astype(np.float64)
+        cols = cm.sum(axis=0).astype(np.float64)
+        diag = np.diagonal(cm).astype(np.float64)
+        present = rows > 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            acc_c = diag / rows
+            ious = diag / (rows + cols - diag)
+        class_average_accuracy = float(np.mean(acc_c[present]))
+        total_accuracy = float(diag.sum() / cm.sum())
+        miou_valid_class = float(np.mean(ious[present]))
+        return miou_valid_class, total_accuracy, class_average_accuracy
