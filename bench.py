@@ -48,49 +48,99 @@ def parse():
     return ap.parse_args()
 
 
-def look_at_pose(eye, target, up=(0.0, 0.0, 1.0)):
-    """cam2world with +z forward (the reference's ray convention: dir=(x,y,1))."""
-    eye = torch.tensor(eye, dtype=torch.float32)
-    f = torch.tensor(target, dtype=torch.float32) - eye
-    f = f / f.norm()
-    upv = torch.tensor(up, dtype=torch.float32)
-    r = torch.linalg.cross(f, upv)
-    r = r / r.norm()
-    d = torch.linalg.cross(f, r)
-    m = torch.eye(4)
-    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = r, d, f, eye
-    return m
-
-
-def synthetic_poses(n, seed=123):
-    """Cameras on a loop inside the bound-4 box (|eye| < 2.5), looking at
-    points near the centre -- every ray hits the box."""
-    g = torch.Generator().manual_seed(seed)
-    poses = []
-    for k in range(n):
-        a = 2 * torch.pi * (k / max(n, 1)) + 0.1
-        eye = (2.0 * torch.cos(torch.tensor(a)).item(),
-               2.0 * torch.sin(torch.tensor(a)).item(),
-               0.3 * torch.randn(1, generator=g).item())
-        tgt = (0.3 * torch.randn(1, generator=g).item(),
-               0.3 * torch.randn(1, generator=g).item(), 0.0)
-        poses.append(look_at_pose(eye, tgt))
-    return torch.stack(poses)
-
-
-def build_field(device, seed=123):
-    """Seeded, untrained field with a lively grid (see DESIGN.md 'bench
-    parameter state'): tcnn-style MLP init, grid ~ U(-3, 3)."""
+def build_field(device, seed=123, train_steps=200, log=None):
+    """SURVEY 8d parameter state: tcnn-style init (grid U(-1e-4,1e-4), Xavier
+    MLPs, seed 123), then `train_steps` Adam steps (lr 1e-2, the reference's
+    NeRF optimizer) on the synthetic box-room scene so that sigma is
+    non-trivial and the w > 1e-4 mask is selective.  Runs on the HIP training
+    path; excluded from the timed region."""
+    from ucsa_neural_rendering_amd import losses as ul
+    from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
     from ucsa_neural_rendering_amd.nerf.network_tcnn_semantics import \
         SemanticNeRFNetwork
+    from ucsa_neural_rendering_amd.nerf.optim import HipAdam
     net = SemanticNeRFNetwork(encoding="hashgrid", bound=4, cuda_ray=False,
                               density_scale=1, num_semantic_classes=N_CLASSES,
-                              seed=seed)
-    g = torch.Generator().manual_seed(77)
-    with torch.no_grad():
-        net.encoder.params.copy_(
-            (torch.rand(net.encoder.params.numel(), generator=g) * 2 - 1) * 3.0)
-    return net.to(device).eval()
+                              seed=seed).to(device).train()
+    ds = SyntheticSceneDataset(0, n_views=16, H=240, W=320,
+                               n_classes=N_CLASSES, device=device)
+    opt = HipAdam(
+        [{"name": "encoding", "params": list(net.encoder.parameters())},
+         {"name": "net", "params": list(net.sigma_net.parameters()) +
+          list(net.color_net.parameters()) +
+          list(net.semantics_net.parameters()), "weight_decay": 1e-6}],
+        lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    g = torch.Generator(device=device).manual_seed(seed)
+    t0 = time.perf_counter()
+    for it in range(train_steps):
+        item = ds[it % len(ds)]
+        inds = torch.randint(0, 240 * 320, (4096,), device=device, generator=g)
+        o, d, nrm = item["rays_o"][inds], item["rays_d"][inds], item["direction_norms"][inds]
+        gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
+        labels = item["label"].reshape(-1)[inds][None]
+        gt_depth = item["depth"].float().reshape(-1)[inds][None]
+        out = net.render(o[None], d[None], nrm[None], perturb=True,
+                         num_steps=T_COARSE, upsample_steps=T_FINE,
+                         rng_t=torch.rand(4096, T_COARSE, device=device, generator=g),
+                         rng_u=torch.rand(4096, T_FINE, device=device, generator=g))
+        lc, ls, ld = ul.nerf_losses(out["image"], out["semantics"], out["depth"],
+                                    gt_rgb, labels, gt_depth, 1.0)
+        loss = ul.nerf_total_loss(lc, ls, ld)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    if log is not None:
+        log["pretrain_steps"] = train_steps
+        log["pretrain_s"] = time.perf_counter() - t0
+        log["pretrain_final_loss"] = float(loss.detach())
+    return net.eval(), ds
+
+
+def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
+    """cfg3's NeRF half at the reference's native sizes: 4096 rays x (256+256)
+    samples, forward + backward + Adam per step."""
+    from ucsa_neural_rendering_amd import losses as ul
+    from ucsa_neural_rendering_amd.nerf.optim import HipAdam
+    import copy
+    net = copy.deepcopy(net).train()
+    opt = HipAdam(
+        [{"name": "encoding", "params": list(net.encoder.parameters())},
+         {"name": "net", "params": list(net.sigma_net.parameters()) +
+          list(net.color_net.parameters()) +
+          list(net.semantics_net.parameters()), "weight_decay": 1e-6}],
+        lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    g = torch.Generator(device=device).manual_seed(7)
+    item = ds[0]
+    inds = torch.randint(0, 240 * 320, (n_rays,), device=device, generator=g)
+    o, d, nrm = item["rays_o"][inds][None], item["rays_d"][inds][None], item["direction_norms"][inds][None]
+    gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
+    labels = item["label"].reshape(-1)[inds][None]
+    gt_depth = item["depth"].float().reshape(-1)[inds][None]
+    rt = torch.rand(n_rays, T, device=device, generator=g)
+    ru = torch.rand(n_rays, t, device=device, generator=g)
+
+    def one():
+        out = net.render(o, d, nrm, perturb=True, num_steps=T, upsample_steps=t,
+                         rng_t=rt, rng_u=ru)
+        lc, ls, ld = ul.nerf_losses(out["image"], out["semantics"], out["depth"],
+                                    gt_rgb, labels, gt_depth, 1.0)
+        loss = ul.nerf_total_loss(lc, ls, ld)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"NeRF train step, {n_rays} rays x ({T}+{t}) samples, "
+                        "fwd+bwd+Adam (reference native sizes)",
+            "ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt}
 
 
 def effective_cores() -> int:
@@ -133,11 +183,17 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
     with torch.no_grad():
         for it in range(2):
             t0 = time.perf_counter()
-            oren.run(fld, o, d, nrm, aabb, num_steps=T_COARSE,
-                     upsample_steps=T_FINE, u=u)
+            ref = oren.run(fld, o, d, nrm, aabb, num_steps=T_COARSE,
+                           upsample_steps=T_FINE, u=u)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-    return n_rays / best, best
+        # the same rays / uniforms through the HIP path: parity + matched PSNR
+        dev = net.encoder.params.device
+        got = net.render(o.to(dev), d.to(dev), nrm.to(dev), num_steps=T_COARSE,
+                         upsample_steps=T_FINE, rng_u=u.to(dev))
+    parity = {k: float((got[k].cpu() - ref[k]).abs().max())
+              for k in ("image", "depth", "semantics")}
+    return n_rays / best, best, parity, ref, got, (o, d)
 
 
 def stage_times(net, o, d, nrm, u, iters=5):
@@ -199,11 +255,13 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ucsa_neural_rendering_amd import ops
-    net = build_field(dev)
+    prelog = {}
+    net, scene_ds = build_field(dev, log=prelog)
     net.hip_ray_chunk = 32768
     intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
     n_views = args.steps + args.warmup
-    poses = synthetic_poses(n_views * world)[rank::world].to(dev)
+    from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
+    poses = _slerp_loop_poses(n_views * world, seed=999)[rank::world].to(dev)
     # inputs resident in HBM before the timed region: rays of every view this
     # rank renders, and the uniforms for the inverse-CDF resampling
     rays = [ops.get_rays(poses[i:i + 1], intr, H, W) for i in range(n_views)]
@@ -275,7 +333,10 @@ def main():
                             "40 classes",
                 "rays_per_step_per_gpu": H * W,
                 "ray_chunk": chunk,
-                "parameter_state": "seeded untrained field, grid U(-3,3)",
+                "parameter_state": "tcnn-style init (seed 123) + %d Adam steps "
+                                   "on the synthetic box-room scene (SURVEY 8d)"
+                                   % prelog.get("pretrain_steps", 0),
+                "pretrain": prelog,
                 "masked_fraction_rho": rho,
                 "sharding": "views round-robin over ranks, no data-path collective",
             },
@@ -307,9 +368,29 @@ def main():
         enc_share = st["encode_c"] + st["encode_f"]
         dom = "roofline_encode" if enc_share >= st["composite"] else "roofline_composite"
         result["roofline"] = dict(result[dom])
+        # quality of the timed renders: last view vs the analytic ground truth
+        t_hit, gt_rgb, gt_lab = scene_ds.room.cast(rays[n_views - 1][0][0], rays[n_views - 1][1][0])
+        mse = torch.mean((out["image"][0] - gt_rgb) ** 2)
+        _, pred_lab = ops.semantic_postproc(out["semantics"][0], want_normalised=False)
+        from ucsa_neural_rendering_amd.utils.metrics import SemanticsMeter
+        meter = SemanticsMeter(N_CLASSES)
+        meter.update(pred_lab, gt_lab)
+        result["quality"] = {"psnr_db": float(-10 * torch.log10(mse)),
+                             "miou": meter.measure()[0],
+                             "note": "novel 640x480 view vs analytic GT after "
+                                     "the pre-training above"}
+        result["train"] = train_throughput(net, scene_ds, dev)
         if not args.no_cpu_baseline:
             threads = effective_cores()
-            v, dt = cpu_baseline(net, poses[0], intr, args.cpu_rays, threads)
+            v, dt, parity, ref, got, (co, cd) = cpu_baseline(
+                net, poses[0], intr, args.cpu_rays, threads)
+            _, gt_c, _ = scene_ds.room.cast(co[0].to(dev), cd[0].to(dev))
+            psnr = lambda img: float(-10 * torch.log10(torch.mean((img - gt_c.to(img.device)) ** 2)))
+            result["cpu_vs_gpu"] = {
+                "max_abs_diff": parity,
+                "psnr_db_cpu": psnr(ref["image"][0]),
+                "psnr_db_gpu": psnr(got["image"][0]),
+            }
             result["cpu_baseline"] = {
                 "value": v,
                 "unit": "rays/s",

@@ -91,14 +91,28 @@ extern "C" int32_t ucsa_mlp_pack_t(int32_t kind, const float* params,
 //   grad[p] = (accumulate ? grad[p] : 0) + sum_{w < n_parts} partial[w][p]
 // summed in wave order (fixed), one thread per parameter.
 // ---------------------------------------------------------------------------
-__global__ void k_reduce_partials(const float* __restrict__ partial,
-                                  uint32_t n_parts, uint32_t n_params,
-                                  int accumulate, float* __restrict__ grad) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_params) return;
-  float s = accumulate ? grad[p] : 0.0f;
-  for (uint32_t w = 0; w < n_parts; ++w) s += partial[(size_t)w * n_params + p];
-  grad[p] = s;
+// blockDim = (32 parameters, 8 slices of the part index): every thread sums
+// parts slice, slice+8, ... in order, then the 8 slice sums are added in
+// slice order -- a fixed tree, so the result is run-to-run identical.
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float* __restrict__ partial, uint32_t n_parts,
+                  uint32_t n_params, int accumulate,
+                  float* __restrict__ grad) {
+  __shared__ float sm[8][33];
+  const uint32_t px = threadIdx.x & 31u, sy = threadIdx.x >> 5;
+  const uint32_t p = blockIdx.x * 32 + px;
+  float s = 0.0f;
+  if (p < n_params)
+    for (uint32_t w = sy; w < n_parts; w += 8)
+      s += partial[(size_t)w * n_params + p];
+  sm[sy][px] = s;
+  __syncthreads();
+  if (sy == 0 && p < n_params) {
+    float t = accumulate ? grad[p] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[k][px];
+    grad[p] = t;
+  }
 }
 
 extern "C" int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,
@@ -108,7 +122,7 @@ extern "C" int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,
   UCSA_CHECK_ARG(grad, 4);
   if (n_params == 0) return 0;
   UCSA_CLEAR_ERR();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ucsa_div_up(n_params, 256)),
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ucsa_div_up(n_params, 32)),
                      dim3(256), 0, (hipStream_t)stream, partial, n_parts,
                      n_params, (int)accumulate, grad);
   return ucsa_launch_status();
