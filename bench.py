@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=49152)
+    ap.add_argument("--pretrain-steps", type=int, default=200,
+                    help="Adam steps on the synthetic scene before timing "
+                         "(SURVEY 8d: 200)")
+    ap.add_argument("--no-train-bench", action="store_true")
     return ap.parse_args()
 
 
@@ -256,7 +260,7 @@ def main():
 
     from ucsa_neural_rendering_amd import ops
     prelog = {}
-    net, scene_ds = build_field(dev, log=prelog)
+    net, scene_ds = build_field(dev, train_steps=args.pretrain_steps, log=prelog)
     net.hip_ray_chunk = 32768
     intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
     n_views = args.steps + args.warmup
@@ -379,7 +383,8 @@ def main():
                              "miou": meter.measure()[0],
                              "note": "novel 640x480 view vs analytic GT after "
                                      "the pre-training above"}
-        result["train"] = train_throughput(net, scene_ds, dev)
+        if not args.no_train_bench:
+            result["train"] = train_throughput(net, scene_ds, dev)
         if not args.no_cpu_baseline:
             threads = effective_cores()
             v, dt, parity, ref, got, (co, cd) = cpu_baseline(

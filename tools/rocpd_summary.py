@@ -34,12 +34,18 @@ def main(path):
         pm, ccols = [], []
     if pm:
         kn = "kernel_name" if "kernel_name" in ccols else "name"
-        q = (f"select {kn}, counter_name, sum(value), count(distinct dispatch_id) "
-             f"from counters_collection group by {kn}, counter_name")
-        print("\n# counters: kernel, counter, sum over dispatches, dispatches, per dispatch")
-        for n, cn, v, nd in c.execute(q):
-            short = n if len(n) <= 50 else n[:47] + "..."
-            print(f"  {short:50s} {cn:24s} {v:18.0f} {nd:6d} {v/max(nd,1):18.1f}")
+        gs = "grid_size" if "grid_size" in ccols else ("grid_size_x" if "grid_size_x" in ccols else None)
+        grp = f"{kn}, {gs}" if gs else kn
+        sel = f"{kn}, {gs if gs else 0}"
+        q = (f"select {sel}, counter_name, sum(value), count(distinct dispatch_id) "
+             f"from counters_collection group by {grp}, counter_name")
+        print("\n# counters: kernel, grid size, counter, sum over dispatches, "
+              "dispatches, per dispatch")
+        for n, gsz, cn, v, nd in c.execute(q):
+            if not n.startswith(("k_", "void k_")):
+                continue
+            short = n if len(n) <= 44 else n[:41] + "..."
+            print(f"  {short:44s} {gsz:10d} {cn:26s} {v:18.0f} {nd:5d} {v/max(nd,1):16.1f}")
 
 
 if __name__ == "__main__":

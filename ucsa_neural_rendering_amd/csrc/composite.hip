@@ -21,7 +21,8 @@
 #include "mfma_mlp.h"
 #include "wave_ops.h"
 
-#define CMP_MAX_WAVES 8
+#define CMP_MAX_WAVES 12
+#define CMP_CBS 2  // column blocks of 16 samples in flight per wave
 #define CONTRIB_STRIDE 45  // 3 rgb + up to 40.. classes, odd stride
 #define ROW_FINE 0x80000000u
 
@@ -85,9 +86,10 @@ __device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
   }
 }
 
-template <int NRB_SEM>
+template <int NRB_SEM, int CBS>
 __global__ void __launch_bounds__(64 * CMP_MAX_WAVES)
 k_composite(CmpArgs a) {
+  constexpr uint32_t G = 16u * CBS;  // survivors shaded per MFMA group
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t nw_block = blockDim.x >> 6;
   const uint32_t g = lane >> 4, j = lane & 15u;
@@ -98,7 +100,7 @@ k_composite(CmpArgs a) {
   float* w_color = cmp_smem;                       // 7168
   float* w_sem = w_color + 7168;                   // 1024 + NRB_SEM*1024
   float* per_wave = w_sem + 1024 + NRB_SEM * 1024;
-  const uint32_t cap = S + 64;                     // entry list capacity
+  const uint32_t cap = S + G;                      // entry list capacity
   // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
   //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
   const uint32_t per_wave_floats = 4 * S + 3 * cap + 16 * cstride;
@@ -136,10 +138,10 @@ k_composite(CmpArgs a) {
 
   // ---- phase C + D on the first `n` (<= 64) entries of the list ---------
   auto shade = [&](uint32_t n) {
-    float ew[4], geo[4][4], sh[4][4];
-    uint32_t eray[4];
+    float ew[CBS], geo[CBS][4], sh[CBS][4];
+    uint32_t eray[CBS];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < CBS; ++cb) {
       uint32_t e = cb * 16 + j;
       const bool live = e < n;
       if (!live) e = n - 1;  // pad with the last real entry, weight 0
@@ -158,11 +160,11 @@ k_composite(CmpArgs a) {
     }
 
     // ---------------- colour net: 32 -> 64 -> 64 -> 16 -------------------
-    float rgb[4][3];
+    float rgb[CBS][3];
     {
-      f32x4 acc1[4][4];
+      f32x4 acc1[CBS][4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -171,17 +173,17 @@ k_composite(CmpArgs a) {
         for (int rb = 0; rb < 4; ++rb) {
           const float wa = w_color[(rb * 8 + ks) * 64 + lane];
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
+          for (int cb = 0; cb < CBS; ++cb) {
             const float x = ks < 4 ? sh[cb][ks] : geo[cb][ks - 4];
             acc1[cb][rb] = mfma16(wa, x, acc1[cb][rb]);
           }
         }
       }
-      float hid[4][16];
+      float hid[CBS][16];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) chain_relu(acc1[cb], hid[cb]);
+      for (int cb = 0; cb < CBS; ++cb) chain_relu(acc1[cb], hid[cb]);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -190,35 +192,35 @@ k_composite(CmpArgs a) {
         for (int rb = 0; rb < 4; ++rb) {
           const float wa = w_color[(COLOR_L1_FRAGS + rb * 16 + ks) * 64 + lane];
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
+          for (int cb = 0; cb < CBS; ++cb)
             acc1[cb][rb] = mfma16(wa, hid[cb][ks], acc1[cb][rb]);
         }
       }
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) chain_relu(acc1[cb], hid[cb]);
-      f32x4 o3[4];
+      for (int cb = 0; cb < CBS; ++cb) chain_relu(acc1[cb], hid[cb]);
+      f32x4 o3[CBS];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) o3[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int cb = 0; cb < CBS; ++cb) o3[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const float wa =
             w_color[(COLOR_L1_FRAGS + COLOR_L2_FRAGS + ks) * 64 + lane];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) o3[cb] = mfma16(wa, hid[cb][ks], o3[cb]);
+        for (int cb = 0; cb < CBS; ++cb) o3[cb] = mfma16(wa, hid[cb][ks], o3[cb]);
       }
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           rgb[cb][c] = 1.0f / (1.0f + expf(-o3[cb][c]));  // rows 0..2 live in g==0
     }
 
     // ---------------- semantics net: 16 -> 64 -> 16*NRB_SEM --------------
-    f32x4 lg[4][NRB_SEM];
+    f32x4 lg[CBS][NRB_SEM];
     {
-      f32x4 acc1[4][4];
+      f32x4 acc1[CBS][4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -227,15 +229,15 @@ k_composite(CmpArgs a) {
         for (int rb = 0; rb < 4; ++rb) {
           const float wa = w_sem[(rb * 4 + ks) * 64 + lane];
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
+          for (int cb = 0; cb < CBS; ++cb)
             acc1[cb][rb] = mfma16(wa, geo[cb][ks], acc1[cb][rb]);
         }
       }
-      float hid[4][16];
+      float hid[CBS][16];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) chain_relu(acc1[cb], hid[cb]);
+      for (int cb = 0; cb < CBS; ++cb) chain_relu(acc1[cb], hid[cb]);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int rb = 0; rb < NRB_SEM; ++rb) lg[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -244,7 +246,7 @@ k_composite(CmpArgs a) {
         for (int rb = 0; rb < NRB_SEM; ++rb) {
           const float wa = w_sem[(SEM_L1_FRAGS + rb * 16 + ks) * 64 + lane];
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
+          for (int cb = 0; cb < CBS; ++cb)
             lg[cb][rb] = mfma16(wa, hid[cb][ks], lg[cb][rb]);
         }
       }
@@ -252,7 +254,7 @@ k_composite(CmpArgs a) {
 
     // ---------------- softmax + contributions + per-ray sums -------------
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < CBS; ++cb) {
       float mx = -INFINITY;
 #pragma unroll
       for (int rb = 0; rb < NRB_SEM; ++rb)
@@ -274,6 +276,7 @@ k_composite(CmpArgs a) {
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
       const float wgt = ew[cb];
+      const float inv_sum = 1.0f / sum;
       float* crow = contrib + j * cstride;
       if (g == 0) {
         crow[0] = wgt * rgb[cb][0];
@@ -285,7 +288,7 @@ k_composite(CmpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const uint32_t cls = rb * 16 + 4 * g + r;
-          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] / sum);
+          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] * inv_sum);
         }
       wave_lds_sync();
       const uint32_t nb = (n > (uint32_t)cb * 16) ? ((n - cb * 16 < 16) ? n - cb * 16 : 16) : 0;
@@ -383,21 +386,21 @@ k_composite(CmpArgs a) {
     wave_lds_sync();
     // ---- C/D: shade full groups of 64 ------------------------------------
     uint32_t head = 0;
-    while (cnt - head >= 64) {
-      // shade() reads entries [0,64): move the window down first if needed
+    while (cnt - head >= G) {
+      // shade() reads entries [0,G): move the window down first if needed
       if (head) {
-        for (uint32_t i = lane; i < 64; i += 64) {
+        for (uint32_t i = lane; i < G; i += 64) {
           lw[i] = lw[head + i];
           lrow[i] = lrow[head + i];
           lray[i] = lray[head + i];
         }
         wave_lds_sync();
       }
-      shade(64);
-      head += 64;
+      shade(G);
+      head += G;
     }
     if (head) {  // compact the tail [head, cnt) to the front
-      const uint32_t rem = cnt - head;  // < 64
+      const uint32_t rem = cnt - head;  // < G <= 64
       float tw = 0.f;
       uint32_t trow = 0, tray = 0;
       if (lane < rem) {
@@ -443,10 +446,10 @@ extern "C" int32_t ucsa_composite_fwd(
   uint32_t cstride = 3 + n_classes;
   if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
   const size_t w_floats = 7168 + 1024 + (size_t)nrb * 1024;
-  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 64) + 16 * cstride;
+  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 16 * CMP_CBS) + 16 * cstride;
   // as many waves per workgroup as fit in ~150 KiB of LDS (one WG per CU)
   uint32_t waves = CMP_MAX_WAVES;
-  while (waves > 1 && (w_floats + waves * per_wave) * 4 > 150 * 1024) waves >>= 1;
+  while (waves > 1 && (w_floats + waves * per_wave) * 4 > 158 * 1024) --waves;
   const size_t smem = (w_floats + waves * per_wave) * 4;
   UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
   // rays per wave: spread over the chip, but at least 4 so the 64-entry
@@ -463,11 +466,12 @@ extern "C" int32_t ucsa_composite_fwd(
 #define LAUNCH(NRB)                                                           \
   do {                                                                        \
     hipError_t e = hipFuncSetAttribute(                                       \
-        reinterpret_cast<const void*>(&k_composite<NRB>),                     \
+        reinterpret_cast<const void*>(&k_composite<NRB, CMP_CBS>),                     \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e != hipSuccess) return -(int32_t)e;                                  \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL(k_composite<NRB>, dim3(blocks), dim3(64 * waves), smem, \
+    hipLaunchKernelGGL((k_composite<NRB, CMP_CBS>), dim3(blocks), dim3(64 * waves),  \
+                       smem,                                                  \
                        s, a);                                                 \
   } while (0)
   switch (nrb) {

@@ -63,16 +63,56 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {
   return fminf(fmaxf(v, lo), hi);
 }
 
+// Hashed level with x-pair loads.  Random 8-byte gathers run at the TCP's
+// divergent-access rate (~0.46 lane-accesses/clk/CU measured, independent of
+// the access width and of the cache policy; tools/ubench/gather.hip), so the
+// lever is FEWER lane-accesses: for even x0 the two x-corners (x0, x0+1) hash
+// to idx and idx^1, i.e. one aligned 16-byte pair -> one access instead of
+// two.  Odd x0 issues the second (predicated) access.  6 instead of 8
+// accesses per sample and level on average; arithmetic order unchanged.
+__device__ __forceinline__ float2 encode_level_hashed(
+    const float2* __restrict__ tab, float x, float y, float z, float scale,
+    uint32_t entries) {
+  const float px = x * scale + 0.5f, py = y * scale + 0.5f,
+              pz = z * scale + 0.5f;
+  const float fx0 = floorf(px), fy0 = floorf(py), fz0 = floorf(pz);
+  const float wx = px - fx0, wy = py - fy0, wz = pz - fz0;
+  const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
+                 gz = (uint32_t)(int32_t)fz0;
+  const uint32_t mask = entries - 1;
+  const bool odd = (gx & 1u) != 0;
+  float2 v[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = ((gy + (q & 1)) * PRIME_Y) ^ ((gz + (q >> 1)) * PRIME_Z);
+    const uint32_t i0 = (gx ^ h) & mask;
+    const float4 pr = *reinterpret_cast<const float4*>(tab + (i0 & ~1u));
+    const bool hi = (i0 & 1u) != 0;
+    v[2 * q] = hi ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
+    float2 other = hi ? make_float2(pr.x, pr.y) : make_float2(pr.z, pr.w);
+    if (odd) other = tab[((gx + 1u) ^ h) & mask];
+    v[2 * q + 1] = other;
+  }
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float w = (c & 1) ? wx : 1.0f - wx;
+    w = w * ((c & 2) ? wy : 1.0f - wy);
+    w = w * ((c & 4) ? wz : 1.0f - wz);
+    acc.x = acc.x + w * v[c].x;
+    acc.y = acc.y + w * v[c].y;
+  }
+  return acc;
+}
+
 template <bool FROM_RAYS>
-__global__ void __launch_bounds__(256)
-k_hashgrid_encode(GridDev g, const float2* __restrict__ table,
-                  const float* __restrict__ rays_o,
-                  const float* __restrict__ rays_d,
-                  const float* __restrict__ zs, Aabb bb, uint32_t T,
-                  uint64_t M, float2* __restrict__ feat) {
-  const uint32_t level = blockIdx.y;
-  const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+__device__ __forceinline__ void sample_x01(const GridDev& g,
+                                           const float* __restrict__ rays_o,
+                                           const float* __restrict__ rays_d,
+                                           const float* __restrict__ zs,
+                                           const Aabb& bb, uint32_t T,
+                                           uint64_t m, float& x01, float& y01,
+                                           float& z01) {
   float px, py, pz;
   if (FROM_RAYS) {
     const uint32_t r = (uint32_t)(m / T);
@@ -89,12 +129,87 @@ k_hashgrid_encode(GridDev g, const float2* __restrict__ table,
     pz = x[2];
   }
   const float two_b = 2.0f * g.bound;
-  const float x01 = (px + g.bound) / two_b, y01 = (py + g.bound) / two_b,
-              z01 = (pz + g.bound) / two_b;
-  const float2 f = encode_level(table + g.offset[level], x01, y01, z01,
-                                g.scale[level], g.res[level], g.entries[level],
-                                g.hashed[level]);
+  x01 = (px + g.bound) / two_b;
+  y01 = (py + g.bound) / two_b;
+  z01 = (pz + g.bound) / two_b;
+}
+
+// Coarse levels [0, n_coarse): cells span several samples of a ray, gathers
+// hit L1/L2, and a per-level launch would be all fixed cost (~25 us each,
+// measured) -- so one thread walks all of them.
+template <bool FROM_RAYS>
+__global__ void __launch_bounds__(256)
+k_hashgrid_encode_coarse(GridDev g, uint32_t n_coarse,
+                         const float2* __restrict__ table,
+                         const float* __restrict__ rays_o,
+                         const float* __restrict__ rays_d,
+                         const float* __restrict__ zs, Aabb bb, uint32_t T,
+                         uint64_t M, float2* __restrict__ feat) {
+  const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float x01, y01, z01;
+  sample_x01<FROM_RAYS>(g, rays_o, rays_d, zs, bb, T, m, x01, y01, z01);
+  for (uint32_t level = 0; level < n_coarse; ++level) {
+    const float2 f = encode_level(table + g.offset[level], x01, y01, z01,
+                                  g.scale[level], g.res[level],
+                                  g.entries[level], g.hashed[level]);
+    feat[(uint64_t)level * M + m] = f;
+  }
+}
+
+// Fine levels [level0, n_levels): level-major (see file header).
+template <bool FROM_RAYS>
+__global__ void __launch_bounds__(256)
+k_hashgrid_encode(GridDev g, uint32_t level0,
+                  const float2* __restrict__ table,
+                  const float* __restrict__ rays_o,
+                  const float* __restrict__ rays_d,
+                  const float* __restrict__ zs, Aabb bb, uint32_t T,
+                  uint64_t M, float2* __restrict__ feat) {
+  const uint32_t level = level0 + blockIdx.y;
+  const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float x01, y01, z01;
+  sample_x01<FROM_RAYS>(g, rays_o, rays_d, zs, bb, T, m, x01, y01, z01);
+  float2 f;
+  if (g.hashed[level])
+    f = encode_level_hashed(table + g.offset[level], x01, y01, z01,
+                            g.scale[level], g.entries[level]);
+  else
+    f = encode_level(table + g.offset[level], x01, y01, z01, g.scale[level],
+                     g.res[level], g.entries[level], 0u);
   feat[(uint64_t)level * M + m] = f;
+}
+
+// how many leading levels go to the fused coarse kernel: all dense levels plus
+// hashed ones whose cells are still wider than ~2 sample spacings
+static uint32_t coarse_levels(const ucsa_grid* grid) {
+  uint32_t n = 0;
+  while (n < grid->n_levels && (!grid->level[n].hashed ||
+                                grid->level[n].scale < 160.0f)) ++n;
+  return n;
+}
+
+template <bool FROM_RAYS>
+static int32_t launch_encode(const ucsa_grid* grid, const float* table,
+                             const float* a, const float* b, const float* z,
+                             Aabb bb, uint32_t T, uint64_t M, float* feat,
+                             void* stream) {
+  const GridDev gd = ucsa_grid_dev(grid);
+  const uint32_t nc = coarse_levels(grid);
+  const dim3 blk(256);
+  UCSA_CLEAR_ERR();
+  if (nc > 0)
+    hipLaunchKernelGGL(k_hashgrid_encode_coarse<FROM_RAYS>,
+                       dim3(ucsa_div_up(M, 256)), blk, 0, (hipStream_t)stream,
+                       gd, nc, (const float2*)table, a, b, z, bb, T, M,
+                       (float2*)feat);
+  if (nc < grid->n_levels)
+    hipLaunchKernelGGL(k_hashgrid_encode<FROM_RAYS>,
+                       dim3(ucsa_div_up(M, 256), grid->n_levels - nc), blk, 0,
+                       (hipStream_t)stream, gd, nc, (const float2*)table, a, b,
+                       z, bb, T, M, (float2*)feat);
+  return ucsa_launch_status();
 }
 
 extern "C" int32_t ucsa_hashgrid_encode_rays(
@@ -109,13 +224,8 @@ extern "C" int32_t ucsa_hashgrid_encode_rays(
   UCSA_CHECK_ARG(feat, 8);
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
-  dim3 grid_dim(ucsa_div_up(M, 256), grid->n_levels);
-  UCSA_CLEAR_ERR();
-  hipLaunchKernelGGL(k_hashgrid_encode<true>, grid_dim, dim3(256), 0,
-                     (hipStream_t)stream, ucsa_grid_dev(grid),
-                     (const float2*)table, rays_o, rays_d, z,
-                     ucsa_aabb(aabb_host), T, M, (float2*)feat);
-  return ucsa_launch_status();
+  return launch_encode<true>(grid, table, rays_o, rays_d, z,
+                             ucsa_aabb(aabb_host), T, M, feat, stream);
 }
 
 extern "C" int32_t ucsa_hashgrid_encode_points(const ucsa_grid* grid,
@@ -129,14 +239,8 @@ extern "C" int32_t ucsa_hashgrid_encode_points(const ucsa_grid* grid,
   UCSA_CHECK_ARG(feat, 4);
   if (M == 0) return 0;
   Aabb bb = {};
-  dim3 grid_dim(ucsa_div_up(M, 256), grid->n_levels);
-  UCSA_CLEAR_ERR();
-  hipLaunchKernelGGL(k_hashgrid_encode<false>, grid_dim, dim3(256), 0,
-                     (hipStream_t)stream, ucsa_grid_dev(grid),
-                     (const float2*)table, x, (const float*)nullptr,
-                     (const float*)nullptr, bb, 1u, (uint64_t)M,
-                     (float2*)feat);
-  return ucsa_launch_status();
+  return launch_encode<false>(grid, table, x, nullptr, nullptr, bb, 1u,
+                              (uint64_t)M, feat, stream);
 }
 
 // ---------------------------------------------------------------------------
