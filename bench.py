@@ -248,6 +248,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # test hook: UCSA_BENCH_BACKEND=gloo runs all ranks on cuda:0 (the 1-GPU
+    # dev box) to exercise the N>1 code path; the driver's real runs use RCCL
+    backend = os.environ.get("UCSA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -255,13 +260,16 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ucsa_neural_rendering_amd import ops
     prelog = {}
     net, scene_ds = build_field(dev, train_steps=args.pretrain_steps, log=prelog)
-    net.hip_ray_chunk = 32768
+    net.hip_ray_chunk = 65536
     intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
     n_views = args.steps + args.warmup
     from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
@@ -292,7 +300,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     rays_total = world * args.steps * H * W

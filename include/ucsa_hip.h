@@ -200,13 +200,18 @@ int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
                            uint32_t n_levels, float* d_feat, float* partial,
                            void* stream);
 
-/* Backward of ucsa_hashgrid_encode_rays: atomically adds into grad_table
- * [total_entries,2] (caller zeroes it).  Autograd of tcnn.Encoding. */
+/* Backward of ucsa_hashgrid_encode_rays: adds into grad_table
+ * [total_entries,2] (caller zeroes it).  Autograd of tcnn.Encoding.
+ * With a workspace of ucsa_hashgrid_bwd_workspace_bytes() the binned two-pass
+ * algorithm is used (no global float atomics); workspace == NULL selects the
+ * direct-atomics kernels. */
+uint64_t ucsa_hashgrid_bwd_workspace_bytes(uint32_t N, uint32_t T,
+                                           uint32_t n_levels);
 int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid_host, const float* rays_o,
                                const float* rays_d, const float* z,
                                const float* aabb_host, uint32_t N, uint32_t T,
                                const float* d_feat, float* grad_table,
-                               void* stream);
+                               void* workspace, void* stream);
 
 /* Backward of ucsa_composite_fwd (autograd of renderer_semantics.py:238-299
  * and the masked color()/semantics()).  Needs the forward's `src` and

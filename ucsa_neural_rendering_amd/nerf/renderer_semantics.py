@@ -45,7 +45,12 @@ class SemanticNeRFRenderer(nn.Module):
                 "reference (joint_train_lightning_net.py:29-35) and not built "
                 "yet (SURVEY 8f rank 1)")
         # rays per HIP enqueue; results do not depend on it
-        self.hip_ray_chunk = 32768
+        self.hip_ray_chunk = 65536
+        # chunks are independent and may alternate over several HIP streams;
+        # measured on MI355X: no gain (every kernel already fills the chip),
+        # so one stream by default
+        self.hip_streams = 1
+        self._side_streams = []
         self._ws = None
         self._aabb_host = {}
 
@@ -71,10 +76,11 @@ class SemanticNeRFRenderer(nn.Module):
             self._aabb_host[key] = (ver, [float(v) for v in buf.detach().cpu()])
         return self._aabb_host[key][1]
 
-    def _workspace(self, nbytes: int, device):
-        if (self._ws is None or self._ws.numel() < nbytes or
-                self._ws.device != device):
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    def _workspace(self, nbytes: int, device, slots: int = 1):
+        if (self._ws is None or self._ws.shape[0] < slots or
+                self._ws.shape[1] < nbytes or self._ws.device != device):
+            self._ws = torch.empty(slots, nbytes, dtype=torch.uint8,
+                                   device=device)
         return self._ws
 
     def run(self, rays_o, rays_d, direction_norms, num_steps=256,
@@ -135,19 +141,33 @@ class SemanticNeRFRenderer(nn.Module):
         depth = torch.empty(N, device=dev)
         sem = torch.empty(N, C, device=dev)
         chunk = max(1, int(self.hip_ray_chunk))
+        n_chunks = (N + chunk - 1) // chunk
+        n_str = max(1, min(int(self.hip_streams), n_chunks))
         ws = self._workspace(
             ops.render_workspace_bytes(min(N, chunk), T, t, f["grid"].n_levels),
-            dev)
-        for head in range(0, N, chunk):
+            dev, n_str)
+        main = torch.cuda.current_stream(dev)
+        if n_str > 1:
+            while len(self._side_streams) < n_str - 1:
+                self._side_streams.append(torch.cuda.Stream(device=dev))
+            streams = [main] + self._side_streams[:n_str - 1]
+            for st in streams[1:]:
+                st.wait_stream(main)  # inputs / packed weights are ready
+        else:
+            streams = [main]
+        for k, head in enumerate(range(0, N, chunk)):
             tail = min(head + chunk, N)
-            ops.render_fwd(
-                f["grid"], f["table"], f["packed_sigma"], f["packed_color"],
-                f["packed_sem"], o[head:tail], d[head:tail], nrm[head:tail],
-                aabb, min_near,
-                None if rng_t is None else rng_t[head:tail],
-                None if rng_u is None else rng_u[head:tail], T, t, C,
-                float(self.density_scale), image[head:tail], depth[head:tail],
-                sem[head:tail], ws)
+            with torch.cuda.stream(streams[k % n_str]):
+                ops.render_fwd(
+                    f["grid"], f["table"], f["packed_sigma"], f["packed_color"],
+                    f["packed_sem"], o[head:tail], d[head:tail], nrm[head:tail],
+                    aabb, min_near,
+                    None if rng_t is None else rng_t[head:tail],
+                    None if rng_u is None else rng_u[head:tail], T, t, C,
+                    float(self.density_scale), image[head:tail],
+                    depth[head:tail], sem[head:tail], ws[k % n_str])
+        for st in streams[1:]:
+            main.wait_stream(st)
         return image, depth, sem
 
     def _run_train(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):

@@ -216,12 +216,27 @@ def sigma_mlp_bwd(feat, d_h, packed_sigma, packed_sigma_t):
     return d_feat, partial
 
 
-def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table):
+_bwd_ws = {}
+
+
+def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
+                      binned: bool = True):
+    """Adds the table gradient.  binned=True: two-pass LDS-binned algorithm
+    (workspace cached per device); False: direct float atomics."""
     N, T = z.shape
+    ws = None
+    if binned:
+        need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(N, T, grid.n_levels))
+        key = z.device
+        ws = _bwd_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=z.device)
+            _bwd_ws[key] = ws
     check(lib().ucsa_hashgrid_bwd_rays(C.byref(grid), _ptr(rays_o),
                                        _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
                                        _ptr(d_feat), _ptr(grad_table),
-                                       _stream()), "ucsa_hashgrid_bwd_rays")
+                                       _ptr(ws), _stream()),
+          "ucsa_hashgrid_bwd_rays")
 
 
 def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
