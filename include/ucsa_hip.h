@@ -131,7 +131,9 @@ int32_t ucsa_sigma_mlp_fwd(const float* feat, const float* packed_sigma,
 /* ---- hierarchical resampling ----------------------------------------------
  * Coarse weights -> pdf over interior bins -> inverse CDF at u.
  * Replaces renderer_semantics.py:182-207 and sample_pdf :10-46.
- *   z [N,T], sigma [N,T], u [N,t] in [0,1); out new_z [N,t]. */
+ *   z [N,T], sigma [N,T], u [N,t] in [0,1); out new_z [N,t], ASCENDING per
+ *   ray (the uniforms are sorted first; the reference only ever consumes
+ *   new_z through its sort/merge, :221-222, so the order is unobservable). */
 int32_t ucsa_resample(const float* z, const float* sigma, const float* u,
                       uint32_t N, uint32_t T, uint32_t t,
                       float density_scale, float* new_z, void* stream);

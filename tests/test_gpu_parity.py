@@ -125,6 +125,9 @@ def test_resample_matches_oracle(ops, T, t):
     deltas, w = oren.alpha_weights(z, sigma, 1.0)
     ref = oren.inverse_cdf(z[:, :-1] + 0.5 * deltas[:, :-1], w[:, 1:-1], u)
     got = ops.resample(z.cuda(), sigma.cuda(), u.cuda(), 1.0).cpu()
+    # the kernel returns the samples of u sorted (see include/ucsa_hip.h)
+    ref = oren.inverse_cdf(z[:, :-1] + 0.5 * deltas[:, :-1], w[:, 1:-1],
+                           torch.sort(u, dim=-1)[0])
     # Reference-inherent instability (DESIGN.md "resampling"): sample_pdf
     # switches denom to 1 when cdf[i+1]-cdf[i] < 1e-5, and an EMPTY bin has
     # pdf = 1e-5/sum(w+1e-5), i.e. within one fp32 cdf ulp of that threshold,

@@ -16,12 +16,12 @@ extern __shared__ __attribute__((aligned(16))) float rs_smem[];
 __global__ void __launch_bounds__(64 * RS_WAVES)
 k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
            const float* __restrict__ u, uint32_t N, uint32_t T, uint32_t t,
-           float density_scale, float* __restrict__ new_z) {
+           uint32_t tpad, float density_scale, float* __restrict__ new_z) {
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t r = blockIdx.x * RS_WAVES + wid;
   if (r >= N) return;  // whole wave exits; no block barriers below
-  // per-wave LDS: zs[T], cdf[T], bins[T]
-  float* zs = rs_smem + (size_t)wid * 3 * T;
+  // per-wave LDS: zs[T], cdf[T], bins[T], us[tpad]
+  float* zs = rs_smem + (size_t)wid * (3 * T + tpad);
   float* cdf = zs + T;
   float* bins = cdf + T;
   const float* zr = z + (size_t)r * T;
@@ -69,11 +69,33 @@ k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
   __builtin_amdgcn_wave_barrier();
 
   // pass 3: invert.  n_cdf = T-1 entries; searchsorted(right=True).
+  // The uniforms are sorted first (bitonic network in LDS): the reference
+  // consumes new_z only through sort/merge (renderer_semantics.py:221-222),
+  // so their order within the ray is unobservable, and ascending fine samples
+  // make consecutive lanes neighbours in space (coherent gathers, and the
+  // hash-grid backward can combine runs instead of contending on atomics).
   const uint32_t n_cdf = T - 1;
   const float* ur = u + (size_t)r * t;
   float* out = new_z + (size_t)r * t;
+  float* us = bins + T;  // [tpad]
+  for (uint32_t q = lane; q < tpad; q += 64) us[q] = q < t ? ur[q] : INFINITY;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t k = 2; k <= tpad; k <<= 1) {
+    for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+      for (uint32_t p = lane; p < (tpad >> 1); p += 64) {
+        // p-th compare-exchange of this stage
+        const uint32_t lo_i = ((p & ~(jj - 1)) << 1) | (p & (jj - 1));
+        const uint32_t hi_i = lo_i | jj;
+        const bool up = (lo_i & k) == 0;
+        const float a0 = us[lo_i], a1 = us[hi_i];
+        if ((a0 > a1) == up) { us[lo_i] = a1; us[hi_i] = a0; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   for (uint32_t q = lane; q < t; q += 64) {
-    const float uu = ur[q];
+    const float uu = us[q];
     uint32_t lo = 0, hi = n_cdf;  // first index with cdf[idx] > uu
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
@@ -99,10 +121,13 @@ extern "C" int32_t ucsa_resample(const float* z, const float* sigma,
   UCSA_CHECK_ARG(T >= 3 && T <= 4096, 4);
   UCSA_CHECK_ARG(new_z, 7);
   if (N == 0 || t == 0) return 0;
-  const size_t smem = (size_t)RS_WAVES * 3 * T * sizeof(float);
+  UCSA_CHECK_ARG(t <= 4096, 5);
+  uint32_t tpad = 2;
+  while (tpad < t) tpad <<= 1;
+  const size_t smem = (size_t)RS_WAVES * (3 * T + tpad) * sizeof(float);
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_resample, dim3(ucsa_div_up(N, RS_WAVES)),
                      dim3(64 * RS_WAVES), smem, (hipStream_t)stream, z, sigma,
-                     u, N, T, t, density_scale, new_z);
+                     u, N, T, t, tpad, density_scale, new_z);
   return ucsa_launch_status();
 }
