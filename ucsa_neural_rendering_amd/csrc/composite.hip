@@ -314,12 +314,28 @@ k_composite(CmpArgs a) {
     for (uint32_t e = lane; e < S; e += 64) zraw[e] = e < T ? zc[e] : zf[e - T];
     wave_lds_sync();
     // ---- A2: rank of every element in the stable sort of [coarse|fine] --
+    // ucsa_resample emits ascending fine samples; then both ranks are binary
+    // searches.  Arbitrary callers may pass unsorted z_f: detect and fall back
+    // to counting (O(t) per element).
+    bool fine_sorted = true;
+    for (uint32_t k = lane; k + 1 < t; k += 64)
+      fine_sorted = fine_sorted && (zraw[T + k] <= zraw[T + k + 1]);
+    fine_sorted = __all(fine_sorted);
     for (uint32_t e = lane; e < S; e += 64) {
       const float ze = zraw[e];
       uint32_t rank;
       if (e < T) {
         uint32_t c = 0;
-        for (uint32_t k = 0; k < t; ++k) c += (zraw[T + k] < ze) ? 1u : 0u;
+        if (fine_sorted) {  // #fine strictly below ze
+          uint32_t lo = 0, hi = t;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (zraw[T + mid] < ze) lo = mid + 1; else hi = mid;
+          }
+          c = lo;
+        } else {
+          for (uint32_t k = 0; k < t; ++k) c += (zraw[T + k] < ze) ? 1u : 0u;
+        }
         rank = e + c;
       } else {
         // coarse elements <= ze come first (coarse list is ascending)
@@ -330,9 +346,13 @@ k_composite(CmpArgs a) {
         }
         uint32_t c = 0;
         const uint32_t kk = e - T;
-        for (uint32_t k = 0; k < t; ++k) {
-          const float zk = zraw[T + k];
-          c += (zk < ze || (zk == ze && k < kk)) ? 1u : 0u;
+        if (fine_sorted) {
+          c = kk;  // equal neighbours keep index order
+        } else {
+          for (uint32_t k = 0; k < t; ++k) {
+            const float zk = zraw[T + k];
+            c += (zk < ze || (zk == ze && k < kk)) ? 1u : 0u;
+          }
         }
         rank = lo + c;
       }
