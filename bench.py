@@ -147,6 +147,51 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
             "ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt}
 
 
+def seg_throughput(device, steps=5, B=8):
+    """cfg3's segmentation half: DeepLabV3-ResNet-101 forward + backward +
+    Adam on [8,3,240,320] uniform-random images / labels, with the
+    reference's CE-on-softmax loss through ucsa_seg_tail.  fp32 like the
+    reference (no autocast around seg), and bf16 channels_last as the MI355X
+    fast path.  Convolutions are MIOpen (library-shaped work)."""
+    from ucsa_neural_rendering_amd import losses as ul
+    from ucsa_neural_rendering_amd.network import DeepLabV3
+    out = {}
+    for mode in ("fp32", "bf16_channels_last"):
+        torch.manual_seed(0)
+        m = DeepLabV3({"pretrained": False, "pretrained_backbone": False,
+                       "num_classes": N_CLASSES}).to(device).train()
+        x = torch.rand(B, 3, 240, 320, device=device)
+        if mode != "fp32":
+            m = m.to(memory_format=torch.channels_last)
+            x = x.contiguous(memory_format=torch.channels_last)
+        y = torch.randint(-1, N_CLASSES, (B, 240, 320), device=device)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+
+        def one():
+            with torch.autocast("cuda", dtype=torch.bfloat16,
+                                enabled=mode != "fp32"):
+                logits = m(x)["out"]
+            loss = ul.seg_loss(logits.float().contiguous(), y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[mode] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt}
+        del m, opt
+        torch.cuda.empty_cache()
+    out["workload"] = ("DeepLabV3-ResNet-101 train step, batch 8 x 3x240x320, "
+                       "CE-on-softmax loss, Adam")
+    return out
+
+
 def effective_cores() -> int:
     """Cores this process may actually use: min(cpu_count, affinity, cgroup
     quota).  (The GPU box shows 256 CPUs but a 16-CPU cgroup quota; 256 OpenMP
@@ -377,6 +422,18 @@ def main():
             },
             "stage_ms_per_chunk": st,
         }
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot
+        # run inside this process); null when the profile file is absent
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles",
+                                              "r01_pmc_traffic.json")))
+            for key, kn in (("roofline_composite", "k_composite"),
+                            ("roofline_encode", "k_hashgrid_encode")):
+                result[key]["traffic"] = (pmc[kn]["fetch_bytes"] +
+                                          pmc[kn]["write_bytes"])
+                result[key]["traffic_source"] = "profiles/r01_pmc_traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
         # "roofline" = the kernel with the largest share of the step
         enc_share = st["encode_c"] + st["encode_f"]
         dom = "roofline_encode" if enc_share >= st["composite"] else "roofline_composite"
@@ -394,6 +451,7 @@ def main():
                                      "the pre-training above"}
         if not args.no_train_bench:
             result["train"] = train_throughput(net, scene_ds, dev)
+            result["seg"] = seg_throughput(dev)
         if not args.no_cpu_baseline:
             threads = effective_cores()
             v, dt, parity, ref, got, (co, cd) = cpu_baseline(

@@ -341,8 +341,11 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
   // (no workspace: direct-atomics path)
   // levels whose cells are wider than about one sample spacing get the
   // run-combining variant (cell = 2*bound/scale, spacing ~ 2*bound*sqrt(3)/T)
+  // without a workspace only levels with cells wider than ~one sample spacing
+  // combine runs; with one, every level handled here is coarse enough
   uint32_t n_run = 0;
-  while (n_run < n_lo && grid->level[n_run].scale < 0.6f * (float)T) ++n_run;
+  while (n_run < n_lo && (workspace != nullptr ||
+                          grid->level[n_run].scale < 0.6f * (float)T)) ++n_run;
   const GridDev gd = ucsa_grid_dev(grid);
   const Aabb bb = ucsa_aabb(aabb_host);
   UCSA_CLEAR_ERR();
