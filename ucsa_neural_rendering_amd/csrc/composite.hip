@@ -23,7 +23,6 @@
 
 #define CMP_MAX_WAVES 12
 #define CMP_CBS 2  // column blocks of 16 samples in flight per wave
-#define CONTRIB_STRIDE 45  // 3 rgb + up to 40.. classes, odd stride
 #define ROW_FINE 0x80000000u
 
 extern __shared__ __attribute__((aligned(16))) float cmp_smem[];

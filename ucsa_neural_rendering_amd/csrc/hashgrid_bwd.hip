@@ -1,15 +1,19 @@
-// Hash-grid backward: scatter d_feat into the table gradient with fp32
-// atomics (restates the autograd of tcnn's GridEncoding; call site reference
+// Hash-grid backward: d_feat -> table gradient (restates the autograd of
+// tcnn's GridEncoding; call site reference
 // nr4seg/nerf/network_tcnn_semantics.py:133-134).
 //
-// Level-major like the forward (one level's 4 MiB gradient slab is L2
-// resident while it is being hit).  Lanes of a wave are consecutive samples
-// of a ray: on coarse levels many of them add to the SAME entry, so equal
-// (index) lanes are first combined inside the wave with a match-and-reduce
-// over the ballot of each distinct index... kept simple here: plain atomics,
-// the contention optimisation is DESIGN.md "next".
-// Float atomics make the table gradient order-dependent at fp32 round-off
-// (run-to-run ~1e-7 relative); see DESIGN.md "determinism".
+// Two regimes, picked per level on the host (ucsa_hashgrid_bwd_rays):
+//  * coarse levels (dense, or cells wider than ~2 sample spacings): lanes of
+//    a wave are consecutive, ASCENDING samples of a ray (ucsa_resample sorts
+//    its uniforms), so neighbours fall into the same cell; equal indices in
+//    consecutive lanes are summed by a segmented wave scan and only the last
+//    lane of each run issues fp32 atomics (k_hashgrid_bwd<true>);
+//  * fine hashed levels: updates are spread over the whole 4 MiB slab and
+//    random fp32 atomics retire at only ~21 G ops/s chip-wide, so records are
+//    binned by table slice and summed in LDS (k_grid_bwd_bin / _accum below).
+// Both use float atomics somewhere (global or LDS), so the table gradient is
+// order-dependent at fp32 round-off (run-to-run ~1e-7 relative); the MLP
+// gradients are reduced in a fixed order and are bit-reproducible.
 #include "ucsa_common.h"
 
 #define PRIME_Y 2654435761u
