@@ -55,12 +55,14 @@ def test_sigma_mlp_backward_matches_autograd(ops):
         assert rel_err(gW, p.grad) <= 2e-5
 
 
-@pytest.mark.parametrize("N,T,t,perturb", [(48, 16, 16, True), (33, 32, 0, False),
-                                           (40, 96, 96, False)])
-def test_render_gradients_match_oracle_autograd(N, T, t, perturb):
+@pytest.mark.parametrize("N,T,t,perturb,inside", [
+    (48, 16, 16, True, True), (33, 32, 0, False, True), (40, 96, 96, False, True),
+    (64, 16, 16, False, False),  # rays from outside: misses and near > far
+])
+def test_render_gradients_match_oracle_autograd(N, T, t, perturb, inside):
     fld = lively_oracle_field().requires_grad_(True)
     net = hip_network_from_oracle(fld).train()
-    o, d, norms = make_rays(N, 300 + N)
+    o, d, norms = make_rays(N, 300 + N, inside=inside)
     g = torch.Generator().manual_seed(N)
     t_rand = torch.rand(N, T, generator=g) if perturb else None
     u = torch.rand(N, max(t, 1), generator=g)[:, :t]

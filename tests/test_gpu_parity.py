@@ -195,6 +195,29 @@ def test_render_matches_oracle_edge_shapes(net, fld, N, T, t, perturb):
     assert float(rel.max()) <= 2e-4
 
 
+def test_render_rays_missing_the_box(net, fld):
+    """Rays that miss the AABB get near = far = FLT_MAX (raymarching.cu:86-104)
+    and still flow through the whole pipeline: every interval is empty except
+    the last (1e10 wide), which takes all the weight."""
+    N, T, t = 200, 16, 16
+    o, d, norms = make_rays(N, 77, inside=False)
+    near, _ = orays.near_far_from_aabb(o, d, AABB4)
+    miss = near == np.float32(3.4028234663852886e38)
+    assert int(miss.sum()) > 20 and int((~miss).sum()) > 20
+    g = torch.Generator().manual_seed(1)
+    u = torch.rand(N, t, generator=g)
+    with torch.no_grad():
+        ref = oren.run(fld, o[None], d[None], norms[None], AABB4, num_steps=T,
+                       upsample_steps=t, u=u)
+        res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                         num_steps=T, upsample_steps=t, rng_u=u.cuda())
+    for k in ("image", "semantics"):
+        assert torch.isfinite(res[k]).all()
+        assert maxabs(res[k], ref[k]) <= 1e-4, k
+    rel = (res["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-3)
+    assert float(rel.max()) <= 2e-4
+
+
 def test_render_empty_batch(net):
     e = torch.empty(1, 0, 3, device="cuda")
     res = net.render(e, e, torch.empty(1, 0, 1, device="cuda"), num_steps=16,

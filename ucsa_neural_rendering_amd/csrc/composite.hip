@@ -313,47 +313,41 @@ k_composite(CmpArgs a) {
     for (uint32_t e = lane; e < S; e += 64) zraw[e] = e < T ? zc[e] : zf[e - T];
     wave_lds_sync();
     // ---- A2: rank of every element in the stable sort of [coarse|fine] --
-    // ucsa_resample emits ascending fine samples; then both ranks are binary
-    // searches.  Arbitrary callers may pass unsorted z_f: detect and fall back
-    // to counting (O(t) per element).
-    bool fine_sorted = true;
+    // Normal case: coarse depths ascend (near < far) and ucsa_resample emits
+    // ascending fine samples, so both ranks are binary searches.  Anything
+    // else (near clamped above far gives DESCENDING coarse depths; arbitrary
+    // callers may pass unsorted z_f) takes the general path: stable rank by
+    // counting over all S elements, exactly torch.sort(stable) semantics.
+    bool sorted_in = true;
+    for (uint32_t k = lane; k + 1 < T; k += 64)
+      sorted_in = sorted_in && (zraw[k] <= zraw[k + 1]);
     for (uint32_t k = lane; k + 1 < t; k += 64)
-      fine_sorted = fine_sorted && (zraw[T + k] <= zraw[T + k + 1]);
-    fine_sorted = __all(fine_sorted);
+      sorted_in = sorted_in && (zraw[T + k] <= zraw[T + k + 1]);
+    sorted_in = __all(sorted_in);
     for (uint32_t e = lane; e < S; e += 64) {
       const float ze = zraw[e];
       uint32_t rank;
-      if (e < T) {
+      if (!sorted_in) {
         uint32_t c = 0;
-        if (fine_sorted) {  // #fine strictly below ze
-          uint32_t lo = 0, hi = t;
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (zraw[T + mid] < ze) lo = mid + 1; else hi = mid;
-          }
-          c = lo;
-        } else {
-          for (uint32_t k = 0; k < t; ++k) c += (zraw[T + k] < ze) ? 1u : 0u;
+        for (uint32_t k = 0; k < S; ++k) {
+          const float zk = zraw[k];
+          c += (zk < ze || (zk == ze && k < e)) ? 1u : 0u;
         }
-        rank = e + c;
+        rank = c;
+      } else if (e < T) {
+        uint32_t lo = 0, hi = t;  // #fine strictly below ze
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (zraw[T + mid] < ze) lo = mid + 1; else hi = mid;
+        }
+        rank = e + lo;
       } else {
-        // coarse elements <= ze come first (coarse list is ascending)
-        uint32_t lo = 0, hi = T;
+        uint32_t lo = 0, hi = T;  // #coarse <= ze (coarse first on ties)
         while (lo < hi) {
           const uint32_t mid = (lo + hi) >> 1;
           if (zraw[mid] <= ze) lo = mid + 1; else hi = mid;
         }
-        uint32_t c = 0;
-        const uint32_t kk = e - T;
-        if (fine_sorted) {
-          c = kk;  // equal neighbours keep index order
-        } else {
-          for (uint32_t k = 0; k < t; ++k) {
-            const float zk = zraw[T + k];
-            c += (zk < ze || (zk == ze && k < kk)) ? 1u : 0u;
-          }
-        }
-        rank = lo + c;
+        rank = lo + (e - T);  // equal fine neighbours keep index order
       }
       const float sg = e < T ? a.sigma_c[(size_t)r * T + e]
                              : a.sigma_f[(size_t)r * t + (e - T)];
