@@ -176,6 +176,16 @@ int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
                         float density_scale, float* image, float* depth,
                         float* semantics, void* ws, void* stream);
 
+/* Pointwise colour / semantics queries: network.color() / network.semantics()
+ * (reference network_tcnn_semantics.py:147-207).  dirs [M,3], geo_feat [M,15],
+ * mask [M] uint8 or NULL; rgb [M,3] and/or probs [M,n_classes] (either may be
+ * NULL); rows with mask == 0 are zero. */
+int32_t ucsa_point_shade(const float* dirs, const float* geo_feat,
+                         const uint8_t* mask, const float* packed_color,
+                         const float* packed_sem, uint32_t M,
+                         uint32_t n_classes, float* rgb, float* probs,
+                         void* stream);
+
 /* ======================= training (backward) ============================== */
 
 /* A fragments of W^T for the dX = W^T dY passes (layout: DESIGN.md).

@@ -112,6 +112,30 @@ def test_density_matches_oracle(net, fld):
         assert maxabs(got["geo_feat"], ref["geo_feat"]) <= 2e-5
 
 
+def test_pointwise_color_semantics_forward(net, fld):
+    """network.color / .semantics / .forward (reference :102-207)."""
+    g = torch.Generator().manual_seed(8)
+    for M in (1, 16, 50, 1000):
+        x = (torch.rand(M, 3, generator=g) * 2 - 1) * 4.0
+        d = torch.randn(M, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        mask = torch.rand(M, generator=g) < 0.6
+        if M == 1:
+            mask[:] = True
+        ref_den = fld.density(x)
+        ref_rgb = fld.color(x, d, mask=mask, geo_feat=ref_den["geo_feat"])
+        ref_sem = fld.semantics(x, d, mask=mask, geo_feat=ref_den["geo_feat"])
+        geo = ref_den["geo_feat"].cuda()
+        rgb = net.color(x.cuda(), d.cuda(), mask=mask.cuda(), geo_feat=geo)
+        sem = net.semantics(x.cuda(), d.cuda(), mask=mask.cuda(), geo_feat=geo)
+        assert maxabs(rgb, ref_rgb) <= 2e-5 and maxabs(sem, ref_sem) <= 2e-5
+        assert float(rgb[~mask.cuda()].abs().sum()) == 0.0
+        s3, c3, p3 = net.forward(x.cuda(), d.cuda())
+        rs, rc, rp = fld.forward(x, d)
+        assert maxabs(c3, rc) <= 5e-5 and maxabs(p3, rp) <= 5e-5
+        assert float(((s3.cpu() - rs).abs() / rs).max()) <= 2e-5
+
+
 # ---------------------------------------------------------------- a5
 @pytest.mark.parametrize("T,t", [(16, 16), (96, 96), (256, 256), (8, 40)])
 def test_resample_matches_oracle(ops, T, t):

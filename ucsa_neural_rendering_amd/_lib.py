@@ -67,6 +67,8 @@ SIGNATURES = {
     "ucsa_render_fwd": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p, _p,
                                     _p, C.POINTER(_f), _f, _p, _p, _u32, _u32,
                                     _u32, _u32, _f, _p, _p, _p, _p, _p]),
+    "ucsa_point_shade": (C.c_int32, [_p, _p, _p, _p, _p, _u32, _u32, _p, _p,
+                                     _p]),
     # ---- training ----
     "ucsa_mlp_pack_t_size": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_t": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),

@@ -172,3 +172,32 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             feat = ops.hashgrid_encode_points(f["grid"], f["table"], x)
             h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
         return {"sigma": sigma, "geo_feat": h[:, 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """reference :147-178.  x is unused by the colour net (as in the
+        reference, where only d and geo_feat feed it).  Inference only."""
+        f = self._field()
+        with torch.no_grad():
+            rgb, _ = ops.point_shade(d, geo_feat, mask, f["packed_color"],
+                                     f["packed_sem"],
+                                     self.num_semantic_classes,
+                                     want_probs=False)
+        return rgb
+
+    def semantics(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """reference :180-207: softmax probabilities, zero rows outside the
+        mask.  Inference only."""
+        f = self._field()
+        with torch.no_grad():
+            _, probs = ops.point_shade(None, geo_feat, mask, f["packed_color"],
+                                       f["packed_sem"],
+                                       self.num_semantic_classes,
+                                       want_rgb=False)
+        return probs
+
+    def forward(self, x, d):
+        """reference :102-128 -> (sigma [M], color [M,3], semantics [M,C])."""
+        den = self.density(x)
+        geo = den["geo_feat"].contiguous()
+        return (den["sigma"], self.color(x, d, geo_feat=geo),
+                self.semantics(x, d, geo_feat=geo))

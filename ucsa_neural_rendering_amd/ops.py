@@ -163,6 +163,22 @@ def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     return image, depth, sem
 
 
+def point_shade(dirs, geo_feat, mask, packed_color, packed_sem, n_classes: int,
+                want_rgb: bool = True, want_probs: bool = True):
+    geo_feat = _f32(geo_feat, "geo_feat").view(-1, 15)
+    M = geo_feat.shape[0]
+    dev = geo_feat.device
+    dirs = None if dirs is None else _f32(dirs, "d").view(M, 3)
+    m8 = None if mask is None else mask.reshape(M).to(torch.uint8).contiguous()
+    rgb = torch.empty(M, 3, device=dev) if want_rgb else None
+    probs = torch.empty(M, n_classes, device=dev) if want_probs else None
+    check(lib().ucsa_point_shade(_ptr(dirs), _ptr(geo_feat), _ptr(m8),
+                                 _ptr(packed_color), _ptr(packed_sem), M,
+                                 n_classes, _ptr(rgb), _ptr(probs), _stream()),
+          "ucsa_point_shade")
+    return rgb, probs
+
+
 def render_workspace_bytes(N: int, T: int, t: int, n_levels: int) -> int:
     return int(lib().ucsa_render_workspace_bytes(N, T, t, n_levels))
 
