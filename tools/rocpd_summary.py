@@ -14,10 +14,13 @@ def main(path):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
-    rows = c.execute(f"select {name_col}, start, end from kernels").fetchall()
+    import os
+    by_grid = os.environ.get("BY_GRID") and "grid_x" in cols
+    sel = f"{name_col}, start, end" + (", grid_x" if by_grid else ", 0")
+    rows = c.execute(f"select {sel} from kernels").fetchall()
     agg = defaultdict(list)
-    for n, s, e in rows:
-        agg[n].append(e - s)
+    for n, s, e, gx in rows:
+        agg[f"[{gx}] {n}" if by_grid else n].append(e - s)
     tot = sum(sum(v) for v in agg.values()) or 1
     print(f"# rocprofv3 kernel-trace summary of {path}")
     print(f"# {'kernel':60s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} "

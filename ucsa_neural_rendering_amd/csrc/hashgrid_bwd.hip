@@ -38,23 +38,49 @@ __device__ __forceinline__ float clampf_b(float v, float lo, float hi) {
 // indices in CONSECUTIVE lanes are summed with a segmented wave scan and only
 // the last lane of each run issues the atomic.  Non-adjacent duplicates just
 // cost an extra atomic.
-__device__ __forceinline__ void run_combine(uint32_t idx, float& vx, float& vy,
-                                            uint32_t lane, bool& is_tail) {
-  const uint32_t prev = (uint32_t)__shfl_up((int)idx, 1, 64);
-  int f = (lane == 0 || prev != idx) ? 1 : 0;  // run head
+// Run structure of a wave: all 8 corners of a sample share the sample's cell,
+// so the run heads (cell differs from the previous lane's) and the scan's
+// "may add from lane-d" predicates are computed once and reused by the 16
+// value scans.
+struct RunPlan {
+  bool add[6];
+  bool tail;
+};
+
+__device__ __forceinline__ RunPlan run_plan(uint32_t cx, uint32_t cy,
+                                            uint32_t cz, bool act,
+                                            uint32_t lane) {
+  // inactive lanes get a cell id no active lane can have
+  const uint32_t kx = act ? cx : 0xFFFFFFFFu;
+  const uint32_t px = (uint32_t)__shfl_up((int)kx, 1, 64);
+  const uint32_t py = (uint32_t)__shfl_up((int)cy, 1, 64);
+  const uint32_t pz = (uint32_t)__shfl_up((int)cz, 1, 64);
+  const bool head = lane == 0 || px != kx || py != cy || pz != cz || !act;
+  int f = head ? 1 : 0;
+  RunPlan p;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float ox = __shfl_up(vx, d, 64);
-    const float oy = __shfl_up(vy, d, 64);
+  for (int s = 0; s < 6; ++s) {
+    const int d = 1 << s;
     const int of = __shfl_up(f, d, 64);
-    if (lane >= (uint32_t)d && !f) {
+    p.add[s] = lane >= (uint32_t)d && !f;
+    if (p.add[s]) f |= of;
+  }
+  const int next_head = __shfl_down(head ? 1 : 0, 1, 64);
+  p.tail = act && (lane == 63 || next_head);
+  return p;
+}
+
+__device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
+                                        float& vy) {
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const float ox = __shfl_up(vx, 1 << s, 64);
+    const float oy = __shfl_up(vy, 1 << s, 64);
+    if (p.add[s]) {
       vx += ox;
       vy += oy;
-      f |= of;
     }
   }
-  const uint32_t next = (uint32_t)__shfl_down((int)idx, 1, 64);
-  is_tail = (lane == 63) || (next != idx);
 }
 
 template <bool RUNRED>
@@ -91,19 +117,20 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
   float* gt = grad_table + (size_t)g.offset[level] * 2;
   const uint32_t res = g.res[level], entries = g.entries[level],
                  hashed = g.hashed[level];
+  RunPlan plan;
+  if (RUNRED) plan = run_plan(gx, gy, gz, act, lane);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     float w = (c & 1) ? wx : 1.0f - wx;
     w = w * ((c & 2) ? wy : 1.0f - wy);
     w = w * ((c & 4) ? wz : 1.0f - wz);
-    uint32_t idx = grid_index_b(gx + (c & 1), gy + ((c >> 1) & 1),
-                                gz + ((c >> 2) & 1), res, entries, hashed);
+    const uint32_t idx = grid_index_b(gx + (c & 1), gy + ((c >> 1) & 1),
+                                      gz + ((c >> 2) & 1), res, entries, hashed);
     float vx = w * df.x, vy = w * df.y;
     if (RUNRED) {
-      if (!act) { idx = 0xFFFFFFFFu; vx = 0.f; vy = 0.f; }
-      bool tail;
-      run_combine(idx, vx, vy, lane, tail);
-      if (tail && idx != 0xFFFFFFFFu) {
+      if (!act) { vx = 0.f; vy = 0.f; }
+      run_sum(plan, vx, vy);
+      if (plan.tail) {
         atomicAdd(gt + (size_t)idx * 2, vx);
         atomicAdd(gt + (size_t)idx * 2 + 1, vy);
       }
@@ -251,7 +278,20 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 256) acc[e] = 0.f;
   __syncthreads();
   const float4* rec = records + ((size_t)level * BIN_COUNT + bin) * bg.cap;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+  // 4 record loads in flight per thread before the LDS adds
+  uint32_t i = threadIdx.x;
+  for (; i + 3 * 256 < n; i += 4 * 256) {
+    float4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = rec[i + k * 256];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t il = __float_as_uint(r[k].x);
+      atomicAdd(&acc[2 * il], r[k].y);
+      atomicAdd(&acc[2 * il + 1], r[k].z);
+    }
+  }
+  for (; i < n; i += 256) {
     const float4 r = rec[i];
     const uint32_t il = __float_as_uint(r.x);
     atomicAdd(&acc[2 * il], r.y);
