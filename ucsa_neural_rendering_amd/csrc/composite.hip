@@ -102,7 +102,7 @@ k_composite(CmpArgs a) {
   const uint32_t cap = S + G;                      // entry list capacity
   // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
   //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
-  const uint32_t per_wave_floats = 4 * S + 3 * cap + 16 * cstride;
+  const uint32_t per_wave_floats = 4 * S + 3 * cap + 16 * cstride + 64;
   float* base = per_wave + (size_t)wid * per_wave_floats;
   float* zraw = base;
   float* zm = zraw + S;
@@ -112,6 +112,7 @@ k_composite(CmpArgs a) {
   uint32_t* lrow = reinterpret_cast<uint32_t*>(lw + cap);
   uint32_t* lray = lrow + cap;
   float* contrib = reinterpret_cast<float*>(lray + cap);
+  float* shpart = contrib + 16 * cstride;  // [64] colour-L1 SH part of one ray
 
   for (uint32_t i = threadIdx.x; i < 7168; i += blockDim.x)
     w_color[i] = a.packed_color[i];
@@ -128,6 +129,7 @@ k_composite(CmpArgs a) {
 
   uint32_t cnt = 0;            // entries waiting in the list (wave-uniform)
   uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose sums sit in `acc`
+  uint32_t sh_ray = 0xFFFFFFFFu;   // ray whose SH part sits in `shpart`
   float acc = 0.0f;            // lane c: running sum of channel c
 
   auto flush_ray = [&](uint32_t ray) {
@@ -137,7 +139,7 @@ k_composite(CmpArgs a) {
 
   // ---- phase C + D on the first `n` (<= 64) entries of the list ---------
   auto shade = [&](uint32_t n) {
-    float ew[CBS], geo[CBS][4], sh[CBS][4];
+    float ew[CBS], geo[CBS][4];
     uint32_t eray[CBS];
 #pragma unroll
     for (int cb = 0; cb < CBS; ++cb) {
@@ -154,28 +156,62 @@ k_composite(CmpArgs a) {
       geo[cb][1] = hv[1];
       geo[cb][2] = hv[2];
       geo[cb][3] = hv[3];
-      const float* d = a.rays_d + (size_t)eray[cb] * 3;
-      sh4_select(d[0], d[1], d[2], g, sh[cb]);
     }
 
     // ---------------- colour net: 32 -> 64 -> 64 -> 16 -------------------
     float rgb[CBS][3];
     {
       f32x4 acc1[CBS][4];
+      // First layer, SH half (k-steps 0..3).  The direction -- hence this
+      // partial sum -- is the same for every sample of a ray, and a column
+      // block usually holds 16 samples of ONE ray: compute it once per ray,
+      // keep it in LDS, and start the accumulators from it.  Same k order as
+      // the plain chain, so results are bit-identical.
 #pragma unroll
-      for (int cb = 0; cb < CBS; ++cb)
+      for (int cb = 0; cb < CBS; ++cb) {
+        const uint32_t ray0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)eray[cb]);
+        const bool uniform = __all(eray[cb] == ray0);
+        float sh[4];
+        if (!uniform || ray0 != sh_ray) {  // SH values only when (re)computed
+          const float* dd = a.rays_d + (size_t)eray[cb] * 3;
+          sh4_select(dd[0], dd[1], dd[2], g, sh);
+        }
+        if (uniform && ray0 != sh_ray) {
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int rb = 0; rb < 4; ++rb) {
+            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < 4; ++ks)
+              p = mfma16(w_color[(rb * 8 + ks) * 64 + lane], sh[ks], p);
+            if (j == 0) *reinterpret_cast<f32x4*>(shpart + 16 * rb + 4 * g) = p;
+          }
+          sh_ray = ray0;
+          wave_lds_sync();
+        }
+        if (uniform) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            acc1[cb][rb] = *reinterpret_cast<const f32x4*>(shpart + 16 * rb + 4 * g);
+        } else {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              p = mfma16(w_color[(rb * 8 + ks) * 64 + lane], sh[ks], p);
+            acc1[cb][rb] = p;
+          }
+        }
+      }
+      // geo half (k-steps 4..7) for all column blocks
+#pragma unroll
+      for (int ks = 4; ks < 8; ++ks) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
           const float wa = w_color[(rb * 8 + ks) * 64 + lane];
 #pragma unroll
-          for (int cb = 0; cb < CBS; ++cb) {
-            const float x = ks < 4 ? sh[cb][ks] : geo[cb][ks - 4];
-            acc1[cb][rb] = mfma16(wa, x, acc1[cb][rb]);
-          }
+          for (int cb = 0; cb < CBS; ++cb)
+            acc1[cb][rb] = mfma16(wa, geo[cb][ks - 4], acc1[cb][rb]);
         }
       }
       float hid[CBS][16];
@@ -291,15 +327,28 @@ k_composite(CmpArgs a) {
         }
       wave_lds_sync();
       const uint32_t nb = (n > (uint32_t)cb * 16) ? ((n - cb * 16 < 16) ? n - cb * 16 : 16) : 0;
-      for (uint32_t e = 0; e < nb; ++e) {
-        const uint32_t ray = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)lray[cb * 16 + e]);  // wave-uniform
-        if (ray != cur_ray) {
-          if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
-          cur_ray = ray;
-          acc = 0.0f;
+      // Per-ray sums in sample order (the order makes results independent of
+      // how rays are chunked / sharded).  All 16 tile rows and ray ids are
+      // fetched first so the sequential adds do not each wait on an LDS read.
+      float cv[16];
+      uint32_t rv[16];
+      const uint32_t ch = lane < 3 + C ? lane : 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        cv[e] = contrib[e * cstride + ch];
+        rv[e] = lray[cb * 16 + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if ((uint32_t)e < nb) {
+          const uint32_t ray = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv[e]);
+          if (ray != cur_ray) {
+            if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+            cur_ray = ray;
+            acc = 0.0f;
+          }
+          acc = acc + cv[e];
         }
-        if (lane < 3 + C) acc = acc + contrib[e * cstride + lane];
       }
       wave_lds_sync();
     }
@@ -459,7 +508,7 @@ extern "C" int32_t ucsa_composite_fwd(
   uint32_t cstride = 3 + n_classes;
   if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
   const size_t w_floats = 7168 + 1024 + (size_t)nrb * 1024;
-  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 16 * CMP_CBS) + 16 * cstride;
+  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 16 * CMP_CBS) + 16 * cstride + 64;
   // as many waves per workgroup as fit in ~150 KiB of LDS (one WG per CU)
   uint32_t waves = CMP_MAX_WAVES;
   while (waves > 1 && (w_floats + waves * per_wave) * 4 > 158 * 1024) --waves;
