@@ -83,6 +83,35 @@ __device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
   }
 }
 
+// Workgroup-private LDS accumulator (open addressing, keyed by table index).
+// All rays of a training batch start in the camera's cell, so on the coarse
+// levels a handful of table entries receive an update from every ray: as
+// global atomics those serialise on one L2 line (measured: 1.2 ms for 393 k
+// samples, independent of the sample count).  Here every workgroup first sums
+// its ~8 k samples into LDS (same-address LDS atomics are cheap) and flushes
+// each distinct entry once; entries that do not fit go straight to memory.
+#define ACC_SLOTS 4096
+#define ACC_EMPTY 0xFFFFFFFFu
+#define ACC_TILES 32  // 256-sample tiles per workgroup
+
+__device__ __forceinline__ void lds_accumulate(uint32_t* keys, float* vals,
+                                               uint32_t idx, float vx, float vy,
+                                               float* gt) {
+  uint32_t slot = (idx * 2654435761u) >> 20;  // 12 bits
+#pragma unroll 1
+  for (int probe = 0; probe < 4; ++probe) {
+    const uint32_t old = atomicCAS(&keys[slot], ACC_EMPTY, idx);
+    if (old == ACC_EMPTY || old == idx) {
+      atomicAdd(&vals[2 * slot], vx);
+      atomicAdd(&vals[2 * slot + 1], vy);
+      return;
+    }
+    slot = (slot + 1) & (ACC_SLOTS - 1);
+  }
+  atomicAdd(gt + (size_t)idx * 2, vx);  // table crowded: not a hot entry
+  atomicAdd(gt + (size_t)idx * 2 + 1, vy);
+}
+
 template <bool RUNRED>
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
@@ -90,53 +119,74 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
                Aabb bb, uint32_t T, uint64_t M, uint32_t level0,
                const float2* __restrict__ d_feat,
                float* __restrict__ grad_table) {
+  __shared__ uint32_t acc_keys[RUNRED ? ACC_SLOTS : 1];
+  __shared__ float acc_vals[RUNRED ? 2 * ACC_SLOTS : 1];
   const uint32_t level = level0 + blockIdx.y;
   const uint32_t lane = threadIdx.x & 63u;
-  uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in_range = m < M;
-  if (!in_range) m = M - 1;
-  float2 df = d_feat[(uint64_t)level * M + m];
-  const bool act = in_range && !(df.x == 0.0f && df.y == 0.0f);
-  if (!RUNRED && !act) return;
-  const uint32_t r = (uint32_t)(m / T);
-  const float zz = zs[m];
-  const float* o = rays_o + (size_t)r * 3;
-  const float* d = rays_d + (size_t)r * 3;
-  const float px = clampf_b(o[0] + d[0] * zz, bb.lo[0], bb.hi[0]);
-  const float py = clampf_b(o[1] + d[1] * zz, bb.lo[1], bb.hi[1]);
-  const float pz = clampf_b(o[2] + d[2] * zz, bb.lo[2], bb.hi[2]);
-  const float two_b = 2.0f * g.bound;
-  const float scale = g.scale[level];
-  const float x = (px + g.bound) / two_b * scale + 0.5f;
-  const float y = (py + g.bound) / two_b * scale + 0.5f;
-  const float z = (pz + g.bound) / two_b * scale + 0.5f;
-  const float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
-  const float wx = x - fx0, wy = y - fy0, wz = z - fz0;
-  const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
-                 gz = (uint32_t)(int32_t)fz0;
   float* gt = grad_table + (size_t)g.offset[level] * 2;
   const uint32_t res = g.res[level], entries = g.entries[level],
                  hashed = g.hashed[level];
-  RunPlan plan;
-  if (RUNRED) plan = run_plan(gx, gy, gz, act, lane);
+  const float two_b = 2.0f * g.bound;
+  const float scale = g.scale[level];
+  if (RUNRED) {
+    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) {
+      acc_keys[i] = ACC_EMPTY;
+      acc_vals[2 * i] = 0.f;
+      acc_vals[2 * i + 1] = 0.f;
+    }
+    __syncthreads();
+  }
+  const int n_tiles = RUNRED ? ACC_TILES : 1;
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    uint64_t m = ((uint64_t)blockIdx.x * n_tiles + tile) * 256 + threadIdx.x;
+    const bool in_range = m < M;
+    if (RUNRED && __syncthreads_or(in_range) == 0) break;
+    if (!in_range) m = M - 1;
+    const float2 df = d_feat[(uint64_t)level * M + m];
+    const bool act = in_range && !(df.x == 0.0f && df.y == 0.0f);
+    if (!RUNRED && !act) return;
+    const uint32_t r = (uint32_t)(m / T);
+    const float zz = zs[m];
+    const float* o = rays_o + (size_t)r * 3;
+    const float* d = rays_d + (size_t)r * 3;
+    const float px = clampf_b(o[0] + d[0] * zz, bb.lo[0], bb.hi[0]);
+    const float py = clampf_b(o[1] + d[1] * zz, bb.lo[1], bb.hi[1]);
+    const float pz = clampf_b(o[2] + d[2] * zz, bb.lo[2], bb.hi[2]);
+    const float x = (px + g.bound) / two_b * scale + 0.5f;
+    const float y = (py + g.bound) / two_b * scale + 0.5f;
+    const float z = (pz + g.bound) / two_b * scale + 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
+    const float wx = x - fx0, wy = y - fy0, wz = z - fz0;
+    const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
+                   gz = (uint32_t)(int32_t)fz0;
+    RunPlan plan;
+    if (RUNRED) plan = run_plan(gx, gy, gz, act, lane);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float w = (c & 1) ? wx : 1.0f - wx;
-    w = w * ((c & 2) ? wy : 1.0f - wy);
-    w = w * ((c & 4) ? wz : 1.0f - wz);
-    const uint32_t idx = grid_index_b(gx + (c & 1), gy + ((c >> 1) & 1),
-                                      gz + ((c >> 2) & 1), res, entries, hashed);
-    float vx = w * df.x, vy = w * df.y;
-    if (RUNRED) {
-      if (!act) { vx = 0.f; vy = 0.f; }
-      run_sum(plan, vx, vy);
-      if (plan.tail) {
+    for (int c = 0; c < 8; ++c) {
+      float w = (c & 1) ? wx : 1.0f - wx;
+      w = w * ((c & 2) ? wy : 1.0f - wy);
+      w = w * ((c & 4) ? wz : 1.0f - wz);
+      const uint32_t idx = grid_index_b(gx + (c & 1), gy + ((c >> 1) & 1),
+                                        gz + ((c >> 2) & 1), res, entries, hashed);
+      float vx = w * df.x, vy = w * df.y;
+      if (RUNRED) {
+        if (!act) { vx = 0.f; vy = 0.f; }
+        run_sum(plan, vx, vy);
+        if (plan.tail) lds_accumulate(acc_keys, acc_vals, idx, vx, vy, gt);
+      } else {
         atomicAdd(gt + (size_t)idx * 2, vx);
         atomicAdd(gt + (size_t)idx * 2 + 1, vy);
       }
-    } else {
-      atomicAdd(gt + (size_t)idx * 2, vx);
-      atomicAdd(gt + (size_t)idx * 2 + 1, vy);
+    }
+  }
+  if (RUNRED) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) {
+      const uint32_t k = acc_keys[i];
+      if (k != ACC_EMPTY) {
+        atomicAdd(gt + (size_t)k * 2, acc_vals[2 * i]);
+        atomicAdd(gt + (size_t)k * 2 + 1, acc_vals[2 * i + 1]);
+      }
     }
   }
 }
@@ -394,7 +444,8 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
   const Aabb bb = ucsa_aabb(aabb_host);
   UCSA_CLEAR_ERR();
   if (n_run > 0)
-    hipLaunchKernelGGL(k_hashgrid_bwd<true>, dim3(ucsa_div_up(M, 256), n_run),
+    hipLaunchKernelGGL(k_hashgrid_bwd<true>,
+                       dim3(ucsa_div_up(M, 256 * ACC_TILES), n_run),
                        dim3(256), 0, (hipStream_t)stream, gd, rays_o, rays_d, z,
                        bb, T, M, 0u, (const float2*)d_feat, grad_table);
   if (n_run < n_lo)
