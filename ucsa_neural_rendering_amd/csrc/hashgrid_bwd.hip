@@ -199,7 +199,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
 // per second (two floats each), i.e. ~0.8 ms per level for the 8.4 M corner
 // updates of a 4096 x 256 training batch; 85 % of a training step.
 // Instead:
-//   pass 1  every workgroup turns its 1024 samples of one level into
+//   pass 1  every workgroup turns its 2048 samples of one level into
 //           (entry, vx, vy) records and appends them to 256 per-level bins
 //           (bin = contiguous slice of the level's table): LDS histogram, one
 //           global reservation per (workgroup, bin), 16-byte record stores;
@@ -211,7 +211,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
 // excess records, so results never depend on the capacity guess.
 // ===========================================================================
 #define BIN_COUNT 256
-#define BIN_TILE 4  // samples per thread in pass 1
+#define BIN_TILE 8  // samples per thread in pass 1
 
 struct BinGeom {
   uint32_t bin_size[UCSA_MAX_LEVELS];  // table entries per bin
@@ -314,7 +314,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
 
 extern __shared__ __attribute__((aligned(16))) float binacc_smem[];
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
                  const uint32_t* __restrict__ gcount,
                  const float4* __restrict__ records,
@@ -325,15 +325,15 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   if (n == 0) return;
   if (n > bg.cap) n = bg.cap;
   float* acc = binacc_smem;  // [bsz][2]
-  for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 256) acc[e] = 0.f;
+  for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) acc[e] = 0.f;
   __syncthreads();
   const float4* rec = records + ((size_t)level * BIN_COUNT + bin) * bg.cap;
   // 4 record loads in flight per thread before the LDS adds
   uint32_t i = threadIdx.x;
-  for (; i + 3 * 256 < n; i += 4 * 256) {
+  for (; i + 3 * 512 < n; i += 4 * 512) {
     float4 r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = rec[i + k * 256];
+    for (int k = 0; k < 4; ++k) r[k] = rec[i + k * 512];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t il = __float_as_uint(r[k].x);
@@ -341,7 +341,7 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
       atomicAdd(&acc[2 * il + 1], r[k].z);
     }
   }
-  for (; i < n; i += 256) {
+  for (; i < n; i += 512) {
     const float4 r = rec[i];
     const uint32_t il = __float_as_uint(r.x);
     atomicAdd(&acc[2 * il], r.y);
@@ -351,7 +351,7 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   const uint32_t first = bin * bsz;
   const uint32_t entries = g.entries[level];
   float* gt = grad_table + (size_t)g.offset[level] * 2;
-  for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 256) {
+  for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) {
     const uint32_t ent = first + (e >> 1);
     if (ent < entries) {
       const float v = acc[e];
@@ -425,7 +425,7 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
                        dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o,
                        rays_d, z, bb, T, M, (const float2*)d_feat, gcount,
                        records, grad_table);
-    hipLaunchKernelGGL(k_grid_bwd_accum, dim3(BIN_COUNT, nl), dim3(256),
+    hipLaunchKernelGGL(k_grid_bwd_accum, dim3(BIN_COUNT, nl), dim3(512),
                        (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
                        gd, bg, n_lo, gcount, records, grad_table);
     const int32_t rc = ucsa_launch_status();
