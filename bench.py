@@ -449,6 +449,25 @@ def main():
                              "miou": meter.measure()[0],
                              "note": "novel 640x480 view vs analytic GT after "
                                      "the pre-training above"}
+        # inference-only option: MLPs on fp16 MFMA (tcnn's numerics); never the
+        # headline `value` (the parity path is fp32)
+        net.precision = "fp16"
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n16 = min(5, args.steps)
+        for i in range(n16):
+            out16 = step(args.warmup + i)
+        torch.cuda.synchronize()
+        dt16 = (time.perf_counter() - t1) / n16
+        net.precision = "fp32"
+        d16 = (out16["image"] - step(args.warmup + n16 - 1)["image"]).abs().max()
+        result["f16_mlp_option"] = {
+            "rays_per_s": H * W / dt16, "ms_per_view": dt16 * 1e3,
+            "max_abs_image_diff_vs_fp32": float(d16),
+            "note": "precision='fp16': three MLPs on 16x16x32 f16 MFMA, fp32 "
+                    "accumulate; hash grid, sampling, compositing fp32"}
         if not args.no_train_bench:
             result["train"] = train_throughput(net, scene_ds, dev)
             result["seg"] = seg_throughput(dev)

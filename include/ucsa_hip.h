@@ -186,6 +186,37 @@ int32_t ucsa_point_shade(const float* dirs, const float* geo_feat,
                          uint32_t n_classes, float* rgb, float* probs,
                          void* stream);
 
+/* ======================= fp16-MFMA inference option ======================== */
+/* tiny-cuda-nn evaluates the three MLPs with fp16 weights / layer inputs and
+ * fp32 accumulation; the entry points below do the same (16x16x32 f16 MFMA)
+ * for inference.  Hash-grid, sampling and compositing stay fp32.  The default
+ * (and parity) path is the fp32 one above. */
+uint32_t ucsa_mlp_pack_f16_halves(int32_t kind, uint32_t n_classes);
+int32_t ucsa_mlp_pack_f16(int32_t kind, const float* params, void* packed_half,
+                          uint32_t n_classes, void* stream);
+int32_t ucsa_sigma_mlp_fwd_f16(const float* feat, const void* packed_sigma_half,
+                               uint32_t M, uint32_t n_levels, float* h,
+                               float* sigma, void* stream);
+int32_t ucsa_composite_fwd_f16(const float* rays_d, const float* norms,
+                               const float* z_c, const float* sigma_c,
+                               const float* h_c, const float* z_f,
+                               const float* sigma_f, const float* h_f,
+                               const void* packed_color_half,
+                               const void* packed_sem_half, uint32_t N,
+                               uint32_t T, uint32_t t, uint32_t n_classes,
+                               float density_scale, float* image, float* depth,
+                               float* semantics, void* stream);
+int32_t ucsa_render_fwd_f16(const ucsa_grid* grid_host, const float* table,
+                            const void* packed_sigma_half,
+                            const void* packed_color_half,
+                            const void* packed_sem_half, const float* rays_o,
+                            const float* rays_d, const float* norms,
+                            const float* aabb_host, float min_near,
+                            const float* t_rand, const float* u, uint32_t N,
+                            uint32_t T, uint32_t t, uint32_t n_classes,
+                            float density_scale, float* image, float* depth,
+                            float* semantics, void* ws, void* stream);
+
 /* ======================= training (backward) ============================== */
 
 /* A fragments of W^T for the dX = W^T dY passes (layout: DESIGN.md).

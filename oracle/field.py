@@ -225,18 +225,27 @@ def mlp_split(spec: MLPSpec, params: torch.Tensor):
     return mats
 
 
-def mlp_forward(spec: MLPSpec, x: torch.Tensor,
-                params: torch.Tensor) -> torch.Tensor:
-    """x [M, n_in] -> [M, n_out]; input padded with 1.0 to in_pad."""
+def _q16(t: torch.Tensor) -> torch.Tensor:
+    """Round to fp16 and back (emulates an fp16 MFMA operand)."""
+    return t.half().float()
+
+
+def mlp_forward(spec: MLPSpec, x: torch.Tensor, params: torch.Tensor,
+                emulate_fp16: bool = False) -> torch.Tensor:
+    """x [M, n_in] -> [M, n_out]; input padded with 1.0 to in_pad.
+    emulate_fp16: weights and every layer's input rounded to fp16, products
+    accumulated in fp32, outputs left in fp32 (the HIP fp16 option; tcnn's
+    FullyFusedMLP numerics up to its fp16 output rounding)."""
     M = x.shape[0]
     if spec.in_pad != spec.n_in:
         ones = torch.ones(M, spec.in_pad - spec.n_in, dtype=x.dtype)
         x = torch.cat([x, ones], dim=-1)
     mats = mlp_split(spec, params)
+    q = _q16 if emulate_fp16 else (lambda t: t)
     h = x
     for W in mats[:-1]:
-        h = torch.relu(h @ W.t())
-    y = h @ mats[-1].t()
+        h = torch.relu(q(h) @ q(W).t())
+    y = q(h) @ q(mats[-1]).t()
     return y[:, :spec.n_out]
 
 
@@ -284,7 +293,9 @@ class OracleField:
 
     def __init__(self, bound: float = 4.0, num_semantic_classes: int = 40,
                  geo_feat_dim: int = 15, hidden_dim: int = 64,
-                 seed: int | None = 123, grid_spec: GridSpec | None = None):
+                 seed: int | None = 123, grid_spec: GridSpec | None = None,
+                 emulate_fp16: bool = False):
+        self.emulate_fp16 = emulate_fp16
         self.bound = float(bound)
         self.C = num_semantic_classes
         self.geo_feat_dim = geo_feat_dim
@@ -316,7 +327,8 @@ class OracleField:
     def density(self, x: torch.Tensor):
         x01 = (x + self.bound) / (2 * self.bound)
         enc = hashgrid_encode(self.grid, x01, self.grid_params)
-        h = mlp_forward(self.sigma_spec, enc, self.sigma_params)
+        h = mlp_forward(self.sigma_spec, enc, self.sigma_params,
+                        self.emulate_fp16)
         sigma = trunc_exp(h[:, 0])
         return {"sigma": sigma, "geo_feat": h[:, 1:]}
 
@@ -330,7 +342,8 @@ class OracleField:
             geo_feat = geo_feat[mask]
         d01 = (d + 1) / 2
         h = torch.cat([sh4_encode(d01), geo_feat], dim=-1)
-        h = torch.sigmoid(mlp_forward(self.color_spec, h, self.color_params))
+        h = torch.sigmoid(mlp_forward(self.color_spec, h, self.color_params,
+                                      self.emulate_fp16))
         if mask is not None:
             rgbs[mask] = h
             return rgbs
@@ -343,7 +356,8 @@ class OracleField:
             if not mask.any():
                 return out
             geo_feat = geo_feat[mask]
-        h = mlp_forward(self.sem_spec, geo_feat, self.sem_params)
+        h = mlp_forward(self.sem_spec, geo_feat, self.sem_params,
+                        self.emulate_fp16)
         p = torch.softmax(h, dim=-1)
         if mask is not None:
             out[mask] = p

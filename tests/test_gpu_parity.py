@@ -294,3 +294,41 @@ def test_full_size_properties(net):
     # sum of semantics == sum of weights == what the image would be for rgb==1
     # (checked through linearity: image <= weight sum componentwise)
     assert (img.max(-1)[0] <= ssum + 1e-4).all()
+
+
+# ---------------------------------------------------------------- fp16 option
+def test_fp16_inference_option_matches_fp16_emulating_oracle(fld):
+    """precision="fp16": the MLPs run on 16x16x32 f16 MFMA (fp16 weights and
+    layer inputs, fp32 accumulate) -- tiny-cuda-nn's numerics.  Checked against
+    the oracle with the same roundings emulated (tight), and against the fp32
+    oracle (loose: fp16 quantisation of weights/activations)."""
+    import copy
+    net16 = hip_network_from_oracle(fld).eval()
+    net16.precision = "fp16"
+    f16 = copy.copy(fld)
+    f16.emulate_fp16 = True
+    N, T, t = 300, 32, 32
+    o, d, norms = make_rays(N, 55)
+    g = torch.Generator().manual_seed(55)
+    u = torch.rand(N, t, generator=g)
+    with torch.no_grad():
+        ref16 = oren.run(f16, o[None], d[None], norms[None], AABB4, num_steps=T,
+                         upsample_steps=t, u=u)
+        ref32 = oren.run(fld, o[None], d[None], norms[None], AABB4, num_steps=T,
+                         upsample_steps=t, u=u)
+        res = net16.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                           num_steps=T, upsample_steps=t, rng_u=u.cuda())
+    # same roundings emulated: only accumulation order and rare rounding-boundary
+    # flips of an fp16 activation differ
+    assert maxabs(res["image"], ref16["image"]) <= 2e-3
+    assert maxabs(res["semantics"], ref16["semantics"]) <= 2e-3
+    rel = (res["depth"].cpu() - ref16["depth"]).abs() / ref16["depth"].abs().clamp_min(1e-3)
+    assert float(rel.max()) <= 5e-3
+    # against the fp32 oracle: quantisation error of the option itself
+    assert maxabs(res["image"], ref32["image"]) <= 2e-2
+    assert maxabs(res["semantics"], ref32["semantics"]) <= 2e-2
+    # training never uses it
+    net16.train()
+    out = net16.render(o[None, :8].cuda(), d[None, :8].cuda(), norms[None, :8].cuda(),
+                       num_steps=T, upsample_steps=t, rng_u=u[:8].cuda())
+    assert out["image"].requires_grad

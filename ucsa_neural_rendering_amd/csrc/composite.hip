@@ -18,7 +18,7 @@
 //    per ray.
 // The semantic weights are the same numbers as the colour weights in the
 // forward pass (they differ only in autograd: detached, :270).
-#include "mfma_mlp.h"
+#include "mfma_mlp_f16.h"
 #include "wave_ops.h"
 
 #define CMP_MAX_WAVES 12
@@ -85,7 +85,7 @@ __device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
   }
 }
 
-template <int NRB_SEM, int CBS>
+template <int NRB_SEM, int CBS, bool HALF>
 __global__ void __launch_bounds__(64 * CMP_MAX_WAVES)
 k_composite(CmpArgs a) {
   constexpr uint32_t G = 16u * CBS;  // survivors shaded per MFMA group
@@ -96,9 +96,13 @@ k_composite(CmpArgs a) {
   const uint32_t cstride = a.contrib_stride;
 
   // ---- LDS carve ------------------------------------------------------
-  float* w_color = cmp_smem;                       // 7168
-  float* w_sem = w_color + 7168;                   // 1024 + NRB_SEM*1024
-  float* per_wave = w_sem + 1024 + NRB_SEM * 1024;
+  // fp32: A fragments as floats; fp16 option: 16-byte half8 fragments
+  constexpr uint32_t WC_FLOATS = HALF ? COLOR_H_FRAGS * 256 : 7168;
+  constexpr uint32_t WS_FLOATS = HALF ? SEM_H_FRAGS(NRB_SEM) * 256
+                                      : 1024 + NRB_SEM * 1024;
+  float* w_color = cmp_smem;
+  float* w_sem = w_color + WC_FLOATS;
+  float* per_wave = w_sem + WS_FLOATS;
   const uint32_t cap = S + G;                      // entry list capacity
   // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
   //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
@@ -114,9 +118,9 @@ k_composite(CmpArgs a) {
   float* contrib = reinterpret_cast<float*>(lray + cap);
   float* shpart = contrib + 16 * cstride;  // [64] colour-L1 SH part of one ray
 
-  for (uint32_t i = threadIdx.x; i < 7168; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
     w_color[i] = a.packed_color[i];
-  for (uint32_t i = threadIdx.x; i < 1024 + NRB_SEM * 1024; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i < WS_FLOATS; i += blockDim.x)
     w_sem[i] = a.packed_sem[i];
   __syncthreads();
 
@@ -158,8 +162,10 @@ k_composite(CmpArgs a) {
       geo[cb][3] = hv[3];
     }
 
-    // ---------------- colour net: 32 -> 64 -> 64 -> 16 -------------------
     float rgb[CBS][3];
+    f32x4 lg[CBS][NRB_SEM];
+    if constexpr (!HALF) {
+    // ---------------- colour net: 32 -> 64 -> 64 -> 16 -------------------
     {
       f32x4 acc1[CBS][4];
       // First layer, SH half (k-steps 0..3).  The direction -- hence this
@@ -251,7 +257,6 @@ k_composite(CmpArgs a) {
     }
 
     // ---------------- semantics net: 16 -> 64 -> 16*NRB_SEM --------------
-    f32x4 lg[CBS][NRB_SEM];
     {
       f32x4 acc1[CBS][4];
 #pragma unroll
@@ -283,6 +288,49 @@ k_composite(CmpArgs a) {
 #pragma unroll
           for (int cb = 0; cb < CBS; ++cb)
             lg[cb][rb] = mfma16(wa, hid[cb][ks], lg[cb][rb]);
+        }
+      }
+    }
+
+    } else {
+      // fp16 option: 24 MFMAs (16x16x32) per column block instead of 160
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        float sh[4];
+        const float* dd = a.rays_d + (size_t)eray[cb] * 3;
+        sh4_select(dd[0], dd[1], dd[2], g, sh);
+        half8 b1, bs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          b1[r] = (_Float16)sh[r];
+          b1[4 + r] = (_Float16)geo[cb][r];
+          bs[r] = (_Float16)geo[cb][r];
+          bs[4 + r] = (_Float16)0.f;
+        }
+        f32x4 a1[4], a2[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
+        half8 h0 = chain_relu_h(a1[0], a1[1]), h1 = chain_relu_h(a1[2], a1[3]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
+          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2[rb]);
+        }
+        h0 = chain_relu_h(a2[0], a2[1]);
+        h1 = chain_relu_h(a2[2], a2[3]);
+        f32x4 o3 = mfma_h(frag_h(w_color, 12, lane), h0, z4);
+        o3 = mfma_h(frag_h(w_color, 13, lane), h1, o3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + expf(-o3[c]));
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
+        h0 = chain_relu_h(a1[0], a1[1]);
+        h1 = chain_relu_h(a1[2], a1[3]);
+#pragma unroll
+        for (int rb = 0; rb < NRB_SEM; ++rb) {
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[cb][rb]);
         }
       }
     }
@@ -486,8 +534,8 @@ k_composite(CmpArgs a) {
 
 static inline uint32_t cmp_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
 
-extern "C" int32_t ucsa_composite_fwd(
-    const float* rays_d, const float* norms, const float* z_c,
+static int32_t composite_launch(
+    bool half, const float* rays_d, const float* norms, const float* z_c,
     const float* sigma_c, const float* h_c, const float* z_f,
     const float* sigma_f, const float* h_f, const float* packed_color,
     const float* packed_sem, uint32_t N, uint32_t T, uint32_t t,
@@ -507,14 +555,15 @@ extern "C" int32_t ucsa_composite_fwd(
   const uint32_t nrb = cmp_pad16(n_classes) / 16;
   uint32_t cstride = 3 + n_classes;
   if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
-  const size_t w_floats = 7168 + 1024 + (size_t)nrb * 1024;
+  const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
+                               : 7168 + 1024 + (size_t)nrb * 1024;
   const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 16 * CMP_CBS) + 16 * cstride + 64;
-  // as many waves per workgroup as fit in ~150 KiB of LDS (one WG per CU)
+  // as many waves per workgroup as fit in LDS (one workgroup per CU)
   uint32_t waves = CMP_MAX_WAVES;
   while (waves > 1 && (w_floats + waves * per_wave) * 4 > 158 * 1024) --waves;
   const size_t smem = (w_floats + waves * per_wave) * 4;
   UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
-  // rays per wave: spread over the chip, but at least 4 so the 64-entry
+  // rays per wave: spread over the chip, but at least 4 so the survivor
   // groups stay dense across ray boundaries
   const uint64_t total_waves = 256ull * waves;
   uint32_t rpw = (uint32_t)((N + total_waves - 1) / total_waves);
@@ -525,23 +574,58 @@ extern "C" int32_t ucsa_composite_fwd(
             packed_color, packed_sem, N, T, t, n_classes, density_scale,
             image, depth, semantics, src, weights, rpw, cstride};
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(NRB)                                                           \
+#define LAUNCH(NRB, H)                                                        \
   do {                                                                        \
     hipError_t e = hipFuncSetAttribute(                                       \
-        reinterpret_cast<const void*>(&k_composite<NRB, CMP_CBS>),                     \
+        reinterpret_cast<const void*>(&k_composite<NRB, CMP_CBS, H>),         \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e != hipSuccess) return -(int32_t)e;                                  \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL((k_composite<NRB, CMP_CBS>), dim3(blocks), dim3(64 * waves),  \
-                       smem,                                                  \
-                       s, a);                                                 \
+    hipLaunchKernelGGL((k_composite<NRB, CMP_CBS, H>), dim3(blocks),          \
+                       dim3(64 * waves), smem, s, a);                         \
   } while (0)
-  switch (nrb) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    default: LAUNCH(4); break;
+  if (half) {
+    switch (nrb) {
+      case 1: LAUNCH(1, true); break;
+      case 2: LAUNCH(2, true); break;
+      case 3: LAUNCH(3, true); break;
+      default: LAUNCH(4, true); break;
+    }
+  } else {
+    switch (nrb) {
+      case 1: LAUNCH(1, false); break;
+      case 2: LAUNCH(2, false); break;
+      case 3: LAUNCH(3, false); break;
+      default: LAUNCH(4, false); break;
+    }
   }
 #undef LAUNCH
   return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_composite_fwd(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const float* packed_color,
+    const float* packed_sem, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, int32_t* src, float* weights, void* stream) {
+  return composite_launch(false, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+                          h_f, packed_color, packed_sem, N, T, t, n_classes,
+                          density_scale, image, depth, semantics, src, weights,
+                          stream);
+}
+
+extern "C" int32_t ucsa_composite_fwd_f16(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_half,
+    const void* packed_sem_half, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, void* stream) {
+  return composite_launch(true, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+                          h_f, (const float*)packed_color_half,
+                          (const float*)packed_sem_half, N, T, t, n_classes,
+                          density_scale, image, depth, semantics, nullptr,
+                          nullptr, stream);
 }

@@ -1,0 +1,140 @@
+// fp16-MFMA inference option: weight packing and the sigma MLP.
+// (call sites: reference nr4seg/nerf/network_tcnn_semantics.py:48-58,133-139;
+// tiny-cuda-nn itself computes these nets in fp16 with fp32 accumulation.)
+#include "mfma_mlp_f16.h"
+
+__device__ __forceinline__ uint32_t chain_col_h(uint32_t s, uint32_t g,
+                                                uint32_t e) {
+  return 16u * (2u * s + (e >> 2)) + 4u * g + (e & 3u);
+}
+
+__global__ void k_mlp_pack_f16(int kind, const float* __restrict__ params,
+                               _Float16* __restrict__ packed, uint32_t n_total,
+                               uint32_t nrb) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total) return;
+  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u;
+  uint32_t f = idx >> 9;
+  const uint32_t g = l >> 4, i = l & 15u;
+  float v = 0.f;
+  if (kind == UCSA_MLP_SIGMA) {
+    if (f < 4) {  // L1: feature 2*(4q+g)+c, e = 2q+c
+      v = params[(f * 16 + i) * 32 + 2u * (4u * (e >> 1) + g) + (e & 1u)];
+    } else {
+      v = params[64 * 32 + i * 64 + chain_col_h(f - 4, g, e)];
+    }
+  } else if (kind == UCSA_MLP_COLOR) {
+    if (f < 4) {
+      uint32_t col;
+      if (e < 4) col = 4u * g + e;  // SH
+      else { const uint32_t m = 4u * g + (e - 4); col = m == 0 ? 31u : 15u + m; }
+      v = params[(f * 16 + i) * 32 + col];
+    } else if (f < 12) {
+      const uint32_t rb = (f - 4) >> 1, s = (f - 4) & 1u;
+      v = params[64 * 32 + (rb * 16 + i) * 64 + chain_col_h(s, g, e)];
+    } else {
+      v = params[64 * 32 + 64 * 64 + i * 64 + chain_col_h(f - 12, g, e)];
+    }
+  } else {
+    if (f < 4) {
+      if (e < 4) {
+        const uint32_t m = 4u * g + e;
+        v = params[(f * 16 + i) * 16 + (m == 0 ? 15u : m - 1u)];
+      }  // e >= 4: K padding, zero
+    } else {
+      const uint32_t rb = (f - 4) >> 1, s = (f - 4) & 1u;
+      v = params[64 * 16 + (rb * 16 + i) * 64 + chain_col_h(s, g, e)];
+    }
+  }
+  packed[idx] = (_Float16)v;
+}
+
+extern "C" uint32_t ucsa_mlp_pack_f16_halves(int32_t kind, uint32_t n_classes) {
+  const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
+  const uint32_t frags = kind == UCSA_MLP_SIGMA ? SIGMA_H_FRAGS
+                         : kind == UCSA_MLP_COLOR ? COLOR_H_FRAGS
+                                                  : SEM_H_FRAGS(nrb);
+  return frags * 64 * 8;
+}
+
+extern "C" int32_t ucsa_mlp_pack_f16(int32_t kind, const float* params,
+                                     void* packed_half, uint32_t n_classes,
+                                     void* stream) {
+  UCSA_CHECK_ARG(kind >= 0 && kind <= 2, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed_half, 2);
+  UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
+  const uint32_t n_total = ucsa_mlp_pack_f16_halves(kind, n_classes);
+  const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack_f16, dim3(ucsa_div_up(n_total, 256)), dim3(256),
+                     0, (hipStream_t)stream, (int)kind, params,
+                     (_Float16*)packed_half, n_total, nrb);
+  return ucsa_launch_status();
+}
+
+// sigma MLP, fp16 inputs/weights, fp32 accumulate, fp32 outputs.
+// 6 MFMAs per 16 samples: load/store bound, 8 column blocks per iteration.
+#define SIGH_UNROLL 8
+
+__global__ void __launch_bounds__(256)
+k_sigma_mlp_f16(const float2* __restrict__ feat, const void* __restrict__ packed,
+                uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  half8 w1[4], w2[2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) w1[rb] = frag_h(packed, rb, lane);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) w2[s] = frag_h(packed, 4 + s, lane);
+  const uint64_t span = 16 * SIGH_UNROLL;
+  for (uint64_t base = wave * span; base < M; base += nwaves * span) {
+    half8 xin[SIGH_UNROLL];
+#pragma unroll
+    for (int sb = 0; sb < SIGH_UNROLL; ++sb) {
+      uint64_t m = base + sb * 16 + j;
+      if (m >= M) m = M - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 v = feat[(uint64_t)(4 * q + g) * M + m];
+        xin[sb][2 * q] = (_Float16)v.x;
+        xin[sb][2 * q + 1] = (_Float16)v.y;
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < SIGH_UNROLL; ++sb) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 a1[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(w1[rb], xin[sb], z4);
+      f32x4 out = mfma_h(w2[0], chain_relu_h(a1[0], a1[1]), z4);
+      out = mfma_h(w2[1], chain_relu_h(a1[2], a1[3]), out);
+      const uint64_t m = base + sb * 16 + j;
+      if (m < M) {
+        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out;
+        if (g == 0) sigma[m] = expf(out[0]);
+      }
+    }
+  }
+}
+
+extern "C" int32_t ucsa_sigma_mlp_fwd_f16(const float* feat,
+                                          const void* packed_sigma_half,
+                                          uint32_t M, uint32_t n_levels,
+                                          float* h, float* sigma,
+                                          void* stream) {
+  UCSA_CHECK_ARG(feat, 0);
+  UCSA_CHECK_ARG(packed_sigma_half, 1);
+  UCSA_CHECK_ARG(n_levels == 16, 3);
+  UCSA_CHECK_ARG(h && sigma, 4);
+  if (M == 0) return 0;
+  const uint32_t need = ucsa_div_up(M, 16 * SIGH_UNROLL * 4);
+  const uint32_t blocks = need < 2048u ? need : 2048u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp_f16, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)feat, packed_sigma_half,
+                     (uint64_t)M, h, sigma);
+  return ucsa_launch_status();
+}

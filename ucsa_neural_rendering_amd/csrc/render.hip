@@ -85,6 +85,41 @@ extern "C" int32_t ucsa_render_fwd(
   return 0;
 }
 
+extern "C" int32_t ucsa_render_fwd_f16(
+    const ucsa_grid* grid, const float* table, const void* packed_sigma_half,
+    const void* packed_color_half, const void* packed_sem_half,
+    const float* rays_o, const float* rays_d, const float* norms,
+    const float* aabb_host, float min_near, const float* t_rand, const float* u,
+    uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
+    float* image, float* depth, float* semantics, void* ws, void* stream) {
+  UCSA_CHECK_ARG(grid, 0);
+  UCSA_CHECK_ARG(ws, 20);
+  UCSA_CHECK_ARG(t == 0 || u, 11);
+  if (N == 0) return 0;
+  const Ws w = carve(ws, N, T, t, grid->n_levels);
+  UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
+                                   w.nears, w.fars, stream));
+  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
+  UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_c,
+                                     aabb_host, N, T, w.feat, stream));
+  UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * T,
+                                  grid->n_levels, w.h_c, w.sigma_c, stream));
+  if (t > 0) {
+    UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
+                           stream));
+    UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_f,
+                                       aabb_host, N, t, w.feat, stream));
+    UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * t,
+                                    grid->n_levels, w.h_f, w.sigma_f, stream));
+  }
+  UCSA_TRY(ucsa_composite_fwd_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                  w.sigma_f, w.h_f, packed_color_half,
+                                  packed_sem_half, N, T, t, n_classes,
+                                  density_scale, image, depth, semantics,
+                                  stream));
+  return 0;
+}
+
 extern "C" int32_t ucsa_version(void) { return UCSA_VERSION; }
 
 extern "C" const char* ucsa_error_string(int32_t code) {

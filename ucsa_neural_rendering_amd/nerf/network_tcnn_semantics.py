@@ -145,6 +145,23 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             self._packed[name + "_t"] = (key, packed)
         return self._packed[name + "_t"][1]
 
+    def _pack_h(self, name: str, net: FullyFusedMLP):
+        p = net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get(name + "_h")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            packed = ops.mlp_pack_f16(net.kind, p, self.num_semantic_classes,
+                                      out=out)
+            self._packed[name + "_h"] = (key, packed)
+        return self._packed[name + "_h"][1]
+
+    def _field_f16(self):
+        return dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
+                    packed_sigma=self._pack_h("sigma", self.sigma_net),
+                    packed_color=self._pack_h("color", self.color_net),
+                    packed_sem=self._pack_h("sem", self.semantics_net))
+
     def _field(self, transposed: bool = False):
         f = dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
                  packed_sigma=self._pack("sigma", self.sigma_net),

@@ -50,6 +50,10 @@ class SemanticNeRFRenderer(nn.Module):
         # measured on MI355X: no gain (every kernel already fills the chip),
         # so one stream by default
         self.hip_streams = 1
+        # "fp32" (default, the parity path) or "fp16": inference-only option
+        # that evaluates the three MLPs like tiny-cuda-nn does (fp16 weights
+        # and layer inputs, fp32 accumulation); training is always fp32
+        self.precision = "fp32"
         self._side_streams = []
         self._ws = None
         self._aabb_host = {}
@@ -133,7 +137,11 @@ class SemanticNeRFRenderer(nn.Module):
         }
 
     def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):
-        f = self._field()
+        if self.precision not in ("fp32", "fp16"):
+            raise ValueError(f"precision must be fp32 or fp16, got {self.precision}")
+        half = self.precision == "fp16"
+        f = self._field_f16() if half else self._field()
+        render = ops.render_fwd_f16 if half else ops.render_fwd
         N = o.shape[0]
         C = self.num_semantic_classes
         dev = o.device
@@ -158,7 +166,7 @@ class SemanticNeRFRenderer(nn.Module):
         for k, head in enumerate(range(0, N, chunk)):
             tail = min(head + chunk, N)
             with torch.cuda.stream(streams[k % n_str]):
-                ops.render_fwd(
+                render(
                     f["grid"], f["table"], f["packed_sigma"], f["packed_color"],
                     f["packed_sem"], o[head:tail], d[head:tail], nrm[head:tail],
                     aabb, min_near,

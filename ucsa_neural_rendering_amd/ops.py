@@ -199,6 +199,42 @@ def render_fwd(grid: Grid, table, packed_sigma, packed_color, packed_sem,
           "ucsa_render_fwd")
 
 
+# ======================= fp16-MFMA inference option =========================
+def mlp_pack_f16(kind: int, params: torch.Tensor, n_classes: int = 0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    params = _f32(params.detach(), "params")
+    n = int(lib().ucsa_mlp_pack_f16_halves(kind, n_classes))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float16, device=params.device)
+    check(lib().ucsa_mlp_pack_f16(kind, _ptr(params), _ptr(out), n_classes,
+                                  _stream()), "ucsa_mlp_pack_f16")
+    return out
+
+
+def sigma_mlp_fwd_f16(feat, packed_sigma_half):
+    L, M, _ = feat.shape
+    h = torch.empty(M, 16, device=feat.device)
+    sigma = torch.empty(M, device=feat.device)
+    check(lib().ucsa_sigma_mlp_fwd_f16(_ptr(feat), _ptr(packed_sigma_half), M,
+                                       L, _ptr(h), _ptr(sigma), _stream()),
+          "ucsa_sigma_mlp_fwd_f16")
+    return h, sigma
+
+
+def render_fwd_f16(grid: Grid, table, packed_sigma_h, packed_color_h,
+                   packed_sem_h, rays_o, rays_d, norms, aabb, min_near: float,
+                   t_rand, u, T: int, t: int, n_classes: int,
+                   density_scale: float, image, depth, semantics,
+                   ws: torch.Tensor):
+    N = rays_o.shape[0]
+    check(lib().ucsa_render_fwd_f16(
+        C.byref(grid), _ptr(table), _ptr(packed_sigma_h), _ptr(packed_color_h),
+        _ptr(packed_sem_h), _ptr(rays_o), _ptr(rays_d), _ptr(norms), fvec(aabb),
+        float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
+        float(density_scale), _ptr(image), _ptr(depth), _ptr(semantics),
+        _ptr(ws), _stream()), "ucsa_render_fwd_f16")
+
+
 # ============================ training (backward) ===========================
 def mlp_pack_t(kind: int, params: torch.Tensor, n_classes: int = 0,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
