@@ -324,6 +324,93 @@ int32_t ucsa_confusion_matrix(const int64_t* preds, const int64_t* truths,
                               uint64_t n, uint32_t C, int64_t* cm,
                               void* stream);
 
+/* ============ occupancy-grid ray marching ===============
+ * The `_raymarching` functions that are dormant in the reference
+ * (bindings.cpp:8-16, raymarching.h:9-18).  Same argument meaning as the
+ * reference's host functions; at::Tensor -> device pointer.  Where the CUDA
+ * kernels hand out output slots with atomicAdd (arrival order), these use
+ * prefix sums over the ray index: deterministic, and one of the orders the
+ * reference can produce.  density_grid is [C,H,H,H] fp32. */
+
+/* Scratch for ucsa_march_rays_train over N rays. */
+uint64_t ucsa_march_workspace_bytes(uint32_t N);
+
+/* Replaces march_rays_train (reference raymarching.cu:138-307,:490-498;
+ * wrapper raymarching.py:54-163).  xyzs, dirs [M,3], deltas [M,2] (dt, and
+ * t - last_t for depth), rays [N,3] int32 = (ray id, first point, n points);
+ * counter[2] int32 += (points, rays), its old values are the bases.  A ray
+ * whose span would reach M is counted but not written.  perturb != 0 jitters
+ * the start by MIN_STEPSIZE * pcg32(n).next_float(). */
+int32_t ucsa_march_rays_train(const float* rays_o, const float* rays_d,
+                              const float* density_grid, float mean_density,
+                              float bound, float dt_gamma, uint32_t N,
+                              uint32_t C, uint32_t H, uint32_t M,
+                              const float* nears, const float* fars,
+                              float* xyzs, float* dirs, float* deltas,
+                              int32_t* rays, int32_t* counter, uint32_t perturb,
+                              void* workspace, void* stream);
+
+/* Replaces composite_rays_train_forward (reference raymarching.cu:318-394,
+ * :501-509) and, with n_sem > 0, the disabled
+ * composite_rays_train_semantics_forward (raymarching.h:12,
+ * raymarching.py:249-309): local_sem [M,n_sem] is composited with the same
+ * weights into semantics [N,n_sem].  Outputs are indexed by ray id. */
+int32_t ucsa_composite_rays_train_fwd(const float* sigmas, const float* rgbs,
+                                      const float* local_sem,
+                                      const float* deltas, const int32_t* rays,
+                                      uint32_t M, uint32_t N, uint32_t n_sem,
+                                      float* weights_sum, float* depth,
+                                      float* image, float* semantics,
+                                      void* stream);
+
+/* Replaces composite_rays_train_backward (reference raymarching.cu:408-487,
+ * :512-520).  Rows of grad_sigmas / grad_rgbs / grad_local_sem that belong to
+ * no composited ray are left untouched (the caller zero-fills,
+ * raymarching.py:225-226).  The semantic weights are detached, as on the live
+ * path (reference renderer_semantics.py:268-271). */
+int32_t ucsa_composite_rays_train_bwd(
+    const float* grad_weights_sum, const float* grad_image,
+    const float* grad_semantics, const float* sigmas, const float* rgbs,
+    const float* deltas, const int32_t* rays, const float* weights_sum,
+    const float* image, uint32_t M, uint32_t N, uint32_t n_sem,
+    float* grad_sigmas, float* grad_rgbs, float* grad_local_sem, void* stream);
+
+/* Replaces march_rays (reference raymarching.cu:528-634,:637-643; wrapper
+ * raymarching.py:367-449): up to n_step points for each of the first n_alive
+ * entries of rays_alive / rays_t into rows [n*n_step, (n+1)*n_step); rows
+ * past a ray's last point are left untouched (zero-filled by the caller). */
+int32_t ucsa_march_rays(uint32_t n_alive, uint32_t n_step,
+                        const int32_t* rays_alive, const float* rays_t,
+                        const float* rays_o, const float* rays_d, float bound,
+                        float dt_gamma, uint32_t C, uint32_t H,
+                        const float* density_grid, float mean_density,
+                        const float* nears, const float* fars, float* xyzs,
+                        float* dirs, float* deltas, uint32_t perturb,
+                        void* stream);
+
+/* Replaces composite_rays (reference raymarching.cu:647-729,:732-738, unbound
+ * in bindings.cpp; wrapper raymarching.py:455-501) and, with n_sem > 0,
+ * composite_rays_semantics (raymarching.py:507-555).  In place on
+ * weights_sum/depth/image/semantics (by ray id) and rays_t (by slot; -1 marks
+ * a ray that stopped: zero delta, or transmittance below 1e-4). */
+int32_t ucsa_composite_rays(uint32_t n_alive, uint32_t n_step,
+                            const int32_t* rays_alive, float* rays_t,
+                            const float* sigmas, const float* rgbs,
+                            const float* local_sem, const float* deltas,
+                            uint32_t n_sem, float* weights_sum, float* depth,
+                            float* image, float* semantics, void* stream);
+
+/* Scratch for ucsa_compact_rays over n_alive slots. */
+uint64_t ucsa_compact_workspace_bytes(uint32_t n_alive);
+
+/* Replaces compact_rays (reference raymarching.cu:838-864; wrapper
+ * raymarching.py:561-592): slots with rays_t_old >= 0 are copied, in order,
+ * to rays_alive / rays_t starting at alive_counter[0], which is advanced. */
+int32_t ucsa_compact_rays(uint32_t n_alive, int32_t* rays_alive,
+                          const int32_t* rays_alive_old, float* rays_t,
+                          const float* rays_t_old, int32_t* alive_counter,
+                          void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

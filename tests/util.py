@@ -50,3 +50,31 @@ def hip_network_from_oracle(fld, device="cuda"):
 
 def maxabs(a, b):
     return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+# ---- occupancy-grid marching scenes (numpy; shared by CPU and GPU tests) ----
+def march_scene(N, seed, bound=2.0, H=32, fill=0.35, outside=True):
+    """Rays aimed into the box plus a blobby cascade grid [C,H,H,H] with about
+    `fill` of the cells above the density threshold."""
+    import math
+    rs = np.random.RandomState(seed)
+    C = 1 + math.ceil(math.log2(bound))
+    lo = 1.6 if outside else 0.6
+    o = ((rs.rand(N, 3) * 2 - 1) * bound * lo).astype(np.float32)
+    tgt = ((rs.rand(N, 3) * 2 - 1) * bound * 0.5).astype(np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    # low-frequency noise thresholded -> connected occupied blobs
+    coarse = rs.rand(C, H // 4, H // 4, H // 4).astype(np.float32)
+    grid = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3)
+    grid = np.where(grid < fill, grid + 0.5, grid * 0.001).astype(np.float32)
+    return o, d, grid, C
+
+
+def slab_near_far(o, d, bound, min_near=0.2):
+    """numpy slab test with the semantics of oracle.rays.near_far_from_aabb."""
+    from oracle import rays as orays
+    aabb = torch.tensor([-bound] * 3 + [bound] * 3, dtype=torch.float32)
+    n, f = orays.near_far_from_aabb(torch.from_numpy(o), torch.from_numpy(d),
+                                    aabb, min_near)
+    return n.numpy(), f.numpy()

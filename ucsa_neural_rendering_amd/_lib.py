@@ -102,6 +102,23 @@ SIGNATURES = {
     "ucsa_seg_tail": (C.c_int32, [_p, _p, _u32, _u32, _u32, _f, _p, _p, _p, _p,
                                   _p, _p]),
     "ucsa_confusion_matrix": (C.c_int32, [_p, _p, C.c_uint64, _u32, _p, _p]),
+    # ---- occupancy-grid ray marching ----
+    "ucsa_march_workspace_bytes": (C.c_uint64, [_u32]),
+    "ucsa_march_rays_train": (C.c_int32, [_p, _p, _p, _f, _f, _f, _u32, _u32,
+                                          _u32, _u32, _p, _p, _p, _p, _p, _p,
+                                          _p, _u32, _p, _p]),
+    "ucsa_composite_rays_train_fwd": (C.c_int32, [_p, _p, _p, _p, _p, _u32,
+                                                  _u32, _u32, _p, _p, _p, _p,
+                                                  _p]),
+    "ucsa_composite_rays_train_bwd": (C.c_int32, [_p] * 9 + [_u32, _u32, _u32,
+                                                            _p, _p, _p, _p]),
+    "ucsa_march_rays": (C.c_int32, [_u32, _u32, _p, _p, _p, _p, _f, _f, _u32,
+                                    _u32, _p, _f, _p, _p, _p, _p, _p, _u32,
+                                    _p]),
+    "ucsa_composite_rays": (C.c_int32, [_u32, _u32, _p, _p, _p, _p, _p, _p,
+                                        _u32, _p, _p, _p, _p, _p]),
+    "ucsa_compact_workspace_bytes": (C.c_uint64, [_u32]),
+    "ucsa_compact_rays": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

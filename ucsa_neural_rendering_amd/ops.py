@@ -408,3 +408,133 @@ def confusion_matrix(preds, truths, n_classes: int, cm=None):
                                       _ptr(cm), _stream()),
           "ucsa_confusion_matrix")
     return cm
+
+
+# ---------------------------------------------------------------------------
+# occupancy-grid ray marching
+# ---------------------------------------------------------------------------
+def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.UcsaError(
+            f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise _lib.UcsaError(f"{name} must be a contiguous int32 tensor")
+    return t
+
+
+def _inplace_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.UcsaError(
+            f"{name} is updated in place: contiguous fp32 on the GPU required")
+    return t
+
+
+_march_ws = {}
+
+
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _march_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8,
+                          device=device)
+        _march_ws[key] = buf
+    return buf
+
+
+def march_rays_train(rays_o, rays_d, density_grid, mean_density: float,
+                     bound: float, dt_gamma: float, M: int, nears, fars, xyzs,
+                     dirs, deltas, rays, counter, perturb: int):
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    grid = _f32(density_grid, "density_grid")
+    N, Cc, H = rays_o.shape[0], grid.shape[0], grid.shape[1]
+    ws = _scratch(int(lib().ucsa_march_workspace_bytes(N)), rays_o.device)
+    check(lib().ucsa_march_rays_train(
+        _ptr(rays_o), _ptr(rays_d), _ptr(grid), mean_density, bound, dt_gamma,
+        N, Cc, H, M, _ptr(_f32(nears, "nears")), _ptr(_f32(fars, "fars")),
+        _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(_i32(rays, "rays")),
+        _ptr(_i32(counter, "step_counter")), int(perturb), _ptr(ws),
+        _stream()), "ucsa_march_rays_train")
+
+
+def composite_rays_train_fwd(sigmas, rgbs, local_sem, deltas, rays):
+    sigmas = _f32(sigmas, "sigmas").view(-1)
+    M, N = sigmas.shape[0], rays.shape[0]
+    rgbs = _f32(rgbs, "rgbs").view(M, 3)
+    deltas = _f32(deltas, "deltas").view(M, 2)
+    dev = sigmas.device
+    n_sem = 0
+    if local_sem is not None:
+        local_sem = _f32(local_sem, "local_semantics").view(M, -1)
+        n_sem = local_sem.shape[1]
+    ws = torch.empty(N, device=dev)
+    depth = torch.empty(N, device=dev)
+    image = torch.empty(N, 3, device=dev)
+    sem = torch.empty(N, n_sem, device=dev) if n_sem else None
+    check(lib().ucsa_composite_rays_train_fwd(
+        _ptr(sigmas), _ptr(rgbs), _ptr(local_sem), _ptr(deltas),
+        _ptr(_i32(rays, "rays")), M, N, n_sem, _ptr(ws), _ptr(depth),
+        _ptr(image), _ptr(sem), _stream()), "ucsa_composite_rays_train_fwd")
+    return ws, depth, image, sem
+
+
+def composite_rays_train_bwd(grad_ws, grad_image, grad_sem, sigmas, rgbs,
+                             deltas, rays, weights_sum, image):
+    M, N = sigmas.shape[0], rays.shape[0]
+    dev = sigmas.device
+    n_sem = 0 if grad_sem is None else grad_sem.shape[1]
+    g_sig = torch.zeros(M, device=dev)
+    g_rgb = torch.zeros(M, 3, device=dev)
+    g_ls = torch.zeros(M, n_sem, device=dev) if n_sem else None
+    check(lib().ucsa_composite_rays_train_bwd(
+        _ptr(_f32(grad_ws, "grad_weights_sum")),
+        _ptr(_f32(grad_image, "grad_image")),
+        _ptr(None if grad_sem is None else _f32(grad_sem, "grad_semantics")),
+        _ptr(sigmas), _ptr(rgbs), _ptr(deltas), _ptr(rays), _ptr(weights_sum),
+        _ptr(image), M, N, n_sem, _ptr(g_sig), _ptr(g_rgb), _ptr(g_ls),
+        _stream()), "ucsa_composite_rays_train_bwd")
+    return g_sig, g_rgb, g_ls
+
+
+def march_rays(n_alive: int, n_step: int, rays_alive, rays_t, rays_o, rays_d,
+               bound: float, dt_gamma: float, density_grid, mean_density: float,
+               nears, fars, xyzs, dirs, deltas, perturb: int):
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    grid = _f32(density_grid, "density_grid")
+    check(lib().ucsa_march_rays(
+        n_alive, n_step, _ptr(_i32(rays_alive, "rays_alive")),
+        _ptr(_f32(rays_t, "rays_t")), _ptr(rays_o), _ptr(rays_d), bound,
+        dt_gamma, grid.shape[0], grid.shape[1], _ptr(grid), mean_density,
+        _ptr(_f32(nears, "nears")), _ptr(_f32(fars, "fars")), _ptr(xyzs),
+        _ptr(dirs), _ptr(deltas), int(perturb), _stream()), "ucsa_march_rays")
+
+
+def composite_rays(n_alive: int, n_step: int, rays_alive, rays_t, sigmas, rgbs,
+                   local_sem, deltas, weights_sum, depth, image, semantics):
+    n_sem = 0
+    if local_sem is not None:
+        local_sem = _f32(local_sem, "local_semantics")
+        n_sem = local_sem.shape[-1]
+        _inplace_f32(semantics, "semantics")
+    check(lib().ucsa_composite_rays(
+        n_alive, n_step, _ptr(_i32(rays_alive, "rays_alive")),
+        _ptr(_inplace_f32(rays_t, "rays_t")), _ptr(_f32(sigmas, "sigmas")),
+        _ptr(_f32(rgbs, "rgbs")), _ptr(local_sem), _ptr(_f32(deltas, "deltas")),
+        n_sem, _ptr(_inplace_f32(weights_sum, "weights_sum")),
+        _ptr(_inplace_f32(depth, "depth")), _ptr(_inplace_f32(image, "image")),
+        _ptr(semantics), _stream()), "ucsa_composite_rays")
+
+
+def compact_rays(n_alive: int, rays_alive, rays_alive_old, rays_t, rays_t_old,
+                 alive_counter):
+    ws = _scratch(int(lib().ucsa_compact_workspace_bytes(n_alive)),
+                  rays_t.device)
+    check(lib().ucsa_compact_rays(
+        n_alive, _ptr(_i32(rays_alive, "rays_alive")),
+        _ptr(_i32(rays_alive_old, "rays_alive_old")),
+        _ptr(_inplace_f32(rays_t, "rays_t")),
+        _ptr(_f32(rays_t_old, "rays_t_old")),
+        _ptr(_i32(alive_counter, "alive_counter")), _ptr(ws), _stream()),
+        "ucsa_compact_rays")
