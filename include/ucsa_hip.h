@@ -186,6 +186,16 @@ int32_t ucsa_point_shade(const float* dirs, const float* geo_feat,
                          uint32_t n_classes, float* rgb, float* probs,
                          void* stream);
 
+/* Same, reading the geometry features from the raw sigma-MLP rows h [M,16]
+ * (ucsa_sigma_mlp_fwd; slot 0, the log-density, is skipped) so that
+ * network.forward(x, d) (reference network_tcnn_semantics.py:102-128) needs
+ * no repacking between density() and color()/semantics(). */
+int32_t ucsa_point_shade_h(const float* dirs, const float* h,
+                           const uint8_t* mask, const float* packed_color,
+                           const float* packed_sem, uint32_t M,
+                           uint32_t n_classes, float* rgb, float* probs,
+                           void* stream);
+
 /* ======================= fp16-MFMA inference option ======================== */
 /* tiny-cuda-nn evaluates the three MLPs with fp16 weights / layer inputs and
  * fp32 accumulation; the entry points below do the same (16x16x32 f16 MFMA)
@@ -410,6 +420,86 @@ int32_t ucsa_compact_rays(uint32_t n_alive, int32_t* rays_alive,
                           const int32_t* rays_alive_old, float* rays_t,
                           const float* rays_t_old, int32_t* alive_counter,
                           void* workspace, void* stream);
+
+/* ---- density-grid maintenance -----------------------------------------------
+ * No counterpart in the reference's FFI: the reference keeps the state
+ * (density_grid [cascade,128,128,128], mean_density, iter_density:
+ * renderer_semantics.py:91-103,111-121) that march_rays* read, but ships no
+ * code that fills it.  These two entries do, for cuda_ray=True. */
+
+/* One point per cell of cascade `cascade` of an [H,H,H] grid over
+ * [-b,b]^3, b = min(2^cascade, bound): the cell centre plus, when seed != 0, a
+ * pcg32(cell, seed) jitter inside the cell.  xyz [H^3,3], cell order
+ * x*H*H + y*H + z (the marcher's lookup order, raymarching.cu:204). */
+int32_t ucsa_density_grid_points(uint32_t cascade, uint32_t H, float bound,
+                                 uint32_t seed, float* xyz, void* stream);
+
+uint64_t ucsa_density_grid_workspace_bytes(void);
+
+/* density_grid[i] = max(density_grid[i]*decay, fresh[i]*fresh_scale) where
+ * both are >= 0 (negative marks "never update"); *mean_density (device) =
+ * mean(max(density_grid, 0)).  n = cascade*H^3. */
+int32_t ucsa_density_grid_update(float* density_grid, const float* fresh,
+                                 uint64_t n, float decay, float fresh_scale,
+                                 float* mean_density, void* workspace,
+                                 void* stream);
+
+/* ---- segmented marching: the inference loop without per-step host round trips
+ * No counterpart in the reference's FFI.  The reference API above pads every
+ * alive ray to n_step rows and needs the survivor count on the host after
+ * every iteration; these entries march up to `cap` samples per alive ray into
+ * an exact-size buffer, composite them with the same early-termination rule
+ * (raymarching.cu:693-706) one wave per ray, and keep the alive count in
+ * device memory.  n_cap = host upper bound of the alive count (launch size);
+ * n_alive_dev = device int32 holding the actual count, or NULL (= n_cap).
+ * Slot n of rays_alive / rays_t / span is alive ray n of this round. */
+uint64_t ucsa_march_segment_workspace_bytes(uint32_t n_cap);
+
+/* Count the samples of each alive ray (<= cap) from rays_t[n] on;
+ * span[n] = (first point, count) int32 [n_cap,2]; workspace uint32[0] = total
+ * points, [1] = alive count used (device; read them back to size the point
+ * buffers).  perturb != 0 jitters the start by MIN_STEPSIZE*pcg32(ray,
+ * perturb) -- pass it in the first round only, and to _write as well. */
+int32_t ucsa_march_segment_count(uint32_t n_cap, const int32_t* n_alive_dev,
+                                 uint32_t cap, const int32_t* rays_alive,
+                                 const float* rays_t, const float* rays_o,
+                                 const float* rays_d, float bound,
+                                 float dt_gamma, uint32_t C, uint32_t H,
+                                 const float* density_grid, float mean_density,
+                                 const float* fars, uint32_t perturb,
+                                 int32_t* span, void* workspace, void* stream);
+
+/* Write the counted samples: xyzs, dirs [M,3], deltas [M,2] as march_rays. */
+int32_t ucsa_march_segment_write(uint32_t n_cap, const int32_t* n_alive_dev,
+                                 const int32_t* rays_alive, const float* rays_t,
+                                 const float* rays_o, const float* rays_d,
+                                 float bound, float dt_gamma, uint32_t C,
+                                 uint32_t H, const float* density_grid,
+                                 float mean_density, const float* fars,
+                                 uint32_t perturb, const int32_t* span,
+                                 float* xyzs, float* dirs, float* deltas,
+                                 void* stream);
+
+/* Composite each slot's span onto weights_sum/depth/image/semantics (by ray
+ * id, accumulated in place; sigma is multiplied by sigma_scale) and set
+ * rays_t[n] = -1 if the ray is finished (transmittance fell below 1e-4, or the
+ * span is shorter than cap), else the ray parameter after its last sample. */
+int32_t ucsa_march_segment_composite(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* sigmas, float sigma_scale, const float* rgbs,
+    const float* local_sem, const float* deltas, uint32_t n_sem,
+    float* weights_sum, float* depth, float* image, float* semantics,
+    void* stream);
+
+/* Stable compaction of the slots with rays_t_old >= 0 into rays_alive/rays_t;
+ * n_alive_out[0] (device, != n_alive_dev) = number of survivors. */
+int32_t ucsa_march_segment_compact(uint32_t n_cap, const int32_t* n_alive_dev,
+                                   int32_t* rays_alive,
+                                   const int32_t* rays_alive_old, float* rays_t,
+                                   const float* rays_t_old,
+                                   int32_t* n_alive_out, void* workspace,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

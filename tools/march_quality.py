@@ -1,0 +1,85 @@
+"""Quality gate + timing of the occupancy-grid marching render (SURVEY 8f rank
+1) against the live uniform+PDF path, on the synthetic room.
+
+  python tools/march_quality.py [pretrain_steps] [H W]
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from ucsa_neural_rendering_amd import ops  # noqa: E402
+from ucsa_neural_rendering_amd.utils.metrics import SemanticsMeter  # noqa: E402
+
+
+def psnr(a, b):
+    return float(-10 * torch.log10(((a - b) ** 2).mean()))
+
+
+def timed(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = fn()
+    torch.cuda.synchronize()
+    return out, (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    dev = torch.device("cuda:0")
+    net, ds = bench.build_field(dev, train_steps=steps, cuda_ray=True)
+    net.eval()
+    res = {"pretrain_steps": steps}
+    t0 = time.perf_counter()
+    net.update_extra_state()
+    torch.cuda.synchronize()
+    res["grid_update_ms"] = (time.perf_counter() - t0) * 1e3
+    _, res["grid_update_ms_warm"] = timed(lambda: net.update_extra_state(), 3)
+    g = net.density_grid
+    thr = min(0.01, net.mean_density)
+    res["mean_density"] = net.mean_density
+    res["occupied_frac"] = [float((g[c] > thr).float().mean()) for c in range(g.shape[0])]
+    views = [3, 7, 12]
+    for name, fn in (
+        ("run_256+256", lambda o, d, n: net.run(o, d, n, num_steps=256, upsample_steps=256)),
+        ("run_96+96", lambda o, d, n: net.run(o, d, n, num_steps=96, upsample_steps=96)),
+        ("march_ref_loop", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, schedule="reference")),
+        ("march_seg_nodtg", lambda o, d, n: net.run_cuda(o, d, n)),
+        ("march_seg", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128)),
+        ("march_seg_16_64", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, march_caps=(16, 64, 1024))),
+        ("march_seg_one", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, march_caps=(1024,))),
+        ("march_seg_open", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, far_closure=False)),
+    ):
+        meter = SemanticsMeter(bench.N_CLASSES)
+        ps, ms, derr = [], [], []
+        for v in views:
+            item = ds[v]
+            o, d, n = item["rays_o"][None], item["rays_d"][None], item["direction_norms"][None]
+            out, t = timed(lambda: fn(o, d, n), 3)
+            gt = item["img"].reshape(3, -1).t()
+            ps.append(psnr(out["image"][0], gt))
+            pred = out["semantics"][0].argmax(-1)
+            meter.update(pred.cpu(), item["label"].reshape(-1).cpu())
+            gd = item["depth"].float().reshape(-1)
+            derr.append(float((out["depth"][0] - gd).abs().mean()))
+            ms.append(t)
+        miou, acc, _ = meter.measure()
+        res[name] = {"psnr": sum(ps) / len(ps), "miou": float(miou),
+                     "acc": float(acc), "depth_l1": sum(derr) / len(derr),
+                     "ms_per_view": sum(ms) / len(ms),
+                     "rays_per_s": o.shape[1] / (sum(ms) / len(ms)) * 1e3}
+        if name.startswith("march"):
+            res[name]["points_per_ray"] = net.last_march_points / o.shape[1]
+            res[name]["rounds"] = net.last_march_rounds
+    for k, v in res.items():
+        print(k, json.dumps(v))
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,8 @@ SIGNATURES = {
                                     _u32, _u32, _f, _p, _p, _p, _p, _p]),
     "ucsa_point_shade": (C.c_int32, [_p, _p, _p, _p, _p, _u32, _u32, _p, _p,
                                      _p]),
+    "ucsa_point_shade_h": (C.c_int32, [_p, _p, _p, _p, _p, _u32, _u32, _p, _p,
+                                       _p]),
     # ---- fp16-MFMA inference option ----
     "ucsa_mlp_pack_f16_halves": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_f16": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
@@ -119,6 +121,22 @@ SIGNATURES = {
                                         _u32, _p, _p, _p, _p, _p]),
     "ucsa_compact_workspace_bytes": (C.c_uint64, [_u32]),
     "ucsa_compact_rays": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p, _p]),
+    "ucsa_march_segment_workspace_bytes": (C.c_uint64, [_u32]),
+    "ucsa_march_segment_count": (C.c_int32, [_u32, _p, _u32, _p, _p, _p, _p,
+                                             _f, _f, _u32, _u32, _p, _f, _p,
+                                             _u32, _p, _p, _p]),
+    "ucsa_march_segment_write": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _f, _f,
+                                             _u32, _u32, _p, _f, _p, _u32, _p,
+                                             _p, _p, _p, _p]),
+    "ucsa_march_segment_composite": (C.c_int32, [_u32, _p, _u32, _p, _p, _p,
+                                                 _p, _f, _p, _p, _p, _u32, _p,
+                                                 _p, _p, _p, _p]),
+    "ucsa_march_segment_compact": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p,
+                                               _p, _p]),
+    "ucsa_density_grid_points": (C.c_int32, [_u32, _u32, _f, _u32, _p, _p]),
+    "ucsa_density_grid_workspace_bytes": (C.c_uint64, []),
+    "ucsa_density_grid_update": (C.c_int32, [_p, _p, C.c_uint64, _f, _f, _p,
+                                             _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -46,7 +46,8 @@ k_point_shade(const float* __restrict__ dirs, const float* __restrict__ geo,
               const uint8_t* __restrict__ mask,
               const float* __restrict__ packed_color,
               const float* __restrict__ packed_sem, uint32_t M, uint32_t C,
-              float* __restrict__ rgb, float* __restrict__ probs) {
+              uint32_t geo_stride, float* __restrict__ rgb,
+              float* __restrict__ probs) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
   float* w_color = ps_smem;
@@ -64,7 +65,9 @@ k_point_shade(const float* __restrict__ dirs, const float* __restrict__ geo,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint32_t slot = 4 * g + r;  // slot 0 = the "ones" pad column
-      gf[r] = slot == 0 ? 1.0f : geo[(size_t)m * 15 + (slot - 1)];
+      // geo_stride 15: geo_feat rows; 16: raw sigma-MLP rows h (slot 0 of h
+      // is the log-density, which the pad column replaces)
+      gf[r] = slot == 0 ? 1.0f : geo[(size_t)m * geo_stride + (geo_stride - 15) + (slot - 1)];
     }
     float out_rgb[3] = {0.f, 0.f, 0.f};
     if (rgb) {
@@ -125,12 +128,12 @@ k_point_shade(const float* __restrict__ dirs, const float* __restrict__ geo,
   }
 }
 
-extern "C" int32_t ucsa_point_shade(const float* dirs, const float* geo_feat,
-                                    const uint8_t* mask,
-                                    const float* packed_color,
-                                    const float* packed_sem, uint32_t M,
-                                    uint32_t n_classes, float* rgb,
-                                    float* probs, void* stream) {
+static int32_t point_shade_launch(const float* dirs, const float* geo_feat,
+                                  uint32_t geo_stride, const uint8_t* mask,
+                                  const float* packed_color,
+                                  const float* packed_sem, uint32_t M,
+                                  uint32_t n_classes, float* rgb, float* probs,
+                                  void* stream) {
   UCSA_CHECK_ARG(geo_feat, 1);
   UCSA_CHECK_ARG(!rgb || dirs, 0);
   UCSA_CHECK_ARG(packed_color && packed_sem, 3);
@@ -144,10 +147,30 @@ extern "C" int32_t ucsa_point_shade(const float* dirs, const float* geo_feat,
   hipStream_t s = (hipStream_t)stream;
   UCSA_CLEAR_ERR();
   switch (nrb) {
-    case 1: hipLaunchKernelGGL(k_point_shade<1>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, rgb, probs); break;
-    case 2: hipLaunchKernelGGL(k_point_shade<2>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, rgb, probs); break;
-    case 3: hipLaunchKernelGGL(k_point_shade<3>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, rgb, probs); break;
-    default: hipLaunchKernelGGL(k_point_shade<4>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, rgb, probs); break;
+    case 1: hipLaunchKernelGGL(k_point_shade<1>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, geo_stride, rgb, probs); break;
+    case 2: hipLaunchKernelGGL(k_point_shade<2>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, geo_stride, rgb, probs); break;
+    case 3: hipLaunchKernelGGL(k_point_shade<3>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, geo_stride, rgb, probs); break;
+    default: hipLaunchKernelGGL(k_point_shade<4>, dim3(blocks), dim3(256), smem, s, dirs, geo_feat, mask, packed_color, packed_sem, M, n_classes, geo_stride, rgb, probs); break;
   }
   return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_point_shade(const float* dirs, const float* geo_feat,
+                                    const uint8_t* mask,
+                                    const float* packed_color,
+                                    const float* packed_sem, uint32_t M,
+                                    uint32_t n_classes, float* rgb,
+                                    float* probs, void* stream) {
+  return point_shade_launch(dirs, geo_feat, 15, mask, packed_color, packed_sem,
+                            M, n_classes, rgb, probs, stream);
+}
+
+extern "C" int32_t ucsa_point_shade_h(const float* dirs, const float* h,
+                                      const uint8_t* mask,
+                                      const float* packed_color,
+                                      const float* packed_sem, uint32_t M,
+                                      uint32_t n_classes, float* rgb,
+                                      float* probs, void* stream) {
+  return point_shade_launch(dirs, h, 16, mask, packed_color, packed_sem, M,
+                            n_classes, rgb, probs, stream);
 }

@@ -775,3 +775,476 @@ extern "C" int32_t ucsa_compact_rays(uint32_t n_alive, int32_t* rays_alive,
                      alive_counter, ws);
   return ucsa_launch_status();
 }
+
+// ===========================================================================
+// Density-grid maintenance.  The reference keeps the state (density_grid
+// [cascade,128,128,128], mean_density, iter_density:
+// renderer_semantics.py:91-103,111-121) but ships no updater -- its parent
+// code base refreshed the grid from the field before each epoch.  These two
+// kernels fill that gap for cuda_ray=True:
+//   cell_points : one jittered point per cell of one cascade (the cell the
+//                 marcher's lookup maps that point back to, see probe());
+//   ema_update  : grid = max(grid * decay, fresh) where both are >= 0, and the
+//                 mean of max(grid, 0) (deterministic block partials).
+// ===========================================================================
+__global__ void __launch_bounds__(RM_BLOCK)
+k_grid_cell_points(uint32_t cas, uint32_t H, float bound, uint32_t seed,
+                   float* __restrict__ xyz) {
+  const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+  const uint32_t n = H * H * H;
+  if (i >= n) return;
+  const uint32_t ix = i / (H * H), iy = (i / H) % H, iz = i % H;
+  const float b = fminf(exp2f((float)cas), bound);
+  const float half_cell = b / (float)H;
+  float jx = 0.f, jy = 0.f, jz = 0.f;
+  if (seed) {
+    Pcg32 rng((uint64_t)cas * n + i, (uint64_t)seed);
+    jx = rng.next_float() * 2 - 1;
+    jy = rng.next_float() * 2 - 1;
+    jz = rng.next_float() * 2 - 1;
+  }
+  xyz[(size_t)i * 3] = b * ((2 * ix + 1) / (float)H - 1) + jx * half_cell;
+  xyz[(size_t)i * 3 + 1] = b * ((2 * iy + 1) / (float)H - 1) + jy * half_cell;
+  xyz[(size_t)i * 3 + 2] = b * ((2 * iz + 1) / (float)H - 1) + jz * half_cell;
+}
+
+extern "C" int32_t ucsa_density_grid_points(uint32_t cascade, uint32_t H,
+                                            float bound, uint32_t seed,
+                                            float* xyz, void* stream) {
+  UCSA_CHECK_ARG(cascade < 32, 0);
+  UCSA_CHECK_ARG(H >= 2 && H <= 1024, 1);
+  UCSA_CHECK_ARG(bound > 0.f, 2);
+  UCSA_CHECK_ARG(xyz, 4);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_grid_cell_points, dim3(ucsa_div_up((uint64_t)H * H * H, RM_BLOCK)),
+                     dim3(RM_BLOCK), 0, (hipStream_t)stream, cascade, H, bound,
+                     seed, xyz);
+  return ucsa_launch_status();
+}
+
+#define EMA_BLOCKS 1024
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_grid_ema(float* __restrict__ grid, const float* __restrict__ fresh,
+           uint64_t n, float decay, float fresh_scale,
+           float* __restrict__ partial) {
+  __shared__ float sm[RM_BLOCK / 64];
+  float acc = 0.f;
+  for (uint64_t i = (uint64_t)blockIdx.x * RM_BLOCK + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * RM_BLOCK) {
+    float g = grid[i];
+    const float f = fresh[i] * fresh_scale;
+    if (g >= 0.f && f >= 0.f) {
+      g = fmaxf(g * decay, f);
+      grid[i] = g;
+    }
+    acc += fmaxf(g, 0.f);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63u) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < RM_BLOCK / 64; ++w) s += sm[w];
+    partial[blockIdx.x] = s;
+  }
+}
+
+__global__ void k_grid_mean(const float* __restrict__ partial, uint32_t nb,
+                            uint64_t n, float* __restrict__ mean) {
+  if (threadIdx.x || blockIdx.x) return;
+  double s = 0.0;
+  for (uint32_t b = 0; b < nb; ++b) s += (double)partial[b];
+  mean[0] = (float)(s / (double)n);
+}
+
+extern "C" uint64_t ucsa_density_grid_workspace_bytes(void) {
+  return 4ull * EMA_BLOCKS;
+}
+
+extern "C" int32_t ucsa_density_grid_update(float* density_grid,
+                                            const float* fresh, uint64_t n,
+                                            float decay, float fresh_scale,
+                                            float* mean_density,
+                                            void* workspace, void* stream) {
+  UCSA_CHECK_ARG(density_grid, 0);
+  UCSA_CHECK_ARG(fresh, 1);
+  UCSA_CHECK_ARG(n > 0, 2);
+  UCSA_CHECK_ARG(mean_density, 5);
+  UCSA_CHECK_ARG(workspace, 6);
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t nb = (uint32_t)(n / RM_BLOCK + 1 < EMA_BLOCKS ? n / RM_BLOCK + 1
+                                                              : EMA_BLOCKS);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_grid_ema, dim3(nb), dim3(RM_BLOCK), 0, s, density_grid,
+                     fresh, n, decay, fresh_scale, (float*)workspace);
+  hipLaunchKernelGGL(k_grid_mean, dim3(1), dim3(64), 0, s,
+                     (const float*)workspace, nb, n, mean_density);
+  return ucsa_launch_status();
+}
+
+// ===========================================================================
+// Segmented marching: the MI355X-native driver of the inference loop.
+//
+// The reference API above marches `n_step` samples for every alive ray into a
+// zero-padded [n_alive*n_step] buffer, evaluates the field on all of it and
+// asks the host for the survivor count after every iteration.  Here a round
+// marches up to `cap` samples per alive ray into an EXACT-SIZE buffer (count
+// -> prefix sums -> write, as in march_rays_train), the field runs once on
+// those points, and one wave per ray composites its span with the reference's
+// early-termination rule (stop after the first sample whose incoming
+// transmittance is below 1e-4, raymarching.cu:693-706).  A few rounds with
+// growing caps replace ~100 host-synchronised iterations; the samples a ray
+// takes, and therefore the result, are the same up to fp32 re-association.
+//
+// The alive count of a round lives in device memory (`n_alive_dev`); launches
+// are sized by the host's upper bound `n_cap` and surplus lanes exit.
+// workspace (uint32): [0] total points, [1] n_alive seen, [2..3] pad,
+//                     [4 .. 4+nb) block sums.   span[n] = (first point, count)
+// ===========================================================================
+__device__ __forceinline__ uint32_t seg_n_alive(const int32_t* n_alive_dev,
+                                                uint32_t n_cap) {
+  if (!n_alive_dev) return n_cap;
+  const uint32_t n = (uint32_t)n_alive_dev[0];
+  return n < n_cap ? n : n_cap;
+}
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_seg_count(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+            uint32_t cap, const int32_t* __restrict__ rays_alive,
+            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+            const float* __restrict__ rays_d, float bound, float dt_gamma,
+            uint32_t C, uint32_t H, const float* __restrict__ grid,
+            float mean_density, const float* __restrict__ fars,
+            uint32_t perturb, int32_t* __restrict__ span,
+            uint32_t* __restrict__ ws) {
+  __shared__ uint32_t sm[16];
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+  uint32_t steps = 0;
+  if (n < n_alive) {
+    const uint32_t index = (uint32_t)rays_alive[n];
+    const float far = fars[index];
+    Marcher m(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid,
+              mean_density, bound, dt_gamma, C, H, far);
+    float t = rays_t[n];
+    if (perturb) {
+      Pcg32 rng((uint64_t)index, (uint64_t)perturb);
+      t += RM_MIN_STEPSIZE * rng.next_float();
+    }
+    float x, y, z;
+    while (t < far && steps < cap) {
+      if (m.probe(t, x, y, z)) {
+        ++steps;
+        t += m.step_size(t);
+      }
+    }
+    span[2 * n + 1] = (int32_t)steps;
+  }
+  uint32_t total;
+  block_excl_scan(steps, sm, &total);
+  if (threadIdx.x == 0) ws[4 + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_seg_offsets(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+              int32_t* __restrict__ span, uint32_t* __restrict__ ws) {
+  __shared__ uint32_t sm[16];
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+  const uint32_t steps = n < n_alive ? (uint32_t)span[2 * n + 1] : 0u;
+  const uint32_t before = prefix_of_blocks(ws + 4, blockIdx.x, sm);
+  uint32_t total;
+  const uint32_t in_block = block_excl_scan(steps, sm, &total);
+  if (n < n_alive) span[2 * n] = (int32_t)(before + in_block);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    ws[0] = before + total;
+    ws[1] = n_alive;
+  }
+}
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_seg_write(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+            const int32_t* __restrict__ rays_alive,
+            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+            const float* __restrict__ rays_d, float bound, float dt_gamma,
+            uint32_t C, uint32_t H, const float* __restrict__ grid,
+            float mean_density, const float* __restrict__ fars,
+            uint32_t perturb, const int32_t* __restrict__ span,
+            float* __restrict__ xyzs, float* __restrict__ dirs,
+            float* __restrict__ deltas) {
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+  if (n >= n_alive) return;
+  const uint32_t count = (uint32_t)span[2 * n + 1];
+  if (count == 0) return;
+  const uint32_t index = (uint32_t)rays_alive[n];
+  const float far = fars[index];
+  Marcher m(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid,
+            mean_density, bound, dt_gamma, C, H, far);
+  float t = rays_t[n];
+  // the depth deltas are measured from the slot's incoming t (like
+  // kernel_march_rays :549,:577): the jitter is part of the first delta
+  float last_t = t;
+  if (perturb) {
+    Pcg32 rng((uint64_t)index, (uint64_t)perturb);
+    t += RM_MIN_STEPSIZE * rng.next_float();
+  }
+  const size_t p0 = (size_t)(uint32_t)span[2 * n];
+  float* px = xyzs + p0 * 3;
+  float* pd = dirs + p0 * 3;
+  float* pl = deltas + p0 * 2;
+  float x, y, z;
+  uint32_t step = 0;
+  while (t < far && step < count) {
+    if (m.probe(t, x, y, z)) {
+      px[0] = x; px[1] = y; px[2] = z;
+      pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+      const float dt = m.step_size(t);
+      t += dt;
+      pl[0] = dt;
+      pl[1] = t - last_t;
+      last_t = t;
+      px += 3; pd += 3; pl += 2;
+      ++step;
+    }
+  }
+}
+
+extern "C" uint64_t ucsa_march_segment_workspace_bytes(uint32_t n_cap) {
+  return 4ull * (4ull + ucsa_div_up(n_cap ? n_cap : 1, RM_BLOCK));
+}
+
+extern "C" int32_t ucsa_march_segment_count(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+    const float* rays_d, float bound, float dt_gamma, uint32_t C, uint32_t H,
+    const float* density_grid, float mean_density, const float* fars,
+    uint32_t perturb, int32_t* span, void* workspace, void* stream) {
+  UCSA_CHECK_ARG(cap >= 1 && cap <= RM_MAX_STEPS, 2);
+  UCSA_CHECK_ARG(rays_alive, 3);
+  UCSA_CHECK_ARG(rays_t, 4);
+  UCSA_CHECK_ARG(rays_o && rays_d, 5);
+  UCSA_CHECK_ARG(bound > 0.f, 7);
+  UCSA_CHECK_ARG(C >= 1 && C <= 32, 9);
+  UCSA_CHECK_ARG(H >= 2 && (uint64_t)C * H * H * H < (1ull << 32), 10);
+  UCSA_CHECK_ARG(density_grid, 11);
+  UCSA_CHECK_ARG(fars, 13);
+  UCSA_CHECK_ARG(span, 15);
+  UCSA_CHECK_ARG(workspace, 16);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* ws = (uint32_t*)workspace;
+  UCSA_CLEAR_ERR();
+  if (n_cap == 0) {
+    (void)hipMemsetAsync(ws, 0, 16, s);
+    return ucsa_launch_status();
+  }
+  const uint32_t nb = ucsa_div_up(n_cap, RM_BLOCK);
+  hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(RM_BLOCK), 0, s, n_cap,
+                     n_alive_dev, cap, rays_alive, rays_t, rays_o, rays_d,
+                     bound, dt_gamma, C, H, density_grid, mean_density, fars,
+                     perturb, span, ws);
+  hipLaunchKernelGGL(k_seg_offsets, dim3(nb), dim3(RM_BLOCK), 0, s, n_cap,
+                     n_alive_dev, span, ws);
+  return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_march_segment_write(
+    uint32_t n_cap, const int32_t* n_alive_dev, const int32_t* rays_alive,
+    const float* rays_t, const float* rays_o, const float* rays_d, float bound,
+    float dt_gamma, uint32_t C, uint32_t H, const float* density_grid,
+    float mean_density, const float* fars, uint32_t perturb,
+    const int32_t* span, float* xyzs, float* dirs, float* deltas,
+    void* stream) {
+  UCSA_CHECK_ARG(rays_alive, 2);
+  UCSA_CHECK_ARG(rays_t, 3);
+  UCSA_CHECK_ARG(rays_o && rays_d, 4);
+  UCSA_CHECK_ARG(density_grid, 10);
+  UCSA_CHECK_ARG(fars, 12);
+  UCSA_CHECK_ARG(span, 14);
+  UCSA_CHECK_ARG(xyzs && dirs && deltas, 15);
+  if (n_cap == 0) return 0;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_seg_write, dim3(ucsa_div_up(n_cap, RM_BLOCK)),
+                     dim3(RM_BLOCK), 0, (hipStream_t)stream, n_cap, n_alive_dev,
+                     rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, C, H,
+                     density_grid, mean_density, fars, perturb, span, xyzs,
+                     dirs, deltas);
+  return ucsa_launch_status();
+}
+
+// One wave per alive slot: composite the slot's span onto the ray's running
+// sums with early termination; rays_t[n] <- -1 when the ray is finished (it
+// stopped early, or its span came back shorter than `cap`, i.e. it reached
+// far), else the ray parameter after its last sample.
+__global__ void __launch_bounds__(64 * CT_WAVES)
+k_seg_composite(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+                uint32_t cap, const int32_t* __restrict__ rays_alive,
+                float* __restrict__ rays_t, const int32_t* __restrict__ span,
+                const float* __restrict__ sigmas, float sigma_scale,
+                const float* __restrict__ rgbs,
+                const float* __restrict__ local_sem,
+                const float* __restrict__ deltas, uint32_t n_sem,
+                float* __restrict__ weights_sum, float* __restrict__ depth,
+                float* __restrict__ image, float* __restrict__ semantics) {
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
+  if (n >= n_alive) return;
+  const uint32_t index = (uint32_t)rays_alive[n];
+  const uint32_t offset = (uint32_t)span[2 * n];
+  const uint32_t count = (uint32_t)span[2 * n + 1];
+  float T_carry = 1.0f - weights_sum[index];
+  float t_carry = rays_t[n];
+  bool stopped = false;  // a sample with incoming T <= 1e-4 has been taken
+  float r = 0, g = 0, b = 0, ws = 0, d = 0;
+  const uint32_t n_cb = (n_sem + 63u) / 64u;
+  float sem_acc[4] = {0, 0, 0, 0};
+
+  for (uint32_t s0 = 0; s0 < count && !stopped; s0 += 64) {
+    const uint32_t s = s0 + lane;
+    const bool live = s < count;
+    const size_t m = (size_t)offset + (live ? s : s0);
+    const float sg = sigmas[m] * sigma_scale;
+    const float2 dl = *reinterpret_cast<const float2*>(deltas + 2 * m);
+    const float alpha = live ? 1.0f - __expf(-sg * dl.x) : 0.0f;
+    const float Tin = wave_incl_scan_mul(1.0f - alpha, lane);
+    float Tex = __shfl_up(Tin, 1, 64);
+    if (lane == 0) Tex = 1.0f;
+    const float T = T_carry * Tex;  // transmittance reaching this sample
+    // the reference takes the sample, then stops if T < 1e-4 (double compare
+    // == T <= 1e-4f): a sample is used iff no earlier one saw T <= 1e-4
+    const uint64_t stop_mask = __ballot(live && T <= 1e-4f);
+    const uint32_t first_stop = stop_mask ? (uint32_t)__ffsll((long long)stop_mask) - 1u : 64u;
+    const bool use = live && lane <= first_stop;
+    const float w = use ? alpha * T : 0.0f;
+    const float t = t_carry + wave_incl_scan_add(live ? dl.y : 0.0f, lane);
+    if (use) {
+      r += w * rgbs[3 * m];
+      g += w * rgbs[3 * m + 1];
+      b += w * rgbs[3 * m + 2];
+      d += w * t;
+      ws += w;
+    }
+    if (n_sem) {
+      const uint32_t cnt = min(min(64u, count - s0), first_stop + 1u);
+      for (uint32_t cb = 0; cb < n_cb && cb < 4; ++cb) {
+        const uint32_t c = cb * 64 + lane;
+        const float* col = local_sem + ((size_t)offset + s0) * n_sem + c;
+        float a = sem_acc[cb];
+        for (uint32_t k = 0; k < cnt; ++k) {
+          const float wk = __shfl(w, (int)k, 64);
+          if (c < n_sem) a += wk * col[(size_t)k * n_sem];
+        }
+        sem_acc[cb] = a;
+      }
+    }
+    stopped = stop_mask != 0;
+    T_carry *= __shfl(Tin, 63, 64);
+    t_carry = __shfl(t, 63, 64);
+  }
+  r = wave_sum(r); g = wave_sum(g); b = wave_sum(b);
+  ws = wave_sum(ws); d = wave_sum(d);
+  if (lane == 0) {
+    weights_sum[index] += ws;
+    depth[index] += d;
+    image[index * 3] += r;
+    image[index * 3 + 1] += g;
+    image[index * 3 + 2] += b;
+    rays_t[n] = (stopped || count < cap) ? -1.0f : t_carry;
+  }
+  for (uint32_t cb = 0; cb < n_cb && cb < 4; ++cb) {
+    const uint32_t c = cb * 64 + lane;
+    if (c < n_sem) semantics[(size_t)index * n_sem + c] += sem_acc[cb];
+  }
+}
+
+extern "C" int32_t ucsa_march_segment_composite(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* sigmas, float sigma_scale, const float* rgbs,
+    const float* local_sem, const float* deltas, uint32_t n_sem,
+    float* weights_sum, float* depth, float* image, float* semantics,
+    void* stream) {
+  UCSA_CHECK_ARG(rays_alive, 3);
+  UCSA_CHECK_ARG(rays_t, 4);
+  UCSA_CHECK_ARG(span, 5);
+  UCSA_CHECK_ARG(sigmas && rgbs, 6);
+  UCSA_CHECK_ARG(n_sem == 0 || local_sem, 9);
+  UCSA_CHECK_ARG(deltas, 10);
+  UCSA_CHECK_ARG(n_sem <= 256, 11);
+  UCSA_CHECK_ARG(weights_sum && depth && image, 12);
+  UCSA_CHECK_ARG(n_sem == 0 || semantics, 15);
+  if (n_cap == 0) return 0;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_seg_composite, dim3(ucsa_div_up(n_cap, CT_WAVES)),
+                     dim3(64 * CT_WAVES), 0, (hipStream_t)stream, n_cap,
+                     n_alive_dev, cap, rays_alive, rays_t, span, sigmas,
+                     sigma_scale, rgbs, local_sem, deltas, n_sem, weights_sum,
+                     depth, image, semantics);
+  return ucsa_launch_status();
+}
+
+// compact_rays with the alive count taken from device memory
+// (count_in_dev may alias nothing written here; count_out_dev receives the
+// number of survivors, starting from 0).
+__global__ void __launch_bounds__(RM_BLOCK)
+k_seg_compact_count(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+                    const float* __restrict__ rays_t_old,
+                    uint32_t* __restrict__ ws) {
+  __shared__ uint32_t sm[16];
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+  const bool keep = n < n_alive && rays_t_old[n] >= 0.0f;
+  uint32_t total;
+  alive_rank(keep, sm, &total);
+  if (threadIdx.x == 0) ws[4 + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_seg_compact_write(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+                    int32_t* __restrict__ rays_alive,
+                    const int32_t* __restrict__ rays_alive_old,
+                    float* __restrict__ rays_t,
+                    const float* __restrict__ rays_t_old,
+                    int32_t* __restrict__ n_alive_out,
+                    const uint32_t* __restrict__ ws) {
+  __shared__ uint32_t sm[16];
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+  const float t = n < n_alive ? rays_t_old[n] : -1.0f;
+  const bool keep = n < n_alive && t >= 0.0f;
+  const uint32_t before = prefix_of_blocks(ws + 4, blockIdx.x, sm);
+  uint32_t total;
+  const uint32_t rank = alive_rank(keep, sm, &total);
+  if (keep) {
+    rays_alive[before + rank] = rays_alive_old[n];
+    rays_t[before + rank] = t;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    n_alive_out[0] = (int32_t)(before + total);
+}
+
+extern "C" int32_t ucsa_march_segment_compact(
+    uint32_t n_cap, const int32_t* n_alive_dev, int32_t* rays_alive,
+    const int32_t* rays_alive_old, float* rays_t, const float* rays_t_old,
+    int32_t* n_alive_out, void* workspace, void* stream) {
+  UCSA_CHECK_ARG(rays_alive && rays_alive_old, 2);
+  UCSA_CHECK_ARG(rays_t && rays_t_old, 4);
+  UCSA_CHECK_ARG(n_alive_out && n_alive_out != n_alive_dev, 6);
+  UCSA_CHECK_ARG(workspace, 7);
+  hipStream_t s = (hipStream_t)stream;
+  UCSA_CLEAR_ERR();
+  if (n_cap == 0) {
+    (void)hipMemsetAsync(n_alive_out, 0, 4, s);
+    return ucsa_launch_status();
+  }
+  const uint32_t nb = ucsa_div_up(n_cap, RM_BLOCK);
+  uint32_t* ws = (uint32_t*)workspace;
+  hipLaunchKernelGGL(k_seg_compact_count, dim3(nb), dim3(RM_BLOCK), 0, s, n_cap,
+                     n_alive_dev, rays_t_old, ws);
+  hipLaunchKernelGGL(k_seg_compact_write, dim3(nb), dim3(RM_BLOCK), 0, s, n_cap,
+                     n_alive_dev, rays_alive, rays_alive_old, rays_t,
+                     rays_t_old, n_alive_out, ws);
+  return ucsa_launch_status();
+}

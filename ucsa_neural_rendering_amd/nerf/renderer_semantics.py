@@ -38,12 +38,17 @@ class SemanticNeRFRenderer(nn.Module):
         aabb_infer = aabb_train.clone()
         self.register_buffer("aabb_train", aabb_train)
         self.register_buffer("aabb_infer", aabb_infer)
+        # extra state for occupancy-grid marching (reference :89-103)
         self.cuda_ray = cuda_ray
         if cuda_ray:
-            raise NotImplementedError(
-                "cuda_ray=True (occupancy-grid marching) is dormant in the "
-                "reference (joint_train_lightning_net.py:29-35) and not built "
-                "yet (SURVEY 8f rank 1)")
+            density_grid = torch.zeros([self.cascade] + [128] * 3)
+            self.register_buffer("density_grid", density_grid)
+            self.mean_density = 0
+            self.iter_density = 0
+            step_counter = torch.zeros(16, 2, dtype=torch.int32)
+            self.register_buffer("step_counter", step_counter)
+            self.mean_count = 0
+            self.local_step = 0
         # rays per HIP enqueue; results do not depend on it
         self.hip_ray_chunk = 65536
         # chunks are independent and may alternate over several HIP streams;
@@ -65,7 +70,177 @@ class SemanticNeRFRenderer(nn.Module):
         raise NotImplementedError()
 
     def reset_extra_state(self):
-        return  # only meaningful with cuda_ray (reference :111-121)
+        """reference :111-121."""
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    # -- occupancy-grid marching (SURVEY 8f rank 1) ---------------------------
+    # The reference keeps the state above and the raymarching functions but no
+    # code that drives them (its parent code base had `update_extra_state` and
+    # `run_cuda`; this fork dropped both and hard-codes cuda_ray=False).  The
+    # two methods below are that driver, written for this build.
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, seed=None):
+        """Refresh density_grid from the field: one jittered sample per cell
+        and cascade, grid = max(grid*decay, density_scale*sigma); then
+        mean_density, and mean_count from the step counters of the last
+        training steps.  Call before rendering and every few training steps."""
+        if not self.cuda_ray:
+            return
+        H = self.density_grid.shape[1]
+        dev = self.density_grid.device
+        if seed is None:
+            seed = self.iter_density + 1
+        fresh = torch.empty_like(self.density_grid)
+        for cas in range(self.cascade):
+            pts = ops.density_grid_points(cas, H, float(self.bound), int(seed),
+                                          dev)
+            fresh[cas] = self.density(pts)["sigma"].view(H, H, H)
+        mean = ops.density_grid_update(self.density_grid, fresh, float(decay),
+                                       float(self.density_scale))
+        self.mean_density = float(mean.item())
+        self.iter_density += 1
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(
+                self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    @torch.no_grad()
+    def run_cuda(self, rays_o, rays_d, direction_norms, dt_gamma=0,
+                 bg_color=None, perturb=False, max_steps=1024, epoch=None,
+                 min_near=0.2, far_closure=True, schedule="segments",
+                 march_caps=(32, 96, 1024), **kwargs):
+        """Inference by occupancy-grid marching with early termination and
+        alive-ray compaction (march_rays -> field -> composite_rays ->
+        compact_rays until no ray is alive).  Same inputs / outputs and the
+        same depth convention as ``run`` (depth = sum w*t / |d|).
+
+        ``far_closure``: ``run`` makes the last interval of every ray 1e10
+        wide (reference :185-186, :238-239), i.e. the sample at ``far`` absorbs
+        whatever transmittance is left, and fields trained through ``run``
+        rely on it.  With far_closure=True the marcher ends every ray the same
+        way (one extra sample at t = far with delta 1e10), so it renders the
+        same model as ``run`` and can be swapped in for it; False gives the
+        plain marching integral.
+
+        ``schedule``: "segments" (default) marches in a few rounds of up to
+        ``march_caps`` samples per alive ray with exact-size buffers and the
+        alive count kept on the device; "reference" is the loop the reference
+        API was made for (n_step <= 8 samples per iteration, zero-padded
+        buffers, one host sync per iteration).  Both take the same samples."""
+        from .raymarching import raymarching
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError(
+                "training through the marcher is not built yet; use run()")
+        prefix = rays_o.shape[:-1]
+        device = rays_o.device
+        if device.type != "cuda":
+            raise ops._lib.UcsaError(
+                "run_cuda needs GPU tensors: the HIP path has no CPU fallback")
+        o = rays_o.contiguous().view(-1, 3).float()
+        d = rays_d.contiguous().view(-1, 3).float()
+        nrm = direction_norms.contiguous().view(-1).float()
+        N = o.shape[0]
+        C = self.num_semantic_classes
+        aabb = self._aabb_list(self.training)
+        nears, fars = ops.near_far_from_aabb(o, d, aabb, min_near)
+        f = self._field()
+        ws = torch.zeros(N, device=device)
+        depth = torch.zeros(N, device=device)
+        image = torch.zeros(N, 3, device=device)
+        sem = torch.zeros(N, C, device=device)
+        self.last_march_points = 0
+        self.last_march_rounds = 0
+        if schedule == "segments":
+            # MI355X-native driver: a few rounds of exact-size spans, the alive
+            # count stays on the device, one host read-back per round
+            seg = ops.MarchSegments(o, d, nears, fars, self.density_grid,
+                                    self.mean_density, self.bound, dt_gamma)
+            n_cap, done = N, 0
+            for cap in march_caps:
+                cap = min(int(cap), max_steps - done)
+                if cap <= 0 or n_cap == 0:
+                    break
+                jitter = int(perturb) if done == 0 else 0
+                total, n_alive = seg.count(n_cap, cap, jitter)
+                if n_alive == 0:
+                    break
+                if total > 0:
+                    xyzs, dirs, deltas = seg.write(n_alive, total, jitter)
+                    feat = ops.hashgrid_encode_points(f["grid"], f["table"],
+                                                      xyzs)
+                    h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
+                    rgbs, probs = ops.point_shade_h(dirs, h, f["packed_color"],
+                                                    f["packed_sem"], C)
+                    seg.composite(n_alive, cap, sigma,
+                                  float(self.density_scale), rgbs, probs,
+                                  deltas, ws, depth, image, sem)
+                    seg.compact(n_alive)
+                self.last_march_points += total
+                self.last_march_rounds += 1
+                n_cap = n_alive if total > 0 else 0
+                done += cap
+            rays_alive, rays_t = seg.alive, seg.t
+        elif schedule == "reference":
+            # the loop of the reference API, one host sync per iteration
+            rays_alive = torch.empty(2, N, dtype=torch.int32, device=device)
+            rays_alive[0] = torch.arange(N, dtype=torch.int32, device=device)
+            rays_t = torch.empty(2, N, device=device)
+            rays_t[0] = nears
+            alive_counter = torch.zeros(1, dtype=torch.int32, device=device)
+            n_alive, step, i = N, 0, 0
+            while step < max_steps and n_alive > 0:
+                a, b = i % 2, (i + 1) % 2
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(
+                    n_alive, n_step, rays_alive[a], rays_t[a], o, d,
+                    self.bound, self.density_grid, self.mean_density, nears,
+                    fars, 128, int(perturb), dt_gamma)
+                feat = ops.hashgrid_encode_points(f["grid"], f["table"], xyzs)
+                h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
+                if self.density_scale != 1:
+                    sigma = sigma * self.density_scale
+                rgbs, probs = ops.point_shade_h(dirs, h, f["packed_color"],
+                                                f["packed_sem"], C)
+                raymarching.composite_rays_semantics(
+                    n_alive, n_step, rays_alive[a], rays_t[a], sigma, rgbs,
+                    probs, deltas, ws, depth, image, sem)
+                alive_counter.zero_()
+                raymarching.compact_rays(n_alive, rays_alive[b], rays_alive[a],
+                                         rays_t[b], rays_t[a], alive_counter)
+                self.last_march_points += n_alive * n_step
+                self.last_march_rounds += 1
+                n_alive = int(alive_counter.item())
+                step += n_step
+                i += 1
+        else:
+            raise ValueError(f"unknown schedule {schedule!r}")
+        if far_closure:
+            feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d,
+                                            fars.view(N, 1), aabb)
+            h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
+            rgbs, probs = ops.point_shade_h(d, h, f["packed_color"],
+                                            f["packed_sem"], C)
+            last = torch.zeros(N, 2, device=device)
+            last[:, 0] = 1e10
+            rays_alive[0] = torch.arange(N, dtype=torch.int32, device=device)
+            rays_t[0] = fars
+            raymarching.composite_rays_semantics(
+                N, 1, rays_alive[0], rays_t[0], sigma, rgbs, probs, last, ws,
+                depth, image, sem)
+        return {
+            "depth": (depth / nrm).view(*prefix),
+            "image": image.view(*prefix, 3),
+            "semantics": sem.view(*prefix, C),
+            "weights_sum": ws.view(*prefix),
+        }
 
     # -- hooks supplied by the field (SemanticNeRFNetwork) -------------------
     def _field(self):
@@ -194,6 +369,14 @@ class SemanticNeRFRenderer(nn.Module):
         ``max_ray_batch``-ray chunks only bounds memory; rays are independent,
         so here ``run`` chunks internally (``hip_ray_chunk``) and one call
         covers the whole batch.  Explicit ``rng_t`` / ``rng_u`` are [B,N,*]."""
+        # The reference always calls run() (:315); with cuda_ray=True and
+        # inference this build marches the occupancy grid instead.
+        if self.cuda_ray and not (torch.is_grad_enabled() and self.training):
+            kwargs.pop("num_steps", None)
+            kwargs.pop("upsample_steps", None)
+            return self.run_cuda(rays_o, rays_d, direction_norms,
+                                 bg_color=bg_color, perturb=perturb,
+                                 epoch=epoch, **kwargs)
         return self.run(rays_o, rays_d, direction_norms=direction_norms,
                         bg_color=bg_color, perturb=perturb, epoch=epoch,
                         **kwargs)

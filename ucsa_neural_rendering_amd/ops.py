@@ -179,6 +179,24 @@ def point_shade(dirs, geo_feat, mask, packed_color, packed_sem, n_classes: int,
     return rgb, probs
 
 
+def point_shade_h(dirs, h, packed_color, packed_sem, n_classes: int,
+                  rgb=None, probs=None):
+    """colour + semantics of M points straight from the sigma-MLP rows
+    h [M,16]; optional preallocated outputs."""
+    M = h.shape[0]
+    dev = h.device
+    dirs = _f32(dirs, "d").view(-1, 3)
+    if rgb is None:
+        rgb = torch.empty(M, 3, device=dev)
+    if probs is None:
+        probs = torch.empty(M, n_classes, device=dev)
+    check(lib().ucsa_point_shade_h(_ptr(dirs), _ptr(h), None,
+                                   _ptr(packed_color), _ptr(packed_sem), M,
+                                   n_classes, _ptr(rgb), _ptr(probs),
+                                   _stream()), "ucsa_point_shade_h")
+    return rgb, probs
+
+
 def render_workspace_bytes(N: int, T: int, t: int, n_levels: int) -> int:
     return int(lib().ucsa_render_workspace_bytes(N, T, t, n_levels))
 
@@ -538,3 +556,102 @@ def compact_rays(n_alive: int, rays_alive, rays_alive_old, rays_t, rays_t_old,
         _ptr(_f32(rays_t_old, "rays_t_old")),
         _ptr(_i32(alive_counter, "alive_counter")), _ptr(ws), _stream()),
         "ucsa_compact_rays")
+
+
+def density_grid_points(cascade: int, H: int, bound: float, seed: int, device):
+    xyz = torch.empty(H * H * H, 3, device=device)
+    check(lib().ucsa_density_grid_points(cascade, H, bound, seed, _ptr(xyz),
+                                         _stream()), "ucsa_density_grid_points")
+    return xyz
+
+
+def density_grid_update(density_grid, fresh, decay: float, fresh_scale: float):
+    """In place on density_grid; returns the new mean density (device [1])."""
+    _inplace_f32(density_grid, "density_grid")
+    fresh = _f32(fresh, "fresh")
+    n = density_grid.numel()
+    mean = torch.empty(1, device=density_grid.device)
+    ws = _scratch(int(lib().ucsa_density_grid_workspace_bytes()),
+                  density_grid.device)
+    check(lib().ucsa_density_grid_update(_ptr(density_grid), _ptr(fresh), n,
+                                         decay, fresh_scale, _ptr(mean),
+                                         _ptr(ws), _stream()),
+          "ucsa_density_grid_update")
+    return mean
+
+
+class MarchSegments:
+    """Buffers + calls of the segmented marcher (``ucsa_march_segment_*``) for
+    one batch of N rays; see include/ucsa_hip.h."""
+
+    def __init__(self, rays_o, rays_d, nears, fars, density_grid,
+                 mean_density: float, bound: float, dt_gamma: float):
+        self.o = _f32(rays_o, "rays_o").view(-1, 3)
+        self.d = _f32(rays_d, "rays_d").view(-1, 3)
+        self.fars = _f32(fars, "fars")
+        self.grid = _f32(density_grid, "density_grid")
+        self.args = (float(bound), float(dt_gamma), self.grid.shape[0],
+                     self.grid.shape[1])
+        self.mean_density = float(mean_density)
+        N = self.o.shape[0]
+        dev = self.o.device
+        self.N = N
+        self.alive = torch.empty(2, N, dtype=torch.int32, device=dev)
+        self.alive[0] = torch.arange(N, dtype=torch.int32, device=dev)
+        self.t = torch.empty(2, N, device=dev)
+        self.t[0] = _f32(nears, "nears")
+        self.span = torch.empty(N, 2, dtype=torch.int32, device=dev)
+        self.n_alive = torch.empty(2, dtype=torch.int32, device=dev)
+        self.ws = torch.empty(
+            int(lib().ucsa_march_segment_workspace_bytes(N)) // 4,
+            dtype=torch.int32, device=dev)
+        self.cur = 0        # which half of alive / t / n_alive is current
+        self.first = True   # round 0: every ray alive, count not on device yet
+
+    def _n_dev(self):
+        return None if self.first else _ptr(self.n_alive[self.cur:])
+
+    def count(self, n_cap: int, cap: int, perturb: int):
+        b, g, C_, H = self.args
+        check(lib().ucsa_march_segment_count(
+            n_cap, self._n_dev(), cap, _ptr(self.alive[self.cur]),
+            _ptr(self.t[self.cur]), _ptr(self.o), _ptr(self.d), b, g, C_, H,
+            _ptr(self.grid), self.mean_density, _ptr(self.fars), int(perturb),
+            _ptr(self.span), _ptr(self.ws), _stream()),
+            "ucsa_march_segment_count")
+        total, n_alive = self.ws[:2].tolist()   # the round's one host sync
+        return total, n_alive
+
+    def write(self, n_cap: int, M: int, perturb: int):
+        b, g, C_, H = self.args
+        dev = self.o.device
+        xyzs = torch.empty(M, 3, device=dev)
+        dirs = torch.empty(M, 3, device=dev)
+        deltas = torch.empty(M, 2, device=dev)
+        check(lib().ucsa_march_segment_write(
+            n_cap, self._n_dev(), _ptr(self.alive[self.cur]),
+            _ptr(self.t[self.cur]), _ptr(self.o), _ptr(self.d), b, g, C_, H,
+            _ptr(self.grid), self.mean_density, _ptr(self.fars), int(perturb),
+            _ptr(self.span), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _stream()),
+            "ucsa_march_segment_write")
+        return xyzs, dirs, deltas
+
+    def composite(self, n_cap: int, cap: int, sigmas, sigma_scale: float, rgbs,
+                  local_sem, deltas, weights_sum, depth, image, semantics):
+        n_sem = 0 if local_sem is None else local_sem.shape[-1]
+        check(lib().ucsa_march_segment_composite(
+            n_cap, self._n_dev(), cap, _ptr(self.alive[self.cur]),
+            _ptr(self.t[self.cur]), _ptr(self.span), _ptr(sigmas),
+            float(sigma_scale), _ptr(rgbs), _ptr(local_sem), _ptr(deltas),
+            n_sem, _ptr(weights_sum), _ptr(depth), _ptr(image),
+            _ptr(semantics), _stream()), "ucsa_march_segment_composite")
+
+    def compact(self, n_cap: int):
+        nxt = 1 - self.cur
+        check(lib().ucsa_march_segment_compact(
+            n_cap, self._n_dev(), _ptr(self.alive[nxt]),
+            _ptr(self.alive[self.cur]), _ptr(self.t[nxt]),
+            _ptr(self.t[self.cur]), _ptr(self.n_alive[nxt:]), _ptr(self.ws),
+            _stream()), "ucsa_march_segment_compact")
+        self.cur = nxt
+        self.first = False
