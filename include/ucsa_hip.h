@@ -492,6 +492,32 @@ int32_t ucsa_march_segment_composite(
     float* weights_sum, float* depth, float* image, float* semantics,
     void* stream);
 
+/* Fused alternative to ucsa_point_shade_h + ucsa_march_segment_composite: the
+ * weights (same early-stop rule) are formed first, the samples with
+ * w > w_min are compacted with wave ballots, only those go through the colour
+ * and semantics nets (MFMA, weights in LDS; h [M,16] = raw sigma-MLP rows,
+ * rays_d [N,3] by ray id), and the per-ray sums are added in place.  w_min = 0
+ * is the reference's composite exactly; 1e-4 is the mask of the live path
+ * (reference renderer_semantics.py:249-250).  weights_sum and depth always
+ * take every sample. */
+int32_t ucsa_march_segment_shade(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* packed_color, const float* packed_sem,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth,
+    float* image, float* semantics, void* stream);
+
+/* Same with the fp16-MFMA nets (packed by ucsa_mlp_pack_f16). */
+int32_t ucsa_march_segment_shade_f16(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const void* packed_color_half,
+    const void* packed_sem_half, uint32_t n_classes, float w_min,
+    float* weights_sum, float* depth, float* image, float* semantics,
+    void* stream);
+
 /* Stable compaction of the slots with rays_t_old >= 0 into rays_alive/rays_t;
  * n_alive_out[0] (device, != n_alive_dev) = number of survivors. */
 int32_t ucsa_march_segment_compact(uint32_t n_cap, const int32_t* n_alive_dev,

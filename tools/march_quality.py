@@ -30,6 +30,14 @@ def timed(fn, iters=5):
     return out, (time.perf_counter() - t0) / iters * 1e3
 
 
+def f16(net, o, d, n):
+    net.precision = "fp16"
+    try:
+        return net.run_cuda(o, d, n, dt_gamma=1 / 128)
+    finally:
+        net.precision = "fp32"
+
+
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     dev = torch.device("cuda:0")
@@ -50,10 +58,11 @@ def main():
         ("run_256+256", lambda o, d, n: net.run(o, d, n, num_steps=256, upsample_steps=256)),
         ("run_96+96", lambda o, d, n: net.run(o, d, n, num_steps=96, upsample_steps=96)),
         ("march_ref_loop", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, schedule="reference")),
-        ("march_seg_nodtg", lambda o, d, n: net.run_cuda(o, d, n)),
         ("march_seg", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128)),
-        ("march_seg_16_64", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, march_caps=(16, 64, 1024))),
+        ("march_seg_unfused", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, fused_shade=False)),
+        ("march_seg_wmin0", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, w_min=0.0)),
         ("march_seg_one", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, march_caps=(1024,))),
+        ("march_seg_f16", lambda o, d, n: f16(net, o, d, n)),
         ("march_seg_open", lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 128, far_closure=False)),
     ):
         meter = SemanticsMeter(bench.N_CLASSES)

@@ -131,6 +131,13 @@ SIGNATURES = {
     "ucsa_march_segment_composite": (C.c_int32, [_u32, _p, _u32, _p, _p, _p,
                                                  _p, _f, _p, _p, _p, _u32, _p,
                                                  _p, _p, _p, _p]),
+    "ucsa_march_segment_shade": (C.c_int32, [_u32, _p, _u32, _p, _p, _p, _p,
+                                             _p, _f, _p, _p, _p, _p, _u32, _f,
+                                             _p, _p, _p, _p, _p]),
+    "ucsa_march_segment_shade_f16": (C.c_int32, [_u32, _p, _u32, _p, _p, _p,
+                                                 _p, _p, _f, _p, _p, _p, _p,
+                                                 _u32, _f, _p, _p, _p, _p,
+                                                 _p]),
     "ucsa_march_segment_compact": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p,
                                                _p, _p]),
     "ucsa_density_grid_points": (C.c_int32, [_u32, _u32, _f, _u32, _p, _p]),

@@ -53,6 +53,15 @@ struct CmpArgs {
   float* w_out;
   uint32_t rays_per_wave;
   uint32_t contrib_stride;
+  // ---- marched spans (MARCH = true; see "marched mode" below) -------------
+  const int32_t* rays_alive;
+  float* rays_t;
+  const int32_t* span;
+  const float* deltas;
+  const int32_t* n_alive_dev;
+  float* weights_sum;
+  uint32_t seg_cap;
+  float w_min;
 };
 
 __device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
@@ -86,7 +95,15 @@ __device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
   }
 }
 
-template <int NRB_SEM, int CBS, bool HALF>
+// Marched mode (MARCH = true): the same shading machinery on
+// the exact-size spans of the segmented marcher (raymarch.hip).  "Ray r" is
+// alive slot r; its samples are rows span[r] = (first, count) of sigma_c /
+// h_c / deltas; phase A is the early-stopping weight scan of
+// k_seg_composite; samples with w > w_min are shaded; sums are ADDED to
+// image / semantics / depth / weights_sum of ray rays_alive[r], and rays_t[r]
+// is set for the next round.  List capacity is 64 + G: survivors are drained
+// after every 64-sample trip.
+template <int NRB_SEM, int CBS, bool HALF, bool MARCH>
 __global__ void __launch_bounds__(64 * CMP_MAX_WAVES)
 k_composite(CmpArgs a) {
   constexpr uint32_t G = 16u * CBS;  // survivors shaded per MFMA group
@@ -104,7 +121,7 @@ k_composite(CmpArgs a) {
   float* w_color = cmp_smem;
   float* w_sem = w_color + WC_FLOATS;
   float* per_wave = w_sem + WS_FLOATS;
-  const uint32_t cap = S + G;                      // entry list capacity
+  const uint32_t cap = MARCH ? 64u + G : S + G;    // entry list capacity
   // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
   //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
   const uint32_t per_wave_floats = 4 * S + 3 * cap + 16 * cstride + 64;
@@ -125,12 +142,19 @@ k_composite(CmpArgs a) {
     w_sem[i] = a.packed_sem[i];
   __syncthreads();
 
+  uint32_t n_rays = a.N;
+  if constexpr (MARCH) {
+    if (a.n_alive_dev) {
+      const uint32_t live = (uint32_t)a.n_alive_dev[0];
+      if (live < n_rays) n_rays = live;
+    }
+  }
   const uint64_t gwave = (uint64_t)blockIdx.x * nw_block + wid;
   const uint64_t r_begin64 = gwave * a.rays_per_wave;
-  if (r_begin64 >= a.N) return;
+  if (r_begin64 >= n_rays) return;
   const uint32_t r_begin = (uint32_t)r_begin64;
-  const uint32_t r_end = (r_begin + a.rays_per_wave < a.N)
-                             ? r_begin + a.rays_per_wave : a.N;
+  const uint32_t r_end = (r_begin + a.rays_per_wave < n_rays)
+                             ? r_begin + a.rays_per_wave : n_rays;
 
   uint32_t cnt = 0;            // entries waiting in the list (wave-uniform)
   uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose sums sit in `acc`
@@ -138,8 +162,13 @@ k_composite(CmpArgs a) {
   float acc = 0.0f;            // lane c: running sum of channel c
 
   auto flush_ray = [&](uint32_t ray) {
-    if (lane < 3) a.image[(size_t)ray * 3 + lane] = acc;
-    else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = acc;
+    if constexpr (MARCH) {  // a ray is owned by one wave per round: plain RMW
+      if (lane < 3) a.image[(size_t)ray * 3 + lane] += acc;
+      else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] += acc;
+    } else {
+      if (lane < 3) a.image[(size_t)ray * 3 + lane] = acc;
+      else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = acc;
+    }
   };
 
   // ---- phase C + D on the first `n` (<= 64) entries of the list ---------
@@ -403,6 +432,99 @@ k_composite(CmpArgs a) {
     }
   };
 
+  // ---- C/D: shade the full groups waiting in the list -------------------
+  auto drain = [&]() {
+    uint32_t head = 0;
+    while (cnt - head >= G) {
+      // shade() reads entries [0,G): move the window down first if needed
+      if (head) {
+        for (uint32_t i = lane; i < G; i += 64) {
+          lw[i] = lw[head + i];
+          lrow[i] = lrow[head + i];
+          lray[i] = lray[head + i];
+        }
+        wave_lds_sync();
+      }
+      shade(G);
+      head += G;
+    }
+    if (head) {  // compact the tail [head, cnt) to the front
+      const uint32_t rem = cnt - head;  // < G <= 64
+      float tw = 0.f;
+      uint32_t trow = 0, tray = 0;
+      if (lane < rem) {
+        tw = lw[head + lane];
+        trow = lrow[head + lane];
+        tray = lray[head + lane];
+      }
+      wave_lds_sync();
+      if (lane < rem) {
+        lw[lane] = tw;
+        lrow[lane] = trow;
+        lray[lane] = tray;
+      }
+      cnt = rem;
+      wave_lds_sync();
+    }
+  };
+
+  if constexpr (MARCH) {
+    // =================== per-slot loop (marched spans) ====================
+    for (uint32_t r = r_begin; r < r_end; ++r) {
+      const uint32_t index = (uint32_t)a.rays_alive[r];
+      const uint32_t offset = (uint32_t)a.span[2 * r];
+      const uint32_t count = (uint32_t)a.span[2 * r + 1];
+      float T_carry = 1.0f - a.weights_sum[index];
+      float t_carry = a.rays_t[r];
+      bool stopped = false;
+      float wsum = 0.0f, dsum = 0.0f;
+      for (uint32_t s0 = 0; s0 < count && !stopped; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool live = s < count;
+        const size_t m = (size_t)offset + (live ? s : s0);
+        const float sg = a.sigma_c[m] * a.density_scale;
+        const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
+        const float alpha = live ? 1.0f - __expf(-sg * dl.x) : 0.0f;
+        const float Tin = wave_incl_scan_mul(1.0f - alpha, lane);
+        float Tex = __shfl_up(Tin, 1, 64);
+        if (lane == 0) Tex = 1.0f;
+        const float Tr = T_carry * Tex;
+        // reference raymarching.cu:693-706: take the sample, stop if T < 1e-4
+        const unsigned long long stop_mask = __ballot(live && Tr <= 1e-4f);
+        const uint32_t first_stop =
+            stop_mask ? (uint32_t)__ffsll((long long)stop_mask) - 1u : 64u;
+        const bool use = live && lane <= first_stop;
+        const float w = use ? alpha * Tr : 0.0f;
+        const float tt = t_carry + wave_incl_scan_add(live ? dl.y : 0.0f, lane);
+        if (use) {
+          wsum += w;
+          dsum += w * tt;
+        }
+        const bool keep = use && (w > a.w_min);
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+          const uint32_t pos =
+              cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          lw[pos] = w;
+          lrow[pos] = (uint32_t)m;
+          lray[pos] = index;
+        }
+        cnt += (uint32_t)__popcll(bal);
+        stopped = stop_mask != 0;
+        T_carry *= wave_bcast(Tin, 63);
+        t_carry = wave_bcast(tt, 63);
+        wave_lds_sync();
+        drain();
+      }
+      wsum = wave_sum(wsum);
+      dsum = wave_sum(dsum);
+      if (lane == 0) {
+        a.weights_sum[index] += wsum;
+        a.depth[index] += dsum;
+        a.rays_t[r] = (stopped || count < a.seg_cap) ? -1.0f : t_carry;
+      }
+    }
+  } else {
   // ======================= per-ray loop ==================================
   for (uint32_t r = r_begin; r < r_end; ++r) {
     // ---- A1: load raw z (coarse then fine) ------------------------------
@@ -495,39 +617,8 @@ k_composite(CmpArgs a) {
       else if (lane < 3 + C) a.semantics[(size_t)r * C + (lane - 3)] = 0.0f;
     }
     wave_lds_sync();
-    // ---- C/D: shade full groups of 64 ------------------------------------
-    uint32_t head = 0;
-    while (cnt - head >= G) {
-      // shade() reads entries [0,G): move the window down first if needed
-      if (head) {
-        for (uint32_t i = lane; i < G; i += 64) {
-          lw[i] = lw[head + i];
-          lrow[i] = lrow[head + i];
-          lray[i] = lray[head + i];
-        }
-        wave_lds_sync();
-      }
-      shade(G);
-      head += G;
-    }
-    if (head) {  // compact the tail [head, cnt) to the front
-      const uint32_t rem = cnt - head;  // < G <= 64
-      float tw = 0.f;
-      uint32_t trow = 0, tray = 0;
-      if (lane < rem) {
-        tw = lw[head + lane];
-        trow = lrow[head + lane];
-        tray = lray[head + lane];
-      }
-      wave_lds_sync();
-      if (lane < rem) {
-        lw[lane] = tw;
-        lrow[lane] = trow;
-        lray[lane] = tray;
-      }
-      cnt = rem;
-      wave_lds_sync();
-    }
+    drain();
+  }
   }
   if (cnt) shade(cnt);
   if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
@@ -574,17 +665,18 @@ static int32_t composite_launch(
   const uint32_t blocks = ucsa_div_up(n_waves, waves);
   CmpArgs a{rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
             packed_color, packed_sem, N, T, t, n_classes, density_scale,
-            image, depth, semantics, src, weights, rpw, cstride};
+            image, depth, semantics, src, weights, rpw, cstride,
+            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0.0f};
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(NRB, H)                                                        \
   do {                                                                        \
     constexpr int CB = H ? CMP_CBS_H : CMP_CBS;                               \
     hipError_t e = hipFuncSetAttribute(                                       \
-        reinterpret_cast<const void*>(&k_composite<NRB, CB, H>),              \
+        reinterpret_cast<const void*>(&k_composite<NRB, CB, H, false>),              \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e != hipSuccess) return -(int32_t)e;                                  \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL((k_composite<NRB, CB, H>), dim3(blocks),               \
+    hipLaunchKernelGGL((k_composite<NRB, CB, H, false>), dim3(blocks),               \
                        dim3(64 * waves), smem, s, a);                         \
   } while (0)
   if (half) {
@@ -631,4 +723,107 @@ extern "C" int32_t ucsa_composite_fwd_f16(
                           (const float*)packed_sem_half, N, T, t, n_classes,
                           density_scale, image, depth, semantics, nullptr,
                           nullptr, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Marched spans: weights with early stop -> ballot compaction of the samples
+// with w > w_min -> colour + semantics nets on the survivors -> per-ray sums
+// added in place.  One kernel instead of point_shade + segment_composite, and
+// rgb / class probabilities never travel through HBM.
+// ---------------------------------------------------------------------------
+static int32_t march_shade_launch(
+    bool half, uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* packed_color, const float* packed_sem,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth,
+    float* image, float* semantics, void* stream) {
+  UCSA_CHECK_ARG(cap >= 1, 2);
+  UCSA_CHECK_ARG(rays_alive, 3);
+  UCSA_CHECK_ARG(rays_t, 4);
+  UCSA_CHECK_ARG(span, 5);
+  UCSA_CHECK_ARG(rays_d, 6);
+  UCSA_CHECK_ARG(sigmas, 7);
+  UCSA_CHECK_ARG(h, 9);
+  UCSA_CHECK_ARG(deltas, 10);
+  UCSA_CHECK_ARG(packed_color && packed_sem, 11);
+  UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 13);
+  UCSA_CHECK_ARG(w_min >= 0.f, 14);
+  UCSA_CHECK_ARG(weights_sum && depth && image && semantics, 15);
+  if (n_cap == 0) return 0;
+  const uint32_t nrb = cmp_pad16(n_classes) / 16;
+  uint32_t cstride = 3 + n_classes;
+  if ((cstride & 1u) == 0) cstride += 1;
+  const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
+                               : 7168 + 1024 + (size_t)nrb * 1024;
+  const uint32_t cbs = half ? CMP_CBS_H : CMP_CBS;
+  const size_t per_wave = 3 * (size_t)(64 + 16 * cbs) + 16 * cstride + 64;
+  const uint32_t waves = CMP_MAX_WAVES;
+  const size_t smem = (w_floats + waves * per_wave) * 4;
+  const uint64_t total_waves = 256ull * waves;
+  uint32_t rpw = (uint32_t)((n_cap + total_waves - 1) / total_waves);
+  if (rpw < 4) rpw = 4;
+  const uint32_t blocks = ucsa_div_up(ucsa_div_up(n_cap, rpw), waves);
+  CmpArgs a{rays_d, nullptr, nullptr, sigmas, h, nullptr, nullptr, nullptr,
+            packed_color, packed_sem, n_cap, 0u, 0u, n_classes, sigma_scale,
+            image, depth, semantics, nullptr, nullptr, rpw, cstride,
+            rays_alive, rays_t, span, deltas, n_alive_dev, weights_sum, cap,
+            w_min};
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_M(NRB, H)                                                      \
+  do {                                                                        \
+    constexpr int CB = H ? CMP_CBS_H : CMP_CBS;                               \
+    hipError_t e = hipFuncSetAttribute(                                       \
+        reinterpret_cast<const void*>(&k_composite<NRB, CB, H, true>),        \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
+    if (e != hipSuccess) return -(int32_t)e;                                  \
+    UCSA_CLEAR_ERR();                                                         \
+    hipLaunchKernelGGL((k_composite<NRB, CB, H, true>), dim3(blocks),         \
+                       dim3(64 * waves), smem, s, a);                         \
+  } while (0)
+  if (half) {
+    switch (nrb) {
+      case 1: LAUNCH_M(1, true); break;
+      case 2: LAUNCH_M(2, true); break;
+      case 3: LAUNCH_M(3, true); break;
+      default: LAUNCH_M(4, true); break;
+    }
+  } else {
+    switch (nrb) {
+      case 1: LAUNCH_M(1, false); break;
+      case 2: LAUNCH_M(2, false); break;
+      case 3: LAUNCH_M(3, false); break;
+      default: LAUNCH_M(4, false); break;
+    }
+  }
+#undef LAUNCH_M
+  return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_march_segment_shade(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* packed_color, const float* packed_sem,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth,
+    float* image, float* semantics, void* stream) {
+  return march_shade_launch(false, n_cap, n_alive_dev, cap, rays_alive, rays_t,
+                            span, rays_d, sigmas, sigma_scale, h, deltas,
+                            packed_color, packed_sem, n_classes, w_min,
+                            weights_sum, depth, image, semantics, stream);
+}
+
+extern "C" int32_t ucsa_march_segment_shade_f16(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const void* packed_color_half,
+    const void* packed_sem_half, uint32_t n_classes, float w_min,
+    float* weights_sum, float* depth, float* image, float* semantics,
+    void* stream) {
+  return march_shade_launch(true, n_cap, n_alive_dev, cap, rays_alive, rays_t,
+                            span, rays_d, sigmas, sigma_scale, h, deltas,
+                            (const float*)packed_color_half,
+                            (const float*)packed_sem_half, n_classes, w_min,
+                            weights_sum, depth, image, semantics, stream);
 }

@@ -116,7 +116,8 @@ class SemanticNeRFRenderer(nn.Module):
     def run_cuda(self, rays_o, rays_d, direction_norms, dt_gamma=0,
                  bg_color=None, perturb=False, max_steps=1024, epoch=None,
                  min_near=0.2, far_closure=True, schedule="segments",
-                 march_caps=(32, 96, 1024), **kwargs):
+                 march_caps=(32, 96, 1024), w_min=1e-4, fused_shade=True,
+                 **kwargs):
         """Inference by occupancy-grid marching with early termination and
         alive-ray compaction (march_rays -> field -> composite_rays ->
         compact_rays until no ray is alive).  Same inputs / outputs and the
@@ -134,7 +135,14 @@ class SemanticNeRFRenderer(nn.Module):
         ``march_caps`` samples per alive ray with exact-size buffers and the
         alive count kept on the device; "reference" is the loop the reference
         API was made for (n_step <= 8 samples per iteration, zero-padded
-        buffers, one host sync per iteration).  Both take the same samples."""
+        buffers, one host sync per iteration).  Both take the same samples.
+
+        ``fused_shade`` (segments only): form the weights first and run the
+        colour / semantics nets only on the samples with w > ``w_min``, inside
+        one kernel (ucsa_march_segment_shade).  w_min = 1e-4 is the mask of
+        ``run`` (reference :249-250); 0 shades every sample like the
+        reference's composite_rays.  ``self.precision = "fp16"`` selects the
+        fp16-MFMA nets here as it does in ``run``."""
         from .raymarching import raymarching
         if torch.is_grad_enabled() and self.training:
             raise NotImplementedError(
@@ -151,7 +159,11 @@ class SemanticNeRFRenderer(nn.Module):
         C = self.num_semantic_classes
         aabb = self._aabb_list(self.training)
         nears, fars = ops.near_far_from_aabb(o, d, aabb, min_near)
-        f = self._field()
+        if self.precision not in ("fp32", "fp16"):
+            raise ValueError(f"precision must be fp32 or fp16, got {self.precision}")
+        half = self.precision == "fp16" and schedule == "segments" and fused_shade
+        f = self._field_f16() if half else self._field()
+        sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
         ws = torch.zeros(N, device=device)
         depth = torch.zeros(N, device=device)
         image = torch.zeros(N, 3, device=device)
@@ -176,12 +188,18 @@ class SemanticNeRFRenderer(nn.Module):
                     xyzs, dirs, deltas = seg.write(n_alive, total, jitter)
                     feat = ops.hashgrid_encode_points(f["grid"], f["table"],
                                                       xyzs)
-                    h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
-                    rgbs, probs = ops.point_shade_h(dirs, h, f["packed_color"],
-                                                    f["packed_sem"], C)
-                    seg.composite(n_alive, cap, sigma,
-                                  float(self.density_scale), rgbs, probs,
-                                  deltas, ws, depth, image, sem)
+                    h, sigma = sigma_mlp(feat, f["packed_sigma"])
+                    if fused_shade:
+                        seg.shade(n_alive, cap, sigma,
+                                  float(self.density_scale), h, deltas,
+                                  f["packed_color"], f["packed_sem"], C,
+                                  float(w_min), ws, depth, image, sem, half)
+                    else:
+                        rgbs, probs = ops.point_shade_h(
+                            dirs, h, f["packed_color"], f["packed_sem"], C)
+                        seg.composite(n_alive, cap, sigma,
+                                      float(self.density_scale), rgbs, probs,
+                                      deltas, ws, depth, image, sem)
                     seg.compact(n_alive)
                 self.last_march_points += total
                 self.last_march_rounds += 1
@@ -223,6 +241,7 @@ class SemanticNeRFRenderer(nn.Module):
         else:
             raise ValueError(f"unknown schedule {schedule!r}")
         if far_closure:
+            f = self._field()
             feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d,
                                             fars.view(N, 1), aabb)
             h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])

@@ -646,6 +646,18 @@ class MarchSegments:
             n_sem, _ptr(weights_sum), _ptr(depth), _ptr(image),
             _ptr(semantics), _stream()), "ucsa_march_segment_composite")
 
+    def shade(self, n_cap: int, cap: int, sigmas, sigma_scale: float, h,
+              deltas, packed_color, packed_sem, n_classes: int, w_min: float,
+              weights_sum, depth, image, semantics, half: bool = False):
+        fn = (lib().ucsa_march_segment_shade_f16 if half
+              else lib().ucsa_march_segment_shade)
+        check(fn(n_cap, self._n_dev(), cap, _ptr(self.alive[self.cur]),
+                 _ptr(self.t[self.cur]), _ptr(self.span), _ptr(self.d),
+                 _ptr(sigmas), float(sigma_scale), _ptr(h), _ptr(deltas),
+                 _ptr(packed_color), _ptr(packed_sem), n_classes, float(w_min),
+                 _ptr(weights_sum), _ptr(depth), _ptr(image), _ptr(semantics),
+                 _stream()), "ucsa_march_segment_shade")
+
     def compact(self, n_cap: int):
         nxt = 1 - self.cur
         check(lib().ucsa_march_segment_compact(
