@@ -266,6 +266,13 @@ int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid_host, const float* rays_o,
                                const float* d_feat, float* grad_table,
                                void* workspace, void* stream);
 
+/* Backward of ucsa_hashgrid_encode_points (x [M,3] explicit points; workspace
+ * of ucsa_hashgrid_bwd_workspace_bytes(M, 1, n_levels) or NULL). */
+int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid_host, const float* x,
+                                 uint32_t M, const float* d_feat,
+                                 float* grad_table, void* workspace,
+                                 void* stream);
+
 /* Backward of ucsa_composite_fwd (autograd of renderer_semantics.py:238-299
  * and the masked color()/semantics()).  Needs the forward's `src` and
  * `weights`.  Out: d_h_c [N*T,16], d_h_f [N*t,16] (all 16 slots; slot 0 is
@@ -421,6 +428,43 @@ int32_t ucsa_compact_rays(uint32_t n_alive, int32_t* rays_alive,
                           const float* rays_t_old, int32_t* alive_counter,
                           void* workspace, void* stream);
 
+/* ---- training through the marcher ---------------------------------------------
+ * Forward / backward of one training batch sampled by ucsa_march_rays_train
+ * (rays [N,3] = ray id, first point, count; M points).  What the reference's
+ * parent code did with march_rays_train -> network -> composite_rays_train,
+ * fused like the inference path: sigma / h [M,16] come from the sigma MLP,
+ * the colour and semantics nets run inside, only on samples with w > w_min.
+ *   fwd: weights_sum, depth (= sum w*t, t measured from the ray origin:
+ *        nears[ray] + the accumulated deltas), image, semantics by ray id --
+ *        ADDED to zero-filled buffers; w_out, t_out [M] (zero-filled) keep
+ *        each sample's weight and ray parameter for the backward.  No early
+ *        stop (raymarching.cu:363 is commented out in the reference as well);
+ *        spans reaching M are skipped (:338).
+ *   bwd: d_image [N,3], d_depth [N] (wrt depth/norms[ray]), d_sem [N,C] ->
+ *        d_h [M,16] (slot 0: d/d log-density incl. the trunc_exp backward),
+ *        scratch G [M], per-wave dW partials
+ *        [ucsa_composite_bwd_parts(N)][7168] and [..][1024+1024*ceil(C/16)].
+ *        Semantic weights are detached (reference renderer_semantics.py:270).
+ *        Unlike the reference's composite_rays_train backward
+ *        (raymarching.py:209) the depth gradient IS propagated, as the live
+ *        path does. */
+int32_t ucsa_march_train_fwd(
+    const int32_t* rays, uint32_t N, uint32_t M, const float* nears,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* packed_color, const float* packed_sem,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth,
+    float* image, float* semantics, float* w_out, float* t_out, void* stream);
+
+int32_t ucsa_march_train_bwd(
+    const int32_t* rays, uint32_t N, uint32_t M, const float* rays_d,
+    const float* norms, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* w_all, const float* t_all,
+    const float* packed_color, const float* packed_sem,
+    const float* packed_color_t, const float* packed_sem_t, uint32_t n_classes,
+    float w_min, const float* d_image, const float* d_depth, const float* d_sem,
+    float* G, float* d_h, float* partial_color, float* partial_sem,
+    void* stream);
+
 /* ---- density-grid maintenance -----------------------------------------------
  * No counterpart in the reference's FFI: the reference keeps the state
  * (density_grid [cascade,128,128,128], mean_density, iter_density:
@@ -498,8 +542,8 @@ int32_t ucsa_march_segment_composite(
  * and semantics nets (MFMA, weights in LDS; h [M,16] = raw sigma-MLP rows,
  * rays_d [N,3] by ray id), and the per-ray sums are added in place.  w_min = 0
  * is the reference's composite exactly; 1e-4 is the mask of the live path
- * (reference renderer_semantics.py:249-250).  weights_sum and depth always
- * take every sample. */
+ * (reference renderer_semantics.py:249-250; depth is masked with it, as
+ * there).  weights_sum always takes every sample. */
 int32_t ucsa_march_segment_shade(
     uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
     const int32_t* rays_alive, float* rays_t, const int32_t* span,

@@ -70,7 +70,8 @@ def main():
         for v in views:
             item = ds[v]
             o, d, n = item["rays_o"][None], item["rays_d"][None], item["direction_norms"][None]
-            out, t = timed(lambda: fn(o, d, n), 3)
+            with torch.no_grad():
+                out, t = timed(lambda: fn(o, d, n), 3)
             gt = item["img"].reshape(3, -1).t()
             ps.append(psnr(out["image"][0], gt))
             pred = out["semantics"][0].argmax(-1)

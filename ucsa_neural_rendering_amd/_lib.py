@@ -91,6 +91,8 @@ SIGNATURES = {
     "ucsa_hashgrid_bwd_rays": (C.c_int32, [C.POINTER(Grid), _p, _p, _p,
                                            C.POINTER(_f), _u32, _u32, _p, _p,
                                            _p, _p]),
+    "ucsa_hashgrid_bwd_points": (C.c_int32, [C.POINTER(Grid), _p, _u32, _p, _p,
+                                             _p, _p]),
     "ucsa_composite_bwd_parts": (C.c_uint32, [_u32]),
     "ucsa_composite_bwd": (C.c_int32, [_p] * 17 + [_u32, _u32, _u32, _u32, _f] +
                            [_p] * 6),
@@ -140,6 +142,12 @@ SIGNATURES = {
                                                  _p]),
     "ucsa_march_segment_compact": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p,
                                                _p, _p]),
+    "ucsa_march_train_fwd": (C.c_int32, [_p, _u32, _u32, _p, _p, _p, _f, _p,
+                                         _p, _p, _p, _u32, _f, _p, _p, _p, _p,
+                                         _p, _p, _p]),
+    "ucsa_march_train_bwd": (C.c_int32, [_p, _u32, _u32, _p, _p, _p, _f, _p,
+                                         _p, _p, _p, _p, _p, _p, _p, _u32, _f,
+                                         _p, _p, _p, _p, _p, _p, _p, _p]),
     "ucsa_density_grid_points": (C.c_int32, [_u32, _u32, _f, _u32, _p, _p]),
     "ucsa_density_grid_workspace_bytes": (C.c_uint64, []),
     "ucsa_density_grid_update": (C.c_int32, [_p, _p, C.c_uint64, _f, _f, _p,

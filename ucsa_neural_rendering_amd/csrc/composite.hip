@@ -62,6 +62,13 @@ struct CmpArgs {
   float* weights_sum;
   uint32_t seg_cap;
   float w_min;
+  // rays_alive / span may be columns of the training marcher's rays [N,3]
+  uint32_t alive_stride, span_stride;
+  // training pass over march_rays_train output: no early stop, rays_t is the
+  // per-RAY start (nears, read-only), spans reaching n_points are skipped
+  // (reference raymarching.cu:338), every sample's weight goes to w_out
+  uint32_t train, n_points;
+  float* t_out;  // training: ray parameter after each sample (depth backward)
 };
 
 __device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
@@ -471,11 +478,12 @@ k_composite(CmpArgs a) {
   if constexpr (MARCH) {
     // =================== per-slot loop (marched spans) ====================
     for (uint32_t r = r_begin; r < r_end; ++r) {
-      const uint32_t index = (uint32_t)a.rays_alive[r];
-      const uint32_t offset = (uint32_t)a.span[2 * r];
-      const uint32_t count = (uint32_t)a.span[2 * r + 1];
+      const uint32_t index = (uint32_t)a.rays_alive[(size_t)r * a.alive_stride];
+      const uint32_t offset = (uint32_t)a.span[(size_t)r * a.span_stride];
+      uint32_t count = (uint32_t)a.span[(size_t)r * a.span_stride + 1];
+      if (a.train && offset + count >= a.n_points) count = 0;
       float T_carry = 1.0f - a.weights_sum[index];
-      float t_carry = a.rays_t[r];
+      float t_carry = a.rays_t[a.train ? index : r];
       bool stopped = false;
       float wsum = 0.0f, dsum = 0.0f;
       for (uint32_t s0 = 0; s0 < count && !stopped; s0 += 64) {
@@ -490,17 +498,18 @@ k_composite(CmpArgs a) {
         if (lane == 0) Tex = 1.0f;
         const float Tr = T_carry * Tex;
         // reference raymarching.cu:693-706: take the sample, stop if T < 1e-4
-        const unsigned long long stop_mask = __ballot(live && Tr <= 1e-4f);
+        const unsigned long long stop_mask =
+            a.train ? 0ull : __ballot(live && Tr <= 1e-4f);
         const uint32_t first_stop =
             stop_mask ? (uint32_t)__ffsll((long long)stop_mask) - 1u : 64u;
         const bool use = live && lane <= first_stop;
         const float w = use ? alpha * Tr : 0.0f;
         const float tt = t_carry + wave_incl_scan_add(live ? dl.y : 0.0f, lane);
-        if (use) {
-          wsum += w;
-          dsum += w * tt;
-        }
         const bool keep = use && (w > a.w_min);
+        if (use) wsum += w;
+        if (keep) dsum += w * tt;  // depth is masked like colour (as in run())
+        if (a.w_out && live) a.w_out[m] = w;
+        if (a.t_out && live) a.t_out[m] = tt;
         const unsigned long long bal = __ballot(keep);
         if (keep) {
           const uint32_t pos =
@@ -521,7 +530,8 @@ k_composite(CmpArgs a) {
       if (lane == 0) {
         a.weights_sum[index] += wsum;
         a.depth[index] += dsum;
-        a.rays_t[r] = (stopped || count < a.seg_cap) ? -1.0f : t_carry;
+        if (!a.train)
+          a.rays_t[r] = (stopped || count < a.seg_cap) ? -1.0f : t_carry;
       }
     }
   } else {
@@ -666,7 +676,8 @@ static int32_t composite_launch(
   CmpArgs a{rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
             packed_color, packed_sem, N, T, t, n_classes, density_scale,
             image, depth, semantics, src, weights, rpw, cstride,
-            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0.0f};
+            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0.0f,
+            1u, 2u, 0u, 0u, nullptr};
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(NRB, H)                                                        \
   do {                                                                        \
@@ -732,8 +743,11 @@ extern "C" int32_t ucsa_composite_fwd_f16(
 // rgb / class probabilities never travel through HBM.
 // ---------------------------------------------------------------------------
 static int32_t march_shade_launch(
-    bool half, uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
-    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    bool half, bool train, uint32_t n_points, float* w_out, float* t_out,
+    uint32_t n_cap,
+    const int32_t* n_alive_dev, uint32_t cap, const int32_t* rays_alive,
+    uint32_t alive_stride, float* rays_t, const int32_t* span,
+    uint32_t span_stride,
     const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
     const float* deltas, const float* packed_color, const float* packed_sem,
     uint32_t n_classes, float w_min, float* weights_sum, float* depth,
@@ -766,9 +780,10 @@ static int32_t march_shade_launch(
   const uint32_t blocks = ucsa_div_up(ucsa_div_up(n_cap, rpw), waves);
   CmpArgs a{rays_d, nullptr, nullptr, sigmas, h, nullptr, nullptr, nullptr,
             packed_color, packed_sem, n_cap, 0u, 0u, n_classes, sigma_scale,
-            image, depth, semantics, nullptr, nullptr, rpw, cstride,
+            image, depth, semantics, nullptr, w_out, rpw, cstride,
             rays_alive, rays_t, span, deltas, n_alive_dev, weights_sum, cap,
-            w_min};
+            w_min, alive_stride, span_stride, train ? 1u : 0u, n_points,
+            t_out};
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_M(NRB, H)                                                      \
   do {                                                                        \
@@ -807,8 +822,10 @@ extern "C" int32_t ucsa_march_segment_shade(
     const float* deltas, const float* packed_color, const float* packed_sem,
     uint32_t n_classes, float w_min, float* weights_sum, float* depth,
     float* image, float* semantics, void* stream) {
-  return march_shade_launch(false, n_cap, n_alive_dev, cap, rays_alive, rays_t,
-                            span, rays_d, sigmas, sigma_scale, h, deltas,
+  return march_shade_launch(false, false, 0u, nullptr, nullptr, n_cap,
+                            n_alive_dev, cap,
+                            rays_alive, 1u, rays_t, span, 2u, rays_d, sigmas,
+                            sigma_scale, h, deltas,
                             packed_color, packed_sem, n_classes, w_min,
                             weights_sum, depth, image, semantics, stream);
 }
@@ -821,9 +838,33 @@ extern "C" int32_t ucsa_march_segment_shade_f16(
     const void* packed_sem_half, uint32_t n_classes, float w_min,
     float* weights_sum, float* depth, float* image, float* semantics,
     void* stream) {
-  return march_shade_launch(true, n_cap, n_alive_dev, cap, rays_alive, rays_t,
-                            span, rays_d, sigmas, sigma_scale, h, deltas,
+  return march_shade_launch(true, false, 0u, nullptr, nullptr, n_cap,
+                            n_alive_dev, cap,
+                            rays_alive, 1u, rays_t, span, 2u, rays_d, sigmas,
+                            sigma_scale, h, deltas,
                             (const float*)packed_color_half,
                             (const float*)packed_sem_half, n_classes, w_min,
                             weights_sum, depth, image, semantics, stream);
+}
+
+// Training forward over the output of ucsa_march_rays_train: rays [N,3] =
+// (ray id, first point, count).  Outputs by ray id; the caller zero-fills
+// weights_sum / depth / image / semantics and w_out [M].
+extern "C" int32_t ucsa_march_train_fwd(
+    const int32_t* rays, uint32_t N, uint32_t M, const float* nears,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* packed_color, const float* packed_sem,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth,
+    float* image, float* semantics, float* w_out, float* t_out,
+    void* stream) {
+  UCSA_CHECK_ARG(rays, 0);
+  UCSA_CHECK_ARG(nears, 3);
+  UCSA_CHECK_ARG(w_out && t_out, 17);
+  if (M == 0) return 0;
+  return march_shade_launch(false, true, M, w_out, t_out, N, nullptr, 1u, rays,
+                            3u,
+                            const_cast<float*>(nears), rays + 1, 3u, rays_d,
+                            sigmas, sigma_scale, h, deltas, packed_color,
+                            packed_sem, n_classes, w_min, weights_sum, depth,
+                            image, semantics, stream);
 }

@@ -50,6 +50,13 @@ struct ShadeBwdArgs {
   float* partial_color;
   float* partial_sem;
   uint32_t rays_per_wave;
+  // marched spans (MARCH = true): rays [N,3] = (ray id, first point, count)
+  // of ucsa_march_rays_train; weights / G are [M], h_c / d_h_c are [M,16],
+  // t_all [M] is the ray parameter of each sample (ucsa_march_train_fwd)
+  const int32_t* rays;
+  const float* t_all;
+  uint32_t n_points;
+  float w_min;
 };
 
 __device__ __forceinline__ void sh4_select_b(float dx, float dy, float dz,
@@ -91,7 +98,7 @@ __device__ __forceinline__ f32x4 gate4(f32x4 pre, f32x4 v) {
   return r;
 }
 
-template <int NRB>
+template <int NRB, bool MARCH>
 __global__ void __launch_bounds__(64 * CB_WAVES)
 k_shade_bwd(ShadeBwdArgs a) {
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -194,7 +201,7 @@ k_shade_bwd(ShadeBwdArgs a) {
         dwsum += di[c] * rgb;
         dy3[c] = wgt * di[c] * rgb * (1.0f - rgb);
       }
-      if (live) a.G[(size_t)ray * S + smp] = dwsum;
+      if (live) a.G[MARCH ? (size_t)smp : (size_t)ray * S + smp] = dwsum;
     }
     // semantics = sum_s w_detached * p ; p = softmax(logits)
     float dot = 0.0f;
@@ -323,11 +330,74 @@ k_shade_bwd(ShadeBwdArgs a) {
     }
   };
 
+  // shade the full blocks of 16 waiting in the list, keep the tail
+  auto drain16 = [&]() {
+    uint32_t head = 0;
+    while (cnt - head >= 16) {
+      if (head) {
+        float tw = 0.f, tz = 0.f;
+        uint32_t tr = 0, ty = 0, ts = 0;
+        if (lane < 16) {
+          tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
+          ts = lsmp[head + lane]; tz = lz[head + lane];
+        }
+        cb_sync();
+        if (lane < 16) {
+          lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
+        }
+        cb_sync();
+      }
+      shade16(16);
+      head += 16;
+    }
+    if (head) {
+      const uint32_t rem = cnt - head;  // < 16
+      float tw = 0.f, tz = 0.f;
+      uint32_t tr = 0, ty = 0, ts = 0;
+      if (lane < rem) {
+        tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
+        ts = lsmp[head + lane]; tz = lz[head + lane];
+      }
+      cb_sync();
+      if (lane < rem) {
+        lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
+      }
+      cnt = rem;
+      cb_sync();
+    }
+  };
+
   const uint64_t r_begin64 = gwave * a.rays_per_wave;
   if (r_begin64 < a.N) {
     const uint32_t r_begin = (uint32_t)r_begin64;
     const uint32_t r_end = (r_begin + a.rays_per_wave < a.N) ? r_begin + a.rays_per_wave : a.N;
     for (uint32_t r = r_begin; r < r_end; ++r) {
+      if constexpr (MARCH) {
+        const uint32_t index = (uint32_t)a.rays[3 * (size_t)r];
+        const uint32_t offset = (uint32_t)a.rays[3 * (size_t)r + 1];
+        uint32_t count = (uint32_t)a.rays[3 * (size_t)r + 2];
+        if (offset + count >= a.n_points) count = 0;
+        for (uint32_t sbase = 0; sbase < count; sbase += 64) {
+          const uint32_t s = sbase + lane;
+          const bool in = s < count;
+          const size_t m = (size_t)offset + (in ? s : sbase);
+          const float w = in ? a.weights[m] : 0.0f;
+          const bool keep = in && w > a.w_min;
+          if (in && !keep) a.G[m] = 0.0f;
+          const unsigned long long bal = __ballot(keep);
+          if (keep) {
+            const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            lw[pos] = w;
+            lrow[pos] = (uint32_t)m;
+            lray[pos] = index;
+            lsmp[pos] = (uint32_t)m;
+            lz[pos] = a.t_all[m];
+          }
+          cnt += (uint32_t)__popcll(bal);
+          cb_sync();
+          drain16();
+        }
+      } else {
       for (uint32_t sbase = 0; sbase < S; sbase += 64) {
         const uint32_t s = sbase + lane;
         float w = 0.0f;
@@ -349,39 +419,8 @@ k_shade_bwd(ShadeBwdArgs a) {
         }
         cnt += (uint32_t)__popcll(bal);
         cb_sync();
-        uint32_t head = 0;
-        while (cnt - head >= 16) {
-          if (head) {
-            float tw = 0.f, tz = 0.f;
-            uint32_t tr = 0, ty = 0, ts = 0;
-            if (lane < 16) {
-              tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
-              ts = lsmp[head + lane]; tz = lz[head + lane];
-            }
-            cb_sync();
-            if (lane < 16) {
-              lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
-            }
-            cb_sync();
-          }
-          shade16(16);
-          head += 16;
-        }
-        if (head) {
-          const uint32_t rem = cnt - head;  // < 16
-          float tw = 0.f, tz = 0.f;
-          uint32_t tr = 0, ty = 0, ts = 0;
-          if (lane < rem) {
-            tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
-            ts = lsmp[head + lane]; tz = lz[head + lane];
-          }
-          cb_sync();
-          if (lane < rem) {
-            lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
-          }
-          cnt = rem;
-          cb_sync();
-        }
+        drain16();
+      }
       }
     }
     if (cnt) shade16(cnt);
@@ -520,18 +559,19 @@ extern "C" int32_t ucsa_composite_bwd(
   ShadeBwdArgs a{rays_d, norms, z_c, z_f, h_c, h_f, src, weights, d_image,
                  d_depth, d_sem, packed_color, packed_sem, packed_color_t,
                  packed_sem_t, N, T, t, n_classes, G, d_h_c, d_h_f,
-                 partial_color, partial_sem, rpw};
+                 partial_color, partial_sem, rpw, nullptr, nullptr, 0u, 0.0f};
   const size_t smem = (7168 + 1024 + (size_t)nrb * 1024 + 6144 +
                        (16 * (size_t)nrb + 16) * 64 +
                        (size_t)CB_WAVES * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
 #define LAUNCH(NRB)                                                           \
   do {                                                                        \
     hipError_t e2 = hipFuncSetAttribute(                                      \
-        reinterpret_cast<const void*>(&k_shade_bwd<NRB>),                     \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, false>),                     \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e2 != hipSuccess) return -(int32_t)e2;                                \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL(k_shade_bwd<NRB>, dim3(blocks), dim3(64 * CB_WAVES),   \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, false>), dim3(blocks),               \
+                       dim3(64 * CB_WAVES),                                   \
                        smem, s, a);                                           \
   } while (0)
   switch (nrb) {
@@ -548,5 +588,123 @@ extern "C" int32_t ucsa_composite_bwd(
   hipLaunchKernelGGL(k_weights_bwd, dim3(ucsa_div_up(N, WB_WAVES)),
                      dim3(64 * WB_WAVES), smem2, s, z_c, z_f, sigma_c, sigma_f,
                      src, weights, G, N, T, t, density_scale, d_h_c, d_h_f);
+  return ucsa_launch_status();
+}
+
+// ===========================================================================
+// Marched training backward: the autograd of
+// ucsa_march_train_fwd.
+//   k_shade_bwd<MARCH>   : as above on the spans of rays [N,3]; G is [M]
+//   k_march_weights_bwd  : one wave per ray:
+//       d_sigma_i = delta_i * scale * (G_i * T_{i+1} - sum_{j>i} G_j w_j)
+//     (the reference's composite_rays_train backward, raymarching.cu:468-474,
+//     with G_i = dL/dw_i), times the trunc_exp backward, into d_h[:,0].
+// ===========================================================================
+#define MW_WAVES 4
+
+__global__ void __launch_bounds__(64 * MW_WAVES)
+k_march_weights_bwd(const int32_t* __restrict__ rays, uint32_t N, uint32_t M,
+                    const float* __restrict__ sigmas, float sigma_scale,
+                    const float* __restrict__ deltas,
+                    const float* __restrict__ w_all, const float* __restrict__ G,
+                    float* __restrict__ d_h) {
+  __shared__ float suf_s[MW_WAVES][1024];
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t r = blockIdx.x * MW_WAVES + wid;
+  if (r >= N) return;
+  const uint32_t offset = (uint32_t)rays[3 * (size_t)r + 1];
+  const uint32_t count = (uint32_t)rays[3 * (size_t)r + 2];
+  if (count == 0 || offset + count >= M) return;
+  float* suf = suf_s[wid];
+  float carry = 0.0f;
+  for (uint32_t rb = 0; rb < count; rb += 64) {
+    const uint32_t k = rb + lane;
+    const bool ok = k < count;
+    const uint32_t i = ok ? count - 1 - k : 0;
+    const float q = ok ? G[(size_t)offset + i] * w_all[(size_t)offset + i] : 0.0f;
+    const float incl = wave_incl_scan_add(q, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0f;
+    if (ok) suf[i] = carry + excl;
+    carry = carry + wave_bcast(incl, 63);
+  }
+  cb_sync();
+  float tcarry = 1.0f;
+  const float lo = expf(-15.0f), hi = expf(15.0f);
+  for (uint32_t sb = 0; sb < count; sb += 64) {
+    const uint32_t s = sb + lane;
+    const bool ok = s < count;
+    const size_t m = (size_t)offset + (ok ? s : sb);
+    const float sig = sigmas[m];
+    const float delta = deltas[2 * m];
+    const float ex = ok ? __expf(-sig * sigma_scale * delta) : 1.0f;
+    const float incl = wave_incl_scan_mul(ex, lane);
+    const float Tnext = tcarry * incl;  // transmittance after this sample
+    tcarry = tcarry * wave_bcast(incl, 63);
+    if (ok) {
+      const float dsigma = delta * sigma_scale * (G[m] * Tnext - suf[s]);
+      d_h[m * 16] = dsigma * fminf(fmaxf(sig, lo), hi);
+    }
+  }
+}
+
+extern "C" int32_t ucsa_march_train_bwd(
+    const int32_t* rays, uint32_t N, uint32_t M, const float* rays_d,
+    const float* norms, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const float* w_all, const float* t_all,
+    const float* packed_color, const float* packed_sem,
+    const float* packed_color_t, const float* packed_sem_t, uint32_t n_classes,
+    float w_min, const float* d_image, const float* d_depth, const float* d_sem,
+    float* G, float* d_h, float* partial_color, float* partial_sem,
+    void* stream) {
+  UCSA_CHECK_ARG(rays, 0);
+  UCSA_CHECK_ARG(rays_d && norms, 3);
+  UCSA_CHECK_ARG(M == 0 || (sigmas && h && deltas && w_all && t_all), 5);
+  UCSA_CHECK_ARG(packed_color && packed_sem && packed_color_t && packed_sem_t, 11);
+  UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 15);
+  UCSA_CHECK_ARG(w_min >= 0.f, 16);
+  UCSA_CHECK_ARG(d_image && d_depth && d_sem, 17);
+  UCSA_CHECK_ARG(M == 0 || (G && d_h), 20);
+  UCSA_CHECK_ARG(partial_color && partial_sem, 22);
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t nrb = cb_pad16(n_classes) / 16;
+  uint32_t rpw, blocks;
+  shade_bwd_geometry(N, rpw, blocks);
+  if (M) {
+    hipError_t e = hipMemsetAsync(d_h, 0, (size_t)M * 16 * sizeof(float), s);
+    if (e != hipSuccess) return -(int32_t)e;
+  }
+  ShadeBwdArgs a{rays_d, norms, nullptr, nullptr, h, nullptr, nullptr, w_all,
+                 d_image, d_depth, d_sem, packed_color, packed_sem,
+                 packed_color_t, packed_sem_t, N, 0u, 0u, n_classes, G, d_h,
+                 nullptr, partial_color, partial_sem, rpw, rays, t_all, M, w_min};
+  const size_t smem = (7168 + 1024 + (size_t)nrb * 1024 + 6144 +
+                       (16 * (size_t)nrb + 16) * 64 +
+                       (size_t)CB_WAVES * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
+#define LAUNCH_M(NRB)                                                         \
+  do {                                                                        \
+    hipError_t e2 = hipFuncSetAttribute(                                      \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, true>),               \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
+    if (e2 != hipSuccess) return -(int32_t)e2;                                \
+    UCSA_CLEAR_ERR();                                                         \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, true>), dim3(blocks),                \
+                       dim3(64 * CB_WAVES), smem, s, a);                      \
+  } while (0)
+  switch (nrb) {
+    case 1: LAUNCH_M(1); break;
+    case 2: LAUNCH_M(2); break;
+    case 3: LAUNCH_M(3); break;
+    default: LAUNCH_M(4); break;
+  }
+#undef LAUNCH_M
+  int32_t rc = ucsa_launch_status();
+  if (rc) return rc;
+  if (M == 0) return 0;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_march_weights_bwd, dim3(ucsa_div_up(N, MW_WAVES)),
+                     dim3(64 * MW_WAVES), 0, s, rays, N, M, sigmas, sigma_scale,
+                     deltas, w_all, G, d_h);
   return ucsa_launch_status();
 }

@@ -145,13 +145,21 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
     const float2 df = d_feat[(uint64_t)level * M + m];
     const bool act = in_range && !(df.x == 0.0f && df.y == 0.0f);
     if (!RUNRED && !act) return;
-    const uint32_t r = (uint32_t)(m / T);
-    const float zz = zs[m];
-    const float* o = rays_o + (size_t)r * 3;
-    const float* d = rays_d + (size_t)r * 3;
-    const float px = clampf_b(o[0] + d[0] * zz, bb.lo[0], bb.hi[0]);
-    const float py = clampf_b(o[1] + d[1] * zz, bb.lo[1], bb.hi[1]);
-    const float pz = clampf_b(o[2] + d[2] * zz, bb.lo[2], bb.hi[2]);
+    float px, py, pz;
+    if (zs) {
+      const uint32_t r = (uint32_t)(m / T);
+      const float zz = zs[m];
+      const float* o = rays_o + (size_t)r * 3;
+      const float* d = rays_d + (size_t)r * 3;
+      px = clampf_b(o[0] + d[0] * zz, bb.lo[0], bb.hi[0]);
+      py = clampf_b(o[1] + d[1] * zz, bb.lo[1], bb.hi[1]);
+      pz = clampf_b(o[2] + d[2] * zz, bb.lo[2], bb.hi[2]);
+    } else {  // explicit points (ucsa_hashgrid_bwd_points): rays_o = x [M,3]
+      const float* xp = rays_o + (size_t)m * 3;
+      px = xp[0];
+      py = xp[1];
+      pz = xp[2];
+    }
     const float x = (px + g.bound) / two_b * scale + 0.5f;
     const float y = (py + g.bound) / two_b * scale + 0.5f;
     const float z = (pz + g.bound) / two_b * scale + 0.5f;
@@ -225,15 +233,26 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
                                             const Aabb& bb, uint32_t T,
                                             uint64_t m, uint32_t (&gi)[3],
                                             float (&wf)[3]) {
-  const uint32_t r = (uint32_t)(m / T);
-  const float zz = zs[m];
-  const float* o = rays_o + (size_t)r * 3;
-  const float* d = rays_d + (size_t)r * 3;
   const float two_b = 2.0f * g.bound;
   const float scale = g.scale[level];
+  float pos[3];
+  if (zs) {
+    const uint32_t r = (uint32_t)(m / T);
+    const float zz = zs[m];
+    const float* o = rays_o + (size_t)r * 3;
+    const float* d = rays_d + (size_t)r * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      pos[a] = clampf_b(o[a] + d[a] * zz, bb.lo[a], bb.hi[a]);
+  } else {  // explicit points: rays_o = x [M,3]
+    const float* xp = rays_o + (size_t)m * 3;
+    pos[0] = xp[0];
+    pos[1] = xp[1];
+    pos[2] = xp[2];
+  }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float p = clampf_b(o[a] + d[a] * zz, bb.lo[a], bb.hi[a]);
+    const float p = pos[a];
     const float x = (p + g.bound) / two_b * scale + 0.5f;
     const float f0 = floorf(x);
     wf[a] = x - f0;
@@ -383,19 +402,13 @@ extern "C" uint64_t ucsa_hashgrid_bwd_workspace_bytes(uint32_t N, uint32_t T,
          (uint64_t)n_levels * BIN_COUNT * bg.cap * sizeof(float4);
 }
 
-extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
-                                          const float* rays_o,
-                                          const float* rays_d, const float* z,
-                                          const float* aabb_host, uint32_t N,
-                                          uint32_t T, const float* d_feat,
-                                          float* grad_table, void* workspace,
-                                          void* stream) {
-  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
-                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
-  UCSA_CHECK_ARG(rays_o && rays_d && z, 1);
-  UCSA_CHECK_ARG(aabb_host, 4);
-  UCSA_CHECK_ARG(d_feat, 7);
-  UCSA_CHECK_ARG(grad_table, 8);
+// z == nullptr: rays_o holds M = N explicit points (T = 1), aabb unused.
+static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
+                                   const float* rays_d, const float* z,
+                                   const float* aabb_host, uint32_t N,
+                                   uint32_t T, const float* d_feat,
+                                   float* grad_table, void* workspace,
+                                   void* stream) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
   // Binning pays where updates are spread over the whole slab (hashed levels
@@ -454,4 +467,36 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
                        dim3(256), 0, (hipStream_t)stream, gd, rays_o, rays_d, z,
                        bb, T, M, n_run, (const float2*)d_feat, grad_table);
   return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
+                                          const float* rays_o,
+                                          const float* rays_d, const float* z,
+                                          const float* aabb_host, uint32_t N,
+                                          uint32_t T, const float* d_feat,
+                                          float* grad_table, void* workspace,
+                                          void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(rays_o && rays_d && z, 1);
+  UCSA_CHECK_ARG(aabb_host, 4);
+  UCSA_CHECK_ARG(d_feat, 7);
+  UCSA_CHECK_ARG(grad_table, 8);
+  return hashgrid_bwd_launch(grid, rays_o, rays_d, z, aabb_host, N, T, d_feat,
+                             grad_table, workspace, stream);
+}
+
+extern "C" int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid,
+                                            const float* x, uint32_t M,
+                                            const float* d_feat,
+                                            float* grad_table, void* workspace,
+                                            void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(x, 1);
+  UCSA_CHECK_ARG(d_feat, 3);
+  UCSA_CHECK_ARG(grad_table, 4);
+  static const float no_aabb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return hashgrid_bwd_launch(grid, x, nullptr, nullptr, no_aabb, M, 1u, d_feat,
+                             grad_table, workspace, stream);
 }

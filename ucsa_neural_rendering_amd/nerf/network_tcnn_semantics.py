@@ -81,6 +81,56 @@ class _RenderFn(torch.autograd.Function):
         return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
 
 
+class _MarchRenderFn(torch.autograd.Function):
+    """Autograd boundary of the marched training pass:
+    occupancy-grid samples (ucsa_march_rays_train) -> hash grid + sigma MLP on
+    the points -> fused weights / compaction / colour + semantics nets /
+    compositing (ucsa_march_train_fwd), and the matching backward.  As in
+    ``_RenderFn`` only the four parameter tensors are differentiable."""
+
+    @staticmethod
+    def forward(ctx, grid_p, sigma_p, color_p, sem_p, net, o, d, nrm, nears,
+                xyzs, deltas, rays, w_min):
+        f = net._field(transposed=True)
+        C = net.num_semantic_classes
+        ds = float(net.density_scale)
+        M = xyzs.shape[0]
+        feat = ops.hashgrid_encode_points(f["grid"], f["table"], xyzs)
+        h, sigma = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
+        ws, depth_raw, image, sem, w, t = ops.march_train_fwd(
+            rays, M, nears, d, sigma, ds, h, deltas, f["packed_color"],
+            f["packed_sem"], C, w_min)
+        ctx.net, ctx.f, ctx.w_min = net, f, w_min
+        ctx.saved = (d, nrm, xyzs, deltas, rays, feat, h, sigma, w, t)
+        ctx.mark_non_differentiable(ws)
+        return image, depth_raw / nrm, sem, ws
+
+    @staticmethod
+    def backward(ctx, d_image, d_depth, d_sem, _d_ws):
+        net, f, w_min = ctx.net, ctx.f, ctx.w_min
+        d, nrm, xyzs, deltas, rays, feat, h, sigma, w, t = ctx.saved
+        C = net.num_semantic_classes
+        M = xyzs.shape[0]
+        d_h, pc, ps = ops.march_train_bwd(
+            rays, M, d, nrm, sigma, float(net.density_scale), h, deltas, w, t,
+            f["packed_color"], f["packed_sem"], f["packed_color_t"],
+            f["packed_sem_t"], C, w_min, d_image.contiguous(),
+            d_depth.contiguous(), d_sem.contiguous())
+        g_color = torch.empty_like(net.color_net.params)
+        g_sem = torch.empty_like(net.semantics_net.params)
+        ops.reduce_partials(pc, g_color, False)
+        ops.reduce_partials(ps, g_sem, False)
+        g_sigma = torch.zeros_like(net.sigma_net.params)
+        g_grid = torch.zeros_like(net.encoder.params)
+        if M > 0:
+            d_feat, part = ops.sigma_mlp_bwd(feat, d_h, f["packed_sigma"],
+                                             f["packed_sigma_t"])
+            ops.reduce_partials(part, g_sigma, False)
+            ops.hashgrid_bwd_points(f["grid"], xyzs, d_feat, g_grid)
+        ctx.saved = None
+        return (g_grid, g_sigma, g_color, g_sem) + (None,) * 9
+
+
 class SemanticNeRFNetwork(SemanticNeRFRenderer):
 
     def __init__(self, encoding="HashGrid", encoding_dir="SphericalHarmonics",
@@ -179,6 +229,15 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
                                    net.color_net.params,
                                    net.semantics_net.params, net, o, d, nrm,
                                    aabb, T, t, rng_t, rng_u, min_near)
+        return call
+
+    def _march_render_fn(self):
+        def call(net, o, d, nrm, nears, xyzs, deltas, rays, w_min):
+            return _MarchRenderFn.apply(net.encoder.params,
+                                        net.sigma_net.params,
+                                        net.color_net.params,
+                                        net.semantics_net.params, net, o, d,
+                                        nrm, nears, xyzs, deltas, rays, w_min)
         return call
 
     # -- pointwise API (reference :102-207) -----------------------------------

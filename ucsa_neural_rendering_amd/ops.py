@@ -309,6 +309,24 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
           "ucsa_hashgrid_bwd_rays")
 
 
+def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
+    """Backward of hashgrid_encode_points: adds into grad_table."""
+    x = _f32(x, "x").view(-1, 3)
+    M = x.shape[0]
+    ws = None
+    if binned:
+        need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(M, 1, grid.n_levels))
+        key = x.device
+        ws = _bwd_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            _bwd_ws[key] = ws
+    check(lib().ucsa_hashgrid_bwd_points(C.byref(grid), _ptr(x), M,
+                                         _ptr(d_feat), _ptr(grad_table),
+                                         _ptr(ws), _stream()),
+          "ucsa_hashgrid_bwd_points")
+
+
 def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
                   weights, packed_color, packed_sem, packed_color_t,
                   packed_sem_t, d_image, d_depth, d_sem, n_classes: int,
@@ -667,3 +685,49 @@ class MarchSegments:
             _stream()), "ucsa_march_segment_compact")
         self.cur = nxt
         self.first = False
+
+
+def march_train_fwd(rays, M: int, nears, rays_d, sigmas, sigma_scale: float, h,
+                    deltas, packed_color, packed_sem, n_classes: int,
+                    w_min: float):
+    """-> weights_sum [N], depth_raw [N] (sum w*t), image [N,3], sem [N,C],
+    w [M], t [M]."""
+    N = rays.shape[0]
+    dev = rays.device
+    ws = torch.zeros(N, device=dev)
+    depth = torch.zeros(N, device=dev)
+    image = torch.zeros(N, 3, device=dev)
+    sem = torch.zeros(N, n_classes, device=dev)
+    w = torch.zeros(M, device=dev)
+    t = torch.zeros(M, device=dev)
+    check(lib().ucsa_march_train_fwd(
+        _ptr(_i32(rays, "rays")), N, M, _ptr(_f32(nears, "nears")),
+        _ptr(_f32(rays_d, "rays_d")), _ptr(sigmas), float(sigma_scale), _ptr(h),
+        _ptr(deltas), _ptr(packed_color), _ptr(packed_sem), n_classes,
+        float(w_min), _ptr(ws), _ptr(depth), _ptr(image), _ptr(sem), _ptr(w),
+        _ptr(t), _stream()), "ucsa_march_train_fwd")
+    return ws, depth, image, sem, w, t
+
+
+def march_train_bwd(rays, M: int, rays_d, norms, sigmas, sigma_scale: float, h,
+                    deltas, w, t, packed_color, packed_sem, packed_color_t,
+                    packed_sem_t, n_classes: int, w_min: float, d_image,
+                    d_depth, d_sem):
+    """-> d_h [M,16], partial_color, partial_sem."""
+    N = rays.shape[0]
+    dev = rays.device
+    G = torch.empty(max(M, 1), device=dev)
+    d_h = torch.empty(max(M, 1), 16, device=dev)
+    parts = int(lib().ucsa_composite_bwd_parts(N))
+    nrb = (n_classes + 15) // 16
+    pc = torch.empty(parts, 7168, device=dev)
+    ps = torch.empty(parts, 1024 + 1024 * nrb, device=dev)
+    check(lib().ucsa_march_train_bwd(
+        _ptr(rays), N, M, _ptr(rays_d), _ptr(norms), _ptr(sigmas),
+        float(sigma_scale), _ptr(h), _ptr(deltas), _ptr(w), _ptr(t),
+        _ptr(packed_color), _ptr(packed_sem), _ptr(packed_color_t),
+        _ptr(packed_sem_t), n_classes, float(w_min),
+        _ptr(_f32(d_image, "d_image")), _ptr(_f32(d_depth, "d_depth")),
+        _ptr(_f32(d_sem, "d_sem")), _ptr(G), _ptr(d_h), _ptr(pc), _ptr(ps),
+        _stream()), "ucsa_march_train_bwd")
+    return d_h[:M], pc, ps
