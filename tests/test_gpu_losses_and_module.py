@@ -152,3 +152,27 @@ def test_train_joint_entrypoint_tiny(tmp_path):
     assert p1 > p0 + 3.0, (p0, p1)
     assert (tmp_path / "experiments/joint_train/test_tiny/deeplab.ckpt").exists()
     assert "test_nerf_mIoU" in r1["test_after_joint"]
+
+
+def test_train_joint_entrypoint_tiny_cuda_ray(tmp_path):
+    """The same entry point with `nerf: {cuda_ray: true}`: NeRF training and
+    evaluation go through the occupancy-grid marcher."""
+    import argparse
+    from scripts import train_joint as tj
+    env = {"results": str(tmp_path / "experiments"), "scannet": str(tmp_path)}
+    cfgp = tmp_path / "exp.yml"
+    cfgp.write_text("x: 1\n")
+    args = argparse.Namespace(exp_name="t", fix_nerf=False, seed=123,
+                              nerf_train_epoch=0, joint_train_epoch=0,
+                              limit_batches=None)
+    exp = _tiny_exp()
+    exp["nerf"].update(cuda_ray=True, dt_gamma=1.0 / 128)
+    r0 = tj.train(exp, env, str(cfgp), str(cfgp), args)
+    exp = _tiny_exp()
+    exp["nerf"].update(cuda_ray=True, dt_gamma=1.0 / 128)
+    args.nerf_train_epoch, args.joint_train_epoch = 25, 1
+    r1 = tj.train(exp, env, str(cfgp), str(cfgp), args)
+    p0 = r0["test_after_nerf"]["test_nerf_PSNR"]
+    p1 = r1["test_after_nerf"]["test_nerf_PSNR"]
+    assert p1 > p0 + 3.0, (p0, p1)
+    assert "test_nerf_mIoU" in r1["test_after_joint"]

@@ -46,11 +46,20 @@ class JointTrainLightningNet(nn.Module):
         super().__init__()
         self.num_classes = exp["model"]["num_classes"]
         self.seg_model = DeepLabV3(exp["model"])
-        self.nerf_model = SemanticNeRFNetwork(
-            encoding="hashgrid", bound=4, cuda_ray=False, density_scale=1,
-            num_semantic_classes=self.num_classes,
-            seed=exp.get("nerf_seed"))
         nerf_cfg = exp.get("nerf", {})  # optional block, defaults = reference
+        # The reference hard-codes cuda_ray=False (:29-35).  `nerf: {cuda_ray:
+        # true}` trains and renders through the occupancy-grid marcher
+        # instead: the density grid is refreshed every 16
+        # NeRF steps and before every evaluation epoch.
+        self.cuda_ray = bool(nerf_cfg.get("cuda_ray", False))
+        self.dt_gamma = float(nerf_cfg.get("dt_gamma", 1.0 / 256))
+        self.nerf_model = SemanticNeRFNetwork(
+            encoding="hashgrid", bound=4, cuda_ray=self.cuda_ray,
+            density_scale=1, num_semantic_classes=self.num_classes,
+            seed=exp.get("nerf_seed"))
+        self.nerf_model.march_training = self.cuda_ray
+        self._nerf_steps = 0
+        self._grid_stale = True  # refresh the density grid before evaluating
         self.n_rays_train = int(nerf_cfg.get("n_rays", 4096))
         self.num_steps = int(nerf_cfg.get("num_steps", 256))
         self.upsample_steps = int(nerf_cfg.get("upsample_steps", 256))
@@ -150,10 +159,16 @@ class JointTrainLightningNet(nn.Module):
                               torch.stack(C * [inds], -1))
         labels = torch.gather(label_nerf.reshape(B, -1), 1, inds)
         gt_depth = torch.gather(depths.reshape(B, -1), 1, inds)
+        if self.cuda_ray:
+            if self._nerf_steps % 16 == 0:
+                self.nerf_model.update_extra_state()
+            self._nerf_steps += 1
+            self._grid_stale = True
         outputs = self.nerf_model.render(
             rays_o, rays_d, direction_norms=direction_norms, staged=False,
             bg_color=None, perturb=True, epoch=self.current_epoch,
-            num_steps=self.num_steps, upsample_steps=self.upsample_steps)
+            num_steps=self.num_steps, upsample_steps=self.upsample_steps,
+            **({"dt_gamma": self.dt_gamma} if self.cuda_ray else {}))
         return ulosses.nerf_losses(outputs["image"], outputs["semantics"],
                                    outputs["depth"], gt_rgb.float(), labels,
                                    gt_depth.float(), uom)
@@ -168,10 +183,15 @@ class JointTrainLightningNet(nn.Module):
             H, W = self._default_H, self._default_W
         else:
             B, C, H, W = batch["img"].shape
+        if self.cuda_ray and self._grid_stale:
+            self.nerf_model.update_extra_state()
+            self._grid_stale = False
         outputs = self.nerf_model.render(
             rays_o, rays_d, direction_norms=direction_norms, staged=True,
             bg_color=1, perturb=False, num_steps=self.num_steps,
-            upsample_steps=self.upsample_steps)
+            upsample_steps=self.upsample_steps,
+            **({"dt_gamma": self.dt_gamma, "far_closure": False}
+               if self.cuda_ray else {}))
         pred_rgb = outputs["image"].reshape(B, H, W, 3)
         sem = outputs["semantics"].reshape(B, H, W, self.num_classes)
         sem_norm, pred_sem = ops.semantic_postproc(sem)
