@@ -32,6 +32,9 @@ def _t(a, dtype=None):
     (4096, 4.0, 32, 1 / 128, False, False),
     (3001, 2.0, 64, 1 / 128, True, True),
     (64, 4.0, 128, 0.0, False, True),
+    (40000, 2.0, 32, 1 / 128, True, True),   # > 32768 rays: lane-per-ray kernels
+    (5000, 4.0, 128, 1 / 256, True, False),  # wave-per-ray, long orbits
+    (777, 1.0, 64, 0.0, False, False),
 ])
 def test_march_rays_train_bit_exact(N, bound, H, dt_gamma, perturb, outside):
     rm = _rm()

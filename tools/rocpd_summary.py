@@ -17,12 +17,24 @@ def main(path):
     import os
     by_grid = os.environ.get("BY_GRID") and "grid_x" in cols
     sel = f"{name_col}, start, end" + (", grid_x" if by_grid else ", 0")
-    rows = c.execute(f"select {sel} from kernels").fetchall()
+    rows = c.execute(f"select {sel} from kernels order by start").fetchall()
+    # TAIL_FRAC=0.2: only the kernels launched in the last 20 % of the traced
+    # wall time (e.g. the steady state after a warm-up phase)
+    tail = float(os.environ.get("TAIL_FRAC", "0") or 0)
+    if tail > 0 and rows:
+        t0, t1 = rows[0][1], rows[-1][2]
+        cut = t1 - tail * (t1 - t0)
+        rows = [r for r in rows if r[1] >= cut]
     agg = defaultdict(list)
     for n, s, e, gx in rows:
         agg[f"[{gx}] {n}" if by_grid else n].append(e - s)
     tot = sum(sum(v) for v in agg.values()) or 1
     print(f"# rocprofv3 kernel-trace summary of {path}")
+    if rows:
+        span = rows[-1][2] - rows[0][1]
+        print(f"# {len(rows)} dispatches over {span/1e6:.1f} ms, GPU busy "
+              f"{tot/1e6:.1f} ms ({100*tot/max(span,1):.0f} %)"
+              + (f", last {tail:.2f} of the trace" if tail > 0 else ""))
     print(f"# {'kernel':60s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} "
           f"{'min_us':>10s} {'max_us':>10s} {'share%':>7s}")
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
