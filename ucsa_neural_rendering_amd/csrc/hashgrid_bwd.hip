@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256)
 k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
                const float* __restrict__ rays_d, const float* __restrict__ zs,
                Aabb bb, uint32_t T, uint64_t M, uint32_t level0,
-               const float2* __restrict__ d_feat,
+               uint32_t tiles, const float2* __restrict__ d_feat,
                float* __restrict__ grad_table) {
   __shared__ uint32_t acc_keys[RUNRED ? ACC_SLOTS : 1];
   __shared__ float acc_vals[RUNRED ? 2 * ACC_SLOTS : 1];
@@ -136,7 +136,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
     }
     __syncthreads();
   }
-  const int n_tiles = RUNRED ? ACC_TILES : 1;
+  const int n_tiles = RUNRED ? (int)tiles : 1;
   for (int tile = 0; tile < n_tiles; ++tile) {
     uint64_t m = ((uint64_t)blockIdx.x * n_tiles + tile) * 256 + threadIdx.x;
     const bool in_range = m < M;
@@ -456,16 +456,21 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
   const GridDev gd = ucsa_grid_dev(grid);
   const Aabb bb = ucsa_aabb(aabb_host);
   UCSA_CLEAR_ERR();
+  // 256-sample tiles per workgroup: ACC_TILES for big batches (fewer flushes
+  // of the LDS accumulator), fewer when that would leave the chip under-filled
+  // (a marched training batch has ~0.3 M points: 34 workgroups per level)
+  uint32_t tiles = ACC_TILES;
+  while (tiles > 1 && ucsa_div_up(M, 256 * tiles) * n_run < 1024) tiles >>= 1;
   if (n_run > 0)
     hipLaunchKernelGGL(k_hashgrid_bwd<true>,
-                       dim3(ucsa_div_up(M, 256 * ACC_TILES), n_run),
+                       dim3(ucsa_div_up(M, 256 * tiles), n_run),
                        dim3(256), 0, (hipStream_t)stream, gd, rays_o, rays_d, z,
-                       bb, T, M, 0u, (const float2*)d_feat, grad_table);
+                       bb, T, M, 0u, tiles, (const float2*)d_feat, grad_table);
   if (n_run < n_lo)
     hipLaunchKernelGGL(k_hashgrid_bwd<false>,
                        dim3(ucsa_div_up(M, 256), n_lo - n_run),
                        dim3(256), 0, (hipStream_t)stream, gd, rays_o, rays_d, z,
-                       bb, T, M, n_run, (const float2*)d_feat, grad_table);
+                       bb, T, M, n_run, 1u, (const float2*)d_feat, grad_table);
   return ucsa_launch_status();
 }
 
