@@ -571,6 +571,30 @@ int32_t ucsa_march_segment_compact(uint32_t n_cap, const int32_t* n_alive_dev,
                                    int32_t* n_alive_out, void* workspace,
                                    void* stream);
 
+/* ---- rendered-image augmentation of the joint step -------
+ * Replaces data_aug (reference joint_train_lightning_net.py:259-302; the
+ * transforms of :89-101 are torchvision 0.12.0 tensor ops, ~40 kernels per
+ * image).  Every random draw is an argument. */
+typedef struct ucsa_aug_params {
+  int32_t order[4];  /* ColorJitter's drawn permutation of 0 brightness,
+                        1 contrast, 2 saturation, 3 hue */
+  float brightness, contrast, saturation, hue; /* the four drawn factors */
+  float angle_deg;   /* tvf.rotate angle (counter-clockwise, degrees) */
+  int32_t flip;      /* != 0: tvf.hflip */
+  int32_t crop_i, crop_j; /* RandomCrop.get_params top / left */
+} ucsa_aug_params;
+
+uint64_t ucsa_augment_workspace_bytes(uint32_t B, uint32_t H, uint32_t W);
+
+/* img [B,3,H,W] in [0,1], label [B,H,W] int64 (-1 unknown) or NULL;
+ * params_host: B structs on the HOST.  out_img [B,3,oh,ow], out_label
+ * [B,oh,ow]: jitter -> rotate (bilinear, resp. nearest on label+1, fill 0) ->
+ * crop to (oh,ow) at (crop_i,crop_j) -> flip. */
+int32_t ucsa_augment(const float* img, const int64_t* label, uint32_t B,
+                     uint32_t H, uint32_t W, const ucsa_aug_params* params_host,
+                     uint32_t oh, uint32_t ow, float* out_img,
+                     int64_t* out_label, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,14 @@ class Grid(C.Structure):
                 ("level", GridLevel * MAX_LEVELS)]
 
 
+class AugParams(C.Structure):
+    _fields_ = [("order", C.c_int32 * 4), ("brightness", C.c_float),
+                ("contrast", C.c_float), ("saturation", C.c_float),
+                ("hue", C.c_float), ("angle_deg", C.c_float),
+                ("flip", C.c_int32), ("crop_i", C.c_int32),
+                ("crop_j", C.c_int32)]
+
+
 _p = C.c_void_p
 _u32 = C.c_uint32
 _f = C.c_float
@@ -148,6 +156,10 @@ SIGNATURES = {
     "ucsa_march_train_bwd": (C.c_int32, [_p, _u32, _u32, _p, _p, _p, _f, _p,
                                          _p, _p, _p, _p, _p, _p, _p, _u32, _f,
                                          _p, _p, _p, _p, _p, _p, _p, _p]),
+    "ucsa_augment_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32]),
+    "ucsa_augment": (C.c_int32, [_p, _p, _u32, _u32, _u32,
+                                 C.POINTER(AugParams), _u32, _u32, _p, _p, _p,
+                                 _p]),
     "ucsa_density_grid_points": (C.c_int32, [_u32, _u32, _f, _u32, _p, _p]),
     "ucsa_density_grid_workspace_bytes": (C.c_uint64, []),
     "ucsa_density_grid_update": (C.c_int32, [_p, _p, C.c_uint64, _f, _f, _p,

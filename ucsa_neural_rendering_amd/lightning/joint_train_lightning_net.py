@@ -83,7 +83,8 @@ class JointTrainLightningNet(nn.Module):
         self._output_size = (240, 320)
         self._flip_p = 0.5
         self._degrees = 10
-        self._jitter = dict(brightness=0.3, contrast=0.3, saturation=0.3)
+        self._jitter = dict(brightness=0.3, contrast=0.3, saturation=0.3,
+                            hue=0.05)
         self._default_H = None
         self._default_W = None
         # thin-Trainer plumbing
@@ -199,33 +200,43 @@ class JointTrainLightningNet(nn.Module):
                 "nerf_semantics": pred_sem, "nerf_semantics_raw": sem_norm}
 
     # ---- rendered-image augmentation (reference :259-302; 8f rank 2) --------
+    @staticmethod
     @torch.no_grad()
-    def data_aug(self, img, label):
-        """img [3,H,W] in [0,1], label [H,W] -> jitter, rotate +-10 deg
-        (bilinear / nearest, fill 0 resp. -1), flip.  Crop to the image's own
-        size and centre crop are identities at 240x320, as in the reference."""
-        label = label[None].float() + 1  # unknown -> 0 so the fill is "unknown"
-        b = 1 + random.uniform(-self._jitter["brightness"], self._jitter["brightness"])
-        c = 1 + random.uniform(-self._jitter["contrast"], self._jitter["contrast"])
-        s = 1 + random.uniform(-self._jitter["saturation"], self._jitter["saturation"])
-        img = (img * b).clamp(0, 1)
-        grey = (0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2])
-        img = ((img - grey.mean()) * c + grey.mean()).clamp(0, 1)
-        grey = (0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2])[None]
-        img = ((img - grey) * s + grey).clamp(0, 1)
-        angle = math.radians(random.uniform(-self._degrees, self._degrees))
+    def data_aug_static(img, label, degrees=10, flip_p=0.5,
+                        jitter=(0.3, 0.3, 0.3, 0.05), output_size=(240, 320),
+                        record=None):
+        """img [3,H,W] in [0,1], label [H,W] -> ColorJitter (drawn order and
+        factors, torchvision 0.12.0 ``ColorJitter.get_params``), rotate
+        (``random.uniform`` angle, reference :266), RandomCrop / CenterCrop to
+        ``output_size`` (identities at 240x320), flip (``torch.rand``, :292).
+        One fused HIP kernel pair (``ucsa_augment``) instead of ~40 torch
+        kernels."""
+        order = torch.randperm(4).tolist()
+        b, c, s, h = jitter
+        draw = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi))
+        params = dict(order=order,
+                      brightness=draw(max(0.0, 1 - b), 1 + b),
+                      contrast=draw(max(0.0, 1 - c), 1 + c),
+                      saturation=draw(max(0.0, 1 - s), 1 + s),
+                      hue=draw(-h, h),
+                      angle_deg=random.uniform(-degrees, degrees))
         H, W = img.shape[-2:]
-        cos, sin = math.cos(angle), math.sin(angle)
-        theta = torch.tensor([[cos, -sin * H / W, 0.0], [sin * W / H, cos, 0.0]],
-                             device=img.device)[None]
-        grid = F.affine_grid(theta, (1, 1, H, W), align_corners=False)
-        img = F.grid_sample(img[None], grid, mode="bilinear",
-                            padding_mode="zeros", align_corners=False)[0]
-        label = F.grid_sample(label[None], grid, mode="nearest",
-                              padding_mode="zeros", align_corners=False)[0]
-        if random.random() < self._flip_p:
-            img, label = img.flip(-1), label.flip(-1)
-        return img, (label[0] - 1).long()
+        th, tw = output_size
+        th, tw = min(th, H), min(tw, W)
+        params["crop_i"] = 0 if H == th else int(torch.randint(0, H - th + 1, (1,)))
+        params["crop_j"] = 0 if W == tw else int(torch.randint(0, W - tw + 1, (1,)))
+        params["flip"] = bool(torch.rand(1) < flip_p)
+        if record is not None:
+            record.update(params)
+        out, out_l = ops.augment(img[None], label[None], [params], (th, tw))
+        return out[0], out_l[0]
+
+    def data_aug(self, img, label):
+        j = self._jitter
+        return self.data_aug_static(
+            img, label, self._degrees, self._flip_p,
+            (j["brightness"], j["contrast"], j["saturation"], j["hue"]),
+            self._output_size)
 
     # ---- training ------------------------------------------------------------
     def training_step(self, batch, batch_idx):

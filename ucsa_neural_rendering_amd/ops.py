@@ -731,3 +731,36 @@ def march_train_bwd(rays, M: int, rays_d, norms, sigmas, sigma_scale: float, h,
         _ptr(_f32(d_sem, "d_sem")), _ptr(G), _ptr(d_h), _ptr(pc), _ptr(ps),
         _stream()), "ucsa_march_train_bwd")
     return d_h[:M], pc, ps
+
+
+def augment(img, label, params, out_size=None):
+    """Rendered-image augmentation (ucsa_augment).  img [B,3,H,W] fp32 in
+    [0,1], label [B,H,W] int64 or None, params: list of B dicts with keys
+    order (4 ints), brightness, contrast, saturation, hue, angle_deg, flip,
+    crop_i, crop_j.  -> out_img [B,3,oh,ow], out_label [B,oh,ow] | None."""
+    img = _f32(img, "img")
+    B, _, H, W = img.shape
+    oh, ow = (H, W) if out_size is None else out_size
+    if label is not None:
+        if not (label.is_cuda and label.dtype == torch.int64):
+            raise _lib.UcsaError("label must be an int64 tensor on the GPU")
+        label = label.contiguous()
+    arr = (_lib.AugParams * B)()
+    for k, q in enumerate(params):
+        arr[k].order[:] = [int(v) for v in q["order"]]
+        arr[k].brightness = float(q["brightness"])
+        arr[k].contrast = float(q["contrast"])
+        arr[k].saturation = float(q["saturation"])
+        arr[k].hue = float(q["hue"])
+        arr[k].angle_deg = float(q["angle_deg"])
+        arr[k].flip = int(bool(q["flip"]))
+        arr[k].crop_i = int(q.get("crop_i", 0))
+        arr[k].crop_j = int(q.get("crop_j", 0))
+    out = torch.empty(B, 3, oh, ow, device=img.device)
+    out_l = (torch.empty(B, oh, ow, dtype=torch.int64, device=img.device)
+             if label is not None else None)
+    ws = _scratch(int(lib().ucsa_augment_workspace_bytes(B, H, W)), img.device)
+    check(lib().ucsa_augment(_ptr(img), _ptr(label), B, H, W, arr, oh, ow,
+                             _ptr(out), _ptr(out_l), _ptr(ws), _stream()),
+          "ucsa_augment")
+    return out, out_l
