@@ -58,6 +58,9 @@ def train(exp, env, exp_cfg_path, env_cfg_path, args):
     model = JointTrainLightningNet(exp, env)
     datamodule = JointTrainDataModule(exp, env)
     datamodule.setup()
+    # ScanNet-layout root: the predict pass writes the PNGs the next stage's
+    # replay reads (reference :695-782)
+    model.predict_to_disk = bool(getattr(datamodule, "_scannet", False))
 
     if exp["trainer"].get("load_from_checkpoint") and exp["general"].get(
             "checkpoint_load"):

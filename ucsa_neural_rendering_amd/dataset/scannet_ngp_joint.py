@@ -1,0 +1,356 @@
+"""Mirror of reference ``nr4seg/dataset/scannet_ngp_joint.py`` (SURVEY 8f
+rank 3): the per-scene dataset that feeds the hot path -- same constructor,
+same on-disk layout (``<root>/<scene>/transforms_train.json`` with ``h, w,
+fl_x, fl_y, cx, cy, one_m_to_scene_uom, frames[file_path, label_path,
+transform_matrix]``, ``depth/<stem>.png`` in millimetres, generated
+``<exp_name>/[novel_viewpoints/]nerf_{image,label}/<stem>.png``), same 80/20
+split, replay selection, Slerp novel viewpoints and item dictionary
+(:320-458), same ``collate`` (:460-495).
+
+What differs, deliberately:
+  * rays are generated on the GPU by ``ucsa_get_rays`` from the pose
+    (reference :417-419 / :380-382 call the per-item CPU ``get_rays``), and
+    every tensor of an item is placed on ``device``;
+  * the replay augmentation (reference ``helper.AugmentationList.apply``,
+    helper.py:157-232) runs in ``ucsa_augment`` with the same draws;
+  * images are decoded with PIL instead of cv2 (not installed).  Files whose
+    size already is ``output_size`` -- what the reference's preprocessing
+    writes -- decode to identical arrays; other sizes are resampled with
+    PIL's BOX (images, cv2.INTER_AREA's equivalent for integer factors) and
+    NEAREST (labels, depth) filters.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import re
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .. import ops
+from .ngp_utils import get_rays, nerf_matrix_to_ngp
+
+__all__ = ["ScanNetNGPJoint"]
+
+_TEN_SCENES = [f"scene{i:04d}_00" for i in range(10)]
+
+
+def _pil():
+    from PIL import Image
+    return Image
+
+
+class ScanNetNGPJoint(Dataset):
+
+    def __init__(self, root, scene_list, mode="train", output_size=(240, 320),
+                 degrees=10, flip_p=0.5, jitter_bcsh=[0.3, 0.3, 0.3, 0.05],
+                 data_augmentation=True, exp_name="debug",
+                 use_novel_viewpoints=False, only_new_scene=True,
+                 fix_nerf=False, replay_buffer_size=None, device="cuda",
+                 val_scene_list=None):
+        super().__init__()
+        self._mode = mode
+        self.H, self.W = output_size
+        self.num_rays = 4096
+        self.root = root
+        self.exp_name = exp_name
+        self.fix_nerf = fix_nerf
+        self.device = torch.device(device)
+        if only_new_scene:
+            scene_list = [scene_list[-1]]
+        self.replay_buffer_size = replay_buffer_size
+        self.replay_per_scene = None
+        if replay_buffer_size is not None:
+            n_old = len(scene_list) - 1
+            if n_old > 0:
+                self.replay_per_scene = replay_buffer_size // n_old
+        if mode in ("val", "train_val"):  # hard-coded in the reference (:66-93)
+            # (val_scene_list: extra, for roots that do not hold all ten scenes)
+            scene_list = list(val_scene_list or _TEN_SCENES)
+        if mode == "predict":
+            self._use_novel_viewpoints = use_novel_viewpoints
+        elif mode == "train":
+            self._use_novel_viewpoints = (use_novel_viewpoints and
+                                          self.replay_per_scene is not None)
+        else:
+            assert not use_novel_viewpoints
+            self._use_novel_viewpoints = False
+        self.get_ngp_info(scene_list)
+        self.length = (len(self.nerf_image_pths) if self._use_novel_viewpoints
+                       else len(self.image_pths))
+        self._output_size = tuple(output_size)
+        self._degrees, self._flip_p = degrees, flip_p
+        self._jitter_bcsh = list(jitter_bcsh)
+        self._data_augmentation = data_augmentation
+
+    # ------------------------------------------------------------------ index
+    def get_ngp_info(self, scene_list):
+        """reference :113-291."""
+        self.poses, self.image_pths, self.label_pths = [], [], []
+        self.nerf_label_pths, self.nerf_image_pths, self.depth_pths = [], [], []
+        self.from_old_scene, self.viewpoint_is_novel = [], []
+        for i, scene_name in enumerate(scene_list):
+            last = i == len(scene_list) - 1
+            scene_root = os.path.join(self.root, scene_name)
+            with open(os.path.join(scene_root, "transforms_train.json")) as f:
+                info = json.load(f)
+            if last:
+                self.ngp_H, self.ngp_W = int(info["h"]), int(info["w"])
+                self.ngp_fl_x, self.ngp_fl_y = info["fl_x"], info["fl_y"]
+                self.ngp_cx, self.ngp_cy = info["cx"], info["cy"]
+                self.one_m_to_scene_uom = info["one_m_to_scene_uom"]
+                self.ngp_intrinsics = np.array([self.ngp_fl_x, self.ngp_fl_y,
+                                                self.ngp_cx, self.ngp_cy])
+            frames = info["frames"]
+            if self._mode != "predict":
+                n_val = int(0.2 * len(frames))
+                frames = frames[-n_val:] if self._mode == "val" else frames[:-n_val]
+            gen_json = os.path.join(scene_root, self.exp_name,
+                                    "novel_viewpoints", "interpolated_data.json")
+            replayed = (self._mode == "train" and
+                        self.replay_per_scene is not None and not last)
+            if replayed:
+                if self._use_novel_viewpoints:
+                    with open(gen_json) as f:
+                        frames = json.load(f)["frames"]
+                random.Random(0).shuffle(frames)
+                frames = frames[:self.replay_per_scene]
+            novel_replay = replayed and self._use_novel_viewpoints
+            novel = self._use_novel_viewpoints and (novel_replay or
+                                                    self._mode == "predict")
+            sub = "novel_viewpoints" if self._use_novel_viewpoints else ""
+            current_poses, gen_images, gen_labels = [], [], []
+            for fr in frames:
+                if novel_replay:
+                    nerf_image_path = fr["nerf_image"]
+                    nerf_label_path = fr["nerf_label"]
+                    pose = np.array(fr["pose"], dtype=np.float32)
+                else:
+                    image_path = os.path.join(scene_root, fr["file_path"])
+                    label_path = os.path.join(scene_root, fr["label_path"])
+                    stem = os.path.basename(image_path).split(".")[0]
+                    depth_path = os.path.join(scene_root, "depth", stem + ".png")
+                    nerf_label_path = os.path.join(scene_root, self.exp_name,
+                                                   sub, "nerf_label",
+                                                   stem + ".png")
+                    nerf_image_path = os.path.join(scene_root, self.exp_name,
+                                                   sub, "nerf_image",
+                                                   stem + ".png")
+                    gen_labels.append(nerf_label_path)
+                    gen_images.append(nerf_image_path)
+                    pose = np.array(fr["transform_matrix"], dtype=np.float32)
+                current_poses.append(pose)
+                self.viewpoint_is_novel.append(bool(novel))
+                if novel:
+                    self.image_pths.append(None)
+                    self.label_pths.append(None)
+                    self.depth_pths.append(None)
+                else:
+                    self.image_pths.append(image_path)
+                    self.label_pths.append(label_path)
+                    self.depth_pths.append(depth_path)
+                self.nerf_label_pths.append(nerf_label_path)
+                self.nerf_image_pths.append(nerf_image_path)
+                if self._mode in ("val", "train_val"):
+                    self.from_old_scene.append(False)
+                else:
+                    self.from_old_scene.append(bool(not last or self.fix_nerf))
+            if self._use_novel_viewpoints and self._mode == "predict":
+                current_poses = self._interpolate_poses(current_poses)
+                assert len(gen_images) == len(gen_labels) == len(current_poses)
+                os.makedirs(os.path.dirname(gen_json), exist_ok=True)
+                with open(gen_json, "w") as f:
+                    json.dump({"frames": [
+                        {"nerf_image": a, "nerf_label": b, "pose": p.tolist()}
+                        for a, b, p in zip(gen_images, gen_labels,
+                                           current_poses)]}, f, indent=5)
+            self.poses += [nerf_matrix_to_ngp(p) for p in current_poses]
+        self.poses = torch.from_numpy(np.stack(self.poses, axis=0))
+
+    @staticmethod
+    def _interpolate_poses(poses):
+        """reference :232-262: Slerp half way between consecutive views (and
+        between the last and the first), mean of the translations."""
+        from scipy.spatial.transform import Rotation, Slerp
+        poses = list(poses) + [poses[0]]
+        times = list(range(len(poses)))
+        slerp = Slerp(times=times, rotations=Rotation.from_matrix(
+            [p[:3, :3] for p in poses]))
+        rots = slerp(times=[0.5 + k for k in range(len(poses) - 1)]).as_matrix()
+        out = []
+        for k in range(len(poses) - 1):
+            m = np.eye(4)
+            m[:3, :3] = rots[k]
+            m[:3, 3] = (poses[k][:3, 3] + poses[k + 1][:3, 3]) / 2.0
+            out.append(m)
+        return out
+
+    # ----------------------------------------------------------------- decode
+    def preprocess_image(self, image_path):
+        """reference :293-300 -> [3,H,W] fp32 in [0,1]."""
+        Image = _pil()
+        im = Image.open(image_path).convert("RGB")
+        if im.size != (self.W, self.H):
+            im = im.resize((self.W, self.H), Image.BOX)
+        a = np.asarray(im, dtype=np.float32) / 255.0
+        return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+    def preprocess_label(self, label_path):
+        """reference :302-308 -> [H,W] int64, -1 unknown, 0..39 NYU40."""
+        Image = _pil()
+        im = Image.open(label_path)
+        if im.size != (self.W, self.H):
+            im = im.resize((self.W, self.H), Image.NEAREST)
+        return torch.from_numpy(np.asarray(im).astype(np.int64)) - 1
+
+    def preprocess_depth(self, depth_path):
+        """reference :310-319 -> [H,W] fp32 metres from uint16 millimetres."""
+        Image = _pil()
+        im = Image.open(depth_path)
+        if im.size != (self.W, self.H):
+            im = im.resize((self.W, self.H), Image.NEAREST)
+        a = np.asarray(im)
+        assert a.ndim == 2 and a.dtype in (np.uint16, np.int32), a.dtype
+        return torch.from_numpy(a.astype(np.float32) / 1000.0)
+
+    # ------------------------------------------------------------ augmentation
+    def _augment(self, img, labels, only_crop=False):
+        """helper.AugmentationList.apply (reference helper.py:157-232) on the
+        device: optional rescale, then jitter / rotate / crop / flip with one
+        set of draws for the image and all its label maps."""
+        oh, ow = self._output_size
+        H, W = img.shape[1:]
+        sf = None
+        if H >= 2 * oh:
+            sf = max(oh / H, ow / W) * 1.2
+        elif H < oh or W < ow:
+            sf = max(oh / H, ow / W) * 1.2
+        if sf is not None:
+            F = torch.nn.functional
+            img = F.interpolate(img[None], scale_factor=(sf, sf),
+                                mode="bilinear", recompute_scale_factor=False,
+                                align_corners=False)[0]
+            labels = [F.interpolate(l[None], scale_factor=(sf, sf),
+                                    mode="nearest",
+                                    recompute_scale_factor=False)[0]
+                      for l in labels]
+            H, W = img.shape[1:]
+        b, c, s, h = self._jitter_bcsh
+        if only_crop:
+            p = dict(order=[0, 1, 2, 3], brightness=1.0, contrast=1.0,
+                     saturation=1.0, hue=0.0, angle_deg=0.0, flip=False)
+            p["crop_i"] = int(round((H - oh) / 2.0))  # CenterCrop
+            p["crop_j"] = int(round((W - ow) / 2.0))
+        else:
+            draw = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi))
+            p = dict(order=torch.randperm(4).tolist(),
+                     brightness=draw(max(0.0, 1 - b), 1 + b),
+                     contrast=draw(max(0.0, 1 - c), 1 + c),
+                     saturation=draw(max(0.0, 1 - s), 1 + s), hue=draw(-h, h),
+                     angle_deg=random.uniform(-self._degrees, self._degrees))
+            p["crop_i"] = 0 if H == oh else int(torch.randint(0, H - oh + 1, (1,)))
+            p["crop_j"] = 0 if W == ow else int(torch.randint(0, W - ow + 1, (1,)))
+            p["flip"] = bool(torch.rand(1) < self._flip_p)
+        img = img.to(self.device)
+        out_img = None
+        out_labels = []
+        for l in labels:  # labels arrive as float (label + 1), [1,H,W]
+            li = l[0].to(self.device).long() - 1
+            out_img, ol = ops.augment(img[None], li[None], [p], (oh, ow))
+            out_labels.append((ol[0] + 1)[None].float())
+        return out_img[0], out_labels
+
+    # ------------------------------------------------------------------ items
+    @torch.no_grad()
+    def __getitem__(self, index):
+        """reference :320-458."""
+        dev = self.device
+        novel = self.viewpoint_is_novel[index]
+        if self.from_old_scene[index]:
+            nerf_label = self.preprocess_label(self.nerf_label_pths[index])
+            nerf_image = self.preprocess_image(self.nerf_image_pths[index])
+            if novel:
+                img, img_fp16, label, depth = nerf_image, None, nerf_label, None
+            else:
+                img = self.preprocess_image(self.image_pths[index])
+                img_fp16 = img.half().to(dev)
+                label = self.preprocess_label(self.label_pths[index])
+                depth = self.preprocess_depth(self.depth_pths[index]).half().to(dev)
+            train_aug = self._mode == "train" and self._data_augmentation
+            img, labels = self._augment(
+                nerf_image if train_aug else img,
+                [(label[None] + 1).float(), (nerf_label[None] + 1).float()],
+                only_crop=not train_aug)
+            label = None if novel else (labels[0][0] - 1).long()
+            nerf_label = (labels[1][0] - 1).long()
+            pose = self.poses[-1].unsqueeze(0)
+            from_old = True
+        else:
+            if novel:
+                img, img_fp16, label, depth = [], [], [], []
+            else:
+                img = self.preprocess_image(self.image_pths[index]).to(dev)
+                img_fp16 = img.half()
+                label = self.preprocess_label(self.label_pths[index]).to(dev)
+                depth = self.preprocess_depth(self.depth_pths[index]).half().to(dev)
+            nerf_label = label
+            pose = self.poses[index].unsqueeze(0)
+            from_old = False
+        rays = get_rays(pose.to(dev), self.ngp_intrinsics, self.ngp_H,
+                        self.ngp_W)
+        item = {
+            "img": img, "label": label, "depth": depth, "img_fp16": img_fp16,
+            "nerf_label": nerf_label, "pose": pose[0].to(dev),
+            "from_old_scene": from_old, "viewpoint_is_novel": novel,
+            "H": self.ngp_H, "W": self.ngp_W, "intrinsics": self.ngp_intrinsics,
+            "one_m_to_scene_uom": self.one_m_to_scene_uom,
+            "rays_o": rays["rays_o"][0], "rays_d": rays["rays_d"][0],
+            "direction_norms": rays["direction_norms"][0],
+        }
+        if novel:
+            names = re.findall(r"scene\d\d\d\d_\d\d", self.nerf_image_pths[index])
+            assert len(names) == 1
+            item["current_scene_name"] = names[0]
+            item["current_index"] = str(
+                os.path.basename(self.nerf_image_pths[index])[:-4])
+        else:
+            item["current_scene_name"] = os.path.normpath(
+                self.image_pths[index]).split(os.path.sep)[-3]
+            item["current_index"] = str(
+                os.path.basename(self.image_pths[index])[:-4])
+        return item
+
+    @staticmethod
+    def collate(batch):
+        """reference :460-495 -> (batch_old, batch_new, batch_cl)."""
+        groups = [defaultdict(list), defaultdict(list), defaultdict(list)]
+        for key in batch[0]:
+            for b in batch:
+                if key in ("replay_img", "replay_label"):
+                    groups[2][key].append(b[key])
+                elif b["from_old_scene"]:
+                    groups[0][key].append(b[key])
+                else:
+                    groups[1][key].append(b[key])
+        out = []
+        for grp, probe in zip(groups, ("img", "img", "replay_img")):
+            if probe not in grp:
+                out.append(None)
+                continue
+            for key in grp:
+                if type(grp[key][0]) == torch.Tensor:
+                    grp[key] = torch.stack(grp[key], dim=0)
+            out.append(grp)
+        return tuple(out)
+
+    def __len__(self):
+        return self.length
+
+    def __str__(self):
+        return ("=" * 90 + "\nScannet Dataset: \n" +
+                f"    Total Samples: {len(self)}  »  Mode: {self._mode} \n" +
+                f"  »  DataAug: {self._data_augmentation}" + "=" * 90)

@@ -183,6 +183,9 @@ def default_collate_dict(batch):
         v = [b[key] for b in batch]
         if isinstance(v[0], torch.Tensor):
             out[key] = torch.stack(v, dim=0)
+        elif type(v[0]).__module__ == "numpy" and hasattr(v[0], "shape"):
+            import numpy as np
+            out[key] = torch.from_numpy(np.stack(v))
         elif isinstance(v[0], (int, float)) and not isinstance(v[0], bool):
             out[key] = torch.tensor(v)
         else:

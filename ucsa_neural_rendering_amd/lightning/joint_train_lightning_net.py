@@ -15,11 +15,11 @@ The four hot-path methods keep their names, arguments and return values:
 * mIoU            -> ``ucsa_confusion_matrix`` + reference formula
 * NeRF optimizer  -> ``HipAdam`` (``ucsa_adam_step``), same two param groups.
 
-Out of scope and therefore reduced: PNG dumps of
-``predict_step`` (returns tensors instead), the Visualizer, WandB logging
-(``self.log`` goes to the JSONL logger of the thin Trainer), and colour-jitter
-hue in ``data_aug``.  PyTorch-Lightning itself is not required: the class is a
-plain ``nn.Module`` with the few LightningModule members the code uses.
+Out of scope and therefore reduced: the colour-coded ``*_vis``
+PNGs of ``predict_step``, the Visualizer and WandB logging (``self.log`` goes
+to the JSONL logger of the thin Trainer).  PyTorch-Lightning itself is not
+required: the class is a plain ``nn.Module`` with the few LightningModule
+members the code uses.
 """
 from __future__ import annotations
 
@@ -409,17 +409,47 @@ class JointTrainLightningNet(nn.Module):
             self.log("test/nerf_PSNR", out["test_nerf_PSNR"])
         return out
 
-    # ---- predict (:695-782, tensors instead of PNG files) ----------------------
+    # ---- predict (:695-782) ---------------------------------------------------
+    # Returns the tensors; with ``predict_to_disk`` (set by train_joint when the
+    # data come from a ScanNet-layout root) also writes the PNGs the next
+    # stage's replay reads (``ScanNetNGPJoint``): nerf_image (RGB), nerf_label
+    # and seg_label (class id + 1, 0 = unknown).  The colour-coded *_vis copies
+    # of the reference are visualisation only and are not written.
+    predict_to_disk = False
+
     def on_predict_epoch_start(self):
         self._mode = "predict"
+        if self.predict_to_disk:
+            for sub in ("", "novel_viewpoints"):
+                for name in ("nerf_image", "nerf_label", "seg_label"):
+                    os.makedirs(os.path.join(self.root_new_scene, sub, name),
+                                exist_ok=True)
 
     def predict_step(self, batch, batch_idx, dataloader_idx=0):
         out = self.forward_nerf_test(batch)
-        seg = self.forward_seg(batch, out["nerf_rgb"].contiguous())
-        return {"nerf_image": out["nerf_rgb"],
-                "nerf_label": out["nerf_semantics"] + 1,  # +1 when saved (:763)
-                "seg_label": seg["seg_semantics"] + 1,
-                "index": batch["current_index"]}
+        novel = bool(batch["viewpoint_is_novel"][0])
+        if novel:
+            seg = self.forward_seg(batch, out["nerf_rgb"].contiguous())
+        else:
+            seg = self.forward_seg(batch)
+        res = {"nerf_image": out["nerf_rgb"],
+               "nerf_label": out["nerf_semantics"] + 1,  # +1 when saved (:763)
+               "seg_label": seg["seg_semantics"] + 1,
+               "index": batch["current_index"]}
+        if self.predict_to_disk:
+            from PIL import Image
+            import numpy as np
+            sub = "novel_viewpoints" if novel else ""
+            for i, idx in enumerate(batch["current_index"]):
+                rgb = (res["nerf_image"][i].permute(1, 2, 0).detach().cpu()
+                       .numpy() * 255).astype(np.uint8)
+                Image.fromarray(rgb).save(os.path.join(
+                    self.root_new_scene, sub, "nerf_image", idx + ".png"))
+                for name in ("nerf_label", "seg_label"):
+                    lab = res[name][i].detach().cpu().numpy().astype(np.uint8)
+                    Image.fromarray(lab).save(os.path.join(
+                        self.root_new_scene, sub, name, idx + ".png"))
+        return res
 
     def on_predict_epoch_end(self):
         return None
