@@ -145,6 +145,14 @@ class SemanticNeRFRenderer(nn.Module):
         d = rays_d.contiguous().view(-1, 3).float()
         nrm = direction_norms.contiguous().view(-1).float()
         C = self.num_semantic_classes
+        N = o.shape[0]
+        if N == 0:
+            return {
+                "depth": torch.empty(*prefix, device=device),
+                "image": torch.empty(*prefix, 3, device=device),
+                "semantics": torch.empty(*prefix, C, device=device),
+                "weights_sum": torch.empty(*prefix, device=device),
+            }
         aabb = self._aabb_list(self.training)
         with torch.no_grad():
             nears, fars = ops.near_far_from_aabb(o, d, aabb, min_near)
@@ -219,6 +227,13 @@ class SemanticNeRFRenderer(nn.Module):
         nrm = direction_norms.contiguous().view(-1).float()
         N = o.shape[0]
         C = self.num_semantic_classes
+        if N == 0:
+            return {
+                "depth": torch.empty(*prefix, device=device),
+                "image": torch.empty(*prefix, 3, device=device),
+                "semantics": torch.empty(*prefix, C, device=device),
+                "weights_sum": torch.empty(*prefix, device=device),
+            }
         aabb = self._aabb_list(self.training)
         nears, fars = ops.near_far_from_aabb(o, d, aabb, min_near)
         if self.precision not in ("fp32", "fp16"):
