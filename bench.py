@@ -245,7 +245,7 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
     return n_rays / best, best, parity, ref, got, (o, d)
 
 
-def stage_times(net, o, d, nrm, u, iters=5):
+def stage_times(net, o, d, nrm, u, iters=5, image_width=0):
     """Per-kernel durations of one chunk, measured with events on the stream
     the kernels run on (torch's current stream)."""
     from ucsa_neural_rendering_amd import ops
@@ -263,13 +263,15 @@ def stage_times(net, o, d, nrm, u, iters=5):
         near, far = ops.near_far_from_aabb(o, d, aabb)
         zc = ops.sample_coarse(near, far, T_COARSE)
         marks[1].record()
-        feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zc, aabb)
+        feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zc, aabb,
+                                        image_width=image_width)
         marks[2].record()
         hc, sc = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
         marks[3].record()
         zf = ops.resample(zc, sc.view(N, T_COARSE), u)
         marks[4].record()
-        feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb)
+        feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb,
+                                        image_width=image_width)
         marks[5].record()
         hf, sf = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
         marks[6].record()
@@ -443,7 +445,7 @@ def main():
         with torch.no_grad():
             return net.render(o, d, nrm, staged=True, perturb=False,
                               num_steps=T_COARSE, upsample_steps=T_FINE,
-                              rng_u=u)
+                              rng_u=u, image_width=W)
 
     for i in range(args.warmup):
         step(i)
@@ -468,11 +470,13 @@ def main():
     result = None
     if rank == 0:
         assert torch.isfinite(out["image"]).all()
-        chunk = net.hip_ray_chunk
+        # the chunk render() really launches: whole 8-row bands of the image
+        chunk = net.hip_ray_chunk - net.hip_ray_chunk % (8 * W)
         o, d, nrm = rays[0]
         st, rho = stage_times(net, o[0, :chunk].contiguous(),
                               d[0, :chunk].contiguous(),
-                              nrm[0, :chunk, 0].contiguous(), u[:chunk])
+                              nrm[0, :chunk, 0].contiguous(), u[:chunk],
+                              image_width=W)
         # --- roofline of the dominant kernel: hash-grid encode -------------
         # algorithmic bytes per sample: L * 8 corners * F * 4 B
         samples = chunk * T_COARSE
@@ -512,7 +516,7 @@ def main():
                 "sharding": "views round-robin over ranks, no data-path collective",
             },
             "roofline_encode": {
-                "kernel": "k_hashgrid_encode",
+                "kernel": "k_hashgrid_encode_tiled",
                 "bound": "hbm",
                 "achieved": enc_gbs,
                 "peak": HBM_PEAK_GBS,
@@ -541,7 +545,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles",
                                               "r01_pmc_traffic.json")))
             for key, kn in (("roofline_composite", "k_composite"),
-                            ("roofline_encode", "k_hashgrid_encode")):
+                            ("roofline_encode", "k_hashgrid_encode_tiled")):
                 result[key]["traffic"] = (pmc[kn]["fetch_bytes"] +
                                           pmc[kn]["write_bytes"])
                 result[key]["traffic_source"] = "profiles/r01_pmc_traffic.json"

@@ -101,6 +101,16 @@ int32_t ucsa_hashgrid_encode_rays(const ucsa_grid* grid_host,
                                   const float* aabb_host, uint32_t N,
                                   uint32_t T, float* feat, void* stream);
 
+/* Same for IMAGE-ORDERED rays: ray r is pixel (r / image_width,
+ * r % image_width) of full rows of an image (any number of rows).  The fine
+ * levels are gathered one 8x8 pixel tile per wave so that neighbouring pixels
+ * share cache lines; the features are bit-identical to
+ * ucsa_hashgrid_encode_rays'. */
+int32_t ucsa_hashgrid_encode_rays_image(
+    const ucsa_grid* grid_host, const float* table, const float* rays_o,
+    const float* rays_d, const float* z, const float* aabb_host, uint32_t N,
+    uint32_t T, uint32_t image_width, float* feat, void* stream);
+
 /* Same encoder for explicit positions x [M,3] in [-bound,bound] (the
  * reference's network.density(x) entry, network_tcnn_semantics.py:130-135). */
 int32_t ucsa_hashgrid_encode_points(const ucsa_grid* grid_host,
@@ -165,7 +175,10 @@ uint64_t ucsa_render_workspace_bytes(uint32_t N, uint32_t T, uint32_t t,
  * renderer_semantics.py:123-299): near/far, coarse sampling, density,
  * resampling, density, merge, masked colour/semantics, compositing.
  *   t_rand [N,T] or NULL; u [N,t]; ws: workspace of
- *   ucsa_render_workspace_bytes(); packed_*: see ucsa_mlp_pack. */
+ *   ucsa_render_workspace_bytes(); packed_*: see ucsa_mlp_pack.
+ *   image_width: 0, or the width of the image whose full rows the rays are
+ *   (ray r = pixel (r / image_width, r % image_width)): selects the
+ *   tile-ordered gather of ucsa_hashgrid_encode_rays_image, same results. */
 int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
                         const float* packed_sigma, const float* packed_color,
                         const float* packed_sem, const float* rays_o,
@@ -173,8 +186,8 @@ int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
                         const float* aabb_host, float min_near,
                         const float* t_rand, const float* u, uint32_t N,
                         uint32_t T, uint32_t t, uint32_t n_classes,
-                        float density_scale, float* image, float* depth,
-                        float* semantics, void* ws, void* stream);
+                        float density_scale, uint32_t image_width, float* image,
+                        float* depth, float* semantics, void* ws, void* stream);
 
 /* Pointwise colour / semantics queries: network.color() / network.semantics()
  * (reference network_tcnn_semantics.py:147-207).  dirs [M,3], geo_feat [M,15],
@@ -224,8 +237,9 @@ int32_t ucsa_render_fwd_f16(const ucsa_grid* grid_host, const float* table,
                             const float* aabb_host, float min_near,
                             const float* t_rand, const float* u, uint32_t N,
                             uint32_t T, uint32_t t, uint32_t n_classes,
-                            float density_scale, float* image, float* depth,
-                            float* semantics, void* ws, void* stream);
+                            float density_scale, uint32_t image_width,
+                            float* image, float* depth, float* semantics,
+                            void* ws, void* stream);
 
 /* ======================= training (backward) ============================== */
 

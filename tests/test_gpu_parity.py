@@ -332,3 +332,40 @@ def test_fp16_inference_option_matches_fp16_emulating_oracle(fld):
     out = net16.render(o[None, :8].cuda(), d[None, :8].cuda(), norms[None, :8].cuda(),
                        num_steps=T, upsample_steps=t, rng_u=u[:8].cuda())
     assert out["image"].requires_grad
+
+
+@pytest.mark.parametrize("H,W,T,t", [(24, 40, 16, 16), (17, 23, 8, 0), (64, 64, 33, 12)])
+def test_image_ordered_gather_is_bit_identical(H, W, T, t):
+    """image_width > 0 only changes which lanes gather together (8x8 pixel
+    tiles instead of runs along a ray): features, and therefore the whole
+    render, must equal the ray-ordered path bit for bit -- ragged tiles,
+    T not a multiple of 16 and chunking across bands included."""
+    from ucsa_neural_rendering_amd import ops
+    fld = lively_oracle_field()
+    net = hip_network_from_oracle(fld).eval()
+    f = net._field()
+    N = H * W
+    o, d, norms = make_rays(N, 11)
+    o, d, norms = o.cuda(), d.cuda(), norms.cuda()
+    aabb = net._aabb_list(False)
+    near, far = ops.near_far_from_aabb(o, d, aabb)
+    z = ops.sample_coarse(near, far, T)
+    a = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb)
+    b = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb,
+                                 image_width=W)
+    assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(1)
+    u = torch.rand(N, max(t, 1), generator=g)[:, :t].cuda()
+    with torch.no_grad():
+        r0 = net.render(o[None], d[None], norms[None], num_steps=T,
+                        upsample_steps=t, rng_u=u if t else None)
+        net.hip_ray_chunk = 8 * W + 5     # -> bands of 8 rows
+        r1 = net.render(o[None], d[None], norms[None], num_steps=T,
+                        upsample_steps=t, rng_u=u if t else None,
+                        image_width=W)
+        net.hip_ray_chunk = 3 * W         # too small for a band: falls back
+        r2 = net.render(o[None], d[None], norms[None], num_steps=T,
+                        upsample_steps=t, rng_u=u if t else None,
+                        image_width=W)
+    for k in ("image", "depth", "semantics"):
+        assert torch.equal(r0[k], r1[k]) and torch.equal(r0[k], r2[k])

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ucsa_hashgrid_encode_rays": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
                                               C.POINTER(_f), _u32, _u32, _p,
                                               _p]),
+    "ucsa_hashgrid_encode_rays_image": (C.c_int32, [C.POINTER(Grid), _p, _p, _p,
+                                                    _p, C.POINTER(_f), _u32,
+                                                    _u32, _u32, _p, _p]),
     "ucsa_hashgrid_encode_points": (C.c_int32, [C.POINTER(Grid), _p, _p, _u32,
                                                 _p, _p]),
     "ucsa_mlp_pack": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
@@ -74,7 +77,7 @@ SIGNATURES = {
     "ucsa_render_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32, _u32]),
     "ucsa_render_fwd": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p, _p,
                                     _p, C.POINTER(_f), _f, _p, _p, _u32, _u32,
-                                    _u32, _u32, _f, _p, _p, _p, _p, _p]),
+                                    _u32, _u32, _f, _u32, _p, _p, _p, _p, _p]),
     "ucsa_point_shade": (C.c_int32, [_p, _p, _p, _p, _p, _u32, _u32, _p, _p,
                                      _p]),
     "ucsa_point_shade_h": (C.c_int32, [_p, _p, _p, _p, _p, _u32, _u32, _p, _p,
@@ -87,8 +90,8 @@ SIGNATURES = {
                                                         _f, _p, _p, _p, _p]),
     "ucsa_render_fwd_f16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                         _p, _p, C.POINTER(_f), _f, _p, _p,
-                                        _u32, _u32, _u32, _u32, _f, _p, _p, _p,
-                                        _p, _p]),
+                                        _u32, _u32, _u32, _u32, _f, _u32, _p,
+                                        _p, _p, _p, _p]),
     # ---- training ----
     "ucsa_mlp_pack_t_size": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_t": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),

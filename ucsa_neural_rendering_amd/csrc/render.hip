@@ -51,30 +51,44 @@ extern "C" uint64_t ucsa_render_workspace_bytes(uint32_t N, uint32_t T,
     if (rc_ != 0) return rc_;   \
   } while (0)
 
+// image_width > 0: image-ordered rays -> tile-ordered gather (same features)
+static int32_t encode(const ucsa_grid* grid, const float* table,
+                      const float* rays_o, const float* rays_d, const float* z,
+                      const float* aabb_host, uint32_t N, uint32_t T,
+                      uint32_t image_width, float* feat, void* stream) {
+  if (image_width)
+    return ucsa_hashgrid_encode_rays_image(grid, table, rays_o, rays_d, z,
+                                           aabb_host, N, T, image_width, feat,
+                                           stream);
+  return ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, z, aabb_host, N,
+                                   T, feat, stream);
+}
+
 extern "C" int32_t ucsa_render_fwd(
     const ucsa_grid* grid, const float* table, const float* packed_sigma,
     const float* packed_color, const float* packed_sem, const float* rays_o,
     const float* rays_d, const float* norms, const float* aabb_host,
     float min_near, const float* t_rand, const float* u, uint32_t N,
     uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
-    float* image, float* depth, float* semantics, void* ws, void* stream) {
+    uint32_t image_width, float* image, float* depth, float* semantics,
+    void* ws, void* stream) {
   UCSA_CHECK_ARG(grid, 0);
-  UCSA_CHECK_ARG(ws, 20);
+  UCSA_CHECK_ARG(ws, 21);
   UCSA_CHECK_ARG(t == 0 || u, 11);
   if (N == 0) return 0;
   const Ws w = carve(ws, N, T, t, grid->n_levels);
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_c,
-                                     aabb_host, N, T, w.feat, stream));
+  UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
+                  image_width, w.feat, stream));
   UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * T, grid->n_levels,
                               w.h_c, w.sigma_c, stream));
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_f,
-                                       aabb_host, N, t, w.feat, stream));
+    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
+                    image_width, w.feat, stream));
     UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * t, grid->n_levels,
                                 w.h_f, w.sigma_f, stream));
   }
@@ -91,24 +105,25 @@ extern "C" int32_t ucsa_render_fwd_f16(
     const float* rays_o, const float* rays_d, const float* norms,
     const float* aabb_host, float min_near, const float* t_rand, const float* u,
     uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
-    float* image, float* depth, float* semantics, void* ws, void* stream) {
+    uint32_t image_width, float* image, float* depth, float* semantics,
+    void* ws, void* stream) {
   UCSA_CHECK_ARG(grid, 0);
-  UCSA_CHECK_ARG(ws, 20);
+  UCSA_CHECK_ARG(ws, 21);
   UCSA_CHECK_ARG(t == 0 || u, 11);
   if (N == 0) return 0;
   const Ws w = carve(ws, N, T, t, grid->n_levels);
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_c,
-                                     aabb_host, N, T, w.feat, stream));
+  UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
+                  image_width, w.feat, stream));
   UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * T,
                                   grid->n_levels, w.h_c, w.sigma_c, stream));
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, w.z_f,
-                                       aabb_host, N, t, w.feat, stream));
+    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
+                    image_width, w.feat, stream));
     UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * t,
                                     grid->n_levels, w.h_f, w.sigma_f, stream));
   }

@@ -190,7 +190,7 @@ class JointTrainLightningNet(nn.Module):
         outputs = self.nerf_model.render(
             rays_o, rays_d, direction_norms=direction_norms, staged=True,
             bg_color=1, perturb=False, num_steps=self.num_steps,
-            upsample_steps=self.upsample_steps,
+            upsample_steps=self.upsample_steps, image_width=W,
             **({"dt_gamma": self.dt_gamma, "far_closure": False}
                if self.cuda_ray else {}))
         pred_rgb = outputs["image"].reshape(B, H, W, 3)

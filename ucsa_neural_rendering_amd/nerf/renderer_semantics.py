@@ -360,11 +360,16 @@ class SemanticNeRFRenderer(nn.Module):
 
     def run(self, rays_o, rays_d, direction_norms, num_steps=256,
             upsample_steps=256, bg_color=None, perturb=False, epoch=None,
-            rng_t=None, rng_u=None, min_near=0.2, **kwargs):
+            rng_t=None, rng_u=None, min_near=0.2, image_width=0, **kwargs):
         """reference :123-299.  rays [B,N,3], direction_norms [B,N,1] ->
         {"depth" [B,N], "image" [B,N,3], "semantics" [B,N,C]}.
         ``bg_color`` is accepted and unused, exactly like the reference
-        (:288-289 assigns it, nothing reads it)."""
+        (:288-289 assigns it, nothing reads it).
+
+        ``image_width`` (optional, inference): set it when the N rays are the
+        pixels of full rows of an image that wide (what ``get_rays`` returns):
+        the hash-grid gather then walks 8x8 pixel tiles, whose lanes share
+        cells (ucsa_hashgrid_encode_rays_image).  Same results."""
         prefix = rays_o.shape[:-1]
         device = rays_o.device
         if device.type != "cuda":
@@ -399,7 +404,8 @@ class SemanticNeRFRenderer(nn.Module):
                 p.requires_grad for p in self.parameters()):
             out = self._run_train(o, d, nrm, aabb, T, t, rng_t, rng_u, min_near)
         else:
-            out = self._run_infer(o, d, nrm, aabb, T, t, rng_t, rng_u, min_near)
+            out = self._run_infer(o, d, nrm, aabb, T, t, rng_t, rng_u, min_near,
+                                  int(image_width))
         image, depth, sem = out
         return {
             "depth": depth.view(*prefix),
@@ -407,7 +413,8 @@ class SemanticNeRFRenderer(nn.Module):
             "semantics": sem.view(*prefix, C),
         }
 
-    def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):
+    def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near,
+                   image_width=0):
         if self.precision not in ("fp32", "fp16"):
             raise ValueError(f"precision must be fp32 or fp16, got {self.precision}")
         half = self.precision == "fp16"
@@ -420,6 +427,10 @@ class SemanticNeRFRenderer(nn.Module):
         depth = torch.empty(N, device=dev)
         sem = torch.empty(N, C, device=dev)
         chunk = max(1, int(self.hip_ray_chunk))
+        if image_width and N % image_width == 0 and chunk >= 8 * image_width:
+            chunk -= chunk % (8 * image_width)  # whole 8-row bands of tiles
+        else:
+            image_width = 0
         n_chunks = (N + chunk - 1) // chunk
         n_str = max(1, min(int(self.hip_streams), n_chunks))
         ws = self._workspace(
@@ -444,7 +455,8 @@ class SemanticNeRFRenderer(nn.Module):
                     None if rng_t is None else rng_t[head:tail],
                     None if rng_u is None else rng_u[head:tail], T, t, C,
                     float(self.density_scale), image[head:tail],
-                    depth[head:tail], sem[head:tail], ws[k % n_str])
+                    depth[head:tail], sem[head:tail], ws[k % n_str],
+                    image_width)
         for st in streams[1:]:
             main.wait_stream(st)
         return image, depth, sem

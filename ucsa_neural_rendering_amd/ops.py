@@ -79,13 +79,21 @@ def sample_coarse(nears, fars, T: int, t_rand=None):
     return z
 
 
-def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb):
-    """-> feat [L, N*T, 2] (level-major)."""
+def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
+                         image_width: int = 0):
+    """-> feat [L, N*T, 2] (level-major).  image_width > 0: the rays are the
+    pixels of full image rows (tile-ordered gather, same result)."""
     rays_o = _f32(rays_o, "rays_o").view(-1, 3)
     rays_d = _f32(rays_d, "rays_d").view(-1, 3)
     z = _f32(z, "z")
     N, T = z.shape
     feat = torch.empty(grid.n_levels, N * T, 2, device=z.device)
+    if image_width:
+        check(lib().ucsa_hashgrid_encode_rays_image(
+            C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
+            fvec(aabb), N, T, int(image_width), _ptr(feat), _stream()),
+            "ucsa_hashgrid_encode_rays_image")
+        return feat
     check(lib().ucsa_hashgrid_encode_rays(C.byref(grid), _ptr(table),
                                           _ptr(rays_o), _ptr(rays_d), _ptr(z),
                                           fvec(aabb), N, T, _ptr(feat),
@@ -204,16 +212,18 @@ def render_workspace_bytes(N: int, T: int, t: int, n_levels: int) -> int:
 def render_fwd(grid: Grid, table, packed_sigma, packed_color, packed_sem,
                rays_o, rays_d, norms, aabb, min_near: float, t_rand, u, T: int,
                t: int, n_classes: int, density_scale: float, image, depth,
-               semantics, ws: torch.Tensor):
-    """All tensors already validated/contiguous; outputs written in place."""
+               semantics, ws: torch.Tensor, image_width: int = 0):
+    """All tensors already validated/contiguous; outputs written in place.
+    image_width > 0: the rays are the pixels of full image rows."""
     N = rays_o.shape[0]
     check(lib().ucsa_render_fwd(C.byref(grid), _ptr(table), _ptr(packed_sigma),
                                 _ptr(packed_color), _ptr(packed_sem),
                                 _ptr(rays_o), _ptr(rays_d), _ptr(norms),
                                 fvec(aabb), float(min_near), _ptr(t_rand),
                                 _ptr(u), N, T, t, n_classes,
-                                float(density_scale), _ptr(image), _ptr(depth),
-                                _ptr(semantics), _ptr(ws), _stream()),
+                                float(density_scale), int(image_width),
+                                _ptr(image), _ptr(depth), _ptr(semantics),
+                                _ptr(ws), _stream()),
           "ucsa_render_fwd")
 
 
@@ -243,14 +253,14 @@ def render_fwd_f16(grid: Grid, table, packed_sigma_h, packed_color_h,
                    packed_sem_h, rays_o, rays_d, norms, aabb, min_near: float,
                    t_rand, u, T: int, t: int, n_classes: int,
                    density_scale: float, image, depth, semantics,
-                   ws: torch.Tensor):
+                   ws: torch.Tensor, image_width: int = 0):
     N = rays_o.shape[0]
     check(lib().ucsa_render_fwd_f16(
         C.byref(grid), _ptr(table), _ptr(packed_sigma_h), _ptr(packed_color_h),
         _ptr(packed_sem_h), _ptr(rays_o), _ptr(rays_d), _ptr(norms), fvec(aabb),
         float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
-        float(density_scale), _ptr(image), _ptr(depth), _ptr(semantics),
-        _ptr(ws), _stream()), "ucsa_render_fwd_f16")
+        float(density_scale), int(image_width), _ptr(image), _ptr(depth),
+        _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_f16")
 
 
 # ============================ training (backward) ===========================
