@@ -1,0 +1,77 @@
+"""Distil per-launch HBM traffic / MFMA busy of the bench-size launches of the
+two dominant kernels from the PMC summaries written by
+tools/refresh_profiles.sh.   python tools/pmc_traffic.py gpurun_out r01 >
+profiles/r01_pmc_traffic.json"""
+import json
+import re
+import sys
+
+
+def counters(path):
+    out = {}
+    on = False
+    for line in open(path):
+        if line.startswith("# counters:"):
+            on = True
+            continue
+        if not on or not line.strip():
+            continue
+        m = re.match(r"\s+(.*?)\s+(\d+)\s+(\S+)\s+(\d+)\s+(\d+)\s+([\d.]+)\s*$", line)
+        if m:
+            name, grid, cn, _, nd, per = m.groups()
+            out.setdefault(name.strip(), {}).setdefault(int(grid), {})[cn] = float(per)
+    return out
+
+
+def pick(tab, prefix):
+    """counters of the largest launch of the first kernel whose name starts
+    with `prefix`."""
+    best = None
+    for name, grids in tab.items():
+        if name.startswith(prefix):
+            g = max(grids)
+            if best is None or g > best[0]:
+                best = (g, grids[g])
+    return best
+
+
+def main(d, tag):
+    fetch = counters(f"{d}/{tag}_pmc1.txt")
+    wr = counters(f"{d}/{tag}_pmc2.txt")
+    sq = counters(f"{d}/{tag}_pmc3.txt")
+    res = {
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                  "TCC_HIT_sum TCC_MISS_sum / --pmc SQ_* (three separate passes, "
+                  "tools/refresh_profiles.sh) of `python3 bench.py --steps 2 "
+                  "--warmup 1 --no-cpu-baseline --no-train-bench --pretrain-steps "
+                  "20`; per-dispatch averages of the largest (bench-size: 61440 "
+                  "rays x 96 samples) launches",
+        "units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are reported in KiB by "
+                 "rocprofv3 and multiplied by 1024 here.  gfx950 note "
+                 "(MI355X_MICROARCH.md HBM section): FETCH_SIZE under-reports "
+                 "wide coalesced streaming reads by 2x; these kernels read by "
+                 "8/16-byte gathers, for which the counter is uncalibrated, so "
+                 "the raw value is given and 2x raw is the upper bound",
+    }
+    for key, prefix in (("k_composite", "void k_composite<3, 2, false, false>"),
+                        ("k_hashgrid_encode_tiled", "k_hashgrid_encode_tiled")):
+        f, w, s = pick(fetch, prefix), pick(wr, prefix), pick(sq, prefix)
+        if not (f and w):
+            continue
+        e = {"grid_threads": f[0],
+             "fetch_bytes": int(f[1].get("FETCH_SIZE", 0) * 1024),
+             "write_bytes": int(w[1].get("WRITE_SIZE", 0) * 1024)}
+        hit, miss = w[1].get("TCC_HIT_sum", 0), w[1].get("TCC_MISS_sum", 0)
+        if hit + miss:
+            e["tcc_hit_rate"] = hit / (hit + miss)
+        if s and s[1].get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles, the MFMA counter
+            # the busy cycles of all 1024 SIMDs: busy / (cycles * 1024)
+            e["mfma_busy_frac"] = (s[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) /
+                                   (s[1]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
+        res[key] = e
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
