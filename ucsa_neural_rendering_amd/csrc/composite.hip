@@ -859,8 +859,14 @@ extern "C" int32_t ucsa_march_train_fwd(
     void* stream) {
   UCSA_CHECK_ARG(rays, 0);
   UCSA_CHECK_ARG(nears, 3);
+  UCSA_CHECK_ARG(rays_d, 4);
+  UCSA_CHECK_ARG(M == 0 || (sigmas && h && deltas), 5);
+  UCSA_CHECK_ARG(packed_color && packed_sem, 9);
+  UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 11);
+  UCSA_CHECK_ARG(w_min >= 0.f, 12);
+  UCSA_CHECK_ARG(weights_sum && depth && image && semantics, 13);
   UCSA_CHECK_ARG(w_out && t_out, 17);
-  if (M == 0) return 0;
+  if (M == 0 || N == 0) return 0;
   return march_shade_launch(false, true, M, w_out, t_out, N, nullptr, 1u, rays,
                             3u,
                             const_cast<float*>(nears), rays + 1, 3u, rays_d,
