@@ -477,22 +477,55 @@ k_composite(CmpArgs a) {
 
   if constexpr (MARCH) {
     // =================== per-slot loop (marched spans) ====================
+    // Marched rays are short (tens of samples a round): the loop is a chain
+    // of dependent loads per ray (slot -> span -> sigma / deltas), ~2.5 us
+    // each and 300 rays per wave.  So the next slot's header and first 64
+    // samples are requested before the current slot is processed.
+    struct Slot {
+      uint32_t index, offset, count;
+      float ws0, t0, sg, dlx, dly;
+    };
+    auto fetch = [&](uint32_t r) {
+      Slot p;
+      p.index = (uint32_t)a.rays_alive[(size_t)r * a.alive_stride];
+      p.offset = (uint32_t)a.span[(size_t)r * a.span_stride];
+      p.count = (uint32_t)a.span[(size_t)r * a.span_stride + 1];
+      if (a.train && p.offset + p.count >= a.n_points) p.count = 0;
+      p.ws0 = a.weights_sum[p.index];
+      p.t0 = a.rays_t[a.train ? p.index : r];
+      p.sg = 0.f; p.dlx = 0.f; p.dly = 0.f;
+      if (p.count) {
+        const size_t m = (size_t)p.offset + (lane < p.count ? lane : 0u);
+        p.sg = a.sigma_c[m];
+        const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
+        p.dlx = dl.x;
+        p.dly = dl.y;
+      }
+      return p;
+    };
+    Slot nxt = fetch(r_begin);
     for (uint32_t r = r_begin; r < r_end; ++r) {
-      const uint32_t index = (uint32_t)a.rays_alive[(size_t)r * a.alive_stride];
-      const uint32_t offset = (uint32_t)a.span[(size_t)r * a.span_stride];
-      uint32_t count = (uint32_t)a.span[(size_t)r * a.span_stride + 1];
-      if (a.train && offset + count >= a.n_points) count = 0;
-      float T_carry = 1.0f - a.weights_sum[index];
-      float t_carry = a.rays_t[a.train ? index : r];
+      const Slot cur = nxt;
+      if (r + 1 < r_end) nxt = fetch(r + 1);
+      const uint32_t index = cur.index, offset = cur.offset, count = cur.count;
+      float T_carry = 1.0f - cur.ws0;
+      float t_carry = cur.t0;
       bool stopped = false;
       float wsum = 0.0f, dsum = 0.0f;
       for (uint32_t s0 = 0; s0 < count && !stopped; s0 += 64) {
         const uint32_t s = s0 + lane;
         const bool live = s < count;
         const size_t m = (size_t)offset + (live ? s : s0);
-        const float sg = a.sigma_c[m] * a.density_scale;
-        const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
-        const float alpha = live ? 1.0f - __expf(-sg * dl.x) : 0.0f;
+        float sg, dlx, dly;
+        if (s0 == 0) {
+          sg = cur.sg; dlx = cur.dlx; dly = cur.dly;
+        } else {
+          sg = a.sigma_c[m];
+          const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
+          dlx = dl.x; dly = dl.y;
+        }
+        sg = sg * a.density_scale;
+        const float alpha = live ? 1.0f - __expf(-sg * dlx) : 0.0f;
         const float Tin = wave_incl_scan_mul(1.0f - alpha, lane);
         float Tex = __shfl_up(Tin, 1, 64);
         if (lane == 0) Tex = 1.0f;
@@ -504,7 +537,7 @@ k_composite(CmpArgs a) {
             stop_mask ? (uint32_t)__ffsll((long long)stop_mask) - 1u : 64u;
         const bool use = live && lane <= first_stop;
         const float w = use ? alpha * Tr : 0.0f;
-        const float tt = t_carry + wave_incl_scan_add(live ? dl.y : 0.0f, lane);
+        const float tt = t_carry + wave_incl_scan_add(live ? dly : 0.0f, lane);
         const bool keep = use && (w > a.w_min);
         if (use) wsum += w;
         if (keep) dsum += w * tt;  // depth is masked like colour (as in run())
