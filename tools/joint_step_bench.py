@@ -8,11 +8,13 @@ import torch
 from ucsa_neural_rendering_amd.lightning import JointTrainDataModule, JointTrainLightningNet, Trainer
 exp = {
     "general": {"name": "bench_joint", "clean_up_folder_if_exists": True, "checkpoint_load": ""},
-    "model": {"pretrained": False, "pretrained_backbone": False, "num_classes": 40},
+    "model": {"pretrained": False, "pretrained_backbone": False, "num_classes": 40,
+              "amp": os.environ.get("AMP", "")},
     "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
     "trainer": {}, "data_module": {"batch_size": int(os.environ.get("BS", "4"))},
     "scenes": ["scene0000_00"], "synthetic": {"n_views": 12, "H": 240, "W": 320},
-    "nerf": {"n_rays": 4096, "num_steps": 256, "upsample_steps": 256}, "nerf_seed": 1,
+    "nerf": {"n_rays": 4096, "num_steps": 256, "upsample_steps": 256,
+             "cuda_ray": bool(int(os.environ.get("CUDA_RAY", "0")))}, "nerf_seed": 1,
 }
 model = JointTrainLightningNet(exp, {"results": "/tmp/exp", "scannet": "/tmp"})
 dm = JointTrainDataModule(exp); dm.setup()
@@ -23,7 +25,10 @@ loader = dm.train_dataloader_joint()
 batches = [tr._to_device(b) for b in loader]
 def step(b):
     model.training_step(b, 0)
-step(batches[0]); torch.cuda.synchronize()
+for _ in range(int(os.environ.get("WARM", "1"))):
+    for b in batches:
+        step(b)
+torch.cuda.synchronize()
 t0 = time.perf_counter(); n = 0
 for b in batches:
     step(b); n += 1
