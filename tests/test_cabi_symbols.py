@@ -76,3 +76,23 @@ def test_product_has_no_oracle_import():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+
+
+def test_reference_import_paths_resolve():
+    """The reference's own import lines work against the alias package
+    (scripts/train_joint.py:9-17, joint_train_lightning_net.py:12-27,
+    joint_train_data_module.py:8 of the reference)."""
+    from nr4seg import ROOT_DIR  # noqa: F401
+    from nr4seg.dataset import ScanNetNGPJoint  # noqa: F401
+    from nr4seg.dataset.ngp_utils import get_rays, nerf_matrix_to_ngp  # noqa: F401
+    from nr4seg.lightning import JointTrainDataModule, JointTrainLightningNet  # noqa: F401
+    from nr4seg.nerf.network_tcnn_semantics import SemanticNeRFNetwork  # noqa: F401
+    from nr4seg.nerf.raymarching import raymarching
+    from nr4seg.nerf.renderer_semantics import SemanticNeRFRenderer  # noqa: F401
+    from nr4seg.network import DeepLabV3  # noqa: F401
+    from nr4seg.utils import flatten_dict, load_yaml  # noqa: F401
+    from nr4seg.utils.metrics import SemanticsMeter  # noqa: F401
+    for name in ("near_far_from_aabb", "march_rays_train", "composite_rays_train",
+                 "composite_rays_train_semantics", "march_rays", "composite_rays",
+                 "composite_rays_semantics", "compact_rays"):
+        assert callable(getattr(raymarching, name)), name
