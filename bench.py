@@ -585,17 +585,22 @@ def main():
             "max_abs_image_diff_vs_fp32": float(d16),
             "note": "precision='fp16': three MLPs on 16x16x32 f16 MFMA, fp32 "
                     "accumulate; hash grid, sampling, compositing fp32"}
+        # The side measurements below (marcher, training, DeepLab, CPU
+        # baseline) are single-GPU figures: at N > 1 the other ranks would only
+        # wait for rank 0, so they run at N = 1 only.
+        extras = world == 1
         # occupancy-grid marching on the same parameters:
         # never the headline `value` (cfg2 is defined at 192 samples/ray)
-        try:
-            result["march_option"] = march_option(net, scene_ds, rays, n_views,
-                                                  out, dev, args)
-        except Exception as e:  # the headline line must survive
-            result["march_option"] = {"error": repr(e)}
-        if not args.no_train_bench:
+        if extras:
+            try:
+                result["march_option"] = march_option(net, scene_ds, rays,
+                                                      n_views, out, dev, args)
+            except Exception as e:  # the headline line must survive
+                result["march_option"] = {"error": repr(e)}
+        if extras and not args.no_train_bench:
             result["train"] = train_throughput(net, scene_ds, dev)
             result["seg"] = seg_throughput(dev)
-        if not args.no_cpu_baseline:
+        if extras and not args.no_cpu_baseline:
             threads = effective_cores()
             v, dt, parity, ref, got, (co, cd) = cpu_baseline(
                 net, poses[0], intr, args.cpu_rays, threads)
