@@ -33,6 +33,12 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Sigmoid and softmax of the shaded samples use the hardware exponential
+// (v_exp_f32 on x*log2e, ~2 ulp): 27 of them per sample were 6 % of the
+// kernel as libm expf (measured), and the outputs are probabilities / colours
+// compared at 1e-4.  The weights (phase A) keep expf: they decide the mask.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
 struct CmpArgs {
   const float* rays_d;
   const float* norms;
@@ -290,7 +296,7 @@ k_composite(CmpArgs a) {
       for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          rgb[cb][c] = 1.0f / (1.0f + expf(-o3[cb][c]));  // rows 0..2 live in g==0
+          rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[cb][c]));  // rows 0..2 live in g==0
     }
 
     // ---------------- semantics net: 16 -> 64 -> 16*NRB_SEM --------------
@@ -359,7 +365,7 @@ k_composite(CmpArgs a) {
         f32x4 o3 = mfma_h(frag_h(w_color, 12, lane), h0, z4);
         o3 = mfma_h(frag_h(w_color, 13, lane), h1, o3);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + expf(-o3[c]));
+        for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[c]));
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
         h0 = chain_relu_h(a1[0], a1[1]);
@@ -389,7 +395,7 @@ k_composite(CmpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
-          const float ex = ok ? expf(lg[cb][rb][r] - mx) : 0.0f;
+          const float ex = ok ? fast_exp(lg[cb][rb][r] - mx) : 0.0f;
           lg[cb][rb][r] = ex;
           sum += ex;
         }

@@ -182,7 +182,7 @@ k_shade_bwd(ShadeBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
-        const float ex = ok ? expf(lg[rb][r] - mx) : 0.0f;
+        const float ex = ok ? __expf(lg[rb][r] - mx) : 0.0f;  // as the forward (composite.hip fast_exp)
         lg[rb][r] = ex;
         sum += ex;
       }
@@ -197,7 +197,7 @@ k_shade_bwd(ShadeBwdArgs a) {
       // image = sum_s w*rgb  ->  d_rgb = w*d_image, d_w += d_image . rgb
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float rgb = 1.0f / (1.0f + expf(-o3[0][c]));
+        const float rgb = 1.0f / (1.0f + __expf(-o3[0][c]));
         dwsum += di[c] * rgb;
         dy3[c] = wgt * di[c] * rgb * (1.0f - rgb);
       }
