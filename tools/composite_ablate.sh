@@ -1,5 +1,5 @@
 #!/bin/bash
-# on the GPU box: time the composite stage with parts of the shading removed
+# on the GPU box: time the composite stage with parts of the kernel removed
 # (results are then WRONG -- timing only) to see what the time is made of
 cd "$GRAFT_REPO_ROOT"
 F=ucsa_neural_rendering_amd/csrc/composite.hip
@@ -21,34 +21,24 @@ st, rho = bench.stage_times(net, o[0, :N].contiguous(), d[0, :N].contiguous(), n
 print(f"composite {st['composite']:.3f} ms")
 PY
 }
+edit() { python3 - "$1" "$2" <<'PY'
+import sys
+p="ucsa_neural_rendering_amd/csrc/composite.hip"; s=open(p).read()
+a,b=sys.argv[1],sys.argv[2]
+assert a in s, a
+open(p,"w").write(s.replace(a,b))
+PY
+}
 echo -n "baseline: "; run
-# 1. no colour L3 MFMAs
-python3 - <<'PY'
-import re
-p="ucsa_neural_rendering_amd/csrc/composite.hip"; s=open(p).read()
-s=s.replace("for (int cb = 0; cb < CBS; ++cb) o3[cb] = mfma16(wa, hid[cb][ks], o3[cb]);","for (int cb = 0; cb < CBS; ++cb) o3[cb][ks & 3] += wa * hid[cb][ks];")
-open(p,"w").write(s)
-PY
-echo -n "colour L3 on VALU-ish (wrong): "; run
+edit "      } else if (e < T) {
+        uint32_t lo = 0, hi = t;  // #fine strictly below ze" "      } else if (true) { rank = e; } else if (e < T) {
+        uint32_t lo = 0, hi = t;  // #fine strictly below ze"
+echo -n "no rank searches (wrong): "; run
 cp /tmp/composite.orig $F
-# 2. no softmax exp (cheap exp)
-sed -i 's/const float ex = ok ? expf(lg\[cb\]\[rb\]\[r\] - mx) : 0.0f;/const float ex = ok ? __expf(lg[cb][rb][r] - mx) : 0.0f;/; s/rgb\[cb\]\[c\] = 1.0f \/ (1.0f + expf(-o3\[cb\]\[c\]));/rgb[cb][c] = 1.0f \/ (1.0f + __expf(-o3[cb][c]));/' $F
-echo -n "fast exp: "; run
+edit "      const f32x4 hv = *reinterpret_cast<const f32x4*>(hp);" "      const f32x4 hv = f32x4{0.1f, 0.2f, 0.3f, (float)row * 1e-9f}; (void)hp;"
+echo -n "no h-row gathers (wrong): "; run
 cp /tmp/composite.orig $F
-# 3. skip the per-ray sequential sums (phase D)
-python3 - <<'PY'
-p="ucsa_neural_rendering_amd/csrc/composite.hip"; s=open(p).read()
-s=s.replace("        if ((uint32_t)e < nb) {\n          const uint32_t ray","        if ((uint32_t)e < nb && e == 0) {\n          const uint32_t ray")
-open(p,"w").write(s)
-PY
-echo -n "phase D only first row (wrong): "; run
-cp /tmp/composite.orig $F
-# 4. skip semantics net entirely: NRB loops -> keep MFMA count but no softmax/contrib for sem
-python3 - <<'PY'
-p="ucsa_neural_rendering_amd/csrc/composite.hip"; s=open(p).read()
-s=s.replace("          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] * inv_sum);","          if (cls < C && rb == 0) crow[3 + cls] = wgt * (lg[cb][rb][r] * inv_sum);")
-open(p,"w").write(s)
-PY
-echo -n "contrib writes rb0 only (wrong): "; run
+edit "    while (cnt - head >= G) {" "    while (false && cnt - head >= G) {"
+echo -n "no shading at all, phase A only (wrong): "; run
 cp /tmp/composite.orig $F
 make -C ucsa_neural_rendering_amd/csrc -j8 > /dev/null 2>&1
