@@ -448,6 +448,9 @@ int32_t ucsa_compact_rays(uint32_t n_alive, int32_t* rays_alive,
  * parent code did with march_rays_train -> network -> composite_rays_train,
  * fused like the inference path: sigma / h [M,16] come from the sigma MLP,
  * the colour and semantics nets run inside, only on samples with w > w_min.
+ *   rays rows must be in point order (row n's span starts where row n-1's
+ *   ends, as ucsa_march_rays_train writes them): a wave streams the points
+ *   of its rows as one contiguous range.
  *   fwd: weights_sum, depth (= sum w*t, t measured from the ray origin:
  *        nears[ray] + the accumulated deltas), image, semantics by ray id --
  *        ADDED to zero-filled buffers; w_out, t_out [M] (zero-filled) keep

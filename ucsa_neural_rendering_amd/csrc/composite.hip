@@ -39,6 +39,41 @@ __device__ __forceinline__ void wave_lds_sync() {
 // compared at 1e-4.  The weights (phase A) keep expf: they decide the mask.
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+// Marched mode: slots (rays) handled by one wave, and segmented wave64 scans
+// (a lane with `head` starts a new segment).
+#define MARCH_RPW_MAX 128
+#define MARCH_SLOT_FLOATS (5 * MARCH_RPW_MAX)
+
+__device__ __forceinline__ float seg_incl_scan_mul(float v, bool head,
+                                                   uint32_t lane) {
+  int f = head ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    const int of = __shfl_up(f, d, 64);
+    if (lane >= (uint32_t)d && !f) {
+      v = o * v;
+      f = of;
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float seg_incl_scan_add(float v, bool head,
+                                                   uint32_t lane) {
+  int f = head ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    const int of = __shfl_up(f, d, 64);
+    if (lane >= (uint32_t)d && !f) {
+      v = o + v;
+      f = of;
+    }
+  }
+  return v;
+}
+
 struct CmpArgs {
   const float* rays_d;
   const float* norms;
@@ -137,7 +172,8 @@ k_composite(CmpArgs a) {
   const uint32_t cap = MARCH ? 64u + G : S + G;    // entry list capacity
   // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
   //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
-  const uint32_t per_wave_floats = 4 * S + 3 * cap + 16 * cstride + 64;
+  const uint32_t per_wave_floats =
+      4 * S + 3 * cap + 16 * cstride + 64 + (MARCH ? MARCH_SLOT_FLOATS : 0);
   float* base = per_wave + (size_t)wid * per_wave_floats;
   float* zraw = base;
   float* zm = zraw + S;
@@ -148,6 +184,12 @@ k_composite(CmpArgs a) {
   uint32_t* lray = lrow + cap;
   float* contrib = reinterpret_cast<float*>(lray + cap);
   float* shpart = contrib + 16 * cstride;  // [64] colour-L1 SH part of one ray
+  // marched mode: per-slot tables of the wave's rays
+  uint32_t* slot_off = reinterpret_cast<uint32_t*>(shpart + 64);
+  uint32_t* slot_cnt = slot_off + MARCH_RPW_MAX;
+  uint32_t* slot_idx = slot_cnt + MARCH_RPW_MAX;
+  float* slot_T0 = reinterpret_cast<float*>(slot_idx + MARCH_RPW_MAX);
+  float* slot_t0 = slot_T0 + MARCH_RPW_MAX;
 
   for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
     w_color[i] = a.packed_color[i];
@@ -482,96 +524,107 @@ k_composite(CmpArgs a) {
   };
 
   if constexpr (MARCH) {
-    // =================== per-slot loop (marched spans) ====================
-    // Marched rays are short (tens of samples a round): the loop is a chain
-    // of dependent loads per ray (slot -> span -> sigma / deltas), ~2.5 us
-    // each and 300 rays per wave.  So the next slot's header and first 64
-    // samples are requested before the current slot is processed.
-    struct Slot {
-      uint32_t index, offset, count;
-      float ws0, t0, sg, dlx, dly;
-    };
-    auto fetch = [&](uint32_t r) {
-      Slot p;
-      p.index = (uint32_t)a.rays_alive[(size_t)r * a.alive_stride];
-      p.offset = (uint32_t)a.span[(size_t)r * a.span_stride];
-      p.count = (uint32_t)a.span[(size_t)r * a.span_stride + 1];
-      if (a.train && p.offset + p.count >= a.n_points) p.count = 0;
-      p.ws0 = a.weights_sum[p.index];
-      p.t0 = a.rays_t[a.train ? p.index : r];
-      p.sg = 0.f; p.dlx = 0.f; p.dly = 0.f;
-      if (p.count) {
-        const size_t m = (size_t)p.offset + (lane < p.count ? lane : 0u);
-        p.sg = a.sigma_c[m];
-        const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
-        p.dlx = dl.x;
-        p.dly = dl.y;
+    // ================= marched spans, streamed 64 points at a time ==========
+    // Marched rays are short (tens of samples a round, ~12 in the first one):
+    // a loop over rays leaves most lanes idle and pays a chain of dependent
+    // loads per ray.  The spans of a wave's slots are CONTIGUOUS in the point
+    // buffers (exclusive prefix sums in slot order), so the wave streams its
+    // points 64 at a time -- sigma / deltas fully coalesced -- whatever rays
+    // they belong to, with segmented scans: a lane that is the first sample of
+    // its ray starts a segment; the ray cut by a chunk boundary continues from
+    // wave-uniform carries.
+    const uint32_t n_slots = r_end - r_begin;  // <= MARCH_RPW_MAX
+    uint32_t p_end = 0;
+    for (uint32_t i = lane; i < n_slots; i += 64) {
+      const uint32_t r = r_begin + i;
+      const uint32_t index = (uint32_t)a.rays_alive[(size_t)r * a.alive_stride];
+      const uint32_t off = (uint32_t)a.span[(size_t)r * a.span_stride];
+      uint32_t c = (uint32_t)a.span[(size_t)r * a.span_stride + 1];
+      if (a.train && off + c >= a.n_points) c = 0;
+      slot_off[i] = off;
+      slot_cnt[i] = c;
+      slot_idx[i] = index;
+      slot_T0[i] = 1.0f - a.weights_sum[index];
+      slot_t0[i] = a.rays_t[a.train ? index : r];
+      if (c) p_end = off + c;  // offsets ascend: the last non-empty slot wins
+      else if (!a.train) a.rays_t[r] = -1.0f;  // nothing marched: finished
+    }
+#pragma unroll
+    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)p_end, d2, 64);
+      p_end = o > p_end ? o : p_end;
+    }
+    wave_lds_sync();
+    const uint32_t p_begin = slot_off[0];
+    // carries of the ray cut by the previous chunk boundary (wave-uniform)
+    float carry_T = 1.0f, carry_Tprev = 1.0f, carry_t = 0.0f, carry_sw = 0.0f,
+          carry_sd = 0.0f;
+    for (uint32_t p0 = p_begin; p0 < p_end; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      const bool live = p < p_end;
+      // slot of the point: last slot whose first point is <= p
+      uint32_t lo = 0, hi = n_slots;
+      const uint32_t pq = live ? p : p_end - 1;
+      while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (slot_off[mid] <= pq) lo = mid; else hi = mid;
       }
-      return p;
-    };
-    Slot nxt = fetch(r_begin);
-    for (uint32_t r = r_begin; r < r_end; ++r) {
-      const Slot cur = nxt;
-      if (r + 1 < r_end) nxt = fetch(r + 1);
-      const uint32_t index = cur.index, offset = cur.offset, count = cur.count;
-      float T_carry = 1.0f - cur.ws0;
-      float t_carry = cur.t0;
-      bool stopped = false;
-      float wsum = 0.0f, dsum = 0.0f;
-      for (uint32_t s0 = 0; s0 < count && !stopped; s0 += 64) {
-        const uint32_t s = s0 + lane;
-        const bool live = s < count;
-        const size_t m = (size_t)offset + (live ? s : s0);
-        float sg, dlx, dly;
-        if (s0 == 0) {
-          sg = cur.sg; dlx = cur.dlx; dly = cur.dly;
-        } else {
-          sg = a.sigma_c[m];
-          const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
-          dlx = dl.x; dly = dl.y;
-        }
-        sg = sg * a.density_scale;
-        const float alpha = live ? 1.0f - __expf(-sg * dlx) : 0.0f;
-        const float Tin = wave_incl_scan_mul(1.0f - alpha, lane);
-        float Tex = __shfl_up(Tin, 1, 64);
-        if (lane == 0) Tex = 1.0f;
-        const float Tr = T_carry * Tex;
-        // reference raymarching.cu:693-706: take the sample, stop if T < 1e-4
-        const unsigned long long stop_mask =
-            a.train ? 0ull : __ballot(live && Tr <= 1e-4f);
-        const uint32_t first_stop =
-            stop_mask ? (uint32_t)__ffsll((long long)stop_mask) - 1u : 64u;
-        const bool use = live && lane <= first_stop;
-        const float w = use ? alpha * Tr : 0.0f;
-        const float tt = t_carry + wave_incl_scan_add(live ? dly : 0.0f, lane);
-        const bool keep = use && (w > a.w_min);
-        if (use) wsum += w;
-        if (keep) dsum += w * tt;  // depth is masked like colour (as in run())
-        if (a.w_out && live) a.w_out[m] = w;
-        if (a.t_out && live) a.t_out[m] = tt;
-        const unsigned long long bal = __ballot(keep);
-        if (keep) {
-          const uint32_t pos =
-              cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-          lw[pos] = w;
-          lrow[pos] = (uint32_t)m;
-          lray[pos] = index;
-        }
-        cnt += (uint32_t)__popcll(bal);
-        stopped = stop_mask != 0;
-        T_carry *= wave_bcast(Tin, 63);
-        t_carry = wave_bcast(tt, 63);
-        wave_lds_sync();
-        drain();
-      }
-      wsum = wave_sum(wsum);
-      dsum = wave_sum(dsum);
-      if (lane == 0) {
-        a.weights_sum[index] += wsum;
-        a.depth[index] += dsum;
+      const uint32_t si = lo;
+      const uint32_t off = slot_off[si], c = slot_cnt[si];
+      const uint32_t index = slot_idx[si];
+      const bool head = live && p == off;
+      const bool tail = live && p == off + c - 1u;
+      const size_t m = live ? p : p_end - 1;
+      const float sg = a.sigma_c[m] * a.density_scale;
+      const float2 dl = *reinterpret_cast<const float2*>(a.deltas + 2 * m);
+      const float alpha = live ? 1.0f - __expf(-sg * dl.x) : 0.0f;
+      const unsigned long long heads = __ballot(head);
+      const uint32_t first_head =
+          heads ? (uint32_t)__ffsll((long long)heads) - 1u : 64u;
+      const bool cont = lane < first_head;  // part of the ray cut by the boundary
+      const float Tin = seg_incl_scan_mul(1.0f - alpha, head, lane);
+      float Tex = __shfl_up(Tin, 1, 64);
+      if (head || lane == 0) Tex = 1.0f;
+      const float Tr = (cont ? carry_T : slot_T0[si]) * Tex;
+      // reference raymarching.cu:693-706: take the sample, then stop if its
+      // incoming T < 1e-4 (T never grows: "some earlier sample saw T <= 1e-4"
+      // is "the previous one did")
+      float Tprev = __shfl_up(Tr, 1, 64);
+      if (lane == 0) Tprev = carry_Tprev;
+      const bool use = live && (a.train || head || !(Tprev <= 1e-4f));
+      const float w = use ? alpha * Tr : 0.0f;
+      const float tt = (cont ? carry_t : slot_t0[si]) +
+                       seg_incl_scan_add(live ? dl.y : 0.0f, head, lane);
+      const bool keep = use && (w > a.w_min);
+      if (a.w_out && live) a.w_out[m] = w;
+      if (a.t_out && live) a.t_out[m] = tt;
+      // per-ray sums: weights over every used sample, depth over the kept ones
+      const float sw = seg_incl_scan_add(w, head, lane) + (cont ? carry_sw : 0.0f);
+      const float sd = seg_incl_scan_add(keep ? w * tt : 0.0f, head, lane) +
+                       (cont ? carry_sd : 0.0f);
+      if (tail) {
+        a.weights_sum[index] += sw;
+        a.depth[index] += sd;
         if (!a.train)
-          a.rays_t[r] = (stopped || count < a.seg_cap) ? -1.0f : t_carry;
+          a.rays_t[r_begin + si] = (Tr <= 1e-4f || c < a.seg_cap) ? -1.0f : tt;
       }
+      const unsigned long long bal = __ballot(keep);
+      if (keep) {
+        const uint32_t pos =
+            cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        lw[pos] = w;
+        lrow[pos] = (uint32_t)m;
+        lray[pos] = index;
+      }
+      cnt += (uint32_t)__popcll(bal);
+      // the ray running past lane 63 (if any) continues in the next chunk
+      carry_T = wave_bcast(Tr * (1.0f - alpha), 63);
+      carry_Tprev = wave_bcast(Tr, 63);
+      carry_t = wave_bcast(tt, 63);
+      carry_sw = wave_bcast(sw, 63);
+      carry_sd = wave_bcast(sd, 63);
+      wave_lds_sync();
+      drain();
     }
   } else {
   // ======================= per-ray loop ==================================
@@ -810,12 +863,14 @@ static int32_t march_shade_launch(
   const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
                                : 7168 + 1024 + (size_t)nrb * 1024;
   const uint32_t cbs = half ? CMP_CBS_H : CMP_CBS;
-  const size_t per_wave = 3 * (size_t)(64 + 16 * cbs) + 16 * cstride + 64;
+  const size_t per_wave =
+      3 * (size_t)(64 + 16 * cbs) + 16 * cstride + 64 + MARCH_SLOT_FLOATS;
   const uint32_t waves = CMP_MAX_WAVES;
   const size_t smem = (w_floats + waves * per_wave) * 4;
   const uint64_t total_waves = 256ull * waves;
   uint32_t rpw = (uint32_t)((n_cap + total_waves - 1) / total_waves);
   if (rpw < 4) rpw = 4;
+  if (rpw > MARCH_RPW_MAX) rpw = MARCH_RPW_MAX;  // slot tables live in LDS
   const uint32_t blocks = ucsa_div_up(ucsa_div_up(n_cap, rpw), waves);
   CmpArgs a{rays_d, nullptr, nullptr, sigmas, h, nullptr, nullptr, nullptr,
             packed_color, packed_sem, n_cap, 0u, 0u, n_classes, sigma_scale,
