@@ -528,9 +528,15 @@ int32_t ucsa_march_segment_count(uint32_t n_cap, const int32_t* n_alive_dev,
                                  float dt_gamma, uint32_t C, uint32_t H,
                                  const float* density_grid, float mean_density,
                                  const float* fars, uint32_t perturb,
-                                 int32_t* span, void* workspace, void* stream);
+                                 int32_t* span, void* workspace, float* stage,
+                                 void* stream);
 
-/* Write the counted samples: xyzs, dirs [M,3], deltas [M,2] as march_rays. */
+/* `stage` (optional, ucsa_march_segment_stage_bytes(n_cap, cap) bytes): when
+ * given to _count, the samples are kept in slot-major staging rows during the
+ * counting march and _write (same `stage`, same `cap`) only copies them into
+ * place -- one march per round instead of two.
+ * Write the counted samples: xyzs, dirs [M,3], deltas [M,2] as march_rays. */
+uint64_t ucsa_march_segment_stage_bytes(uint32_t n_cap, uint32_t cap);
 int32_t ucsa_march_segment_write(uint32_t n_cap, const int32_t* n_alive_dev,
                                  const int32_t* rays_alive, const float* rays_t,
                                  const float* rays_o, const float* rays_d,
@@ -539,6 +545,7 @@ int32_t ucsa_march_segment_write(uint32_t n_cap, const int32_t* n_alive_dev,
                                  float mean_density, const float* fars,
                                  uint32_t perturb, const int32_t* span,
                                  float* xyzs, float* dirs, float* deltas,
+                                 const float* stage, uint32_t cap,
                                  void* stream);
 
 /* Composite each slot's span onto weights_sum/depth/image/semantics (by ray

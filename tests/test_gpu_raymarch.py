@@ -323,10 +323,11 @@ def _oracle_loop(o, d, grid, bound, near, far, dt_gamma, n_sem=7):
     return out, pts
 
 
+@pytest.mark.parametrize("staged", [True, False])
 @pytest.mark.parametrize("caps,dt_gamma", [((1024,), 0.0), ((8, 40, 1024), 0.0),
                                            ((32, 96, 1024), 1 / 128),
                                            ((1, 2, 3, 1024), 1 / 128)])
-def test_segmented_marcher_equals_reference_loop(caps, dt_gamma):
+def test_segmented_marcher_equals_reference_loop(caps, dt_gamma, staged):
     """ucsa_march_segment_* (exact-size spans, device-side alive count, wave
     per ray composite with early stop) against the oracle driven through the
     reference-API loop: same samples, so same sums up to re-association."""
@@ -337,6 +338,8 @@ def test_segmented_marcher_equals_reference_loop(caps, dt_gamma):
     ref, ref_pts = _oracle_loop(o, d, grid, bound, near, far, dt_gamma)
     seg = ops.MarchSegments(_t(o), _t(d), _t(near), _t(far), _t(grid), 0.1,
                             bound, dt_gamma)
+    if not staged:          # two marches per round (count, then write)
+        seg.stage_limit = 0
     ws = torch.zeros(N, device="cuda")
     dep = torch.zeros(N, device="cuda")
     img = torch.zeros(N, 3, device="cuda")
@@ -350,6 +353,7 @@ def test_segmented_marcher_equals_reference_loop(caps, dt_gamma):
             break
         if total:
             x, dd, dl = seg.write(n_alive, total, 0)
+            assert (seg.stage is not None) == staged
             s, c, l = _field(x.cpu().numpy())
             seg.composite(n_alive, cap, _t(s), 1.0, _t(c), _t(l), dl, ws, dep,
                           img, sem)

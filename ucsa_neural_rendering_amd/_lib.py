@@ -135,12 +135,13 @@ SIGNATURES = {
     "ucsa_compact_workspace_bytes": (C.c_uint64, [_u32]),
     "ucsa_compact_rays": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p, _p]),
     "ucsa_march_segment_workspace_bytes": (C.c_uint64, [_u32]),
+    "ucsa_march_segment_stage_bytes": (C.c_uint64, [_u32, _u32]),
     "ucsa_march_segment_count": (C.c_int32, [_u32, _p, _u32, _p, _p, _p, _p,
                                              _f, _f, _u32, _u32, _p, _f, _p,
-                                             _u32, _p, _p, _p]),
+                                             _u32, _p, _p, _p, _p]),
     "ucsa_march_segment_write": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _f, _f,
                                              _u32, _u32, _p, _f, _p, _u32, _p,
-                                             _p, _p, _p, _p]),
+                                             _p, _p, _p, _p, _u32, _p]),
     "ucsa_march_segment_composite": (C.c_int32, [_u32, _p, _u32, _p, _p, _p,
                                                  _p, _f, _p, _p, _p, _u32, _p,
                                                  _p, _p, _p, _p]),

@@ -1180,7 +1180,7 @@ k_seg_count(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
             uint32_t C, uint32_t H, const float* __restrict__ grid,
             float mean_density, const float* __restrict__ fars,
             uint32_t perturb, int32_t* __restrict__ span,
-            uint32_t* __restrict__ ws) {
+            uint32_t* __restrict__ ws, float* __restrict__ stage) {
   __shared__ uint32_t sm[16];
   const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
   const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
@@ -1191,15 +1191,27 @@ k_seg_count(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
     Marcher m(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid,
               mean_density, bound, dt_gamma, C, H, far);
     float t = rays_t[n];
+    float last_t = t;  // as k_seg_write: the jitter is part of the first delta
     if (perturb) {
       Pcg32 rng((uint64_t)index, (uint64_t)perturb);
       t += RM_MIN_STEPSIZE * rng.next_float();
     }
     float x, y, z;
+    // stage != NULL: the samples go to slot-major staging rows [n*cap + k]
+    // = (x, y, z, dt, t - last_t) right away and k_seg_pack copies them to
+    // their exact-size place once the offsets are known -- one march per
+    // round instead of two
+    float* st = stage ? stage + (size_t)n * cap * 5 : nullptr;
     while (t < far && steps < cap) {
       if (m.probe(t, x, y, z)) {
+        const float dt = m.step_size(t);
+        t += dt;
+        if (st) {
+          st[0] = x; st[1] = y; st[2] = z; st[3] = dt; st[4] = t - last_t;
+          st += 5;
+          last_t = t;
+        }
         ++steps;
-        t += m.step_size(t);
       }
     }
     span[2 * n + 1] = (int32_t)steps;
@@ -1274,6 +1286,30 @@ k_seg_write(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
   }
 }
 
+// staging rows -> exact-size buffers: thread (slot n, sample k)
+__global__ void __launch_bounds__(RM_BLOCK)
+k_seg_pack(uint32_t n_cap, const int32_t* __restrict__ n_alive_dev,
+           uint32_t cap, const int32_t* __restrict__ rays_alive,
+           const float* __restrict__ rays_d, const int32_t* __restrict__ span,
+           const float* __restrict__ stage, float* __restrict__ xyzs,
+           float* __restrict__ dirs, float* __restrict__ deltas) {
+  const uint32_t n_alive = seg_n_alive(n_alive_dev, n_cap);
+  const uint64_t e = (uint64_t)blockIdx.x * RM_BLOCK + threadIdx.x;
+  const uint32_t n = (uint32_t)(e / cap), k = (uint32_t)(e % cap);
+  if (n >= n_alive || k >= (uint32_t)span[2 * n + 1]) return;
+  const float* st = stage + ((size_t)n * cap + k) * 5;
+  const size_t p = (size_t)(uint32_t)span[2 * n] + k;
+  const float* d = rays_d + (size_t)(uint32_t)rays_alive[n] * 3;
+  xyzs[p * 3] = st[0]; xyzs[p * 3 + 1] = st[1]; xyzs[p * 3 + 2] = st[2];
+  dirs[p * 3] = d[0]; dirs[p * 3 + 1] = d[1]; dirs[p * 3 + 2] = d[2];
+  deltas[p * 2] = st[3]; deltas[p * 2 + 1] = st[4];
+}
+
+extern "C" uint64_t ucsa_march_segment_stage_bytes(uint32_t n_cap,
+                                                   uint32_t cap) {
+  return (uint64_t)n_cap * cap * 5 * sizeof(float);
+}
+
 extern "C" uint64_t ucsa_march_segment_workspace_bytes(uint32_t n_cap) {
   return 4ull * (4ull + ucsa_div_up(n_cap ? n_cap : 1, RM_BLOCK));
 }
@@ -1283,7 +1319,8 @@ extern "C" int32_t ucsa_march_segment_count(
     const int32_t* rays_alive, const float* rays_t, const float* rays_o,
     const float* rays_d, float bound, float dt_gamma, uint32_t C, uint32_t H,
     const float* density_grid, float mean_density, const float* fars,
-    uint32_t perturb, int32_t* span, void* workspace, void* stream) {
+    uint32_t perturb, int32_t* span, void* workspace, float* stage,
+    void* stream) {
   UCSA_CHECK_ARG(cap >= 1 && cap <= RM_MAX_STEPS, 2);
   UCSA_CHECK_ARG(rays_alive, 3);
   UCSA_CHECK_ARG(rays_t, 4);
@@ -1306,7 +1343,7 @@ extern "C" int32_t ucsa_march_segment_count(
   hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(RM_BLOCK), 0, s, n_cap,
                      n_alive_dev, cap, rays_alive, rays_t, rays_o, rays_d,
                      bound, dt_gamma, C, H, density_grid, mean_density, fars,
-                     perturb, span, ws);
+                     perturb, span, ws, stage);
   hipLaunchKernelGGL(k_seg_offsets, dim3(nb), dim3(RM_BLOCK), 0, s, n_cap,
                      n_alive_dev, span, ws);
   return ucsa_launch_status();
@@ -1318,7 +1355,7 @@ extern "C" int32_t ucsa_march_segment_write(
     float dt_gamma, uint32_t C, uint32_t H, const float* density_grid,
     float mean_density, const float* fars, uint32_t perturb,
     const int32_t* span, float* xyzs, float* dirs, float* deltas,
-    void* stream) {
+    const float* stage, uint32_t cap, void* stream) {
   UCSA_CHECK_ARG(rays_alive, 2);
   UCSA_CHECK_ARG(rays_t, 3);
   UCSA_CHECK_ARG(rays_o && rays_d, 4);
@@ -1328,6 +1365,14 @@ extern "C" int32_t ucsa_march_segment_write(
   UCSA_CHECK_ARG(xyzs && dirs && deltas, 15);
   if (n_cap == 0) return 0;
   UCSA_CLEAR_ERR();
+  if (stage) {  // the samples were staged by ucsa_march_segment_count
+    UCSA_CHECK_ARG(cap >= 1 && cap <= RM_MAX_STEPS, 19);
+    hipLaunchKernelGGL(k_seg_pack, dim3(ucsa_div_up((uint64_t)n_cap * cap, RM_BLOCK)),
+                       dim3(RM_BLOCK), 0, (hipStream_t)stream, n_cap,
+                       n_alive_dev, cap, rays_alive, rays_d, span, stage, xyzs,
+                       dirs, deltas);
+    return ucsa_launch_status();
+  }
   hipLaunchKernelGGL(k_seg_write, dim3(ucsa_div_up(n_cap, RM_BLOCK)),
                      dim3(RM_BLOCK), 0, (hipStream_t)stream, n_cap, n_alive_dev,
                      rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, C, H,

@@ -476,6 +476,17 @@ def _inplace_f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 _march_ws = {}
+_named_ws = {}
+
+
+def _scratch_named(name: str, nbytes: int, device) -> torch.Tensor:
+    """A grow-only scratch buffer of its own (not shared with _scratch's)."""
+    key = (name, device, torch.cuda.current_stream().cuda_stream)
+    buf = _named_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _named_ws[key] = buf
+    return buf
 
 
 def _scratch(nbytes: int, device) -> torch.Tensor:
@@ -635,17 +646,26 @@ class MarchSegments:
             dtype=torch.int32, device=dev)
         self.cur = 0        # which half of alive / t / n_alive is current
         self.first = True   # round 0: every ray alive, count not on device yet
+        self.stage = None   # staging rows of the current round (or None)
+        self.stage_cap = 0
+        # rounds whose staging rows fit this many bytes march once (the
+        # samples are staged while counting, then copied into place)
+        self.stage_limit = 1 << 30
 
     def _n_dev(self):
         return None if self.first else _ptr(self.n_alive[self.cur:])
 
     def count(self, n_cap: int, cap: int, perturb: int):
         b, g, C_, H = self.args
+        need = int(lib().ucsa_march_segment_stage_bytes(n_cap, cap))
+        self.stage, self.stage_cap = None, cap
+        if 0 < need <= self.stage_limit:
+            self.stage = _scratch_named("march_stage", need, self.o.device)
         check(lib().ucsa_march_segment_count(
             n_cap, self._n_dev(), cap, _ptr(self.alive[self.cur]),
             _ptr(self.t[self.cur]), _ptr(self.o), _ptr(self.d), b, g, C_, H,
             _ptr(self.grid), self.mean_density, _ptr(self.fars), int(perturb),
-            _ptr(self.span), _ptr(self.ws), _stream()),
+            _ptr(self.span), _ptr(self.ws), _ptr(self.stage), _stream()),
             "ucsa_march_segment_count")
         total, n_alive = self.ws[:2].tolist()   # the round's one host sync
         return total, n_alive
@@ -660,7 +680,8 @@ class MarchSegments:
             n_cap, self._n_dev(), _ptr(self.alive[self.cur]),
             _ptr(self.t[self.cur]), _ptr(self.o), _ptr(self.d), b, g, C_, H,
             _ptr(self.grid), self.mean_density, _ptr(self.fars), int(perturb),
-            _ptr(self.span), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _stream()),
+            _ptr(self.span), _ptr(xyzs), _ptr(dirs), _ptr(deltas),
+            _ptr(self.stage), self.stage_cap, _stream()),
             "ucsa_march_segment_write")
         return xyzs, dirs, deltas
 
