@@ -35,6 +35,7 @@ def _t(a, dtype=None):
     (40000, 2.0, 32, 1 / 128, True, True),   # > 32768 rays: lane-per-ray kernels
     (5000, 4.0, 128, 1 / 256, True, False),  # wave-per-ray, long orbits
     (777, 1.0, 64, 0.0, False, False),
+    (9000, 2.0, 32, 1 / 128, False, True),   # wave-per-ray without staging rows
 ])
 def test_march_rays_train_bit_exact(N, bound, H, dt_gamma, perturb, outside):
     rm = _rm()

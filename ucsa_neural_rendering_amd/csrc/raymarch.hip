@@ -404,7 +404,8 @@ k_march_count_w(const float* __restrict__ rays_o, const float* __restrict__ rays
                 const float* __restrict__ grid, float mean_density, float bound,
                 float dt_gamma, uint32_t N, uint32_t C, uint32_t H,
                 const float* __restrict__ nears, const float* __restrict__ fars,
-                uint32_t perturb, uint32_t* __restrict__ steps_out) {
+                uint32_t perturb, uint32_t* __restrict__ steps_out,
+                float* __restrict__ stage) {
   __shared__ float u_s[WM_WAVES][64];
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t n = blockIdx.x * WM_WAVES + wid;
@@ -417,10 +418,52 @@ k_march_count_w(const float* __restrict__ rays_o, const float* __restrict__ rays
     Pcg32 rng((uint64_t)n, 1u);
     t += RM_MIN_STEPSIZE * rng.next_float();
   }
+  // stage != NULL: keep the samples (x, y, z, dt, t_after - last_t) in the
+  // ray's staging rows so that k_march_pack_w only has to copy them into
+  // place once the offsets are known (one march per batch instead of two)
+  float* st = stage ? stage + (size_t)n * RM_MAX_STEPS * 5 : nullptr;
   const uint32_t steps = wave_march(
       m, t, t, RM_MAX_STEPS, u_s[wid], lane,
-      [](uint32_t, float, float, float, float, float, float) {});
+      [&](uint32_t rank, float x, float y, float z, float dt, float t_after,
+          float last_t) {
+        if (st) {
+          float* q = st + (size_t)rank * 5;
+          q[0] = x; q[1] = y; q[2] = z; q[3] = dt; q[4] = t_after - last_t;
+        }
+      });
   if (lane == 0) steps_out[n] = steps;
+}
+
+// staging rows -> the ray's span (one wave per ray)
+__global__ void __launch_bounds__(64 * WM_WAVES)
+k_march_pack_w(const float* __restrict__ rays_d, uint32_t N, uint32_t M,
+               const float* __restrict__ stage, float* __restrict__ xyzs,
+               float* __restrict__ dirs, float* __restrict__ deltas,
+               int32_t* __restrict__ rays, const uint32_t* __restrict__ steps_in,
+               const uint32_t* __restrict__ first,
+               const uint32_t* __restrict__ hdr) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = blockIdx.x * WM_WAVES + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const uint32_t num_steps = steps_in[n];
+  const uint32_t point_index = first[n];
+  const uint32_t ray_index = hdr[1] + n;
+  if (lane == 0 && ray_index < N) {
+    rays[ray_index * 3] = (int32_t)n;
+    rays[ray_index * 3 + 1] = (int32_t)point_index;
+    rays[ray_index * 3 + 2] = (int32_t)num_steps;
+  }
+  if (num_steps == 0 || point_index + num_steps >= M) return;
+  const float dx = rays_d[(size_t)n * 3], dy = rays_d[(size_t)n * 3 + 1],
+              dz = rays_d[(size_t)n * 3 + 2];
+  const float* st = stage + (size_t)n * RM_MAX_STEPS * 5;
+  for (uint32_t k = lane; k < num_steps; k += 64) {
+    const float* q = st + (size_t)k * 5;
+    const size_t p = (size_t)point_index + k;
+    xyzs[p * 3] = q[0]; xyzs[p * 3 + 1] = q[1]; xyzs[p * 3 + 2] = q[2];
+    dirs[p * 3] = dx; dirs[p * 3 + 1] = dy; dirs[p * 3 + 2] = dz;
+    deltas[p * 2] = q[3]; deltas[p * 2 + 1] = q[4];
+  }
 }
 
 // one workgroup: exclusive scan of steps[N] -> first[N], counters
@@ -507,9 +550,18 @@ k_march_write_w(const float* __restrict__ rays_o, const float* __restrict__ rays
 
 // ray batches up to this size march one wave per ray
 #define WM_MAX_RAYS 32768u
+// ... and up to this size with staging rows (20 KB per ray: 168 MB)
+#define WM_STAGE_RAYS 8192u
+
+static uint64_t march_ws_head_bytes(uint32_t N) {
+  const uint64_t b = 4ull * (4ull + ucsa_div_up(N ? N : 1, RM_BLOCK) + 2ull * N);
+  return (b + 255ull) & ~255ull;
+}
 
 extern "C" uint64_t ucsa_march_workspace_bytes(uint32_t N) {
-  return 4ull * (4ull + ucsa_div_up(N ? N : 1, RM_BLOCK) + 2ull * N);
+  uint64_t b = march_ws_head_bytes(N);
+  if (N <= WM_STAGE_RAYS) b += (uint64_t)N * RM_MAX_STEPS * 5 * sizeof(float);
+  return b;
 }
 
 extern "C" int32_t ucsa_march_rays_train(
@@ -538,11 +590,19 @@ extern "C" int32_t ucsa_march_rays_train(
     uint32_t* steps = ws + 4 + nb;
     uint32_t* first = steps + N;
     const uint32_t nbw = ucsa_div_up(N, WM_WAVES);
+    float* stage = N <= WM_STAGE_RAYS
+        ? (float*)((char*)workspace + march_ws_head_bytes(N)) : nullptr;
     hipLaunchKernelGGL(k_march_count_w, dim3(nbw), dim3(64 * WM_WAVES), 0, s,
                        rays_o, rays_d, density_grid, mean_density, bound,
-                       dt_gamma, N, C, H, nears, fars, perturb, steps);
+                       dt_gamma, N, C, H, nears, fars, perturb, steps, stage);
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, N, steps, first,
                        counter, ws);
+    if (stage) {
+      hipLaunchKernelGGL(k_march_pack_w, dim3(nbw), dim3(64 * WM_WAVES), 0, s,
+                         rays_d, N, M, stage, xyzs, dirs, deltas, rays, steps,
+                         first, ws);
+      return ucsa_launch_status();
+    }
     hipLaunchKernelGGL(k_march_write_w, dim3(nbw), dim3(64 * WM_WAVES), 0, s,
                        rays_o, rays_d, density_grid, mean_density, bound,
                        dt_gamma, N, C, H, M, nears, fars, xyzs, dirs, deltas,
