@@ -255,6 +255,15 @@ int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,
                              uint32_t n_params, int32_t accumulate,
                              float* grad, void* stream);
 
+/* The same for up to 4 (partial, grad) pairs in ONE launch (the MLP gradients
+ * of a training step).  All arrays are HOST arrays of `count` entries; the
+ * summation order per parameter is that of ucsa_reduce_partials. */
+int32_t ucsa_reduce_partials_multi(uint32_t count, const float* const* partials,
+                                   const uint32_t* n_parts,
+                                   const uint32_t* n_params,
+                                   float* const* grads, int32_t accumulate,
+                                   void* stream);
+
 /* Backward of ucsa_sigma_mlp_fwd (autograd of tcnn.Network in density(),
  * reference network_tcnn_semantics.py:135).  d_h [M,16] is the gradient wrt
  * the RAW outputs (slot 0 already multiplied by the trunc_exp backward,

@@ -96,6 +96,9 @@ SIGNATURES = {
     "ucsa_mlp_pack_t_size": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_t": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_reduce_partials": (C.c_int32, [_p, _u32, _u32, C.c_int32, _p, _p]),
+    "ucsa_reduce_partials_multi": (C.c_int32, [_u32, C.POINTER(_p),
+                                               C.POINTER(_u32), C.POINTER(_u32),
+                                               C.POINTER(_p), C.c_int32, _p]),
     "ucsa_sigma_mlp_bwd_parts": (C.c_uint32, [_u32]),
     "ucsa_sigma_mlp_bwd": (C.c_int32, [_p, _p, _p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_hashgrid_bwd_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32]),

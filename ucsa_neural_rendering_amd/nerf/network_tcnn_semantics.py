@@ -118,15 +118,15 @@ class _MarchRenderFn(torch.autograd.Function):
             d_depth.contiguous(), d_sem.contiguous())
         g_color = torch.empty_like(net.color_net.params)
         g_sem = torch.empty_like(net.semantics_net.params)
-        ops.reduce_partials(pc, g_color, False)
-        ops.reduce_partials(ps, g_sem, False)
         g_sigma = torch.zeros_like(net.sigma_net.params)
         g_grid = torch.zeros_like(net.encoder.params)
+        pairs = [(pc, g_color), (ps, g_sem)]
         if M > 0:
             d_feat, part = ops.sigma_mlp_bwd(feat, d_h, f["packed_sigma"],
                                              f["packed_sigma_t"])
-            ops.reduce_partials(part, g_sigma, False)
+            pairs.append((part, g_sigma))
             ops.hashgrid_bwd_points(f["grid"], xyzs, d_feat, g_grid)
+        ops.reduce_partials_multi(pairs)   # one launch for the three MLPs
         ctx.saved = None
         return (g_grid, g_sigma, g_color, g_sem) + (None,) * 9
 

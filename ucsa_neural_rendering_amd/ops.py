@@ -283,6 +283,18 @@ def reduce_partials(partial: torch.Tensor, grad: torch.Tensor,
                                      _stream()), "ucsa_reduce_partials")
 
 
+def reduce_partials_multi(pairs, accumulate: bool = False):
+    """[(partial [parts, n], grad [n]), ...] (<= 4 pairs) in one launch."""
+    k = len(pairs)
+    P = (C.c_void_p * k)(*[p.data_ptr() for p, _ in pairs])
+    G = (C.c_void_p * k)(*[g.data_ptr() for _, g in pairs])
+    NP = (C.c_uint32 * k)(*[p.shape[0] for p, _ in pairs])
+    NN = (C.c_uint32 * k)(*[p.shape[1] for p, _ in pairs])
+    check(lib().ucsa_reduce_partials_multi(k, P, NP, NN, G,
+                                           1 if accumulate else 0, _stream()),
+          "ucsa_reduce_partials_multi")
+
+
 def sigma_mlp_bwd(feat, d_h, packed_sigma, packed_sigma_t):
     """-> d_feat [L,M,2], dW partials [parts, 3072]."""
     L, M, _ = feat.shape
