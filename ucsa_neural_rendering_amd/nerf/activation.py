@@ -1,24 +1,29 @@
-"""Mirror of reference ``nr4seg/nerf/activation.py``: ``trunc_exp``.
+"""``trunc_exp`` of reference ``nr4seg/nerf/activation.py:7-21``: the density
+activation exp(x) whose derivative is evaluated at clamp(x, -15, 15).
 
-Inside the HIP field the exponential and its clamped backward are fused into
-the sigma-MLP kernels; this autograd Function exists for API parity and for
-callers that apply it to their own tensors."""
+Inside the HIP field both halves are fused into the sigma-MLP kernels (forward
+``sigma = exp(h0)``, backward in ``k_weights_bwd`` / ``k_march_weights_bwd``);
+this autograd Function is the API-parity entry for callers that apply it to
+their own tensors."""
 import torch
-from torch.autograd import Function
+
+_LIMIT = 15.0
 
 
-class _trunc_exp(Function):
-
-    @staticmethod
-    def forward(ctx, x):
-        x = x.float()  # reference: custom_fwd(cast_inputs=torch.float)
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+class TruncExp(torch.autograd.Function):
+    """y = exp(float32(x)); dL/dx = dL/dy * exp(clamp(x, -15, 15))."""
 
     @staticmethod
-    def backward(ctx, g):
-        x = ctx.saved_tensors[0]
-        return g * torch.exp(x.clamp(-15, 15))
+    def forward(ctx, inp):
+        as_f32 = inp.to(torch.float32)  # the reference casts with custom_fwd
+        ctx.save_for_backward(as_f32)
+        return as_f32.exp()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (as_f32,) = ctx.saved_tensors
+        return grad_out * torch.clamp(as_f32, min=-_LIMIT, max=_LIMIT).exp()
 
 
-trunc_exp = _trunc_exp.apply
+def trunc_exp(x):
+    return TruncExp.apply(x)
