@@ -53,6 +53,10 @@ class JointTrainLightningNet(nn.Module):
         # NeRF steps and before every evaluation epoch.
         self.cuda_ray = bool(nerf_cfg.get("cuda_ray", False))
         self.dt_gamma = float(nerf_cfg.get("dt_gamma", 1.0 / 256))
+        # far_closure: end every marched ray like run() does (needed to render
+        # a field that was trained through run(); a field trained through the
+        # marcher carries its own opacity)
+        self.far_closure = bool(nerf_cfg.get("far_closure", False))
         self.nerf_model = SemanticNeRFNetwork(
             encoding="hashgrid", bound=4, cuda_ray=self.cuda_ray,
             density_scale=1, num_semantic_classes=self.num_classes,
@@ -204,7 +208,7 @@ class JointTrainLightningNet(nn.Module):
             rays_o, rays_d, direction_norms=direction_norms, staged=True,
             bg_color=1, perturb=False, num_steps=self.num_steps,
             upsample_steps=self.upsample_steps, image_width=W,
-            **({"dt_gamma": self.dt_gamma, "far_closure": False}
+            **({"dt_gamma": self.dt_gamma, "far_closure": self.far_closure}
                if self.cuda_ray else {}))
         pred_rgb = outputs["image"].reshape(B, H, W, 3)
         sem = outputs["semantics"].reshape(B, H, W, self.num_classes)
