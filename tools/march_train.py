@@ -62,7 +62,10 @@ def train(march, steps, dt_gamma, dev, seed=123):
         labels = item["label"].reshape(-1)[inds][None]
         gt_depth = item["depth"].float().reshape(-1)[inds][None]
         if march:
-            out = net.render(o[None], d[None], nrm[None], perturb=True, dt_gamma=dt_gamma)
+            g_now = dt_gamma
+            if COARSE_START and it < COARSE_START:
+                g_now = max(dt_gamma, 1 / 64)   # coarse steps while the air is still full
+            out = net.render(o[None], d[None], nrm[None], perturb=True, dt_gamma=g_now)
         else:
             out = net.render(o[None], d[None], nrm[None], perturb=True, num_steps=256, upsample_steps=256)
         lc, ls, ld = ul.nerf_losses(out["image"], out["semantics"], out["depth"], gt_rgb, labels, gt_depth, 1.0)
@@ -82,6 +85,7 @@ def train(march, steps, dt_gamma, dev, seed=123):
     return net, ds, res
 
 
+COARSE_START = int(os.environ.get("COARSE_START", "0"))
 DECAY_EARLY = float(os.environ.get("DECAY_EARLY", "0"))  # 0: built-in schedule
 EARLY_STEPS = int(os.environ.get("EARLY_STEPS", "256"))
 
