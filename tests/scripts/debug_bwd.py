@@ -1,5 +1,6 @@
-import sys, torch
-sys.path.insert(0, '/root/repo')
+"""Debug aid: gradients of the HIP render vs the oracle on a tiny batch (checker script, lives under tests/ because it imports the oracle)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import renderer as oren
 from tests.util import AABB4, hip_network_from_oracle, lively_oracle_field, make_rays
 N,T,t,perturb = [int(x) for x in sys.argv[1:5]] if len(sys.argv)>4 else (48,16,16,1)

@@ -1,7 +1,7 @@
 """Deterministic marcher-render timing (fixed parameters, fixed occupancy grid,
 fixed rays) for A/B comparisons of kernel variants."""
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests.util import hip_network_from_oracle, lively_oracle_field, march_scene
 from ucsa_neural_rendering_amd import ops
 dev = torch.device("cuda:0")

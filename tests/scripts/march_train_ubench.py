@@ -1,6 +1,6 @@
 """march_rays_train timing: dense vs sparse grids, staged (N <= 8192) vs not."""
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests.util import march_scene, slab_near_far
 from ucsa_neural_rendering_amd.nerf.raymarching import raymarching as rm
 for fill, label in ((1.1, "dense"), (0.06, "sparse")):

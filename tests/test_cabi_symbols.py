@@ -70,12 +70,13 @@ def test_null_arguments_are_rejected_before_any_launch(built_lib):
 
 def test_product_has_no_oracle_import():
     """The shipped package must never route through the CPU oracle."""
-    pkg = os.path.join(ROOT, "ucsa_neural_rendering_amd")
-    for dp, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith(".py"):
-                txt = open(os.path.join(dp, f)).read()
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|tests)\b", re.M)
+    for sub in ("ucsa_neural_rendering_amd", "nr4seg", "tools", "scripts"):
+        for dp, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith(".py"):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert not pat.search(txt), os.path.join(dp, f)
 
 
 def test_reference_import_paths_resolve():
