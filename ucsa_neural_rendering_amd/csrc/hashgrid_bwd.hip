@@ -83,6 +83,25 @@ __device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
   }
 }
 
+// (x, y) += (vx, vy) on an 8-byte aligned pair of LDS floats.  ds_add_f32 is
+// serialised per lane on gfx950 (measured, tools/ubench/lds_atomic.hip: two of
+// them per record retire at 100 G records/s chip-wide, integer LDS atomics at
+// 1670 G/s); one 64-bit compare-and-swap loop on the pair does 800 G/s and is
+// the same arithmetic (plain fp32 adds in arrival order).
+__device__ __forceinline__ void lds_add_pair(float* pair, float vx, float vy) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(pair);
+  unsigned long long seen = *reinterpret_cast<volatile unsigned long long*>(q);
+  unsigned long long expect;
+  do {
+    expect = seen;
+    const float sx = __uint_as_float((uint32_t)expect) + vx;
+    const float sy = __uint_as_float((uint32_t)(expect >> 32)) + vy;
+    seen = atomicCAS(q, expect,
+                     (unsigned long long)__float_as_uint(sx) |
+                         ((unsigned long long)__float_as_uint(sy) << 32));
+  } while (seen != expect);
+}
+
 // Workgroup-private LDS accumulator (open addressing, keyed by table index).
 // All rays of a training batch start in the camera's cell, so on the coarse
 // levels a handful of table entries receive an update from every ray: as
@@ -102,8 +121,7 @@ __device__ __forceinline__ void lds_accumulate(uint32_t* keys, float* vals,
   for (int probe = 0; probe < 4; ++probe) {
     const uint32_t old = atomicCAS(&keys[slot], ACC_EMPTY, idx);
     if (old == ACC_EMPTY || old == idx) {
-      atomicAdd(&vals[2 * slot], vx);
-      atomicAdd(&vals[2 * slot + 1], vy);
+      lds_add_pair(&vals[2 * slot], vx, vy);
       return;
     }
     slot = (slot + 1) & (ACC_SLOTS - 1);
@@ -120,7 +138,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
                uint32_t tiles, const float2* __restrict__ d_feat,
                float* __restrict__ grad_table) {
   __shared__ uint32_t acc_keys[RUNRED ? ACC_SLOTS : 1];
-  __shared__ float acc_vals[RUNRED ? 2 * ACC_SLOTS : 1];
+  __shared__ __attribute__((aligned(8))) float acc_vals[RUNRED ? 2 * ACC_SLOTS : 2];
   const uint32_t level = level0 + blockIdx.y;
   const uint32_t lane = threadIdx.x & 63u;
   float* gt = grad_table + (size_t)g.offset[level] * 2;
@@ -212,7 +230,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
 //           (bin = contiguous slice of the level's table): LDS histogram, one
 //           global reservation per (workgroup, bin), 16-byte record stores;
 //   pass 2  one workgroup per (level, bin) streams its records and sums them
-//           into the bin's slice held in LDS (ds_add_f32), then adds the slice
+//           into the bin's slice held in LDS (lds_add_pair), then adds the slice
 //           to the gradient with plain stores -- the slice is owned by exactly
 //           one workgroup, no global float atomics at all.
 // A bin that overflows its capacity falls back to direct atomics for the
@@ -354,17 +372,12 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = rec[i + k * 512];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t il = __float_as_uint(r[k].x);
-      atomicAdd(&acc[2 * il], r[k].y);
-      atomicAdd(&acc[2 * il + 1], r[k].z);
-    }
+    for (int k = 0; k < 4; ++k)
+      lds_add_pair(&acc[2 * __float_as_uint(r[k].x)], r[k].y, r[k].z);
   }
   for (; i < n; i += 512) {
     const float4 r = rec[i];
-    const uint32_t il = __float_as_uint(r.x);
-    atomicAdd(&acc[2 * il], r.y);
-    atomicAdd(&acc[2 * il + 1], r.z);
+    lds_add_pair(&acc[2 * __float_as_uint(r.x)], r.y, r.z);
   }
   __syncthreads();
   const uint32_t first = bin * bsz;
