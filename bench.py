@@ -63,6 +63,7 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
     from ucsa_neural_rendering_amd.nerf.network_tcnn_semantics import \
         SemanticNeRFNetwork
     from ucsa_neural_rendering_amd.nerf.optim import HipAdam
+    from ucsa_neural_rendering_amd.ops import tile_order
     net = SemanticNeRFNetwork(encoding="hashgrid", bound=4, cuda_ray=cuda_ray,
                               density_scale=1, num_semantic_classes=N_CLASSES,
                               seed=seed).to(device).train()
@@ -78,7 +79,7 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
     t0 = time.perf_counter()
     for it in range(train_steps):
         item = ds[it % len(ds)]
-        inds = torch.randint(0, 240 * 320, (4096,), device=device, generator=g)
+        inds = tile_order(torch.randint(0, 240 * 320, (4096,), device=device, generator=g), 320)
         o, d, nrm = item["rays_o"][inds], item["rays_d"][inds], item["direction_norms"][inds]
         gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
         labels = item["label"].reshape(-1)[inds][None]
@@ -104,7 +105,7 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
 def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
     """cfg3's NeRF half at the reference's native sizes: 4096 rays x (256+256)
     samples, forward + backward + Adam per step."""
-    from ucsa_neural_rendering_amd import losses as ul
+    from ucsa_neural_rendering_amd import losses as ul, ops
     from ucsa_neural_rendering_amd.nerf.optim import HipAdam
     import copy
     net = copy.deepcopy(net).train()
@@ -117,6 +118,7 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
     g = torch.Generator(device=device).manual_seed(7)
     item = ds[0]
     inds = torch.randint(0, 240 * 320, (n_rays,), device=device, generator=g)
+    inds = ops.tile_order(inds, 320)  # as JointTrainLightningNet.get_rays_train does
     o, d, nrm = item["rays_o"][inds][None], item["rays_d"][inds][None], item["direction_norms"][inds][None]
     gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
     labels = item["label"].reshape(-1)[inds][None]
@@ -338,6 +340,7 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
     if steps > 0:
         from ucsa_neural_rendering_amd import losses as ul
         from ucsa_neural_rendering_amd.nerf.optim import HipAdam
+        from ucsa_neural_rendering_amd.ops import tile_order
         t = SemanticNeRFNetwork(encoding="hashgrid", bound=4, cuda_ray=True,
                                 density_scale=1, seed=123,
                                 num_semantic_classes=N_CLASSES).to(dev).train()
@@ -359,7 +362,7 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
             if it % 16 == 0:
                 t.update_extra_state()
             item = scene_ds[it % len(scene_ds)]
-            inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)
+            inds = tile_order(torch.randint(0, 240 * 320, (4096,), device=dev, generator=g), 320)
             o = t.render(item["rays_o"][inds][None], item["rays_d"][inds][None],
                          item["direction_norms"][inds][None], perturb=True,
                          dt_gamma=1 / 256)

@@ -84,3 +84,22 @@ def test_replay_selection_and_novel_viewpoints(tmp_path):
     assert n.image_pths[0] is None and "novel_viewpoints" in n.nerf_image_pths[0]
     R = n.poses[0][:3, :3].double().numpy()
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+
+
+def test_tile_order_keeps_the_multiset_and_groups_tiles():
+    """ops.tile_order: same pixel indices (duplicates kept), tile by tile."""
+    import torch
+    from ucsa_neural_rendering_amd.ops import tile_order
+    g = torch.Generator().manual_seed(3)
+    W, H = 50, 37   # not multiples of the tile
+    inds = torch.randint(0, W * H, (700,), generator=g)
+    out = tile_order(inds, W, tile=16)
+    assert out.shape == inds.shape
+    assert torch.equal(out.sort().values, inds.sort().values)
+    ty, tx = (out // W) // 16, (out % W) // 16
+    tile_id = ty * 4 + tx
+    assert bool((tile_id[1:] >= tile_id[:-1]).all())      # tiles in order
+    same = tile_id[1:] == tile_id[:-1]
+    inner = (out // W % 16) * 16 + out % W % 16
+    assert bool((inner[1:][same] >= inner[:-1][same]).all())  # row-major inside
+    assert tile_order(inds.view(1, -1), W).shape == (1, 700)

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from ucsa_neural_rendering_amd import losses as ul  # noqa: E402
+from ucsa_neural_rendering_amd import losses as ul, ops  # noqa: E402
 from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset  # noqa: E402
 from ucsa_neural_rendering_amd.nerf.network_tcnn_semantics import SemanticNeRFNetwork  # noqa: E402
 from ucsa_neural_rendering_amd.nerf.optim import HipAdam  # noqa: E402
@@ -57,6 +57,8 @@ def train(march, steps, dt_gamma, dev, seed=123):
             net.update_extra_state(decay=(DECAY_EARLY if it < EARLY_STEPS else 0.95) if DECAY_EARLY else None)
         item = ds[it % len(ds)]
         inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)
+        if TILE_ORDER:
+            inds = ops.tile_order(inds, 320)
         o, d, nrm = item["rays_o"][inds], item["rays_d"][inds], item["direction_norms"][inds]
         gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
         labels = item["label"].reshape(-1)[inds][None]
@@ -85,6 +87,7 @@ def train(march, steps, dt_gamma, dev, seed=123):
     return net, ds, res
 
 
+TILE_ORDER = int(os.environ.get("TILE_ORDER", "1"))
 COARSE_START = int(os.environ.get("COARSE_START", "0"))
 DECAY_EARLY = float(os.environ.get("DECAY_EARLY", "0"))  # 0: built-in schedule
 EARLY_STEPS = int(os.environ.get("EARLY_STEPS", "256"))

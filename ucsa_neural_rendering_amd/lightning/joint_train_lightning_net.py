@@ -71,6 +71,9 @@ class JointTrainLightningNet(nn.Module):
         self._nerf_steps = 0
         self._grid_stale = True  # refresh the density grid before evaluating
         self.n_rays_train = int(nerf_cfg.get("n_rays", 4096))
+        # "tile" (default): the drawn pixels are handed to the renderer tile
+        # by tile (ops.tile_order); "random": in the order drawn
+        self.ray_order = str(nerf_cfg.get("ray_order", "tile"))
         self.num_steps = int(nerf_cfg.get("num_steps", 256))
         self.upsample_steps = int(nerf_cfg.get("upsample_steps", 256))
 
@@ -135,6 +138,8 @@ class JointTrainLightningNet(nn.Module):
         H, W = int(batch["H"][bs]), int(batch["W"][bs])
         N = min(N, H * W)
         inds = torch.randint(0, H * W, size=[N], device=device)  # may duplicate
+        if self.ray_order == "tile":  # same pixels, neighbours adjacent
+            inds = ops.tile_order(inds, W)
         o, d, n = ops.get_rays(poses, (fx, fy, cx, cy), H, W, inds=inds)
         return o, d, n, inds.expand([1, N])
 
