@@ -15,6 +15,7 @@
 // order-dependent at fp32 round-off (run-to-run ~1e-7 relative); the MLP
 // gradients are reduced in a fixed order and are bit-reproducible.
 #include "ucsa_common.h"
+#include "wave_ops.h"
 
 #define PRIME_Y 2654435761u
 #define PRIME_Z 805459861u
@@ -241,6 +242,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
 
 struct BinGeom {
   uint32_t bin_size[UCSA_MAX_LEVELS];  // table entries per bin
+  uint32_t bin_shift[UCSA_MAX_LEVELS]; // log2(bin_size) when a power of two, else 32
   uint32_t cap;                        // records per bin
 };
 
@@ -286,15 +288,24 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                const float2* __restrict__ d_feat,
                uint32_t* __restrict__ gcount, float4* __restrict__ records,
                float* __restrict__ grad_table) {
+  static_assert(BIN_COUNT == 256, "one thread per bin");
   __shared__ uint32_t hist[BIN_COUNT], base[BIN_COUNT], cursor[BIN_COUNT];
+  __shared__ uint32_t it_cnt[BIN_COUNT], it_off[BIN_COUNT], wave_tot[4];
+  __shared__ float4 stage[256 * 8];  // one iteration's records, bin-sorted
   const uint32_t level = level0 + blockIdx.y;
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t res = g.res[level], entries = g.entries[level],
-                 hashed = g.hashed[level], bsz = bg.bin_size[level];
+                 hashed = g.hashed[level], bsz = bg.bin_size[level],
+                 bshift = bg.bin_shift[level];
+  auto bin_of = [&](uint32_t idx) -> uint32_t {
+    return bshift < 32 ? idx >> bshift : idx / bsz;
+  };
   hist[threadIdx.x] = 0;
   cursor[threadIdx.x] = 0;
+  it_cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t m0 = (uint64_t)blockIdx.x * (256 * BIN_TILE) + threadIdx.x;
-  // count
+  // pass 1: the workgroup's records per bin -> one global reservation per bin
 #pragma unroll
   for (int it = 0; it < BIN_TILE; ++it) {
     const uint64_t m = m0 + (uint64_t)it * 256;
@@ -308,7 +319,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     for (int c = 0; c < 8; ++c) {
       const uint32_t idx = grid_index_b(gi[0] + (c & 1), gi[1] + ((c >> 1) & 1),
                                         gi[2] + ((c >> 2) & 1), res, entries, hashed);
-      atomicAdd(&hist[idx / bsz], 1u);
+      atomicAdd(&hist[bin_of(idx)], 1u);
     }
   }
   __syncthreads();
@@ -319,33 +330,77 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
   __syncthreads();
   float* gt = grad_table + (size_t)g.offset[level] * 2;
   float4* rec_level = records + (size_t)level * BIN_COUNT * bg.cap;
-#pragma unroll
+  // pass 2, 256 samples at a time: the 2048 records are counting-sorted by bin
+  // in LDS and stored from there, so that consecutive lanes write consecutive
+  // records of a bin (scattered 16-byte stores retire at ~180 G/s chip-wide,
+  // like divergent gathers: 0.47 of this kernel's 0.64 ms before).
+#pragma unroll 1
   for (int it = 0; it < BIN_TILE; ++it) {
     const uint64_t m = m0 + (uint64_t)it * 256;
-    if (m >= M) continue;
-    const float2 df = d_feat[(uint64_t)level * M + m];
-    if (df.x == 0.0f && df.y == 0.0f) continue;
-    uint32_t gi[3];
-    float wf[3];
-    sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    bool act = m < M;
+    float2 df = make_float2(0.f, 0.f);
+    if (act) {
+      df = d_feat[(uint64_t)level * M + m];
+      act = !(df.x == 0.0f && df.y == 0.0f);
+    }
+    uint32_t key[8];   // bin << 16 | rank inside the bin (this iteration)
+    uint32_t loc[8];
+    float wgt[8];
+    if (act) {
+      uint32_t gi[3];
+      float wf[3];
+      sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float w = (c & 1) ? wf[0] : 1.0f - wf[0];
-      w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
-      w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
-      const uint32_t idx = grid_index_b(gi[0] + (c & 1), gi[1] + ((c >> 1) & 1),
-                                        gi[2] + ((c >> 2) & 1), res, entries, hashed);
-      const uint32_t bin = idx / bsz;
-      const uint32_t pos = base[bin] + atomicAdd(&cursor[bin], 1u);
-      const float vx = w * df.x, vy = w * df.y;
-      if (pos < bg.cap) {
-        rec_level[(size_t)bin * bg.cap + pos] =
-            make_float4(__uint_as_float(idx - bin * bsz), vx, vy, 0.f);
-      } else {  // bin full: direct atomics keep the result exact
-        atomicAdd(gt + (size_t)idx * 2, vx);
-        atomicAdd(gt + (size_t)idx * 2 + 1, vy);
+      for (int c = 0; c < 8; ++c) {
+        float w = (c & 1) ? wf[0] : 1.0f - wf[0];
+        w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
+        w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
+        const uint32_t idx = grid_index_b(gi[0] + (c & 1), gi[1] + ((c >> 1) & 1),
+                                          gi[2] + ((c >> 2) & 1), res, entries, hashed);
+        const uint32_t bin = bin_of(idx);
+        loc[c] = idx - bin * bsz;
+        wgt[c] = w;
+        key[c] = (bin << 16) | atomicAdd(&it_cnt[bin], 1u);
       }
     }
+    __syncthreads();
+    {  // exclusive prefix of it_cnt over the bins (thread = bin)
+      const uint32_t v = it_cnt[threadIdx.x];
+      const uint32_t inc = wave_incl_scan_add_u32(v, lane);
+      if (lane == 63) wave_tot[wid] = inc;
+      __syncthreads();
+      uint32_t before = 0;
+      for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
+      it_off[threadIdx.x] = before + inc - v;
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t bin = key[c] >> 16;
+        stage[it_off[bin] + (key[c] & 0xFFFFu)] =
+            make_float4(__uint_as_float(loc[c]), wgt[c] * df.x, wgt[c] * df.y,
+                        __uint_as_float(bin));
+      }
+    }
+    __syncthreads();
+    const uint32_t total = it_off[BIN_COUNT - 1] + it_cnt[BIN_COUNT - 1];
+    for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 256) {
+      const float4 r = stage[sidx];
+      const uint32_t bin = __float_as_uint(r.w);
+      const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
+      if (pos < bg.cap) {
+        rec_level[(size_t)bin * bg.cap + pos] = make_float4(r.x, r.y, r.z, 0.f);
+      } else {  // bin full: direct atomics keep the result exact
+        const size_t idx = (size_t)bin * bsz + __float_as_uint(r.x);
+        atomicAdd(gt + idx * 2, r.y);
+        atomicAdd(gt + idx * 2 + 1, r.z);
+      }
+    }
+    __syncthreads();
+    cursor[threadIdx.x] += it_cnt[threadIdx.x];
+    it_cnt[threadIdx.x] = 0;
+    __syncthreads();
   }
 }
 
@@ -397,6 +452,9 @@ static BinGeom bin_geometry(const ucsa_grid* grid, uint64_t M) {
   for (uint32_t l = 0; l < UCSA_MAX_LEVELS; ++l) {
     const uint32_t e = l < grid->n_levels ? grid->level[l].entries : 0;
     bg.bin_size[l] = e ? (e + BIN_COUNT - 1) / BIN_COUNT : 1;
+    bg.bin_shift[l] = 32;
+    for (uint32_t sh = 0; sh < 32; ++sh)
+      if (bg.bin_size[l] == (1u << sh)) bg.bin_shift[l] = sh;
   }
   uint64_t cap = 2 * (8 * M / BIN_COUNT + 1);
   if (cap < 4096) cap = 4096;
