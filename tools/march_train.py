@@ -57,7 +57,7 @@ def train(march, steps, dt_gamma, dev, seed=123):
             net.update_extra_state(decay=(DECAY_EARLY if it < EARLY_STEPS else 0.95) if DECAY_EARLY else None)
         item = ds[it % len(ds)]
         inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)
-        if TILE_ORDER:
+        if TILE_ORDER if TILE_ORDER >= 0 else not march:   # default: live path only
             inds = ops.tile_order(inds, 320)
         o, d, nrm = item["rays_o"][inds], item["rays_d"][inds], item["direction_norms"][inds]
         gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
@@ -87,7 +87,7 @@ def train(march, steps, dt_gamma, dev, seed=123):
     return net, ds, res
 
 
-TILE_ORDER = int(os.environ.get("TILE_ORDER", "1"))
+TILE_ORDER = int(os.environ.get("TILE_ORDER", "-1"))
 COARSE_START = int(os.environ.get("COARSE_START", "0"))
 DECAY_EARLY = float(os.environ.get("DECAY_EARLY", "0"))  # 0: built-in schedule
 EARLY_STEPS = int(os.environ.get("EARLY_STEPS", "256"))

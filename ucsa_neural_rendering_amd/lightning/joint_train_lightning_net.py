@@ -71,9 +71,12 @@ class JointTrainLightningNet(nn.Module):
         self._nerf_steps = 0
         self._grid_stale = True  # refresh the density grid before evaluating
         self.n_rays_train = int(nerf_cfg.get("n_rays", 4096))
-        # "tile" (default): the drawn pixels are handed to the renderer tile
-        # by tile (ops.tile_order); "random": in the order drawn
-        self.ray_order = str(nerf_cfg.get("ray_order", "tile"))
+        # "tile": the drawn pixels are handed to the renderer tile by tile
+        # (ops.tile_order; default on the live path, where it makes the grid
+        # backward 2x faster); "random": in the order drawn (default with
+        # cuda_ray, where it measured no gain)
+        self.ray_order = str(nerf_cfg.get(
+            "ray_order", "random" if nerf_cfg.get("cuda_ray", False) else "tile"))
         self.num_steps = int(nerf_cfg.get("num_steps", 256))
         self.upsample_steps = int(nerf_cfg.get("upsample_steps", 256))
 
