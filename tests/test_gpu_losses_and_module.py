@@ -50,8 +50,16 @@ def test_nerf_loss_kernel_values_and_gradients(ops):
     # all-invalid branch -> None, no semantic gradient
     z = torch.zeros_like(sem).cuda().requires_grad_()
     _, hs0, _ = ul.nerf_losses(b[0].detach(), z, b[2].detach(), gt.cuda(),
-                               labels.cuda(), gtd.cuda(), 0.7)
+                               labels.cuda(), gtd.cuda(), 0.7, none_if_invalid=True)
     assert hs0 is None
+    # default (no host read-back): a zero term with zero gradient, i.e. the
+    # same total loss and gradients as skipping the term
+    z2 = torch.zeros_like(sem).cuda().requires_grad_()
+    hc1, hs1, hd1 = ul.nerf_losses(b[0].detach(), z2, b[2].detach(), gt.cuda(),
+                                   labels.cuda(), gtd.cuda(), 0.7)
+    assert float(hs1) == 0.0
+    ul.nerf_total_loss(hc1, hs1, hd1).backward()
+    assert z2.grad is None or float(z2.grad.abs().max()) == 0.0
 
 
 def test_semantic_postproc(ops):

@@ -456,9 +456,12 @@ def _live_trained_gate(seed):
     # the air, which varies from run to run: reported above, not asserted)
     assert 0 < pts <= 1024
     for k in ("image", "depth", "semantics"):
-        # unfused segments == reference-style loop == fused with w_min 0
-        assert float((o_unf[k] - o_ref[k]).abs().max()) <= 2e-4
-        assert float((o_all[k] - o_ref[k]).abs().max()) <= 2e-4
+        # unfused segments == reference-style loop == fused with w_min 0, up
+        # to the order of the fp32 sums (depth is a sum of up to ~1000 terms
+        # of size <= 7: relative tolerance)
+        tol = 2e-4 * max(1.0, float(o_ref[k].abs().max()))
+        assert float((o_unf[k] - o_ref[k]).abs().max()) <= tol
+        assert float((o_all[k] - o_ref[k]).abs().max()) <= tol
         # the w > 1e-4 mask drops at most 1e-4 per sample
         assert float((o_seg[k] - o_ref[k]).abs().max()) <= 0.05
     net.reset_extra_state()

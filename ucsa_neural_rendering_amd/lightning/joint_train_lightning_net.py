@@ -170,8 +170,11 @@ class JointTrainLightningNet(nn.Module):
 
     # ---- a3-a12 ----------------------------------------------------------------
     def forward_nerf_train(self, batch, output_seg, bs):
-        """reference :167-223 -> (loss_color, loss_semantics | None,
-        loss_depth)."""
+        """reference :167-223 -> (loss_color, loss_semantics, loss_depth).
+        Where the reference returns ``loss_semantics = None`` (every ray with
+        invalid semantics, :212-213) this returns a zero with zero gradient:
+        same total and gradients, without a host read-back per step
+        (``losses.nerf_losses``)."""
         rays_o, rays_d, direction_norms, inds = self.get_rays_train(batch, bs)
         images = batch["img_fp16"][[bs], ...]
         label_nerf = output_seg["seg_semantics"][[bs], ...]

@@ -115,12 +115,15 @@ class SemanticNeRFRenderer(nn.Module):
             fresh[cas] = self.density(pts)["sigma"].view(H, H, H)
         mean = ops.density_grid_update(self.density_grid, fresh, float(decay),
                                        float(self.density_scale))
-        self.mean_density = float(mean.item())
         self.iter_density += 1
         total_step = min(16, self.local_step)
+        # one read-back for both numbers (each one drains the queue)
+        points = self.step_counter[:max(total_step, 1), 0].sum()
+        mean_v, points_v = torch.stack(
+            [mean.view(()).double(), points.double()]).tolist()
+        self.mean_density = float(mean_v)
         if total_step > 0:
-            self.mean_count = int(
-                self.step_counter[:total_step, 0].sum().item() / total_step)
+            self.mean_count = int(points_v / total_step)
         self.local_step = 0
 
     def _march_render_fn(self):
