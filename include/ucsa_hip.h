@@ -322,6 +322,22 @@ int32_t ucsa_adam_step(float* params, const float* grads, float* exp_avg,
                        float beta1, float beta2, float eps, float weight_decay,
                        float inv_grad_scale, void* stream);
 
+/* The same step under torch.amp.GradScaler(enabled=True) (reference
+ * joint_train_lightning_net.py:46,:509-513) without a host read-back: the
+ * scale and the found-inf flag are DEVICE scalars (what GradScaler hands to
+ * optimizers with _step_supports_amp_scaling).  found_inf[0] != 0: nothing is
+ * written and the step does not count -- the bias corrections use
+ * step - skipped[0].  Call ucsa_adam_count_skipped once per optimizer step
+ * after the last tensor (skipped[0] += found_inf[0] != 0). */
+int32_t ucsa_adam_step_scaled(float* params, const float* grads, float* exp_avg,
+                              float* exp_avg_sq, uint64_t n, uint32_t step,
+                              float lr, float beta1, float beta2, float eps,
+                              float weight_decay, const float* grad_scale,
+                              const float* found_inf, const uint32_t* skipped,
+                              void* stream);
+int32_t ucsa_adam_count_skipped(const float* found_inf, uint32_t* skipped,
+                                void* stream);
+
 /* ======================= losses / post-processing / metric ================ */
 
 /* Scratch floats needed by the reductions below for n rays / pixels. */

@@ -190,3 +190,42 @@ def test_binned_grid_backward_equals_direct_atomics(ops, spread):
     assert float((g_bin - g_dir).abs().max()) <= 2e-4 * scale
     assert torch.equal(g_bin == 0, g_dir == 0) or \
         float(((g_bin == 0) != (g_dir == 0)).float().mean()) < 1e-6
+
+
+def test_hip_adam_under_grad_scaler_matches_torch_adam_without_readback():
+    """HipAdam declares _step_supports_amp_scaling: GradScaler hands it the
+    scale and the found-inf flag as device tensors (ucsa_adam_step_scaled).
+    Same trajectory as torch.optim.Adam under its own GradScaler, including a
+    step with a non-finite gradient (skipped, not counted, scale backed off)
+    and a plain step() afterwards."""
+    from ucsa_neural_rendering_amd.nerf.optim import HipAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    w0 = torch.randn(1000, generator=g)
+    a = torch.nn.Parameter(w0.clone().to(dev))
+    b = torch.nn.Parameter(w0.clone().to(dev))
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6)
+    oa, ob = HipAdam([a], **kw), torch.optim.Adam([b], **kw)
+    sa = torch.amp.GradScaler("cuda", enabled=True, init_scale=1024.0)
+    sb = torch.amp.GradScaler("cuda", enabled=True, init_scale=1024.0)
+    assert getattr(oa, "_step_supports_amp_scaling", False)
+    target = torch.randn(1000, generator=g).to(dev)
+    for it in range(8):
+        for p, o, s in ((a, oa, sa), (b, ob, sb)):
+            o.zero_grad()
+            loss = ((p - target) ** 2).mean()
+            if it == 3:
+                loss = loss * float("inf")      # non-finite gradients
+            s.scale(loss).backward()
+            s.step(o)
+            s.update()
+        assert float(sa.get_scale()) == float(sb.get_scale())
+    assert float(sa.get_scale()) == 512.0       # backed off once
+    assert maxabs(a.detach(), b.detach()) <= 2e-6
+    assert int(oa._skipped[dev][0]) == 1
+    for p, o in ((a, oa), (b, ob)):             # plain step keeps the count
+        o.zero_grad()
+        ((p - target) ** 2).mean().backward()
+        o.step()
+    assert maxabs(a.detach(), b.detach()) <= 2e-6
+    assert torch.isfinite(a).all()

@@ -184,3 +184,54 @@ def test_train_joint_entrypoint_tiny_cuda_ray(tmp_path):
     p1 = r1["test_after_nerf"]["test_nerf_PSNR"]
     assert p1 > p0 + 3.0, (p0, p1)
     assert "test_nerf_mIoU" in r1["test_after_joint"]
+
+
+def test_frozen_seg_forward_graph_replay_equals_eager(tmp_path):
+    """NeRF-only steps replay the eval-mode DeepLab forward as a HIP graph:
+    same outputs as the eager eval forward, parameter updates made between
+    replays are seen, a new input shape gets its own capture, and the
+    model's train/eval flags are left as they were."""
+    from ucsa_neural_rendering_amd.lightning import JointTrainLightningNet
+    exp = _tiny_exp()
+    model = JointTrainLightningNet(exp, {"results": str(tmp_path), "scannet": str(tmp_path)}).cuda()
+    model.train()
+    g = torch.Generator().manual_seed(5)
+
+    def eager(img):
+        model.seg_model.eval()
+        with torch.no_grad():
+            o = model.forward_seg({"img": img})
+        model.seg_model.train()
+        return o
+
+    img = torch.rand(2, 3, 48, 64, generator=g).cuda()
+    want = eager(img)
+    got = model.forward_seg_frozen({"img": img})
+    assert model.seg_model.training
+    assert len(model._seg_graphs) == 1 and next(iter(model._seg_graphs.values())) is not False, \
+        "the forward was not captured"
+    assert float((got["seg_semantics_raw"] - want["seg_semantics_raw"]).abs().max()) <= 1e-5
+    assert (got["seg_semantics"] != want["seg_semantics"]).float().mean() < 1e-3
+    # another image through the same graph
+    img2 = torch.rand(2, 3, 48, 64, generator=g).cuda()
+    want2 = eager(img2)
+    got2 = model.forward_seg_frozen({"img": img2})
+    assert len(model._seg_graphs) == 1
+    assert float((got2["seg_semantics_raw"] - want2["seg_semantics_raw"]).abs().max()) <= 1e-5
+    # in-place parameter update (an optimizer step) is seen by the replay
+    with torch.no_grad():
+        model.seg_model._model.classifier[-1].bias[0] += 3.0
+    want3 = eager(img2)
+    got3 = model.forward_seg_frozen({"img": img2})
+    assert float((want3["seg_semantics_raw"] - want2["seg_semantics_raw"]).abs().max()) > 1e-4
+    assert float((got3["seg_semantics_raw"] - want3["seg_semantics_raw"]).abs().max()) <= 1e-5
+    # a different shape: second capture
+    img4 = torch.rand(1, 3, 48, 64, generator=g).cuda()
+    want4 = eager(img4)
+    got4 = model.forward_seg_frozen({"img": img4})
+    assert len(model._seg_graphs) == 2
+    assert float((got4["seg_semantics_raw"] - want4["seg_semantics_raw"]).abs().max()) <= 1e-5
+    # switch: eager path
+    model.seg_graph = False
+    got5 = model.forward_seg_frozen({"img": img4})
+    assert float((got5["seg_semantics_raw"] - want4["seg_semantics_raw"]).abs().max()) <= 1e-6

@@ -112,6 +112,9 @@ SIGNATURES = {
                            [_p] * 6),
     "ucsa_adam_step": (C.c_int32, [_p, _p, _p, _p, C.c_uint64, _u32, _f, _f,
                                    _f, _f, _f, _f, _p]),
+    "ucsa_adam_step_scaled": (C.c_int32, [_p, _p, _p, _p, C.c_uint64, _u32,
+                                          _f, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "ucsa_adam_count_skipped": (C.c_int32, [_p, _p, _p]),
     # ---- losses / post-processing / metric ----
     "ucsa_loss_partial_floats": (C.c_uint32, [_u32]),
     "ucsa_nerf_loss": (C.c_int32, [_p] * 6 + [_u32, _u32, _f, _f, _f, _f] +

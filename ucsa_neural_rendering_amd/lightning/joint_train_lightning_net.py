@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import math
 import os
+import warnings
 import random
 
 import torch
@@ -68,6 +69,9 @@ class JointTrainLightningNet(nn.Module):
         self.seg_amp = str(exp["model"].get("amp", "")).lower() == "bf16"
         if self.seg_amp:
             self.seg_model = self.seg_model.to(memory_format=torch.channels_last)
+        # NeRF-only steps replay the frozen segmentation forward as a HIP graph
+        self.seg_graph = bool(exp["model"].get("seg_graph", True))
+        self._seg_graphs = {}
         self._nerf_steps = 0
         self._grid_stale = True  # refresh the density grid before evaluating
         self.n_rays_train = int(nerf_cfg.get("n_rays", 4096))
@@ -106,7 +110,7 @@ class JointTrainLightningNet(nn.Module):
         # thin-Trainer plumbing
         self.trainer = None
         self._optimizers = None
-        self.logged = {}
+        self._logged_raw = {}
 
     # ---- LightningModule members used by the code --------------------------
     @property
@@ -114,9 +118,16 @@ class JointTrainLightningNet(nn.Module):
         return self.trainer.current_epoch if self.trainer else 0
 
     def log(self, name, value, **kw):
-        self.logged[name] = float(value)
+        # tensors stay on the device (no read-back per training step);
+        # `logged` converts on access, the logger in batches
+        self._logged_raw[name] = value.detach() if torch.is_tensor(value) else value
         if self.trainer is not None and udist.world()[0] == 0:
             self.trainer.logger.log(name, value, self.trainer.global_step)
+
+    @property
+    def logged(self):
+        """Last logged value of every metric, as floats."""
+        return {k: float(v) for k, v in self._logged_raw.items()}
 
     def optimizers(self, use_pl_optimizer=False):
         if self._optimizers is None:
@@ -167,6 +178,66 @@ class JointTrainLightningNet(nn.Module):
                                 want_prob=True)
         return {"seg_semantics": tail["argmax"],
                 "seg_semantics_raw": tail["prob"], "seg_logits": logits}
+
+    @torch.no_grad()
+    def forward_seg_frozen(self, batch):
+        """``forward_seg`` of the NeRF-only step (reference :478-481: eval mode,
+        no gradient) replayed as a HIP graph.  One DeepLabV3-R101 forward is
+        ~350 launches of a few microseconds each -- on one image the host, not
+        the GPU, sets its pace (measured 5.6 ms of Python/launch time, plus
+        2.4 ms for walking the module tree in ``.eval()`` / ``.train()``) -- so
+        it is captured once per input shape (``torch.cuda.CUDAGraph``, i.e.
+        hipGraph) and replayed; parameters are read from their own storage, so
+        optimizer steps in between are seen.  ``model: {seg_graph: false}`` or
+        any capture failure falls back to the eager call."""
+        image = batch["img"]
+        if not self.seg_graph or not image.is_cuda:
+            return self._forward_seg_eval_eager(batch)
+        first = next(self.seg_model.parameters())
+        key = (tuple(image.shape), image.dtype, self.seg_amp, first.data_ptr())
+        entry = self._seg_graphs.get(key)
+        if entry is None:
+            entry = self._capture_seg_graph(image)
+            self._seg_graphs[key] = entry
+        if entry is False:
+            return self._forward_seg_eval_eager(batch)
+        graph, static_in, out = entry
+        static_in.copy_(image)
+        graph.replay()
+        return out  # static buffers: consumed before the next replay
+
+    def _forward_seg_eval_eager(self, batch):
+        self.seg_model.eval()
+        try:
+            return self.forward_seg(batch)
+        finally:
+            self.seg_model.train()
+
+    def _capture_seg_graph(self, image):
+        was_training = self.seg_model.training
+        self.seg_model.eval()
+        try:
+            static_in = image.clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):  # MIOpen picks its kernels here
+                for _ in range(3):
+                    self.forward_seg(None, static_in)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.forward_seg(None, static_in)
+            out = {k: v for k, v in out.items() if k != "seg_logits"}
+            return graph, static_in, out
+        except Exception as e:  # noqa: BLE001 -- any capture problem: eager
+            warnings.warn(f"segmentation forward not captured as a HIP graph "
+                          f"({type(e).__name__}: {e}); running it eagerly")
+            torch.cuda.synchronize()
+            return False
+        finally:
+            self.seg_model.train(was_training)
 
     # ---- a3-a12 ----------------------------------------------------------------
     def forward_nerf_train(self, batch, output_seg, bs):
@@ -297,10 +368,7 @@ class JointTrainLightningNet(nn.Module):
     def training_step_nerf(self, batch):
         """reference :473-513."""
         optimizer_seg, optimizer_nerf = self.optimizers()
-        with torch.no_grad():
-            self.seg_model.eval()
-            output_seg = self.forward_seg(batch)
-            self.seg_model.train()
+        output_seg = self.forward_seg_frozen(batch)
         for bs in range(batch["img"].shape[0]):
             lc, ls, ld = self.forward_nerf_train(batch, output_seg, bs)
             self._nerf_update(optimizer_nerf, lc, ls, ld)

@@ -28,19 +28,50 @@ def seed_everything(seed: int):
 
 class JsonlLogger:
     """Plain JSONL metrics logger (same metric names as the reference's
-    self.log calls; WandB is out of scope)."""
+    self.log calls; WandB is out of scope).
 
-    def __init__(self, save_dir=None):
+    Values may be device tensors: they are kept as such and converted in
+    batches (``flush``: one device read-back and one file append for up to
+    ``flush_every`` records), so logging a loss does not synchronise the
+    training step that produced it."""
+
+    def __init__(self, save_dir=None, flush_every=512):
         self.path = os.path.join(save_dir, "metrics.jsonl") if save_dir else None
-        self.history = []
+        self._history = []
+        self._pending = []
+        self.flush_every = int(flush_every)
 
     def log(self, name, value, step=None):
-        rec = {"name": name, "value": float(value), "step": step,
-               "time": time.time()}
-        self.history.append(rec)
+        if torch.is_tensor(value):
+            value = value.detach()
+        self._pending.append((name, value, step, time.time()))
+        if len(self._pending) >= self.flush_every:
+            self.flush()
+
+    def flush(self):
+        pend, self._pending = self._pending, []
+        if not pend:
+            return
+        tens = [(i, v) for i, (_, v, _, _) in enumerate(pend) if torch.is_tensor(v)]
+        vals = [None if torch.is_tensor(v) else float(v) for (_, v, _, _) in pend]
+        by_dev = {}
+        for i, v in tens:
+            by_dev.setdefault(v.device, []).append((i, v))
+        for items in by_dev.values():
+            flat = torch.stack([v.reshape(()).double() for _, v in items]).tolist()
+            for (i, _), f in zip(items, flat):
+                vals[i] = f
+        recs = [{"name": n, "value": vals[i], "step": st, "time": tm}
+                for i, (n, _, st, tm) in enumerate(pend)]
+        self._history.extend(recs)
         if self.path:
             with open(self.path, "a") as f:
-                f.write(json.dumps(rec) + "\n")
+                f.write("".join(json.dumps(r) + "\n" for r in recs))
+
+    @property
+    def history(self):
+        self.flush()
+        return self._history
 
     def log_hyperparams(self, params):
         pass
@@ -68,11 +99,20 @@ class Trainer:
         if not getattr(model, "_optimizers", None):
             model._optimizers = model.configure_optimizers()
 
+    # per-item scalars the module only ever reads as Python numbers
+    # (intrinsics -> float, H/W -> int, flags -> bool): left on the host, a
+    # device copy would cost one read-back per use and training step
+    _HOST_KEYS = frozenset(["intrinsics", "H", "W", "one_m_to_scene_uom",
+                            "viewpoint_is_novel", "from_old_scene",
+                            "current_index"])
+
     def _to_device(self, obj):
         if torch.is_tensor(obj):
             return obj.to(self.device, non_blocking=True)
         if isinstance(obj, dict):
-            return {k: self._to_device(v) for k, v in obj.items()}
+            return {k: (v.cpu() if torch.is_tensor(v) and k in self._HOST_KEYS
+                        else v if k in self._HOST_KEYS else self._to_device(v))
+                    for k, v in obj.items()}
         if isinstance(obj, (list, tuple)):
             return type(obj)(self._to_device(v) for v in obj)
         return obj
@@ -86,6 +126,11 @@ class Trainer:
                 break
             yield i, self._to_device(b)
 
+    def _flush_logs(self):
+        flush = getattr(self.logger, "flush", None)
+        if flush is not None:
+            flush()
+
     # -- loops ---------------------------------------------------------------
     def fit(self, model, train_dataloaders=None, val_dataloaders=None):
         self._attach(model)
@@ -97,6 +142,7 @@ class Trainer:
                 model.training_step(batch, i)
                 self.global_step += 1
             model.on_train_epoch_end()
+            self._flush_logs()
             if val_dataloaders is not None and (
                     epoch + 1) % self.check_val_every_n_epoch == 0:
                 self.validate(model, dataloaders=val_dataloaders)
@@ -111,6 +157,7 @@ class Trainer:
                 for i, batch in self._batches(loader):
                     outs.append(getattr(model, f"{kind}_step")(batch, i, li))
         res = getattr(model, f"on_{kind}_epoch_end")()
+        self._flush_logs()
         model.train()
         return res if res is not None else outs
 

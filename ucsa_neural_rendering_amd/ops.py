@@ -409,6 +409,28 @@ def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float,
           "ucsa_adam_step")
 
 
+def adam_step_scaled(p, g, m, v, step: int, lr: float, beta1: float,
+                     beta2: float, eps: float, weight_decay: float,
+                     grad_scale: torch.Tensor, found_inf: torch.Tensor,
+                     skipped: torch.Tensor):
+    """Adam step under GradScaler with the scale / found-inf flag on the
+    device (no read-back); `skipped` int32[1] counts the skipped steps."""
+    for x in (p, g, m, v):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    assert grad_scale.dtype == torch.float32 and found_inf.dtype == torch.float32
+    assert skipped.dtype == torch.int32
+    check(lib().ucsa_adam_step_scaled(
+        _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), float(lr),
+        float(beta1), float(beta2), float(eps), float(weight_decay),
+        _ptr(grad_scale), _ptr(found_inf), _ptr(skipped), _stream()),
+        "ucsa_adam_step_scaled")
+
+
+def adam_count_skipped(found_inf: torch.Tensor, skipped: torch.Tensor):
+    check(lib().ucsa_adam_count_skipped(_ptr(found_inf), _ptr(skipped),
+                                        _stream()), "ucsa_adam_count_skipped")
+
+
 # ===================== losses / post-processing / metric ====================
 def nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom: float,
               w_sem: float = 0.04, w_depth: float = 0.1,
