@@ -79,7 +79,7 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
     t0 = time.perf_counter()
     for it in range(train_steps):
         item = ds[it % len(ds)]
-        inds = tile_order(torch.randint(0, 240 * 320, (4096,), device=device, generator=g), 320)
+        inds = tile_order(torch.randint(0, 240 * 320, (4096,), device=device, generator=g), 320, H=240)
         o, d, nrm = item["rays_o"][inds], item["rays_d"][inds], item["direction_norms"][inds]
         gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
         labels = item["label"].reshape(-1)[inds][None]
@@ -118,7 +118,7 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
     g = torch.Generator(device=device).manual_seed(7)
     item = ds[0]
     inds = torch.randint(0, 240 * 320, (n_rays,), device=device, generator=g)
-    inds = ops.tile_order(inds, 320)  # as JointTrainLightningNet.get_rays_train does
+    inds = ops.tile_order(inds, 320, H=240)  # as JointTrainLightningNet.get_rays_train does
     o, d, nrm = item["rays_o"][inds][None], item["rays_d"][inds][None], item["direction_norms"][inds][None]
     gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
     labels = item["label"].reshape(-1)[inds][None]

@@ -74,6 +74,15 @@ int32_t ucsa_get_rays(const float* poses, uint32_t B, float fx, float fy,
                       const int64_t* inds, uint32_t n, float* rays_o,
                       float* rays_d, float* norms, void* stream);
 
+/* The pixel indices drawn by get_rays_train (reference
+ * joint_train_lightning_net.py:141; int64 [n], duplicates allowed, values in
+ * [0, H*W)), reordered tile by tile (tile x tile pixels, row-major inside a
+ * tile): the same multiset, neighbours adjacent, which makes the hash-grid
+ * backward of the batch about twice as fast.  n <= 8192 (one
+ * workgroup sorts in LDS); out may not alias inds. */
+int32_t ucsa_tile_order(const int64_t* inds, uint32_t n, uint32_t H, uint32_t W,
+                        uint32_t tile, int64_t* out, void* stream);
+
 /* Replaces _backend.near_far_from_aabb (reference
  * nr4seg/nerf/raymarching/src/raymarching.cu:62-126, bindings.cpp:6).
  * aabb is 6 HOST floats (xmin,ymin,zmin,xmax,ymax,zmax). */

@@ -369,3 +369,23 @@ def test_image_ordered_gather_is_bit_identical(H, W, T, t):
                         image_width=W)
     for k in ("image", "depth", "semantics"):
         assert torch.equal(r0[k], r1[k]) and torch.equal(r0[k], r2[k])
+
+
+@pytest.mark.parametrize("n,H,W,tile", [(1, 5, 7, 16), (700, 37, 50, 16), (4096, 240, 320, 16),
+                                        (4097, 240, 320, 8), (8192, 480, 640, 16), (33, 9, 9, 4)])
+def test_tile_order_kernel_equals_torch_ordering(ops, n, H, W, tile):
+    """ucsa_tile_order (one workgroup, LDS bitonic sort of the tile keys) gives
+    exactly the ordering of the torch formulation (the key is a bijection of
+    the pixel index, so the sorted sequence is unique), duplicates included;
+    larger batches and CPU tensors take the torch path."""
+    g = torch.Generator().manual_seed(n)
+    inds = torch.randint(0, H * W, (n,), generator=g)
+    inds[: n // 5] = inds[n // 2: n // 2 + n // 5]          # duplicates
+    want = ops.tile_order(inds, W, tile)                     # CPU: torch path
+    got = ops.tile_order(inds.cuda(), W, tile, H=H)          # GPU: kernel
+    assert got.dtype == torch.int64 and got.shape == inds.shape
+    assert torch.equal(got.cpu(), want)
+    got2 = ops.tile_order(inds.cuda().view(1, -1), W, tile)  # H not given
+    assert torch.equal(got2.cpu().view(-1), want)
+    big = torch.randint(0, H * W, (9000,), generator=g)
+    assert torch.equal(ops.tile_order(big.cuda(), W, tile).cpu(), ops.tile_order(big, W, tile))

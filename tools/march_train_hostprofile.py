@@ -4,7 +4,8 @@ import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from ucsa_neural_rendering_amd import losses as ul
+from ucsa_neural_rendering_amd import losses as ul, ops
+TILE = int(os.environ.get('TILE_ORDER', '0'))
 from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
 from ucsa_neural_rendering_amd.nerf.network_tcnn_semantics import SemanticNeRFNetwork
 from ucsa_neural_rendering_amd.nerf.optim import HipAdam
@@ -26,6 +27,8 @@ def step(it):
         net.update_extra_state()
     item = ds[it % len(ds)]
     inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)
+    if TILE:
+        inds = ops.tile_order(inds, 320, H=240)
     o, d, nrm = item["rays_o"][inds], item["rays_d"][inds], item["direction_norms"][inds]
     gt_rgb = item["img"].reshape(3, -1).t()[inds][None]
     labels = item["label"].reshape(-1)[inds][None]
@@ -48,6 +51,8 @@ t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print(f"300 steps: host loop {t_host/300*1e3:.2f} ms/step, with final sync {t_all/300*1e3:.2f} ms/step")
+if os.environ.get("NO_PROFILE"):
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 for it in range(800, 1100):

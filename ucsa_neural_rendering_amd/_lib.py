@@ -57,6 +57,7 @@ SIGNATURES = {
                                    C.c_double]),
     "ucsa_get_rays": (C.c_int32, [_p, _u32, _f, _f, _f, _f, _u32, _u32, _p,
                                   _u32, _p, _p, _p, _p]),
+    "ucsa_tile_order": (C.c_int32, [_p, _u32, _u32, _u32, _u32, _p, _p]),
     "ucsa_near_far_from_aabb": (C.c_int32, [_p, _p, C.POINTER(_f), _u32, _f,
                                             _p, _p, _p]),
     "ucsa_sample_coarse": (C.c_int32, [_p, _p, _p, _u32, _u32, _p, _p]),

@@ -58,6 +58,73 @@ extern "C" int32_t ucsa_get_rays(const float* poses, uint32_t B, float fx,
 }
 
 // ---------------------------------------------------------------------------
+// Training pixel indices (get_rays_train, reference
+// joint_train_lightning_net.py:141) handed over tile by tile: the same multiset
+// of indices, ordered by (tile row, tile column, row in tile, column in tile).
+// The key is a bijection of the pixel index, so only 32-bit keys are sorted
+// (one workgroup, bitonic network in LDS) and decoded afterwards.
+// ---------------------------------------------------------------------------
+#define TILE_ORDER_MAX 8192
+
+__global__ void __launch_bounds__(1024)
+k_tile_order(const int64_t* __restrict__ inds, uint32_t n, uint32_t n_pad,
+             uint32_t W, uint32_t tile, int64_t* __restrict__ out) {
+  __shared__ uint32_t keys[TILE_ORDER_MAX];
+  const uint32_t tiles_x = (W + tile - 1u) / tile, tt = tile * tile;
+  for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
+    uint32_t k = 0xFFFFFFFFu;
+    if (i < n) {
+      const uint32_t pix = (uint32_t)inds[i], y = pix / W, x = pix % W;
+      k = ((y / tile) * tiles_x + x / tile) * tt + (y % tile) * tile + x % tile;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const uint32_t a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    const uint32_t k = keys[i], t_id = k / tt, r = k % tt;
+    const uint32_t y = (t_id / tiles_x) * tile + r / tile,
+                   x = (t_id % tiles_x) * tile + r % tile;
+    out[i] = (int64_t)y * W + x;
+  }
+}
+
+extern "C" int32_t ucsa_tile_order(const int64_t* inds, uint32_t n, uint32_t H,
+                                   uint32_t W, uint32_t tile, int64_t* out,
+                                   void* stream) {
+  UCSA_CHECK_ARG(inds, 0);
+  UCSA_CHECK_ARG(n <= TILE_ORDER_MAX, 1);
+  UCSA_CHECK_ARG(H > 0 && W > 0 && (uint64_t)H * W < 0x7FFFFFFFull, 2);
+  UCSA_CHECK_ARG(tile >= 1 && tile <= 1024, 4);
+  // the key of the last pixel must fit 32 bits below the padding value
+  UCSA_CHECK_ARG((uint64_t)((H + tile - 1) / tile) * ((W + tile - 1) / tile) *
+                     tile * tile < 0xFFFFFFFFull, 4);
+  UCSA_CHECK_ARG(out, 5);
+  if (n == 0) return 0;
+  uint32_t n_pad = 2;
+  while (n_pad < n) n_pad <<= 1;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                     inds, n, n_pad, W, tile, out);
+  return ucsa_launch_status();
+}
+
+// ---------------------------------------------------------------------------
 // a2: slab test.  reference raymarching.cu:62-115.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void near_far_one(const float ox, const float oy,

@@ -153,7 +153,7 @@ class JointTrainLightningNet(nn.Module):
         N = min(N, H * W)
         inds = torch.randint(0, H * W, size=[N], device=device)  # may duplicate
         if self.ray_order == "tile":  # same pixels, neighbours adjacent
-            inds = ops.tile_order(inds, W)
+            inds = ops.tile_order(inds, W, H=H)
         o, d, n = ops.get_rays(poses, (fx, fy, cx, cy), H, W, inds=inds)
         return o, d, n, inds.expand([1, N])
 
