@@ -169,7 +169,10 @@ k_composite(CmpArgs a) {
   float* w_color = cmp_smem;
   float* w_sem = w_color + WC_FLOATS;
   float* per_wave = w_sem + WS_FLOATS;
-  const uint32_t cap = MARCH ? 64u + G : S + G;    // entry list capacity
+  // entry list capacity: survivors are drained after every 64-sample trip
+  // (fewer than G wait afterwards), so 64 + G entries always suffice -- a list
+  // of S + G used to cap 512-sample frames at 6 waves per workgroup
+  const uint32_t cap = 64u + G;
   // per wave: zraw[S] (later weights), zm[S], sgm[S], srcs[S],
   //           lw[cap], lrow[cap], lray[cap], contrib[16*cstride]
   const uint32_t per_wave_floats =
@@ -680,7 +683,7 @@ k_composite(CmpArgs a) {
     wave_lds_sync();
     // ---- A3: weights, mask, depth, compaction ---------------------------
     float carry = 1.0f, dsum = 0.0f;
-    const uint32_t cnt0 = cnt;
+    uint32_t kept = 0;  // survivors of this ray (wave-uniform)
     for (uint32_t sbase = 0; sbase < S; sbase += 64) {
       const uint32_t s = sbase + lane;
       float alpha = 0.0f, zi = 0.0f;
@@ -711,15 +714,16 @@ k_composite(CmpArgs a) {
         lray[pos] = r;
       }
       cnt += (uint32_t)__popcll(bal);
+      kept += (uint32_t)__popcll(bal);
+      wave_lds_sync();
+      drain();
     }
     dsum = wave_sum(dsum);
     if (lane == 0) a.depth[r] = dsum / a.norms[r];
-    if (cnt == cnt0) {  // nothing survived the mask: all-zero outputs
+    if (kept == 0) {  // nothing survived the mask: all-zero outputs
       if (lane < 3) a.image[(size_t)r * 3 + lane] = 0.0f;
       else if (lane < 3 + C) a.semantics[(size_t)r * C + (lane - 3)] = 0.0f;
     }
-    wave_lds_sync();
-    drain();
   }
   }
   if (cnt) shade(cnt);
@@ -752,7 +756,7 @@ static int32_t composite_launch(
   const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
                                : 7168 + 1024 + (size_t)nrb * 1024;
   const uint32_t cbs = half ? CMP_CBS_H : CMP_CBS;
-  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(S + 16 * cbs) + 16 * cstride + 64;
+  const size_t per_wave = 4 * (size_t)S + 3 * (size_t)(64 + 16 * cbs) + 16 * cstride + 64;
   // as many waves per workgroup as fit in LDS (one workgroup per CU)
   uint32_t waves = CMP_MAX_WAVES;
   while (waves > 1 && (w_floats + waves * per_wave) * 4 > 158 * 1024) --waves;
