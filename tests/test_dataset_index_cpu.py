@@ -103,3 +103,41 @@ def test_tile_order_keeps_the_multiset_and_groups_tiles():
     inner = (out // W % 16) * 16 + out % W % 16
     assert bool((inner[1:][same] >= inner[:-1][same]).all())  # row-major inside
     assert tile_order(inds.view(1, -1), W).shape == (1, 700)
+
+
+def test_jsonl_logger_buffers_and_flushes(tmp_path):
+    """Metrics are kept as given (tensors included) and converted / written
+    in batches: nothing on disk before a flush, everything after, in order."""
+    import json
+    import torch
+    from ucsa_neural_rendering_amd.lightning.trainer import JsonlLogger
+    lg = JsonlLogger(str(tmp_path), flush_every=4)
+    lg.log("a", torch.tensor(1.5), 0)
+    lg.log("b", 2, 1)
+    lg.log("c", torch.tensor([3.25]), 2)
+    path = tmp_path / "metrics.jsonl"
+    assert not path.exists()
+    lg.log("d", 4.0, 3)                      # 4th record: automatic flush
+    rows = [json.loads(l) for l in path.read_text().splitlines()]
+    assert [(r["name"], r["value"], r["step"]) for r in rows] == \
+        [("a", 1.5, 0), ("b", 2.0, 1), ("c", 3.25, 2), ("d", 4.0, 3)]
+    lg.log("e", torch.tensor(5.0), 4)
+    assert len(path.read_text().splitlines()) == 4
+    assert [r["name"] for r in lg.history] == ["a", "b", "c", "d", "e"]   # history flushes
+    assert len(path.read_text().splitlines()) == 5
+
+
+def test_trainer_keeps_per_item_scalars_on_the_host():
+    import torch
+    from ucsa_neural_rendering_amd.lightning.trainer import Trainer
+    tr = Trainer(device="cpu")
+    batch = {"img": torch.zeros(2, 3, 4, 4), "intrinsics": torch.ones(2, 4),
+             "H": torch.tensor([4, 4]), "W": torch.tensor([4, 4]),
+             "one_m_to_scene_uom": torch.tensor([1.0, 1.0]),
+             "current_index": ["000001", "000002"], "nested": [{"H": torch.tensor([1])}]}
+    out = tr._to_device(batch)
+    assert set(out) == set(batch)
+    for k in ("intrinsics", "H", "W", "one_m_to_scene_uom"):
+        assert out[k].device.type == "cpu" and torch.equal(out[k], batch[k])
+    assert out["current_index"] == batch["current_index"]
+    assert out["nested"][0]["H"].device.type == "cpu"
