@@ -306,15 +306,24 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
   __syncthreads();
   const uint64_t m0 = (uint64_t)blockIdx.x * (256 * BIN_TILE) + threadIdx.x;
   // pass 1: the workgroup's records per bin -> one global reservation per bin
+  // Consecutive threads are consecutive samples of a ray (or consecutive
+  // marched points): where they fall into the same cell -- importance samples
+  // clustered on a surface, the small steps of a marcher near the camera --
+  // their updates are summed by a segmented wave scan first and only the last
+  // lane of a run emits records (same plan in both passes).
 #pragma unroll
   for (int it = 0; it < BIN_TILE; ++it) {
     const uint64_t m = m0 + (uint64_t)it * 256;
-    if (m >= M) continue;
-    const float2 df = d_feat[(uint64_t)level * M + m];
-    if (df.x == 0.0f && df.y == 0.0f) continue;
-    uint32_t gi[3];
+    bool act = m < M;
+    if (act) {
+      const float2 df = d_feat[(uint64_t)level * M + m];
+      act = !(df.x == 0.0f && df.y == 0.0f);
+    }
+    uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3];
-    sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    if (act) sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    if (!(act && plan.tail)) continue;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t idx = grid_index_b(gi[0] + (c & 1), gi[1] + ((c >> 1) & 1),
@@ -345,21 +354,27 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     }
     uint32_t key[8];   // bin << 16 | rank inside the bin (this iteration)
     uint32_t loc[8];
-    float wgt[8];
-    if (act) {
-      uint32_t gi[3];
-      float wf[3];
-      sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    float valx[8], valy[8];
+    uint32_t gi[3] = {0u, 0u, 0u};
+    float wf[3] = {0.f, 0.f, 0.f};
+    if (act) sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    const bool has_runs = __any(plan.add[0]);  // some lane continues a run
+    const bool emit = act && plan.tail;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float w = (c & 1) ? wf[0] : 1.0f - wf[0];
-        w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
-        w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
+    for (int c = 0; c < 8; ++c) {
+      float w = (c & 1) ? wf[0] : 1.0f - wf[0];
+      w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
+      w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
+      float vx = act ? w * df.x : 0.0f, vy = act ? w * df.y : 0.0f;
+      if (has_runs) run_sum(plan, vx, vy);
+      valx[c] = vx;
+      valy[c] = vy;
+      if (emit) {
         const uint32_t idx = grid_index_b(gi[0] + (c & 1), gi[1] + ((c >> 1) & 1),
                                           gi[2] + ((c >> 2) & 1), res, entries, hashed);
         const uint32_t bin = bin_of(idx);
         loc[c] = idx - bin * bsz;
-        wgt[c] = w;
         key[c] = (bin << 16) | atomicAdd(&it_cnt[bin], 1u);
       }
     }
@@ -374,12 +389,12 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
       it_off[threadIdx.x] = before + inc - v;
     }
     __syncthreads();
-    if (act) {
+    if (emit) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint32_t bin = key[c] >> 16;
         stage[it_off[bin] + (key[c] & 0xFFFFu)] =
-            make_float4(__uint_as_float(loc[c]), wgt[c] * df.x, wgt[c] * df.y,
+            make_float4(__uint_as_float(loc[c]), valx[c], valy[c],
                         __uint_as_float(bin));
       }
     }
