@@ -249,11 +249,13 @@ def test_render_empty_batch(net):
     assert res["image"].shape == (1, 0, 3)
 
 
-def test_chunking_and_sharding_are_bit_identical(net):
+@pytest.mark.parametrize("N,T,t", [(5000, 32, 32), (30000, 256, 256)])
+def test_chunking_and_sharding_are_bit_identical(net, N, T, t):
     """Rays are independent: any chunking / ray-sharding of the batch must
     reproduce the single-call result exactly (the multi-GPU render relies on
-    this)."""
-    N, T, t = 5000, 32, 32
+    this).  The 512-sample case fills whole workgroups of the composite
+    kernel at the reference's native sample count (9 waves, survivor list
+    drained every 64 samples)."""
     o, d, norms = make_rays(N, 9)
     g = torch.Generator().manual_seed(9)
     u = torch.rand(N, t, generator=g).cuda()
