@@ -28,18 +28,41 @@ import torch.nn.functional as F
 __all__ = ["DeepLabV3"]
 
 
+class PointwiseConv2d(nn.Conv2d):
+    """1x1 convolution (same parameters and state_dict keys as nn.Conv2d).
+    On a channels_last input it is one GEMM over all pixels of the batch
+    (``F.linear`` on the NHWC view) instead of MIOpen's one GEMM launch per
+    image: measured 33.9 -> 30.4 ms for the bf16 channels_last train step of
+    DeepLabV3-R101 on 8 x 240x320 (tools/seg_pointwise_exp.py).  Any other
+    layout, a stride or a 1x1 map goes through the ordinary convolution."""
+
+    def forward(self, x):
+        if (self.stride == (1, 1) and x.dim() == 4 and x.shape[1] > 1
+                and x.shape[2] * x.shape[3] > 1
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and not x.is_contiguous()):
+            w = self.weight.view(self.out_channels, self.in_channels)
+            y = F.linear(x.permute(0, 2, 3, 1), w, self.bias)
+            return y.permute(0, 3, 1, 2)
+        return super().forward(x)
+
+
+def _conv1x1(cin, cout, stride=1, bias=False):
+    return PointwiseConv2d(cin, cout, 1, stride=stride, bias=bias)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = _conv1x1(inplanes, planes)
         self.bn1 = nn.BatchNorm2d(planes)
         # torchvision "v1.5": the stride sits on the 3x3 convolution
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride,
                                padding=dilation, dilation=dilation, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = _conv1x1(planes, planes * 4)
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -87,8 +110,8 @@ class ResNetBackbone(nn.Module):
             stride = 1
         if stride != 1 or self.inplanes != planes * 4:
             downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride,
-                          bias=False), nn.BatchNorm2d(planes * 4))
+                _conv1x1(self.inplanes, planes * 4, stride=stride),
+                nn.BatchNorm2d(planes * 4))
         layers = [Bottleneck(self.inplanes, planes, stride, downsample,
                              previous_dilation)]
         self.inplanes = planes * 4
@@ -129,13 +152,13 @@ class ASPP(nn.Module):
 
     def __init__(self, cin, rates, cout=256):
         super().__init__()
-        mods = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False),
+        mods = [nn.Sequential(_conv1x1(cin, cout),
                               nn.BatchNorm2d(cout), nn.ReLU())]
         mods += [ASPPConv(cin, cout, r) for r in rates]
         mods.append(ASPPPooling(cin, cout))
         self.convs = nn.ModuleList(mods)
         self.project = nn.Sequential(
-            nn.Conv2d(len(self.convs) * cout, cout, 1, bias=False),
+            _conv1x1(len(self.convs) * cout, cout),
             nn.BatchNorm2d(cout), nn.ReLU(), nn.Dropout(0.5))
 
     def forward(self, x):
@@ -148,7 +171,7 @@ class DeepLabHead(nn.Sequential):
         super().__init__(ASPP(cin, [12, 24, 36]),
                          nn.Conv2d(256, 256, 3, padding=1, bias=False),
                          nn.BatchNorm2d(256), nn.ReLU(),
-                         nn.Conv2d(256, num_classes, 1))
+                         _conv1x1(256, num_classes, bias=True))
 
 
 class _DeepLabV3Model(nn.Module):
