@@ -36,6 +36,8 @@ def _t(a, dtype=None):
     (5000, 4.0, 128, 1 / 256, True, False),  # wave-per-ray, long orbits
     (777, 1.0, 64, 0.0, False, False),
     (9000, 2.0, 32, 1 / 128, False, True),   # wave-per-ray without staging rows
+    (600, 0.25, 256, 1 / 128, True, True),   # 2*bound/H < MIN_STEPSIZE: dt is dt_max
+    (33000, 0.25, 256, 0.0, False, True),    # same, lane-per-ray kernels
 ])
 def test_march_rays_train_bit_exact(N, bound, H, dt_gamma, perturb, outside):
     rm = _rm()

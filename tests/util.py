@@ -58,7 +58,7 @@ def march_scene(N, seed, bound=2.0, H=32, fill=0.35, outside=True):
     `fill` of the cells above the density threshold."""
     import math
     rs = np.random.RandomState(seed)
-    C = 1 + math.ceil(math.log2(bound))
+    C = max(1, 1 + math.ceil(math.log2(bound)))
     lo = 1.6 if outside else 0.6
     o = ((rs.rand(N, 3) * 2 - 1) * bound * lo).astype(np.float32)
     tgt = ((rs.rand(N, 3) * 2 - 1) * bound * 0.5).astype(np.float32)

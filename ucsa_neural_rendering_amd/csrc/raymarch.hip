@@ -73,8 +73,10 @@ struct Marcher {
     rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
     bound = bound_;
     dt_gamma = dt_gamma_;
-    dt_min = RM_MIN_STEPSIZE;
     dt_max = 2 * bound_ / H_;
+    // fmin(fmax(x, dt_min), dt_max) is dt_max whenever dt_max < dt_min (tiny
+    // bounds); with dt_min lowered to dt_max the median of three says the same
+    dt_min = fminf(RM_MIN_STEPSIZE, dt_max);
     thresh = fminf(RM_DENSITY_THRESH, mean_density);
     far = far_;
     H = H_;
@@ -85,7 +87,9 @@ struct Marcher {
   }
 
   __device__ __forceinline__ float step_size(float t) const {
-    return rm_clamp(t * dt_gamma, dt_min, dt_max);
+    // median of three == clamp for dt_min <= dt_max and finite t (one
+    // instruction instead of max + min in the wave marcher's serial chain)
+    return __builtin_amdgcn_fmed3f(t * dt_gamma, dt_min, dt_max);
   }
 
   // One look at the cascade grid at ray parameter t (reference :188-220):
@@ -310,17 +314,14 @@ __device__ __forceinline__ uint32_t wave_march(const Marcher& m, float t_start,
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   while (!done && t_base < m.far && steps < limit) {
     // ---- 64 orbit points (sequential by nature, uniform across the wave) --
-    float t = t_base, u = 0.0f, dtv = 0.0f;
+    float t = t_base, u = 0.0f;
 #pragma unroll 8
     for (uint32_t i = 0; i < 64; ++i) {
-      const float ss = m.step_size(t);
-      if (lane == i) {
-        u = t;
-        dtv = ss;
-      }
-      t += ss;
+      if (lane == i) u = t;
+      t += m.step_size(t);
     }
     const float u_end = t;
+    const float dtv = m.step_size(u);  // same function of the same t
     u_lds[lane] = u;
     wm_sync();
     // ---- look all of them up ---------------------------------------------
