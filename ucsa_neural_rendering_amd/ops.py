@@ -76,7 +76,7 @@ def tile_order(inds: torch.Tensor, W: int, tile: int = 16,
         flat = flat.contiguous()
         out = torch.empty_like(flat)
         # H only bounds the key range; any image containing the indices will do
-        rows = int(H) if H is not None else (0x7FFFFFFE // int(W)) // 2
+        rows = int(H) if H is not None else min((0x7FFFFFFE // int(W)) // 2, 1 << 20)
         check(lib().ucsa_tile_order(_ptr(flat), flat.numel(), rows, int(W),
                                     int(tile), _ptr(out), _stream()),
               "ucsa_tile_order")
