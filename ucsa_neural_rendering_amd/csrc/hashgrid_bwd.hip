@@ -46,6 +46,7 @@ __device__ __forceinline__ float clampf_b(float v, float lo, float hi) {
 struct RunPlan {
   bool add[6];
   bool tail;
+  uint32_t live;  // bit s: some lane of the wave adds at step s (wave-uniform)
 };
 
 __device__ __forceinline__ RunPlan run_plan(uint32_t cx, uint32_t cy,
@@ -59,12 +60,16 @@ __device__ __forceinline__ RunPlan run_plan(uint32_t cx, uint32_t cy,
   const bool head = lane == 0 || px != kx || py != cy || pz != cz || !act;
   int f = head ? 1 : 0;
   RunPlan p;
+  p.live = 0;
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     const int d = 1 << s;
     const int of = __shfl_up(f, d, 64);
     p.add[s] = lane >= (uint32_t)d && !f;
     if (p.add[s]) f |= of;
+    // runs are mostly a few samples long: the far steps add nothing and
+    // run_sum skips their shuffles (16 value scans per sample and level)
+    if (__any(p.add[s])) p.live |= 1u << s;
   }
   const int next_head = __shfl_down(head ? 1 : 0, 1, 64);
   p.tail = act && (lane == 63 || next_head);
@@ -75,6 +80,7 @@ __device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
                                         float& vy) {
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
+    if (!((p.live >> s) & 1u)) continue;  // wave-uniform
     const float ox = __shfl_up(vx, 1 << s, 64);
     const float oy = __shfl_up(vy, 1 << s, 64);
     if (p.add[s]) {
@@ -359,7 +365,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     float wf[3] = {0.f, 0.f, 0.f};
     if (act) sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
     const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
-    const bool has_runs = __any(plan.add[0]);  // some lane continues a run
+    const bool has_runs = plan.live != 0;  // some lane continues a run
     const bool emit = act && plan.tail;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
