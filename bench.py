@@ -359,7 +359,7 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
             if it == steps - 100:
                 torch.cuda.synchronize()
                 t_tail = time.perf_counter()
-            if it % 16 == 0:
+            if t.refresh_due(it):
                 t.update_extra_state()
             item = scene_ds[it % len(scene_ds)]
             inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)

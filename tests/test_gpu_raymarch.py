@@ -638,7 +638,7 @@ def test_field_trained_through_the_marcher_quality_and_sparsity():
         lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
     g = torch.Generator(device=dev).manual_seed(1)
     for it in range(800):
-        if it % 16 == 0:
+        if net.refresh_due(it):
             net.update_extra_state()
         item = ds[it % len(ds)]
         inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)

@@ -53,7 +53,8 @@ def train(march, steps, dt_gamma, dev, seed=123):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
-        if march and it % 16 == 0:
+        if march and ((it % 16 == 0 or (it < EARLY_REFRESH_STEPS and it % REFRESH_EARLY == 0))
+                      if REFRESH_EARLY else net.refresh_due(it)):
             net.update_extra_state(decay=(DECAY_EARLY if it < EARLY_STEPS else 0.95) if DECAY_EARLY else None)
         item = ds[it % len(ds)]
         inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)
@@ -89,6 +90,8 @@ def train(march, steps, dt_gamma, dev, seed=123):
 
 TILE_ORDER = int(os.environ.get("TILE_ORDER", "-1"))
 COARSE_START = int(os.environ.get("COARSE_START", "0"))
+REFRESH_EARLY = int(os.environ.get("REFRESH_EARLY", "0"))   # 0: the renderer's schedule (refresh_due); n: every n steps at first
+EARLY_REFRESH_STEPS = int(os.environ.get("EARLY_REFRESH_STEPS", "128"))
 DECAY_EARLY = float(os.environ.get("DECAY_EARLY", "0"))  # 0: built-in schedule
 EARLY_STEPS = int(os.environ.get("EARLY_STEPS", "256"))
 

@@ -23,7 +23,7 @@ g = torch.Generator(device=dev).manual_seed(123)
 
 
 def step(it):
-    if it % 16 == 0:
+    if net.refresh_due(it):
         net.update_extra_state()
     item = ds[it % len(ds)]
     inds = torch.randint(0, 240 * 320, (4096,), device=dev, generator=g)

@@ -260,7 +260,7 @@ class JointTrainLightningNet(nn.Module):
         labels = torch.gather(label_nerf.reshape(B, -1), 1, inds)
         gt_depth = torch.gather(depths.reshape(B, -1), 1, inds)
         if self.cuda_ray:
-            if self._nerf_steps % 16 == 0:
+            if self.nerf_model.refresh_due(self._nerf_steps):
                 self.nerf_model.update_extra_state()
             self._nerf_steps += 1
             self._grid_stale = True
