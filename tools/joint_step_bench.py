@@ -9,7 +9,8 @@ from ucsa_neural_rendering_amd.lightning import JointTrainDataModule, JointTrain
 exp = {
     "general": {"name": "bench_joint", "clean_up_folder_if_exists": True, "checkpoint_load": ""},
     "model": {"pretrained": False, "pretrained_backbone": False, "num_classes": 40,
-              "amp": os.environ.get("AMP", "")},
+              "amp": os.environ.get("AMP", ""),
+              "channels_last": bool(int(os.environ.get("CL", "0")))},
     "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
     "trainer": {}, "data_module": {"batch_size": int(os.environ.get("BS", "4"))},
     "scenes": ["scene0000_00"], "synthetic": {"n_views": 12, "H": 240, "W": 320},

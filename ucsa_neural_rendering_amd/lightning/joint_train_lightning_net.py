@@ -67,7 +67,10 @@ class JointTrainLightningNet(nn.Module):
         # runs the segmentation network under bf16 autocast in channels_last
         # (MIOpen's fast path on MI355X: 49 -> 34 ms per 8-image train step)
         self.seg_amp = str(exp["model"].get("amp", "")).lower() == "bf16"
-        if self.seg_amp:
+        # `model: {channels_last: true}`: fp32, NHWC layout (1x1 convolutions as
+        # one GEMM, MIOpen's NHWC kernels without layout transposes)
+        self.seg_channels_last = bool(exp["model"].get("channels_last", False))
+        if self.seg_amp or self.seg_channels_last:
             self.seg_model = self.seg_model.to(memory_format=torch.channels_last)
         # NeRF-only steps replay the frozen segmentation forward as a HIP graph
         self.seg_graph = bool(exp["model"].get("seg_graph", True))
@@ -159,6 +162,8 @@ class JointTrainLightningNet(nn.Module):
 
     def _seg_logits(self, image):
         if not self.seg_amp:
+            if self.seg_channels_last:
+                image = image.contiguous(memory_format=torch.channels_last)
             return self.seg_model(image)["out"]
         image = image.contiguous(memory_format=torch.channels_last)
         with torch.autocast("cuda", dtype=torch.bfloat16):
