@@ -10,6 +10,8 @@ dev = torch.device("cuda", 0)
 net, ds = bench.build_field(dev, train_steps=100)
 H, W, T, t = 240, 320, 256, 256
 IW = int(os.environ.get('IMAGE_WIDTH', str(W)))
+if os.environ.get('CHUNK'):
+    net.hip_ray_chunk = int(os.environ['CHUNK'])
 poses = _slerp_loop_poses(6, seed=999).to(dev)
 rays = [ops.get_rays(poses[i:i+1], (0.89*W, 0.89*W, W/2, H/2), H, W) for i in range(6)]
 u = torch.rand(H*W, t, device=dev)
