@@ -235,3 +235,27 @@ def test_frozen_seg_forward_graph_replay_equals_eager(tmp_path):
     model.seg_graph = False
     got5 = model.forward_seg_frozen({"img": img4})
     assert float((got5["seg_semantics_raw"] - want4["seg_semantics_raw"]).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("opts", [{"channels_last": True}, {"amp": "bf16"}, {"seg_graph": False}])
+def test_module_layout_and_precision_options_train(tmp_path, opts):
+    """`model: {channels_last | amp: bf16 | seg_graph: false}`: a NeRF-only
+    epoch and a joint epoch run and log finite losses."""
+    from ucsa_neural_rendering_amd.lightning import (JointTrainDataModule,
+                                                     JointTrainLightningNet, Trainer)
+    exp = _tiny_exp()
+    exp["model"].update(opts)
+    env = {"results": str(tmp_path / "r"), "scannet": str(tmp_path)}
+    model = JointTrainLightningNet(exp, env)
+    dm = JointTrainDataModule(exp)
+    dm.setup()
+    tr = Trainer(max_epochs=1, default_root_dir=str(tmp_path), limit_batches=2)
+    model.joint_train = False
+    tr.fit(model, train_dataloaders=dm.train_dataloader_nerf())
+    model.joint_train = True
+    tr.fit(model, train_dataloaders=dm.train_dataloader_joint())
+    logged = model.logged
+    for k in ("train/loss_nerf_rgb", "train/loss_depth", "train/loss_seg"):
+        assert k in logged and logged[k] == logged[k] and abs(logged[k]) < 1e6, (k, logged)
+    rows = tr.logger.history
+    assert any(r["name"] == "train/loss_seg" for r in rows)

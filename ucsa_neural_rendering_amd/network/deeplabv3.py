@@ -143,9 +143,19 @@ class ASPPPooling(nn.Sequential):
 
     def forward(self, x):
         size = x.shape[-2:]
-        for mod in self:
-            x = mod(x)
-        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        dtype, cl = x.dtype, (x.dim() == 4 and not x.is_contiguous()
+                              and x.is_contiguous(memory_format=torch.channels_last))
+        # The pooled branch is a [B, C, 1, 1] tensor: negligible work, and its
+        # bf16 / NHWC batch-norm + upsample kernels crash on small maps
+        # (segfault seen with 48x64 inputs under bf16 autocast), so it always
+        # runs in fp32, NCHW, outside autocast.
+        with torch.autocast(x.device.type, enabled=False):
+            y = self[0](x).float().contiguous()
+            for mod in list(self)[1:]:
+                y = mod(y)
+            y = F.interpolate(y, size=size, mode="bilinear", align_corners=False)
+        y = y.to(dtype)
+        return y.contiguous(memory_format=torch.channels_last) if cl else y
 
 
 class ASPP(nn.Module):
