@@ -23,14 +23,12 @@ members the code uses.
 """
 from __future__ import annotations
 
-import math
 import os
 import warnings
 import random
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import dist as udist
 from .. import losses as ulosses
