@@ -5,7 +5,9 @@ joint fit -> test -> predict -> save ``deeplab.ckpt``.  PyTorch-Lightning's
 Trainer is replaced by the thin one in ucsa_neural_rendering_amd.lightning
 (PL is not installed on the MI355X image); data come from the synthetic scene
 data module.  Under torchrun (one process per GPU) the NeRF and DeepLab
-gradients are summed over RCCL inside the module.
+gradients are averaged over RCCL inside the module, every rank
+trains on its own frames / pixels and evaluates its own shard of the frames
+(metrics are reduced; files are written by the rank that owns the frame).
 """
 import argparse
 import os
@@ -56,8 +58,18 @@ def train(exp, env, exp_cfg_path, env_cfg_path, args):
     exp["general"]["name"] = model_path
 
     model = JointTrainLightningNet(exp, env)
+    if world > 1:
+        # identical initial parameters on every rank (same seed above), then
+        # rank-specific random streams: each rank draws its own pixels,
+        # stratified-sampling noise and augmentations (DDP semantics; the
+        # gradients are averaged inside the module)
+        seed_everything(args.seed + rank)
+        torch.distributed.barrier()  # rank 0 has created the folder
+    exp["seed"] = args.seed          # shared shuffling seed of the samplers
     datamodule = JointTrainDataModule(exp, env)
     datamodule.setup()
+    if world > 1:
+        torch.distributed.barrier()  # files written by rank 0 during setup
     # ScanNet-layout root: the predict pass writes the PNGs the next stage's
     # replay reads (reference :695-782)
     model.predict_to_disk = bool(getattr(datamodule, "_scannet", False))

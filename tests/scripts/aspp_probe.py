@@ -1,0 +1,94 @@
+"""Diagnosis of the crash the ASPP pooling branch used to route around
+(commit ffc025e: "bf16/NHWC kernels segfault on small maps").  Every candidate
+op runs in its OWN subprocess (a segfault kills only that child); prints one
+line per case.  Run on the GPU box:  python tests/scripts/aspp_probe.py"""
+import subprocess
+import sys
+
+CASES = {
+    # name: python source run with x = [B,2048,h,w] channels_last bf16 on cuda
+    "pool": "y = F.adaptive_avg_pool2d(x, 1)",
+    "pool+conv1x1": "y = conv(F.adaptive_avg_pool2d(x, 1))",
+    "pool+conv+bn_train": "bn.train(); y = bn(conv(F.adaptive_avg_pool2d(x, 1)))",
+    "pool+conv+bn_eval": "bn.eval(); y = bn(conv(F.adaptive_avg_pool2d(x, 1)))",
+    "bn_train_on_1x1_cl": "bn.train(); y = bn(torch.randn(B,256,1,1,device='cuda').to(dt).contiguous(memory_format=torch.channels_last))",
+    "bn_train_on_1x1_nchw": "bn.train(); y = bn(torch.randn(B,256,1,1,device='cuda').to(dt))",
+    "interp_1x1_cl": "y = F.interpolate(torch.randn(B,256,1,1,device='cuda').to(dt).contiguous(memory_format=torch.channels_last), size=(h,w), mode='bilinear', align_corners=False)",
+    "interp_1x1_nchw": "y = F.interpolate(torch.randn(B,256,1,1,device='cuda').to(dt), size=(h,w), mode='bilinear', align_corners=False)",
+    "full_branch": "bn.train(); y = F.interpolate(F.relu(bn(conv(F.adaptive_avg_pool2d(x, 1)))), size=(h,w), mode='bilinear', align_corners=False)",
+    "full_branch_bwd": "bn.train(); x.requires_grad_(); y = F.interpolate(F.relu(bn(conv(F.adaptive_avg_pool2d(x, 1)))), size=(h,w), mode='bilinear', align_corners=False); y.float().sum().backward()",
+}
+
+TEMPLATE = """
+import torch, torch.nn.functional as F
+B, h, w = {B}, {h}, {w}
+dt = torch.{dt}
+torch.manual_seed(0)
+conv = torch.nn.Conv2d(2048, 256, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+bn = torch.nn.BatchNorm2d(256).cuda()
+x = torch.randn(B, 2048, h, w, device='cuda').contiguous(memory_format=torch.channels_last)
+with torch.autocast('cuda', dtype=torch.bfloat16, enabled={amp}):
+    {body}
+torch.cuda.synchronize()
+print('ok', tuple(y.shape), y.dtype, bool(torch.isfinite(y.float()).all()))
+"""
+
+
+WHOLE = """
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, {root!r})
+from ucsa_neural_rendering_amd.network import deeplabv3 as D
+def plain(self, x):   # torchvision's ASPPPooling.forward
+    size = x.shape[-2:]
+    for mod in self:
+        x = mod(x)
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+D.ASPPPooling.forward = plain
+torch.manual_seed(0)
+m = D.DeepLabV3({{"num_classes": 40, "backbone": "resnet50"}}).cuda()
+x = torch.rand({B}, 3, {H}, {W}, device="cuda")
+if {cl}:
+    m = m.to(memory_format=torch.channels_last); x = x.contiguous(memory_format=torch.channels_last)
+m.train({train})
+with torch.autocast("cuda", dtype=torch.bfloat16, enabled={amp}):
+    y = m(x)["out"]
+if {train}:
+    y.float().mean().backward()
+torch.cuda.synchronize()
+print("ok", tuple(y.shape), y.dtype, bool(torch.isfinite(y.float()).all()))
+"""
+
+
+def whole_model():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for (B, H, W) in [(2, 48, 64), (1, 48, 64), (8, 240, 320)]:
+        for amp in (True, False):
+            for cl in (True, False):
+                for train in (True, False):
+                    src = WHOLE.format(root=root, B=B, H=H, W=W, amp=amp, cl=cl, train=train)
+                    r = subprocess.run([sys.executable, "-c", src], capture_output=True,
+                                       text=True, timeout=600)
+                    tail = (r.stdout.strip().splitlines() or [""])[-1]
+                    err = (r.stderr.strip().splitlines() or [""])[-1][:200]
+                    print(f"whole B={B} {H}x{W} amp={amp} cl={cl} train={train} rc={r.returncode} "
+                          f"{tail} {err if r.returncode else ''}", flush=True)
+
+
+def main():
+    whole_model()
+    for (B, h, w) in [(2, 6, 8), (8, 30, 40), (1, 6, 8)]:
+        for amp in (True, False):
+            for name, body in CASES.items():
+                src = TEMPLATE.format(B=B, h=h, w=w, dt="bfloat16" if amp else "float32",
+                                      amp=amp, body=body)
+                r = subprocess.run([sys.executable, "-c", src], capture_output=True,
+                                   text=True, timeout=300)
+                tail = (r.stdout.strip().splitlines() or [""])[-1]
+                err = (r.stderr.strip().splitlines() or [""])[-1][:160]
+                print(f"B={B} {h}x{w} amp={amp} {name:24s} rc={r.returncode} {tail} {err if r.returncode else ''}",
+                      flush=True)
+
+
+if __name__ == "__main__":
+    main()

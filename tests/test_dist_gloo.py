@@ -139,3 +139,141 @@ def test_ray_sharded_gradients_equal_single_process():
     for a, b, c in zip(r0, r1, ref):
         assert torch.equal(a, b)  # identical on every rank -> identical Adam
         assert torch.allclose(a, c, rtol=1e-5, atol=1e-8)
+
+
+# ---- sharded NeRF optimizer ------------------------------
+def _cpu_adam_ops(monkeypatch_target):
+    """The HIP Adam entry points replaced by the oracle's Adam (test
+    infrastructure): the CPU tests exercise the collectives, slicing, state
+    layout and scaler protocol of ShardedHipAdam, not the kernel (that is
+    tests/test_gpu_backward.py::test_adam_kernel_matches_torch_adam)."""
+    from oracle import losses as olosses
+
+    def adam_step(p, g, m, v, step, lr, b1, b2, eps, wd, inv_grad_scale=1.0):
+        np_, nm, nv = olosses.adam_step(p, g * inv_grad_scale, m, v, step, lr, b1,
+                                        b2, eps, wd)
+        p.copy_(np_), m.copy_(nm), v.copy_(nv)
+
+    def adam_step_scaled(p, g, m, v, step, lr, b1, b2, eps, wd, gs, fi, skipped):
+        if float(fi) != 0.0:
+            return
+        adam_step(p, g / gs, m, v, step - int(skipped), lr, b1, b2, eps, wd)
+
+    def adam_count_skipped(fi, skipped):
+        if float(fi) != 0.0:
+            skipped += 1
+
+    monkeypatch_target.adam_step = adam_step
+    monkeypatch_target.adam_step_scaled = adam_step_scaled
+    monkeypatch_target.adam_count_skipped = adam_count_skipped
+
+
+def _opt_problem():
+    g = torch.Generator().manual_seed(11)
+    big0 = torch.randn(4099, generator=g)          # not a multiple of the world
+    s1 = torch.randn(48, generator=g)
+    s2 = torch.randn(7, generator=g)
+    tgt = [torch.randn(4099, generator=g), torch.randn(48, generator=g),
+           torch.randn(7, generator=g)]
+    return [big0, s1, s2], tgt
+
+
+def _sharded_trajectory(rank, world, sharded, scaler_on, comm_dtype=None):
+    from ucsa_neural_rendering_amd import ops
+    from ucsa_neural_rendering_amd.nerf import optim as uoptim
+    _cpu_adam_ops(ops)
+    uoptim.HipAdam._require_gpu = staticmethod(lambda p: None)  # CPU tensors in this test
+    init, tgt = _opt_problem()
+    ps = [torch.nn.Parameter(t.clone()) for t in init]
+    groups = [{"name": "encoding", "params": ps[:1]},
+              {"name": "net", "params": ps[1:], "weight_decay": 1e-6}]
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    if sharded:
+        opt = uoptim.ShardedHipAdam(groups, shard_min_numel=1024,
+                                    comm_dtype=comm_dtype, **kw)
+    else:
+        opt = uoptim.HipAdam(groups, **kw)
+    scaler = uoptim.CollectiveGradScaler("cpu", enabled=scaler_on, init_scale=64.0)
+    gen = torch.Generator().manual_seed(100 + rank)           # per-rank data
+    hist = []
+    for it in range(6):
+        opt.zero_grad()
+        noise = [torch.randn(t.shape, generator=gen) * 0.1 for t in tgt]
+        loss = sum((((p - t - n) ** 2).mean() for p, t, n in zip(ps, tgt, noise)))
+        if it == 2 and rank == 1 and scaler_on:
+            loss = loss * float("inf")                         # one rank overflows
+        scaler.scale(loss).backward()
+        if not sharded:
+            udist.average_grads_(ps)
+        scaler.step(opt)
+        scaler.update()
+        hist.append(float(scaler.get_scale()) if scaler_on else 0.0)
+    state_elems = sum(v.numel() for st in opt.state.values() for k, v in st.items()
+                      if torch.is_tensor(v))
+    return ([p.detach().clone() for p in ps], hist, state_elems,
+            getattr(opt, "last_comm_bytes", None))
+
+
+def _traj_sharded_scaled(rank, world):
+    return _sharded_trajectory(rank, world, True, True)
+
+
+def _traj_replicated_scaled(rank, world):
+    return _sharded_trajectory(rank, world, False, True)
+
+
+def _traj_sharded_plain(rank, world):
+    return _sharded_trajectory(rank, world, True, False)
+
+
+def _traj_replicated_plain(rank, world):
+    return _sharded_trajectory(rank, world, False, False)
+
+
+def _traj_sharded_fp16(rank, world):
+    return _sharded_trajectory(rank, world, True, True, torch.float16)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_sharded_adam_equals_replicated_adam(scaled):
+    """reduce-scatter + Adam on 1/N + all-gather == all-reduce + full Adam,
+    bit for bit at world 2 (a+b is commutative, /2 is exact); the replicas
+    stay identical; an overflow on ONE rank skips the step on BOTH and backs
+    the scale off on both (collective found-inf); the moment buffers hold
+    ~1/N of the big tensor."""
+    a = spawn(_traj_sharded_scaled if scaled else _traj_sharded_plain)
+    b = spawn(_traj_replicated_scaled if scaled else _traj_replicated_plain)
+    for r in range(2):
+        for x, y in zip(a[r][0], b[r][0]):
+            assert torch.equal(x, y)
+    for x, y in zip(a[0][0], a[1][0]):
+        assert torch.equal(x, y)
+    assert a[0][1] == a[1][1] == b[0][1] == b[1][1]
+    if scaled:
+        assert a[0][1][1] == 64.0 and a[0][1][2] == 32.0      # backed off once
+    # 2 moments x (4099 // 2 rounded to 4 + tail) + the small tensors, vs 2 x all
+    assert a[0][2] < b[0][2] * 0.6
+    assert a[0][3] is not None and a[0][3] > 0
+
+
+def test_sharded_adam_fp16_gradient_payload_stays_close():
+    a = spawn(_traj_sharded_fp16)
+    b = spawn(_traj_sharded_scaled)
+    for x, y in zip(a[0][0], a[1][0]):
+        assert torch.equal(x, y)                               # replicas identical
+    for x, y in zip(a[0][0], b[0][0]):
+        assert float((x - y).abs().max()) <= 5e-3
+    assert a[0][3] < b[0][3]                                   # fewer bytes on the links
+
+
+def _gms(rank, world):
+    n_loc = 10 + 4 * rank
+    valid = torch.tensor(3.0 + rank)
+    a, b = udist.global_mean_scale(n_loc, valid)
+    return float(a), float(b)
+
+
+def test_global_mean_scale_world2():
+    r0, r1 = spawn(_gms)
+    assert abs(r0[0] - 10 / 24) < 1e-6 and abs(r1[0] - 14 / 24) < 1e-6
+    assert abs(r0[1] - 3 / 7) < 1e-6 and abs(r1[1] - 4 / 7) < 1e-6

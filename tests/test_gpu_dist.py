@@ -93,3 +93,96 @@ def test_two_rank_training_keeps_replicas_identical_and_sharded_render_matches()
     assert torch.equal(r0["head"], r1["head"])
     assert r0["gathered_equal"] is True
     assert all(l == l for l in r0["losses"] + r1["losses"])  # finite
+
+
+# ---- the LightningModule under torch.distributed --------
+def _module_worker(rank, world, port, root, sharded, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import argparse
+    from ucsa_neural_rendering_amd import dist as udist
+    from ucsa_neural_rendering_amd.lightning import joint_train_lightning_net as jl
+    from scripts import train_joint as tj
+    torch.cuda.set_device(0)
+    udist.init_from_env("gloo")
+    try:
+        drawn = []
+        orig = jl.JointTrainLightningNet.get_rays_train
+
+        def spy(self, batch, bs, N=None):
+            out = orig(self, batch, bs, N)
+            if len(drawn) < 4:
+                drawn.append((str(batch["current_index"][bs]), out[3][0, :64].cpu().clone()))
+            return out
+
+        jl.JointTrainLightningNet.get_rays_train = spy
+        keep = {}
+        orig_end = jl.JointTrainLightningNet.on_predict_epoch_end
+
+        def grab(self):   # NeRF parameters at the end of the run
+            keep["params"] = [p.detach().cpu().clone()
+                              for p in self.nerf_model.parameters()]
+            return orig_end(self)
+
+        jl.JointTrainLightningNet.on_predict_epoch_end = grab
+        orig_save = torch.save
+
+        def save_spy(obj, path, *a, **k):
+            keep["saved_by"] = rank
+            return orig_save(obj, path, *a, **k)
+
+        torch.save = save_spy
+        exp = {
+            "general": {"name": "joint_train/dist_tiny", "clean_up_folder_if_exists": True,
+                        "checkpoint_load": ""},
+            "model": {"pretrained": False, "pretrained_backbone": False,
+                      "num_classes": 40, "backbone": "resnet50"},
+            "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
+            "trainer": {"load_from_checkpoint": False},
+            "data_module": {"batch_size": 2},
+            "scenes": ["scene0000_00"],
+            "synthetic": {"n_views": 10, "H": 48, "W": 64},
+            "nerf": {"n_rays": 512, "num_steps": 32, "upsample_steps": 32,
+                     "sharded_optimizer": sharded},
+            "nerf_seed": 1,
+        }
+        env = {"results": os.path.join(root, "experiments"), "scannet": root}
+        cfgp = os.path.join(root, "exp.yml")
+        if rank == 0:
+            open(cfgp, "w").write("x: 1\n")
+        torch.distributed.barrier()
+        args = argparse.Namespace(exp_name="t", fix_nerf=False, seed=123,
+                                  nerf_train_epoch=2, joint_train_epoch=1,
+                                  limit_batches=None)
+        res = tj.train(exp, env, cfgp, cfgp, args)
+        ret[rank] = dict(drawn=drawn, results=res, saved_by=keep.get("saved_by"),
+                         params=keep.get("params"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [True, False])
+def test_two_rank_train_joint_shards_frames_and_pixels(tmp_path, sharded):
+    """scripts/train_joint.py under two ranks: the ranks train on DIFFERENT
+    frames and draw DIFFERENT pixels (rank-offset seed, DistributedSampler),
+    the NeRF replicas stay bit-identical after the run (sharded optimizer and
+    replicated all-reduce alike), evaluation is split and its metrics reduced
+    (both ranks report the same numbers), and only rank 0 saves the
+    checkpoint."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_module_worker, args=(2, _free_port(), str(tmp_path), sharded, ret),
+             nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    frames0 = [f for f, _ in r0["drawn"]]
+    frames1 = [f for f, _ in r1["drawn"]]
+    assert frames0 and frames1 and frames0[0] != frames1[0]       # different frames
+    assert not torch.equal(r0["drawn"][0][1], r1["drawn"][0][1])   # different pixels
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)                                   # replicas identical
+    for k in ("test_after_nerf", "test_after_joint"):
+        assert r0["results"][k]["test_nerf_PSNR"] == pytest.approx(
+            r1["results"][k]["test_nerf_PSNR"], abs=1e-9)
+        assert r0["results"][k]["test_nerf_mIoU"] == pytest.approx(
+            r1["results"][k]["test_nerf_mIoU"], abs=1e-12)
+    assert r0["saved_by"] == 0 and r1["saved_by"] is None

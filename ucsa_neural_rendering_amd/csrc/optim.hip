@@ -12,11 +12,13 @@ __global__ void __launch_bounds__(256)
 k_adam(float* __restrict__ p, const float* __restrict__ g,
        float* __restrict__ m, float* __restrict__ v, uint64_t n, float lr,
        float beta1, float beta2, float eps, float wd, float bc1,
-       float bc2_sqrt, float inv_scale) {
+       float bc2_sqrt, float inv_scale, bool vec) {
+  // vec: all four base pointers are 16-byte aligned (always true for whole
+  // torch tensors; a slice handed over by the sharded optimizer may not be)
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
   for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
        i < n; i += stride) {
-    if (i + 4 <= n) {
+    if (vec && i + 4 <= n) {
       float4 pp = *reinterpret_cast<float4*>(p + i);
       const float4 gg = *reinterpret_cast<const float4*>(g + i);
       float4 mm = *reinterpret_cast<float4*>(m + i);
@@ -38,7 +40,8 @@ k_adam(float* __restrict__ p, const float* __restrict__ g,
       *reinterpret_cast<float4*>(m + i) = mm;
       *reinterpret_cast<float4*>(v + i) = vv;
     } else {
-      for (uint64_t k = i; k < n; ++k) {
+      const uint64_t e = i + 4 < n ? i + 4 : n;
+      for (uint64_t k = i; k < e; ++k) {
         float gr = g[k] * inv_scale;
         if (wd != 0.0f) gr = gr + wd * p[k];
         const float mk = beta1 * m[k] + (1.0f - beta1) * gr;
@@ -68,11 +71,13 @@ extern "C" int32_t ucsa_adam_step(float* params, const float* grads,
   const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
   uint32_t blocks = ucsa_div_up(n, 256 * 4);
   if (blocks > 256 * 8) blocks = 256 * 8;
+  const bool vec = (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg |
+                     (uintptr_t)exp_avg_sq) & 15u) == 0;
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
                      eps, weight_decay, (float)bc1, (float)std::sqrt(bc2),
-                     inv_grad_scale);
+                     inv_grad_scale, vec);
   return ucsa_launch_status();
 }
 

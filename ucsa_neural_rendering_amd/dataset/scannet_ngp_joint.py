@@ -31,6 +31,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+from .. import dist as udist
 from .. import ops
 from .ngp_utils import get_rays, nerf_matrix_to_ngp
 
@@ -163,11 +164,13 @@ class ScanNetNGPJoint(Dataset):
                 current_poses = self._interpolate_poses(current_poses)
                 assert len(gen_images) == len(gen_labels) == len(current_poses)
                 os.makedirs(os.path.dirname(gen_json), exist_ok=True)
-                with open(gen_json, "w") as f:
-                    json.dump({"frames": [
+                if udist.world()[0] == 0:  # one writer under torch.distributed
+                    frames_out = [
                         {"nerf_image": a, "nerf_label": b, "pose": p.tolist()}
                         for a, b, p in zip(gen_images, gen_labels,
-                                           current_poses)]}, f, indent=5)
+                                           current_poses)]
+                    with open(gen_json, "w") as f:
+                        json.dump({"frames": frames_out}, f, indent=5)
             self.poses += [nerf_matrix_to_ngp(p) for p in current_poses]
         self.poses = torch.from_numpy(np.stack(self.poses, axis=0))
 

@@ -11,9 +11,20 @@ renders / trains its own rays.
   one 57 kB buffer) once per step; every rank then applies the same Adam step.
   Over fully connected xGMI (7 links/GPU) RCCL's direct reduce-scatter +
   all-gather moves 52/8 MB per link per phase; nothing here forces a ring.
-* the reference normalises its losses by N (or by the number of valid depth
-  pixels); ``global_mean_scale`` turns local sums into terms of the global
-  mean so that SUM-reduced gradients equal the single-process gradient.
+* loss normalisation, two documented modes:
+  - DDP semantics (what the reference's Lightning DDP does and what the
+    module / ``bench.py --mode train`` use): every rank draws its OWN rays,
+    normalises its loss terms by its local counts, gradients are SUMMED and
+    divided by the world size (``average_grads_``) -- the mean of per-rank
+    means.
+  - one shared batch split over the ranks (``shard_range``):
+    ``global_mean_scale`` returns the factors (n_local/n_global for the
+    colour and semantics terms, valid_local/valid_global for the depth term)
+    that turn the locally normalised terms into the terms of the GLOBAL mean,
+    so that SUM-reduced gradients equal the single-process gradient exactly.
+* sharded optimizer (``nerf.optim.ShardedHipAdam``):
+  ``reduce_scatter_sum_`` of the hash-grid gradient, Adam on each rank's 1/N
+  slice, ``all_gather_into_`` of the updated slice.
 * metrics: the 40x40 confusion matrix is all-reduced instead of the
   reference's all_gather of label maps (joint_train_lightning_net.py:666-667).
 """
@@ -88,6 +99,74 @@ def allreduce_sum_(tensors: Sequence[torch.Tensor], small_bytes: int = 1 << 20):
 def allreduce_grads_(params: Iterable[torch.nn.Parameter]):
     grads = [p.grad for p in params if p.grad is not None]
     allreduce_sum_(grads)
+
+
+def average_grads_(params: Iterable[torch.nn.Parameter]):
+    """DDP semantics: SUM all-reduce of the gradients, then / world."""
+    params = [p for p in params if p.grad is not None]
+    _, w = world()
+    if w == 1:
+        return
+    allreduce_sum_([p.grad for p in params])
+    for p in params:
+        p.grad.div_(w)
+
+
+def reduce_scatter_sum_(out: torch.Tensor, inp: torch.Tensor):
+    """out[per] = sum over ranks of inp[rank*per:(rank+1)*per] (1-D,
+    inp.numel() == world * out.numel())."""
+    dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+
+
+def all_gather_into_(out: torch.Tensor, inp: torch.Tensor):
+    """out[rank*per:(rank+1)*per] = inp of that rank (1-D)."""
+    dist.all_gather_into_tensor(out, inp)
+
+
+def allreduce_sum_tensor(t: torch.Tensor) -> torch.Tensor:
+    if is_dist() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class RankShardSampler(torch.utils.data.Sampler):
+    """Evaluation / predict loaders under torch.distributed: rank r takes
+    items r, r+W, r+2W, ... in order -- no padding, no duplicates (a
+    DistributedSampler would repeat frames to equalise the ranks, which would
+    count them twice in the confusion matrix)."""
+
+    def __init__(self, n: int, rank: int, world_size: int):
+        self.idx = list(range(rank, n, world_size))
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+
+def allreduce_max_(t: torch.Tensor) -> torch.Tensor:
+    if is_dist() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def global_mean_scale(n_local: int, valid_local: torch.Tensor):
+    """One shared batch split over the ranks: factors that turn locally
+    normalised loss terms into terms of the global mean.  ``valid_local`` is
+    this rank's number of valid depth pixels (a tensor, stays on its device:
+    one 2-element all-reduce, no host read-back).  Returns (scale_mean,
+    scale_depth) as 0-d tensors: multiply the colour / semantics terms by the
+    first and the depth term by the second, then SUM-reduce the gradients
+    (no division by the world size)."""
+    v = torch.stack([torch.as_tensor(float(n_local), dtype=torch.float64,
+                                     device=valid_local.device),
+                     valid_local.detach().to(torch.float64).reshape(())])
+    tot = v.clone()
+    if is_dist() and dist.get_world_size() > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    sc = (v / tot.clamp_min(1.0)).to(torch.float32)
+    return sc[0], sc[1]
 
 
 def global_count(local_count: torch.Tensor) -> torch.Tensor:

@@ -13,6 +13,7 @@ import os
 import torch
 from torch.utils.data import DataLoader
 
+from .. import dist as udist
 from ..dataset.scannet_ngp_joint import ScanNetNGPJoint, _TEN_SCENES
 
 from ..dataset.synthetic_scene import (SyntheticSceneDataset,
@@ -86,6 +87,20 @@ class JointTrainDataModule:
         self._setup = True
 
     def _dl(self, ds, bs, shuffle, collate, drop_last=False):
+        """One process per GPU: training loaders get a DistributedSampler
+        (every rank its own frames, reshuffled per epoch by the Trainer's
+        ``set_epoch``; what Lightning DDP does in the reference), evaluation
+        and predict loaders a strided shard without duplicates."""
+        rank, world = udist.world()
+        if world > 1:
+            if shuffle:
+                sampler = torch.utils.data.distributed.DistributedSampler(
+                    ds, num_replicas=world, rank=rank, shuffle=True,
+                    seed=int(self.exp.get("seed", 0)), drop_last=False)
+            else:
+                sampler = udist.RankShardSampler(len(ds), rank, world)
+            return DataLoader(ds, batch_size=bs, sampler=sampler, num_workers=0,
+                              drop_last=drop_last, collate_fn=collate)
         return DataLoader(ds, batch_size=bs, shuffle=shuffle, num_workers=0,
                           drop_last=drop_last, collate_fn=collate)
 

@@ -34,7 +34,7 @@ from .. import dist as udist
 from .. import losses as ulosses
 from .. import ops
 from ..nerf.network_tcnn_semantics import SemanticNeRFNetwork
-from ..nerf.optim import HipAdam
+from ..nerf.optim import CollectiveGradScaler, HipAdam, ShardedHipAdam
 from ..network import DeepLabV3
 from ..utils.metrics import SemanticsMeter
 
@@ -87,7 +87,16 @@ class JointTrainLightningNet(nn.Module):
 
         self.weight_depth = ulosses.WEIGHT_DEPTH
         self.weight_semantics = ulosses.WEIGHT_SEMANTICS
-        self.nerf_scaler = torch.amp.GradScaler("cuda", enabled=True)
+        # found-inf flag MAX-reduced over the ranks (== GradScaler with one)
+        self.nerf_scaler = CollectiveGradScaler("cuda", enabled=True)
+        # multi-GPU: reduce-scatter + per-rank Adam slice + all-gather
+        #  instead of all-reduce + replicated Adam;
+        # `nerf: {sharded_optimizer: false}` keeps the replicated step,
+        # `nerf: {grad_comm_dtype: fp16|bf16}` halves the gradient payload
+        self.sharded_optimizer = bool(nerf_cfg.get("sharded_optimizer", True))
+        self.grad_comm_dtype = {None: None, "": None, "fp32": None,
+                                "fp16": torch.float16, "bf16": torch.bfloat16}[
+            nerf_cfg.get("grad_comm_dtype")]
         self.automatic_optimization = False
         self.joint_train = False
         self.fix_nerf = exp.get("fix_nerf", False)
@@ -349,7 +358,11 @@ class JointTrainLightningNet(nn.Module):
 
     def _nerf_update(self, optimizer_nerf, loss_color, loss_semantics,
                      loss_depth):
-        """reference :497-513 (+ RCCL sum of the ray-sharded gradients)."""
+        """reference :497-513.  Under torch.distributed every rank has drawn
+        its own rays on its own frames (DDP semantics, reference
+        scripts/train_joint.py:137-142): the gradients are averaged over the
+        ranks -- inside ``ShardedHipAdam.step`` (reduce-scatter / all-gather),
+        or by one all-reduce here for the replicated ``HipAdam``."""
         for nm, v in (("loss_nerf_rgb", loss_color), ("loss_depth", loss_depth),
                       ("loss_nerf_semantics", loss_semantics)):
             if v is not None:
@@ -358,13 +371,8 @@ class JointTrainLightningNet(nn.Module):
         optimizer_nerf.zero_grad()
         total = self.nerf_scaler.scale(total)
         self.manual_backward(total)
-        if udist.world()[1] > 1:
-            ps = list(self.nerf_model.parameters())
-            udist.allreduce_grads_(ps)
-            w = udist.world()[1]
-            for p in ps:
-                if p.grad is not None:
-                    p.grad.div_(w)
+        if not getattr(optimizer_nerf, "handles_collectives", False):
+            udist.average_grads_(self.nerf_model.parameters())
         self.nerf_scaler.step(optimizer_nerf)
         self.nerf_scaler.update()
 
@@ -419,12 +427,7 @@ class JointTrainLightningNet(nn.Module):
         loss = ulosses.seg_loss(logits, label_seg)  # CE on softmax (:456-458)
         optimizer_seg.zero_grad()
         self.manual_backward(loss)
-        if udist.world()[1] > 1:
-            ps = list(self.seg_model.parameters())
-            udist.allreduce_grads_(ps)
-            for p in ps:
-                if p.grad is not None:
-                    p.grad.div_(udist.world()[1])
+        udist.average_grads_(self.seg_model.parameters())
         optimizer_seg.step()
         self.log(f"{self._mode}/loss_seg", loss.detach())
 
@@ -461,6 +464,7 @@ class JointTrainLightningNet(nn.Module):
             m = self._meter[f"{mode}_seg"]
             if m.conf_mat is None:
                 continue
+            self._reduce_meter(m)
             m_iou, total_acc, m_acc = m.measure()
             tag = self.prev_scene_name
             self.log(f"{mode}/seg_total_accuracy_{tag}", total_acc)
@@ -494,9 +498,7 @@ class JointTrainLightningNet(nn.Module):
         for net_name in ["nerf", "25k"]:
             m = self._meter[f"test_{net_name}"]
             if m.conf_mat is not None:
-                if udist.world()[1] > 1:  # sum the 40x40 matrix, not label maps
-                    cm = torch.from_numpy(m.conf_mat).cuda()
-                    m.conf_mat = udist.allreduce_confusion_(cm).cpu().numpy()
+                self._reduce_meter(m)
                 m_iou, total_acc, m_acc = m.measure()
                 self.log(f"test/{net_name}_total_accuracy", total_acc)
                 self.log(f"test/{net_name}_mean_accuracy", m_acc)
@@ -504,9 +506,26 @@ class JointTrainLightningNet(nn.Module):
                 out[f"test_{net_name}_mIoU"] = m_iou
                 m.clear()
         if self._psnr:
-            out["test_nerf_PSNR"] = sum(self._psnr) / len(self._psnr)
+            tot = torch.tensor([sum(self._psnr), float(len(self._psnr))],
+                               dtype=torch.float64)
+            if udist.world()[1] > 1:  # the ranks evaluated disjoint frames
+                tot = udist.allreduce_sum_tensor(tot.to(self._reduce_device()))
+            out["test_nerf_PSNR"] = float(tot[0] / tot[1])
             self.log("test/nerf_PSNR", out["test_nerf_PSNR"])
         return out
+
+    def _reduce_device(self):
+        import torch.distributed as tdist
+        return (next(self.parameters()).device
+                if tdist.get_backend() == "nccl" else torch.device("cpu"))
+
+    def _reduce_meter(self, m):
+        """Sum the 40x40 confusion matrix over the ranks (each evaluated its
+        own frames) instead of the reference's all_gather of label maps
+        (:666-667)."""
+        if udist.world()[1] > 1:
+            cm = torch.from_numpy(m.conf_mat).to(self._reduce_device())
+            m.conf_mat = udist.allreduce_confusion_(cm).cpu().numpy()
 
     # ---- predict (:695-782) ---------------------------------------------------
     # Returns the tensors; with ``predict_to_disk`` (set by train_joint when the
@@ -572,7 +591,10 @@ class JointTrainLightningNet(nn.Module):
         else:
             raise ValueError(name)
         lr_nerf = self._exp["optimizer"]["lr_nerf"]
-        optimizer_nerf = HipAdam(
+        sharded = self.sharded_optimizer and udist.world()[1] > 1
+        ctor = ShardedHipAdam if sharded else HipAdam
+        extra = {"comm_dtype": self.grad_comm_dtype} if sharded else {}
+        optimizer_nerf = ctor(
             [{"name": "encoding",
               "params": list(self.nerf_model.encoder.parameters())},
              {"name": "net",
@@ -580,5 +602,5 @@ class JointTrainLightningNet(nn.Module):
               list(self.nerf_model.color_net.parameters()) +
               list(self.nerf_model.semantics_net.parameters()),
               "weight_decay": 1e-6}],
-            lr=lr_nerf, betas=(0.9, 0.99), eps=1e-15)
+            lr=lr_nerf, betas=(0.9, 0.99), eps=1e-15, **extra)
         return optimizer_seg, optimizer_nerf

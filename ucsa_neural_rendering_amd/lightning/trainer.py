@@ -138,6 +138,10 @@ class Trainer:
             self.current_epoch = epoch
             model.train()
             model.on_train_epoch_start()
+            set_epoch = getattr(getattr(train_dataloaders, "sampler", None),
+                                "set_epoch", None)
+            if set_epoch is not None:  # DistributedSampler: reshuffle per epoch
+                set_epoch(epoch)
             for i, batch in self._batches(train_dataloaders):
                 model.training_step(batch, i)
                 self.global_step += 1

@@ -9,12 +9,37 @@ its NeRF optimizer through one, :46,:509-513) it declares
 ``_step_supports_amp_scaling``: the scaler then hands over its scale and its
 found-inf flag as device tensors instead of reading the flag back, and the
 kernel (``ucsa_adam_step_scaled``) unscales / skips on the device -- no host
-synchronisation per training step."""
+synchronisation per training step.
+
+``ShardedHipAdam`` is the multi-GPU form: the hash-grid
+gradient is reduce-scattered, every rank runs Adam on its 1/N slice with 1/N
+of the moment buffers, and the updated slices are all-gathered.
+``CollectiveGradScaler`` makes the scaler's found-inf flag collective (one
+4-byte all-reduce), which the sharded step needs and the replicated one
+tolerates."""
 from __future__ import annotations
 
 import torch
 
+from .. import dist as udist
 from .. import ops
+
+
+class CollectiveGradScaler(torch.amp.GradScaler):
+    """``torch.amp.GradScaler`` whose found-inf flag is the MAX over the
+    ranks (what torch's own ShardedGradScaler does for FSDP): every rank then
+    skips the same steps and keeps the same scale, also when each rank has
+    only looked at its own, not yet reduced, gradients.  With one process it
+    is exactly ``GradScaler``."""
+
+    def _unscale_grads_(self, optimizer, inv_scale, found_inf, allow_fp16):
+        out = super()._unscale_grads_(optimizer, inv_scale, found_inf,
+                                      allow_fp16)
+        if udist.world()[1] > 1:
+            for t in out.values():
+                udist.allreduce_max_(t)
+            optimizer._found_inf_is_collective = True
+        return out
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -26,56 +51,203 @@ class HipAdam(torch.optim.Optimizer):
         self._step_supports_amp_scaling = True
         self._skipped = {}  # device -> int32[1]: steps skipped by the scaler
 
+    @staticmethod
+    def _require_gpu(p):
+        if not p.is_cuda:
+            raise RuntimeError("HipAdam updates GPU parameters only "
+                               "(no CPU fallback)")
+
+    def _scaler_state(self):
+        """(grad_scale, found_inf, scaled): set by GradScaler.step() around
+        the call (device tensors); grad_scale None = already unscaled."""
+        grad_scale = getattr(self, "grad_scale", None)
+        found_inf = getattr(self, "found_inf", None)
+        return grad_scale, found_inf, found_inf is not None
+
+    def _apply(self, p, g, m, v, step, group, grad_scale, found_inf, scaled,
+               devices, extra_div=1.0):
+        """One tensor (or slice): p, g, m, v are flat fp32 views of equal
+        length.  ``extra_div``: the gradient is additionally divided by it
+        (world size, when g is a SUM over ranks)."""
+        b1, b2 = group["betas"]
+        dev = p.device
+        skipped = self._skipped.get(dev)
+        if scaled or skipped is not None:
+            if skipped is None:
+                skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._skipped[dev] = skipped
+            if scaled:
+                gs = (torch.ones(1, device=dev) if grad_scale is None
+                      else grad_scale.to(dev, torch.float32).reshape(1))
+                fi = found_inf.to(dev, torch.float32).reshape(1)
+            else:  # plain step after scaled ones: keep the step count
+                gs = torch.ones(1, device=dev)
+                fi = torch.zeros(1, device=dev)
+            if extra_div != 1.0:
+                gs = gs * float(extra_div)
+            ops.adam_step_scaled(p, g, m, v, step, group["lr"], b1, b2,
+                                 group["eps"], group["weight_decay"], gs, fi,
+                                 skipped)
+            if scaled:
+                devices.add((dev, fi))
+        else:
+            ops.adam_step(p, g, m, v, step, group["lr"], b1, b2, group["eps"],
+                          group["weight_decay"],
+                          inv_grad_scale=1.0 / float(extra_div))
+
+    def _finish(self, devices):
+        for dev, fi in {d: f for d, f in devices}.items():
+            ops.adam_count_skipped(fi, self._skipped[dev])
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        # set by GradScaler.step() around this call (device tensors)
-        grad_scale = getattr(self, "grad_scale", None)
-        found_inf = getattr(self, "found_inf", None)
-        scaled = found_inf is not None  # grad_scale None: already unscaled
+        grad_scale, found_inf, scaled = self._scaler_state()
         devices = set()
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                if not p.is_cuda:
-                    raise RuntimeError("HipAdam updates GPU parameters only "
-                                       "(no CPU fallback)")
+                self._require_gpu(p)
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                skipped = self._skipped.get(p.device)
-                if scaled or skipped is not None:
-                    if skipped is None:
-                        skipped = torch.zeros(1, dtype=torch.int32, device=p.device)
-                        self._skipped[p.device] = skipped
-                    if scaled:
-                        gs = (torch.ones(1, device=p.device) if grad_scale is None
-                              else grad_scale.to(p.device, torch.float32).reshape(1))
-                        fi = found_inf.to(p.device, torch.float32).reshape(1)
-                    else:  # plain step after scaled ones: keep the step count
-                        gs = torch.ones(1, device=p.device)
-                        fi = torch.zeros(1, device=p.device)
-                    ops.adam_step_scaled(
-                        p.data, p.grad.contiguous(), st["exp_avg"],
-                        st["exp_avg_sq"], st["step"], group["lr"], b1, b2,
-                        group["eps"], group["weight_decay"], gs, fi, skipped)
-                    if scaled:
-                        devices.add((p.device, fi))
-                else:
-                    ops.adam_step(p.data, p.grad.contiguous(), st["exp_avg"],
-                                  st["exp_avg_sq"], st["step"], group["lr"], b1,
-                                  b2, group["eps"], group["weight_decay"])
+                self._apply(p.data, p.grad.contiguous(), st["exp_avg"],
+                            st["exp_avg_sq"], st["step"], group, grad_scale,
+                            found_inf, scaled, devices)
                 # the kernel wrote through the raw pointer: tell autograd (and the
                 # packed-weight cache keyed on ._version) that p changed
                 torch.autograd.graph.increment_version(p)
-        for dev, fi in {d: f for d, f in devices}.items():
-            ops.adam_count_skipped(fi, self._skipped[dev])
+        self._finish(devices)
+        return loss
+
+
+class ShardedHipAdam(HipAdam):
+    """the NeRF optimizer of
+    ``joint_train_lightning_net.py:897-919`` with its state and work sharded
+    over the ranks of ``torch.distributed`` (RCCL over xGMI).
+
+    ``step()`` contains the gradient collectives (do NOT all-reduce the
+    gradients before it):
+
+    * a parameter of >= ``shard_min_numel`` elements (the 13 M-element hash
+      grid): ``reduce_scatter`` of its flat gradient (SUM), Adam on this
+      rank's contiguous 1/N slice -- the two moment buffers exist for that
+      slice only -- then ``all_gather`` of the updated slices into the
+      replicated parameter.  The slice length is a multiple of 4 (16-byte
+      aligned slices); the < 4N elements past the last slice are handled
+      like a small parameter.
+    * small parameters (the three MLPs, 14 k elements): one coalesced SUM
+      all-reduce, the same Adam step on every rank.
+    * ``average=True`` (DDP semantics) divides the summed gradients by N
+      inside the Adam kernel (the unscale factor), not in a pass of its own.
+    * ``comm_dtype`` (None | torch.float16 | torch.bfloat16): the gradient
+      payload of the reduce-scatter is cast to it (halves the bytes on the
+      links; under GradScaler the gradients are already scaled into fp16's
+      range).  Moments, parameters and the all-gather stay fp32.
+    * under ``CollectiveGradScaler`` the found-inf flag is already the MAX
+      over ranks when it arrives here; with a plain GradScaler it is
+      MAX-reduced here (4 bytes) so that every rank skips the same step --
+      the scaler's own copy then still differs, hence use the collective one.
+
+    Per step and rank this moves (N-1)/N x 52 MB twice, like the ring
+    all-reduce it replaces, but Adam reads/writes 28 B x 13 M / N instead of
+    28 B x 13 M, and the moments take 2 x 52 MB / N.  With one process it
+    is ``HipAdam``."""
+
+    handles_collectives = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, shard_min_numel=1 << 20, average=True,
+                 comm_dtype=None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps,
+                         weight_decay=weight_decay)
+        self.shard_min_numel = int(shard_min_numel)
+        self.average = bool(average)
+        self.comm_dtype = comm_dtype
+        self.last_comm_bytes = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        rank, world = udist.world()
+        if world == 1:
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        grad_scale, found_inf, scaled = self._scaler_state()
+        if scaled and not getattr(self, "_found_inf_is_collective", False):
+            found_inf = udist.allreduce_max_(found_inf.clone())
+        div = float(world) if self.average else 1.0
+        devices = set()
+        small = []  # (group, p_view, g_view, state, key)
+        comm = 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                self._require_gpu(p)
+                st = self.state[p]
+                g = p.grad.contiguous().view(-1)
+                pf = p.data.view(-1)
+                n = g.numel()
+                if not st:
+                    st["step"] = 0
+                st["step"] += 1
+                if n < self.shard_min_numel:
+                    if "exp_avg" not in st:
+                        st["exp_avg"] = torch.zeros_like(pf)
+                        st["exp_avg_sq"] = torch.zeros_like(pf)
+                    small.append((group, pf, g, st["exp_avg"], st["exp_avg_sq"],
+                                  st["step"]))
+                    torch.autograd.graph.increment_version(p)
+                    continue
+                per = (n // world) // 4 * 4   # slices stay 16-byte aligned
+                body = per * world
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros(per, device=p.device)
+                    st["exp_avg_sq"] = torch.zeros(per, device=p.device)
+                    st["tail_exp_avg"] = torch.zeros(n - body, device=p.device)
+                    st["tail_exp_avg_sq"] = torch.zeros(n - body, device=p.device)
+                if self.comm_dtype is not None:
+                    gh = g[:body].to(self.comm_dtype)
+                    oh = torch.empty(per, dtype=self.comm_dtype, device=p.device)
+                    udist.reduce_scatter_sum_(oh, gh)
+                    g_shard = oh.float()
+                    comm += body * gh.element_size()
+                else:
+                    g_shard = torch.empty(per, device=p.device)
+                    udist.reduce_scatter_sum_(g_shard, g[:body])
+                    comm += body * 4
+                p_shard = pf[rank * per:(rank + 1) * per]
+                self._apply(p_shard, g_shard, st["exp_avg"], st["exp_avg_sq"],
+                            st["step"], group, grad_scale, found_inf, scaled,
+                            devices, extra_div=div)
+                udist.all_gather_into_(pf[:body], p_shard.clone())
+                comm += body * 4
+                if n > body:
+                    small.append((group, pf[body:], g[body:], st["tail_exp_avg"],
+                                  st["tail_exp_avg_sq"], st["step"]))
+                torch.autograd.graph.increment_version(p)
+        if small:
+            flat = torch.cat([g for (_, _, g, _, _, _) in small])
+            udist.allreduce_sum_([flat], small_bytes=0)
+            comm += flat.numel() * 4
+            off = 0
+            for group, pv, g, m, v, step in small:
+                k = g.numel()
+                # copies: the kernels need 16-byte-aligned-agnostic flat fp32
+                # views; slices of `flat` are fine as they are contiguous
+                self._apply(pv, flat[off:off + k], m, v, step, group, grad_scale,
+                            found_inf, scaled, devices, extra_div=div)
+                off += k
+        self.last_comm_bytes = comm
+        self._finish(devices)
         return loss
