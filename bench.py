@@ -12,10 +12,24 @@ collective ("scaling": "weak"); the only collectives are the timing barrier
 and the max-over-ranks of the elapsed time.
 
 One JSON line on rank 0; extra objects:
-  roofline      hash-grid encode kernel (dominant, HBM/gather bound)
-  roofline_mlp  composite kernel's colour/semantics MLPs (fp32 MFMA bound)
-  cpu_baseline  the CPU oracle (oracle/, "port") timed on the host cores on a
-                bounded sample of the same workload
+  roofline            dominant kernel (hash-grid gather; algorithmic bytes vs
+                      the 8 TB/s HBM line, measured HBM traffic, the resource
+                      that actually binds it)
+  roofline_composite  colour/semantics MLPs: fp32-MFMA peak (the mode it runs
+                      in) AND the FP16-dense peak SURVEY 8d prices the MLP
+                      stage against
+  roofline_step       whole view: algorithmic bytes and FLOP / ms_per_step
+  cpu_baseline        the CPU oracle (oracle/, "port") timed on the host cores
+                      on a bounded sample of the same workload
+  train_dp            (N > 1) the data-parallel NeRF training step: every rank
+                      its own 4096 rays, RCCL reduce-scatter / all-gather (or
+                      all-reduce) of the gradients, Adam
+
+Other modes (never the driver's default):
+  --mode train   value = rays/s TRAINED (4096 rays x (256+256) per rank and
+                 step, fwd + bwd + gradient collectives + Adam), weak scaling
+  --mode cfg4    BASELINE cfg4: 512 novel views of 640x480 round-robin over the
+                 ranks, no data-path collective, optional gather to rank 0
 """
 from __future__ import annotations
 
@@ -36,6 +50,9 @@ T_COARSE, T_FINE = 96, 96
 N_CLASSES = 40
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak
+F16_MFMA_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA (SURVEY 8d's MLP roofline)
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+PMC_JSON = "profiles/r02_pmc_traffic.json"
 
 
 def parse():
@@ -49,6 +66,15 @@ def parse():
                     help="Adam steps on the synthetic scene before timing "
                          "(SURVEY 8d: 200)")
     ap.add_argument("--no-train-bench", action="store_true")
+    ap.add_argument("--mode", choices=["render", "train", "cfg4"], default="render")
+    ap.add_argument("--replicated-adam", action="store_true",
+                    help="train legs: all-reduce + full Adam on every rank "
+                         "instead of the sharded optimizer")
+    ap.add_argument("--grad-comm-dtype", choices=["fp32", "fp16", "bf16"],
+                    default="fp32")
+    ap.add_argument("--views", type=int, default=512, help="cfg4: views in total")
+    ap.add_argument("--gather", action="store_true",
+                    help="cfg4: gather the images on rank 0 inside the timed region")
     return ap.parse_args()
 
 
@@ -148,6 +174,119 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
                         "fwd+bwd+Adam (reference native sizes; the 4096 random "
                         "pixels are handed over tile-ordered, ops.tile_order)",
             "ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt}
+
+
+def _nerf_optimizer(net, world, replicated=False, comm_dtype=None):
+    from ucsa_neural_rendering_amd.nerf.optim import HipAdam, ShardedHipAdam
+    groups = [{"name": "encoding", "params": list(net.encoder.parameters())},
+              {"name": "net", "params": list(net.sigma_net.parameters()) +
+               list(net.color_net.parameters()) +
+               list(net.semantics_net.parameters()), "weight_decay": 1e-6}]
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    if world > 1 and not replicated:
+        return ShardedHipAdam(groups, comm_dtype=comm_dtype, **kw)
+    return HipAdam(groups, **kw)
+
+
+def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
+                 n_rays=4096, T=256, t=256, replicated=False, comm_dtype=None):
+    """The data-parallel NeRF training step north_star describes (reference
+    DDP site scripts/train_joint.py:137-142, step
+    joint_train_lightning_net.py:497-513): every rank draws ITS OWN `n_rays`
+    pixels of ITS OWN frame, forward + backward on the HIP path, then the
+    NeRF-parameter gradients are averaged over RCCL -- reduce-scatter + Adam on
+    a 1/N slice + all-gather (ShardedHipAdam) or one all-reduce + replicated
+    Adam -- weak scaling: `value` = world x n_rays / step time."""
+    import copy
+    from ucsa_neural_rendering_amd import dist as udist, losses as ul, ops
+    net = copy.deepcopy(net).train()
+    opt = _nerf_optimizer(net, world, replicated, comm_dtype)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)      # rank-specific draws
+    params = list(net.parameters())
+
+    def one(it):
+        item = ds[(it * world + rank) % len(ds)]                # rank-specific frame
+        inds = torch.randint(0, 240 * 320, (n_rays,), device=dev, generator=g)
+        inds = ops.tile_order(inds, 320, H=240)
+        out = net.render(item["rays_o"][inds][None], item["rays_d"][inds][None],
+                         item["direction_norms"][inds][None], perturb=True,
+                         num_steps=T, upsample_steps=t,
+                         rng_t=torch.rand(n_rays, T, device=dev, generator=g),
+                         rng_u=torch.rand(n_rays, t, device=dev, generator=g))
+        lc, ls, ld = ul.nerf_losses(out["image"], out["semantics"], out["depth"],
+                                    item["img"].reshape(3, -1).t()[inds][None],
+                                    item["label"].reshape(-1)[inds][None],
+                                    item["depth"].float().reshape(-1)[inds][None], 1.0)
+        loss = ul.nerf_total_loss(lc, ls, ld)
+        opt.zero_grad()
+        loss.backward()
+        if not getattr(opt, "handles_collectives", False):
+            udist.average_grads_(params)
+        opt.step()
+        return loss
+
+    for it in range(warmup):
+        one(it)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        loss = one(warmup + it)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    res = {}
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # replicas must still be identical: compare a parameter checksum
+        cs = torch.stack([p.detach().double().sum() for p in params])
+        cs = cs.to(dev if backend == "nccl" else "cpu")
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        res["replicas_identical"] = bool(torch.equal(lo, hi))
+        # the collectives alone, on gradient-sized buffers (k iterations)
+        n_grid = net.encoder.params.numel()
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        buf = torch.zeros(n_grid, device=cdev)
+        per = (n_grid // world) // 4 * 4
+        shard = torch.zeros(per, device=cdev)
+
+        def timed(fn, k=10):
+            fn()
+            if cdev.type == "cuda":
+                torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            if cdev.type == "cuda":
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / k * 1e3
+
+        res["allreduce_ms"] = timed(lambda: dist.all_reduce(buf))
+        res["reduce_scatter_allgather_ms"] = timed(lambda: (
+            dist.reduce_scatter_tensor(shard, buf[:per * world]),
+            dist.all_gather_into_tensor(buf[:per * world], shard)))
+        res["collective_ranks"] = dist.get_world_size()
+        res["collective_backend"] = dist.get_backend()
+        res["grad_payload_bytes"] = n_grid * 4
+    dt = elapsed / steps
+    res.update({
+        "workload": f"data-parallel NeRF train step: {n_rays} rays x ({T}+{t}) "
+                    "samples per rank (own frame, own pixels, tile-ordered), "
+                    "fwd+bwd, gradient average over the ranks, Adam",
+        "optimizer": type(opt).__name__ + ("" if comm_dtype is None else f"[{comm_dtype}]"),
+        "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt,
+        "rays_per_step_total": world * n_rays, "final_loss": float(loss.detach()),
+        "comm_bytes_per_step_per_rank": getattr(opt, "last_comm_bytes", None),
+    })
+    return res
 
 
 def seg_throughput(device, steps=5, B=8):
@@ -443,6 +582,13 @@ def main():
     prelog = {}
     net, scene_ds = build_field(dev, train_steps=args.pretrain_steps, log=prelog)
     net.hip_ray_chunk = 65536
+    comm_dtype = {"fp32": None, "fp16": torch.float16,
+                  "bf16": torch.bfloat16}[args.grad_comm_dtype]
+    if args.mode == "train":
+        return main_train(args, net, scene_ds, dev, dist, world, rank, backend,
+                          prelog, comm_dtype)
+    if args.mode == "cfg4":
+        return main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog)
     intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
     n_views = args.steps + args.warmup
     from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
@@ -501,6 +647,12 @@ def main():
         mlp_flop = masked * (12544 + 7040)
         mlp_tf = mlp_flop / (st["composite"] * 1e-3) / 1e12
         sig_tf = samples * 6144 / (0.5 * (st["sigma_c"] + st["sigma_f"]) * 1e-3) / 1e12
+        ms_step = elapsed / args.steps * 1e3
+        S = T_COARSE + T_FINE
+        # whole view, SURVEY 8d / BASELINE.md 2.4 definitions
+        step_bytes_fp32 = H * W * (204 + S * 1024)        # this build: fp32 table
+        step_bytes_fp16 = H * W * (204 + S * 512)         # the definition's fp16 table
+        step_flop = H * W * S * (6144 + rho * 19584)
         result = {
             "metric": "rays/sec",
             "value": value,
@@ -508,7 +660,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -538,6 +690,12 @@ def main():
                 "traffic": None,
                 "launch_ms": enc_ms,
                 "algorithmic_bytes_per_launch": enc_bytes,
+                "note": "achieved = ALGORITHMIC gather bytes (1024 B/sample) / "
+                        "launch time: a nominal figure against the HBM line, "
+                        "NOT HBM utilisation (hbm_utilisation below is: measured "
+                        "traffic / time / peak).  The table slice a launch phase "
+                        "works on is L2/MALL resident; what binds the kernel is "
+                        "the L2->L1 path of divergent gathers (binding_resource)",
             },
             "roofline_composite": {
                 "kernel": "k_composite (colour+semantics MLPs, fp32 MFMA)",
@@ -546,22 +704,60 @@ def main():
                 "peak": F32_MFMA_PEAK_TF,
                 "unit": "TFLOP/s",
                 "frac": mlp_tf / F32_MFMA_PEAK_TF,
+                "frac_of_fp16_dense_peak": mlp_tf / F16_MFMA_PEAK_TF,
                 "launch_ms": st["composite"],
                 "traffic": None,
                 "sigma_mlp_tflops": sig_tf,
+                "note": "peak = fp32-input MFMA (the instruction the parity mode "
+                        "issues, 1/16 of the fp16 rate); frac_of_fp16_dense_peak "
+                        "is the same achieved rate against SURVEY 8d's 2.5 PF line",
+            },
+            "roofline_step": {
+                "what": "one 640x480 view end to end (ms_per_step)",
+                "hbm": {"algorithmic_bytes_fp32_table": step_bytes_fp32,
+                        "achieved_gbs_fp32_table": step_bytes_fp32 / ms_step / 1e6,
+                        "frac_fp32_table": step_bytes_fp32 / ms_step / 1e6 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_fp16_table_definition": step_bytes_fp16,
+                        "frac_fp16_table_definition":
+                            step_bytes_fp16 / ms_step / 1e6 / HBM_PEAK_GBS,
+                        "peak_gbs": HBM_PEAK_GBS},
+                "mfma": {"algorithmic_flop": step_flop,
+                         "achieved_tflops": step_flop / ms_step / 1e9,
+                         "frac_of_fp16_dense_peak":
+                             step_flop / ms_step / 1e9 / F16_MFMA_PEAK_TF,
+                         "frac_of_fp32_mfma_peak":
+                             step_flop / ms_step / 1e9 / F32_MFMA_PEAK_TF,
+                         "peak_fp16_dense_tflops": F16_MFMA_PEAK_TF},
             },
             "stage_ms_per_chunk": st,
         }
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot
-        # run inside this process); null when the profile file is absent
+        # run inside this process): only when they were collected on the same
+        # parameter state (pretrain steps) as this run, else null
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles",
-                                              "r01_pmc_traffic.json")))
-            for key, kn in (("roofline_composite", "k_composite"),
-                            ("roofline_encode", "k_hashgrid_encode_tiled")):
-                result[key]["traffic"] = (pmc[kn]["fetch_bytes"] +
-                                          pmc[kn]["write_bytes"])
-                result[key]["traffic_source"] = "profiles/r01_pmc_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, PMC_JSON)))
+            if int(pmc.get("pretrain_steps", -1)) == int(args.pretrain_steps):
+                for key, kn in (("roofline_composite", "k_composite"),
+                                ("roofline_encode", "k_hashgrid_encode_tiled")):
+                    tr = pmc[kn]["fetch_bytes"] + pmc[kn]["write_bytes"]
+                    r = result[key]
+                    r["traffic"] = tr
+                    r["traffic_source"] = PMC_JSON
+                    r["hbm_utilisation"] = tr / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    if "tcc_hit_rate" in pmc[kn]:
+                        r["tcc_hit_rate"] = pmc[kn]["tcc_hit_rate"]
+                    if key == "roofline_composite" and "mfma_busy_frac" in pmc[kn]:
+                        r["mfma_pipe_busy_frac"] = pmc[kn]["mfma_busy_frac"]
+                e = result["roofline_encode"]
+                if "l2_request_bytes" in pmc["k_hashgrid_encode_tiled"]:
+                    l2b = pmc["k_hashgrid_encode_tiled"]["l2_request_bytes"]
+                    e["binding_resource"] = {
+                        "resource": "L2 -> L1 (TCP) path of divergent gathers",
+                        "achieved_gbs": l2b / (e["launch_ms"] * 1e-3) / 1e9,
+                        "peak_gbs": L2_PEAK_GBS,
+                        "frac": l2b / (e["launch_ms"] * 1e-3) / 1e9 / L2_PEAK_GBS,
+                        "bytes_per_launch": l2b,
+                        "source": "TCC request counter x 128-B lines (" + PMC_JSON + ")"}
         except (OSError, KeyError, ValueError):
             pass
         # "roofline" = the kernel with the largest share of the step
@@ -608,8 +804,10 @@ def main():
             try:
                 result["march_option"] = march_option(net, scene_ds, rays,
                                                       n_views, out, dev, args)
-            except Exception as e:  # the headline line must survive
-                result["march_option"] = {"error": repr(e)}
+            except Exception as e:  # the headline line must survive, loudly
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                result["march_option"] = {"error": repr(e), "failed": True}
         if extras and not args.no_train_bench:
             result["train"] = train_throughput(net, scene_ds, dev)
             result["seg"] = seg_throughput(dev)
@@ -633,10 +831,109 @@ def main():
                           f"T={T_COARSE}/t={T_FINE}, best of 2 ({dt:.1f} s each)",
             }
             result["speedup_vs_cpu"] = value / v
+    if world > 1:
+        # the data-parallel training step with its gradient collectives: all
+        # ranks take part; rank 0 reports it next to the render line
+        tr = dp_train_leg(net, scene_ds, dev, dist, world, rank, backend,
+                          steps=min(args.steps, 20), replicated=args.replicated_adam,
+                          comm_dtype=comm_dtype)
+        if rank == 0:
+            result["train_dp"] = tr
+    if rank == 0:
         print(json.dumps(result))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _finish(dist, rank, result):
+    if rank == 0:
+        print(json.dumps(result))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_train(args, net, scene_ds, dev, dist, world, rank, backend, prelog,
+               comm_dtype):
+    """--mode train: `value` = rays/s trained by the data-parallel step."""
+    tr = dp_train_leg(net, scene_ds, dev, dist, world, rank, backend,
+                      steps=args.steps, warmup=args.warmup,
+                      replicated=args.replicated_adam, comm_dtype=comm_dtype)
+    result = {
+        "metric": "rays/sec", "value": tr["rays_per_s"], "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": tr["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg3 NeRF half, data-parallel: " + tr["workload"],
+                   "mode": "train", "pretrain": prelog,
+                   "optimizer": tr["optimizer"]},
+        "train_dp": tr,
+    }
+    _finish(dist, rank, result)
+
+
+def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
+    """--mode cfg4: `--views` novel 640x480 views round-robin over the ranks
+    (BASELINE cfg4: 512), parameters replicated, no data-path collective;
+    `--gather` additionally collects the images on rank 0 inside the timed
+    region (the only collective a render job can need)."""
+    from ucsa_neural_rendering_amd import dist as udist, ops
+    from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
+    intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
+    mine = udist.shard_round_robin(args.views, rank, world)
+    poses = _slerp_loop_poses(args.views, seed=999)[mine].to(dev)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    u = torch.rand(H * W, T_FINE, device=dev, generator=g)
+
+    def view(i):
+        o, d, nrm = ops.get_rays(poses[i:i + 1], intr, H, W)   # a1 inside the job
+        with torch.no_grad():
+            return net.render(o, d, nrm, staged=True, perturb=False,
+                              num_steps=T_COARSE, upsample_steps=T_FINE,
+                              rng_u=u, image_width=W)
+
+    for i in range(min(args.warmup, len(mine))):
+        view(i)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kept = []
+    for i in range(len(mine)):
+        out = view(i)
+        if args.gather:
+            kept.append((out["image"][0] * 255).to(torch.uint8))
+    if args.gather and dist:
+        loc = torch.stack(kept) if kept else torch.empty(0, H * W, 3, dtype=torch.uint8, device=dev)
+        if backend != "nccl":
+            loc = loc.cpu()
+        sizes = [len(udist.shard_round_robin(args.views, r, world)) for r in range(world)]
+        udist.gather_rows(loc, sizes)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    result = {
+        "metric": "rays/sec", "value": args.views * H * W / elapsed,
+        "unit": "rays/s", "n_gpus": world, "steps": args.views,
+        "warmup": args.warmup, "ms_per_step": elapsed / max(1, len(mine)) * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfg4: {args.views} novel views x 640x480 x 192 "
+                               "samples/ray, views round-robin over the ranks, "
+                               "get_rays + render per view",
+                   "mode": "cfg4", "views_per_rank": len(mine),
+                   "gather_to_rank0": bool(args.gather), "pretrain": prelog,
+                   "total_s": elapsed},
+    }
+    _finish(dist, rank, result)
 
 
 if __name__ == "__main__":

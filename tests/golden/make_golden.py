@@ -356,6 +356,228 @@ def main():
     save("g7_meter.npz", preds=preds, truths=truths, conf_mat=m.conf_mat,
          miou=miou, total_acc=acc, class_avg_acc=float(cacc), C=C)
 
+    make_dataset_fixture()
+    make_loss_fixture()
+
+
+# ---------------------------------------------------------------------------
+# G6: the NeRF losses of forward_nerf_train (reference
+# nr4seg/lightning/joint_train_lightning_net.py:167-223: gather of the ground
+# truth at the drawn pixels from the fp16 image / depth, the invalid-semantics
+# rule, MSE / NLL(log(p+1e-15)) / L1 on valid depth) and the weighting of
+# :503-507.  The module imports PyTorch-Lightning, torchvision, cv2 and the
+# CUDA-only field at import time: all stubbed (none is used by this method);
+# the method then runs on a stand-in `self` whose get_rays_train / render
+# return recorded tensors.
+# ---------------------------------------------------------------------------
+def load_reference_lightning():
+    for name in ("cv2", "torchvision", "torchvision.transforms",
+                 "torchvision.transforms.functional", "pytorch_lightning",
+                 "nr4seg.nerf.network_tcnn_semantics", "nr4seg.network",
+                 "nr4seg.visualizer"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = \
+        sys.modules["torchvision.transforms.functional"]
+    sys.modules["pytorch_lightning"].LightningModule = torch.nn.Module
+    sys.modules["nr4seg.nerf.network_tcnn_semantics"].SemanticNeRFNetwork = object
+    sys.modules["nr4seg.network"].DeepLabV3 = object
+    sys.modules["nr4seg.visualizer"].Visualizer = object
+    if "nr4seg.dataset.ngp_utils" not in sys.modules:
+        _load("nr4seg.dataset.ngp_utils", "nr4seg/dataset/ngp_utils.py")
+    if "nr4seg.utils.metrics" not in sys.modules:
+        _load("nr4seg.utils.metrics", "nr4seg/utils/metrics.py")
+    return _load("nr4seg.lightning.joint_train_lightning_net",
+                 "nr4seg/lightning/joint_train_lightning_net.py")
+
+
+def make_loss_fixture():
+    import warnings
+    warnings.simplefilter("ignore")
+    mod = load_reference_lightning()
+    cls = mod.JointTrainLightningNet
+    g = torch.Generator().manual_seed(31)
+    H, W, C, N = 12, 16, 40, 150
+    out = {}
+    for tag in ("a", "b"):
+        img16 = torch.rand(2, 3, H, W, generator=g).half()
+        depth16 = (torch.rand(2, H, W, generator=g) * 3).half()
+        depth16[:, ::3, ::2] = 0                       # invalid depth pixels
+        seg = torch.randint(0, C, (2, H, W), generator=g)
+        inds = torch.randint(0, H * W, (1, N), generator=g)   # duplicates allowed
+        uom = 0.73
+        image = torch.rand(1, N, 3, generator=g).requires_grad_()
+        depth = (torch.rand(1, N, generator=g) * 3).requires_grad_()
+        sem0 = torch.rand(1, N, C, generator=g) * 0.05
+        if tag == "a":
+            sem0[0, :9] = 0                            # some invalid rows
+        else:
+            sem0[:] = 0                                # every row invalid -> None
+        sem = sem0.clone().requires_grad_()
+
+        class _Nerf:
+            def render(self, *a, **k):
+                # the method writes into outputs["semantics"] in place
+                return {"image": image * 1.0, "semantics": sem * 1.0,
+                        "depth": depth * 1.0}
+
+        me = types.SimpleNamespace(
+            get_rays_train=lambda batch, bs: (None, None, None, inds),
+            nerf_model=_Nerf(), current_epoch=0,
+            criterion_nerf_rgb=torch.nn.MSELoss(reduction="none"),
+            criterion_nerf_semantics=torch.nn.NLLLoss(ignore_index=-1, reduction="none"),
+            criterion_nerf_depth=torch.nn.L1Loss(reduction="none"))
+        # fp16-ROUNDED values held in fp32 tensors: on the GPU the method runs
+        # under CUDA autocast, which casts the operands of mse_loss / l1_loss /
+        # nll_loss to fp32; that context is inert here (no CUDA), and CPU
+        # autograd refuses mixed Half/Float operands, so the cast is made up
+        # front -- same values, same fp32 arithmetic
+        batch = {"img_fp16": img16.float(), "depth": depth16.float(),
+                 "one_m_to_scene_uom": torch.tensor([uom, uom])}
+        bs = 1
+        lc, ls, ld = cls.forward_nerf_train(me, batch, {"seg_semantics": seg}, bs)
+        total = lc
+        if ls is not None:
+            total = total + ls * 0.04                  # weight_semantics (:45)
+        total = total + ld * 0.1                       # weight_depth (:44)
+        total.backward()
+        out.update({
+            f"{tag}_img_fp16": img16.float(), f"{tag}_depth_fp16": depth16.float(),
+            f"{tag}_seg": seg, f"{tag}_inds": inds, f"{tag}_uom": uom, f"{tag}_bs": bs,
+            f"{tag}_image": image, f"{tag}_depth": depth, f"{tag}_sem": sem0,
+            f"{tag}_loss_color": lc, f"{tag}_loss_depth": ld,
+            f"{tag}_loss_sem": float("nan") if ls is None else ls,
+            f"{tag}_sem_is_none": ls is None, f"{tag}_total": total,
+            f"{tag}_g_image": image.grad, f"{tag}_g_depth": depth.grad,
+            f"{tag}_g_sem": torch.zeros_like(sem0) if sem.grad is None else sem.grad})
+    save("g6_nerf_losses.npz", **out)
+
+
+# ---------------------------------------------------------------------------
+# G8: the per-scene dataset's INDEX logic: 80/20 split,
+# path construction, replay selection (random.Random(0).shuffle + per-scene
+# quota), old/new flags, Slerp novel viewpoints and the interpolated_data.json
+# hand-over -- reference nr4seg/dataset/scannet_ngp_joint.py:113-291, imported
+# here with stubs for cv2 (only used by __getitem__'s decoders) and for
+# helper.AugmentationList (torchvision).  Only transforms_train.json files are
+# needed for this part of the class; they are generated below from a seed and
+# stored in the fixture together with what the reference made of them.
+# ---------------------------------------------------------------------------
+def dataset_layout(root, n_frames):
+    """Ten scenes with seeded poses; returns {scene: frames}."""
+    import json
+    out = {}
+    for k in range(10):
+        name = f"scene{k:04d}_00"
+        rs = np.random.RandomState(100 + k)
+        frames = []
+        for i in range(n_frames[k]):
+            m = np.eye(4)
+            q, _ = np.linalg.qr(rs.randn(3, 3))
+            m[:3, :3] = q * np.sign(np.linalg.det(q))
+            m[:3, 3] = rs.randn(3)
+            frames.append({"file_path": f"color/{i * 10}.jpg",
+                           "label_path": f"label_40/{i * 10}.png",
+                           "transform_matrix": m.tolist()})
+        os.makedirs(os.path.join(root, name), exist_ok=True)
+        info = {"h": 240, "w": 320, "fl_x": 290.0 + k, "fl_y": 291.0 + k,
+                "cx": 160.0, "cy": 120.0, "one_m_to_scene_uom": 0.3 + 0.01 * k,
+                "frames": frames}
+        with open(os.path.join(root, name, "transforms_train.json"), "w") as f:
+            json.dump(info, f)
+        out[name] = info
+    return out
+
+
+DATASET_CASES = [
+    # (tag, kwargs) -- scene_list is always given in full; the class trims it
+    ("train_new_only", dict(scene_list=["scene0000_00", "scene0001_00", "scene0002_00"],
+                            mode="train")),
+    ("train_fix_nerf", dict(scene_list=["scene0002_00"], mode="train", fix_nerf=True)),
+    ("val", dict(scene_list=["scene0002_00"], mode="val", only_new_scene=False)),
+    ("train_val", dict(scene_list=["scene0002_00"], mode="train_val", only_new_scene=False)),
+    ("predict", dict(scene_list=["scene0000_00", "scene0001_00"], mode="predict")),
+    # writes <scene>/e/novel_viewpoints/interpolated_data.json for scenes 0, 1
+    ("predict_novel_0", dict(scene_list=["scene0000_00"], mode="predict",
+                             use_novel_viewpoints=True)),
+    ("predict_novel_1", dict(scene_list=["scene0000_00", "scene0001_00"], mode="predict",
+                             use_novel_viewpoints=True)),
+    ("joint_replay", dict(scene_list=["scene0000_00", "scene0001_00", "scene0002_00"],
+                          mode="train", only_new_scene=False, replay_buffer_size=7)),
+    ("joint_replay_novel", dict(scene_list=["scene0000_00", "scene0001_00", "scene0002_00"],
+                                mode="train", only_new_scene=False, replay_buffer_size=7,
+                                use_novel_viewpoints=True)),
+    ("joint_no_replay", dict(scene_list=["scene0000_00", "scene0002_00"], mode="train",
+                             only_new_scene=False)),
+]
+
+
+def dataset_state(ds, root):
+    """What the index holds, with paths made relative to the root."""
+    rel = lambda p: None if p is None else os.path.relpath(p, root)
+    return {
+        "length": len(ds),
+        "image_pths": [rel(p) for p in ds.image_pths],
+        "label_pths": [rel(p) for p in ds.label_pths],
+        "depth_pths": [rel(p) for p in ds.depth_pths],
+        "nerf_image_pths": [rel(p) for p in ds.nerf_image_pths],
+        "nerf_label_pths": [rel(p) for p in ds.nerf_label_pths],
+        "from_old_scene": [bool(v) for v in ds.from_old_scene],
+        "viewpoint_is_novel": [bool(v) for v in ds.viewpoint_is_novel],
+        "poses": np.asarray(ds.poses, dtype=np.float64).tolist(),
+        "ngp_intrinsics": [float(v) for v in ds.ngp_intrinsics],
+        "one_m_to_scene_uom": float(ds.one_m_to_scene_uom),
+        "ngp_HW": [int(ds.ngp_H), int(ds.ngp_W)],
+    }
+
+
+def make_dataset_fixture():
+    import contextlib
+    import io
+    import json
+    import tempfile
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    helper = types.ModuleType("nr4seg.dataset.helper")
+    helper.AugmentationList = lambda *a, **k: None
+    sys.modules["nr4seg.dataset.helper"] = helper
+    if "nr4seg.dataset.ngp_utils" not in sys.modules:
+        _load("nr4seg.dataset.ngp_utils", "nr4seg/dataset/ngp_utils.py")
+    mod = _load("nr4seg.dataset.scannet_ngp_joint",
+                "nr4seg/dataset/scannet_ngp_joint.py")
+    n_frames = [10, 12, 15, 5, 5, 5, 6, 5, 5, 7]
+    with tempfile.TemporaryDirectory() as root:
+        dataset_layout(root, n_frames)
+        cases = {}
+        for tag, kw in DATASET_CASES:
+            with contextlib.redirect_stdout(io.StringIO()):  # the class prints
+                ds = mod.ScanNetNGPJoint(root, exp_name="e", **kw)
+            cases[tag] = dataset_state(ds, root)
+        gen = {}
+        for k in (0, 1):
+            pth = os.path.join(root, f"scene{k:04d}_00", "e", "novel_viewpoints",
+                               "interpolated_data.json")
+            with open(pth) as f:
+                fr = json.load(f)["frames"]
+            gen[f"scene{k:04d}_00"] = [
+                {"nerf_image": os.path.relpath(x["nerf_image"], root),
+                 "nerf_label": os.path.relpath(x["nerf_label"], root),
+                 "pose": x["pose"]} for x in fr]
+    path = os.path.join(HERE, "g8_dataset_index.json")
+    with open(path, "w") as f:
+        json.dump({"n_frames": n_frames, "cases": cases,
+                   "interpolated_data": gen}, f)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} kB)")
+
 
 if __name__ == "__main__":
-    main()
+    if "--dataset-only" in sys.argv:
+        load_reference()
+        make_dataset_fixture()
+    elif "--losses-only" in sys.argv:
+        load_reference()
+        make_loss_fixture()
+    else:
+        main()

@@ -1,30 +1,47 @@
 """Row a14 at BASELINE cfg3's size: the DeepLabV3 mirror
 (``network/deeplabv3.py``; reference ``nr4seg/network/deeplabv3.py:6-19``,
 called at ``joint_train_lightning_net.py:159-165`` and ``:456-461``) on the
-MI355X against the SAME module run in fp32 on the host CPU -- logits,
+MI355X against the SAME module evaluated on the host CPU -- logits,
 CE-on-softmax loss (``ucsa_seg_tail`` vs the torch modules the reference
-instantiates) and every parameter gradient, for ``[8, 3, 240, 320]`` inputs
-and 40 classes, ResNet-50 (cfg3's wording) and ResNet-101 (the reference's
-model).
+instantiates), every parameter gradient and the BatchNorm running statistics,
+for ``[8, 3, 240, 320]`` inputs and 40 classes, ResNet-50 (cfg3's wording)
+and ResNet-101 (the reference's model).
 
-Layouts / precisions covered: fp32 NCHW (the reference's), fp32
-channels_last (``PointwiseConv2d`` = one GEMM over the NHWC view), bf16
-autocast + channels_last (the optional fast path; its own, looser tolerance).
+How the fp32 tolerance is stated.  A randomly initialised 50/100-layer ReLU
+network amplifies rounding errors by ~1e3-1e4 (measured here: the CPU's own
+fp32 NCHW and fp32 channels_last runs of this module differ by 3e-4 in the
+logits and 3e-2 relative L2 in the gradients; ReLU gates next to zero flip).
+A fixed "1e-3" on the gradients would therefore test the conditioning of the
+random network, not the GPU.  The test computes the truth in **fp64 on the
+CPU** and requires
 
-Stated tolerances (fp32): logits <= 1e-3 absolute, loss <= 1e-5 relative,
-parameter gradients <= 1e-3 relative L2 over all parameters.  bf16: logits
-<= 0.25 absolute / 3e-2 relative L2, gradients <= 0.15 relative L2.
+    error(GPU fp32 vs fp64)  <=  3 x error(CPU fp32 vs fp64)  (+ 1e-6 floor)
+
+for train-mode logits, eval-mode logits, running statistics and gradients
+(relative L2 over all parameters), i.e. the MI355X path is as accurate as the
+reference's own CPU/PyTorch fp32 path on identical inputs, and in absolute
+terms: logits <= 5e-3 x max|logit|, loss <= 2e-6 relative.  Layouts: fp32 NCHW
+(the reference's) and fp32 channels_last (``PointwiseConv2d`` = one GEMM over
+the NHWC view).
+
+bf16 (``model: {amp: bf16}``, optional fast path, never the parity path): at
+that amplification a whole-network comparison is noise (measured: logits 0.7
+relative L2), so the bf16 / channels_last kernels are checked SECTION by
+section (stem + layer1, a dilated layer4 block, the ASPP head incl. the
+pooling branch at batch 2 -- the shape that used to crash, see
+``ASPPPooling.forward``) on identical fp32 inputs: outputs, input gradients
+and parameter gradients <= 4e-2 relative L2 against the CPU fp32 section.
 
 Dropout(0.5) in the ASPP projection draws from the device RNG, which cannot
-be replayed across devices: the train-mode pass runs with BatchNorm in batch-
-statistics mode and Dropout disabled (p -> identity) on both sides.  That
+be replayed across devices: Dropout is disabled on both sides.  The train-mode
 pass runs with BatchNorm momentum 1, so the running statistics it leaves are
 the batch's (compared too), and the eval-mode forward that follows (the
 pseudo-label pass, reference :374-381) runs on realistic statistics.
 
 If torchvision is importable on the box, the same state_dict is loaded
 (strict) into ``torchvision.models.segmentation.deeplabv3_resnet*`` and the
-logits compared -- that pins the mirror to the third-party model itself."""
+logits compared -- that pins the mirror to the third-party model itself
+(absent on this image: skipped)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -68,10 +85,10 @@ def _train_mode(m):
     return m
 
 
-def _cpu_reference(backbone):
-    """fp32 CPU: eval logits; train-mode logits, loss, gradients."""
-    m = _model(backbone)
+def _cpu_pass(backbone, dtype):
+    m = _model(backbone).to(dtype)
     x, y = _inputs()
+    x = x.to(dtype)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     _train_mode(m)
     out = m(x)["out"]
@@ -84,8 +101,33 @@ def _cpu_reference(backbone):
     m.eval()   # running statistics = the batch's (momentum 1)
     with torch.no_grad():
         ev = m(x)["out"]
-    return dict(sd=sd, eval_logits=ev, logits=out.detach(), loss=float(loss),
+    return dict(sd=sd, eval_logits=ev, logits=out.detach(), loss=float(loss.detach()),
                 grads=grads, stats=stats)
+
+
+def _cpu_reference(backbone):
+    """truth = fp64 CPU; `floor` = what the CPU's own fp32 run is off by."""
+    truth = _cpu_pass(backbone, torch.float64)
+    c32 = _cpu_pass(backbone, torch.float32)
+    truth["sd"] = c32["sd"]                        # fp32 weights for the GPU model
+    truth["floor"] = _errors(c32, truth)
+    return truth
+
+
+def _flat(grads, keys):
+    return torch.cat([grads[k].reshape(-1).double().cpu() for k in keys])
+
+
+def _errors(run, truth):
+    keys = list(truth["grads"])
+    st = max(float((run["stats"][k].double().cpu() - v).abs().max() /
+                   max(1.0, float(v.abs().max()))) for k, v in truth["stats"].items())
+    return dict(
+        logits=float((run["logits"].double().cpu() - truth["logits"]).abs().max()),
+        eval_logits=float((run["eval_logits"].double().cpu() - truth["eval_logits"]).abs().max()),
+        loss=abs(run["loss"] - truth["loss"]) / abs(truth["loss"]),
+        grad=_rel_l2(_flat(run["grads"], keys), _flat(truth["grads"], keys)),
+        stats=st)
 
 
 _REF = {}
@@ -125,58 +167,95 @@ def _gpu_run(backbone, mode):
     m.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         ev = m(x)["out"].float()
-    return dict(eval_logits=ev, logits=out.detach().float(), loss=float(loss),
+    return dict(eval_logits=ev, logits=out.detach().float(), loss=float(loss.detach()),
                 grads=grads, stats=stats)
 
 
 @pytest.mark.parametrize("backbone", ["resnet50", "resnet101"])
 @pytest.mark.parametrize("mode", ["fp32_nchw", "channels_last"])
 def test_deeplab_fp32_forward_backward_matches_cpu(backbone, mode):
-    ref = _ref(backbone)
+    truth = _ref(backbone)
+    floor = truth["floor"]
     got = _gpu_run(backbone, mode)
-    scale = max(1.0, float(ref["logits"].abs().max()))
-    print(f"[{backbone} {mode}] max|logits| {scale:.3f}  train dlogits "
-          f"{float((got['logits'].cpu() - ref['logits']).abs().max()):.3e}  eval dlogits "
-          f"{float((got['eval_logits'].cpu() - ref['eval_logits']).abs().max()):.3e}  "
-          f"loss {got['loss']:.7f} vs {ref['loss']:.7f}")
-    assert float((got["logits"].cpu() - ref["logits"]).abs().max()) <= 1e-3 * scale
-    # BatchNorm running statistics after the pass (momentum 1: the batch's)
-    for k, v in ref["stats"].items():
-        assert float((got["stats"][k].cpu() - v).abs().max()) <= 1e-4 * max(
-            1.0, float(v.abs().max())), k
-    scale = max(1.0, float(ref["eval_logits"].abs().max()))
-    assert float((got["eval_logits"].cpu() - ref["eval_logits"]).abs().max()) <= 1e-3 * scale
-    assert abs(got["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"])
-    flat_g = torch.cat([got["grads"][k].reshape(-1).cpu() for k in ref["grads"]])
-    flat_r = torch.cat([ref["grads"][k].reshape(-1) for k in ref["grads"]])
-    print(f"[{backbone} {mode}] grad rel L2 {_rel_l2(flat_g, flat_r):.3e}")
-    assert _rel_l2(flat_g, flat_r) <= 1e-3
-    # no parameter is left without a gradient, none is wildly off on its own
-    worst = max((_rel_l2(got["grads"][k], ref["grads"][k]), k)
-                for k in ref["grads"] if float(ref["grads"][k].norm()) > 1e-6 * float(flat_r.norm()))
-    print(f"[{backbone} {mode}] worst single parameter {worst}")
-    assert worst[0] <= 2e-2, worst
+    err = _errors(got, truth)
+    scale = max(1.0, float(truth["logits"].abs().max()))
+    print(f"[{backbone} {mode}] max|logit| {scale:.3f}; error vs fp64  GPU fp32: "
+          + " ".join(f"{k} {v:.3e}" for k, v in err.items())
+          + "  |  CPU fp32: " + " ".join(f"{k} {v:.3e}" for k, v in floor.items()))
+    for k in ("logits", "eval_logits", "grad", "stats"):
+        assert err[k] <= 3.0 * floor[k] + 1e-6, (k, err[k], floor[k])
+    assert err["logits"] <= 5e-3 * scale and err["eval_logits"] <= 5e-3 * scale
+    assert err["loss"] <= 2e-6
+    # every parameter received a gradient
+    assert all(got["grads"][k] is not None for k in truth["grads"])
 
 
-@pytest.mark.parametrize("backbone", ["resnet50", "resnet101"])
-def test_deeplab_bf16_channels_last_within_its_tolerance(backbone):
-    """`model: {amp: bf16}` (optional fast path, never the parity path)."""
-    ref = _ref(backbone)
-    got = _gpu_run(backbone, "bf16")
-    flat_g = torch.cat([got["grads"][k].reshape(-1).float().cpu() for k in ref["grads"]])
-    flat_r = torch.cat([ref["grads"][k].reshape(-1) for k in ref["grads"]])
-    print(f"[{backbone} bf16] logits rel L2 {_rel_l2(got['logits'], ref['logits']):.3e} max "
-          f"{float((got['logits'].cpu() - ref['logits']).abs().max()):.3e}  eval rel L2 "
-          f"{_rel_l2(got['eval_logits'], ref['eval_logits']):.3e}  loss {got['loss']:.6f} vs "
-          f"{ref['loss']:.6f}  grad rel L2 {_rel_l2(flat_g, flat_r):.3e}")
-    assert _rel_l2(got["logits"], ref["logits"]) <= 3e-2
-    assert float((got["logits"].cpu() - ref["logits"]).abs().max()) <= 0.25 * max(
-        1.0, float(ref["logits"].abs().max()))
-    assert _rel_l2(got["eval_logits"], ref["eval_logits"]) <= 3e-2
-    assert abs(got["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"])
-    flat_g = torch.cat([got["grads"][k].reshape(-1).float().cpu() for k in ref["grads"]])
-    flat_r = torch.cat([ref["grads"][k].reshape(-1) for k in ref["grads"]])
-    assert _rel_l2(flat_g, flat_r) <= 0.15
+def _sections(backbone="resnet50"):
+    """(name, module factory, input shape): shallow pieces of the network."""
+    from ucsa_neural_rendering_amd.network.deeplabv3 import (Bottleneck, DeepLabHead,
+                                                              ResNetBackbone, _LAYERS)
+    import torch.nn as nn
+
+    def stem():
+        b = ResNetBackbone(_LAYERS[backbone])
+        return nn.Sequential(b.conv1, b.bn1, b.relu, b.maxpool, b.layer1)
+
+    def dilated_block():
+        ds = nn.Sequential(nn.Conv2d(1024, 2048, 1, bias=False), nn.BatchNorm2d(2048))
+        return nn.Sequential(Bottleneck(1024, 512, 1, ds, dilation=2),
+                             Bottleneck(2048, 512, dilation=4))
+
+    def head():
+        return DeepLabHead(2048, C)
+
+    return [("stem+layer1", stem, (8, 3, H, W)),
+            ("layer4 dilated blocks", dilated_block, (4, 1024, 30, 40)),
+            ("ASPP head, batch 8", head, (8, 2048, 30, 40)),
+            ("ASPP head, batch 2 (pooled BN on [2,256,1,1])", head, (2, 2048, 6, 8))]
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_deeplab_bf16_channels_last_sections(idx):
+    """`model: {amp: bf16}`: bf16 autocast + channels_last, section by
+    section (see the module docstring) against the CPU fp32 section."""
+    name, make, shape = _sections()[idx]
+    torch.manual_seed(idx)
+    ref = make()
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    g = torch.Generator().manual_seed(50 + idx)
+    x = torch.rand(*shape, generator=g)
+    ref.train()
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    cot = torch.randn(yr.shape, generator=g)
+    (yr * cot).sum().backward()
+    import copy
+    m = copy.deepcopy(ref).cuda().to(memory_format=torch.channels_last)
+    m.zero_grad()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yg = m(xg)
+    (yg.float() * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    e_out = _rel_l2(yg.float(), yr)
+    e_dx = _rel_l2(xg.grad, xr.grad)
+    pg = torch.cat([p.grad.reshape(-1).float().cpu() for p in m.parameters()])
+    pr = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    e_dw = _rel_l2(pg, pr)
+    print(f"[bf16 section {name}] out {e_out:.3e} dX {e_dx:.3e} dW {e_dw:.3e}")
+    assert e_out <= 4e-2 and e_dx <= 4e-2 and e_dw <= 4e-2, (name, e_out, e_dx, e_dw)
+    # fp32 channels_last on the same section: tight
+    m32 = copy.deepcopy(ref).cuda().to(memory_format=torch.channels_last)
+    x32 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    y32 = m32(x32)
+    (y32 * cot.cuda()).sum().backward()
+    p32 = torch.cat([p.grad.reshape(-1).cpu() for p in m32.parameters()])
+    print(f"[fp32 section {name}] out {_rel_l2(y32, yr):.3e} dX {_rel_l2(x32.grad, xr.grad):.3e} "
+          f"dW {_rel_l2(p32, pr):.3e}")
+    assert _rel_l2(y32, yr) <= 1e-4 and _rel_l2(x32.grad, xr.grad) <= 1e-3
+    assert _rel_l2(p32, pr) <= 1e-3
 
 
 @pytest.mark.parametrize("backbone", ["resnet50", "resnet101"])
@@ -198,5 +277,7 @@ def test_deeplab_matches_torchvision_when_present(backbone):
         want = t(x)["out"]
         got = t.cuda()(x.cuda())["out"]
     scale = max(1.0, float(ref["eval_logits"].abs().max()))
-    assert float((want - ref["eval_logits"]).abs().max()) <= 1e-4 * scale
-    assert float((got.cpu() - ref["eval_logits"]).abs().max()) <= 1e-3 * scale
+    fl = ref["floor"]["eval_logits"]
+    assert float((want.double() - ref["eval_logits"]).abs().max()) <= 3 * fl + 1e-6
+    assert float((got.cpu().double() - ref["eval_logits"]).abs().max()) <= 3 * fl + 1e-6
+    assert fl <= 5e-3 * scale

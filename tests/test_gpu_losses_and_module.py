@@ -259,3 +259,31 @@ def test_module_layout_and_precision_options_train(tmp_path, opts):
         assert k in logged and logged[k] == logged[k] and abs(logged[k]) < 1e6, (k, logged)
     rows = tr.logger.history
     assert any(r["name"] == "train/loss_seg" for r in rows)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_nerf_loss_kernel_matches_reference_fixture(ops, tag):
+    """ucsa_nerf_loss against G6: values and gradients produced by the
+    reference's own forward_nerf_train + weighting (:167-223, :503-507)."""
+    from tests.test_oracle_golden import _g6_case
+    from ucsa_neural_rendering_amd import losses as ul
+    g = load_golden("g6_nerf_losses.npz")
+    gt_rgb, labels, gt_depth = _g6_case(g, tag)
+    image = g[f"{tag}_image"].clone().cuda().requires_grad_()
+    depth = g[f"{tag}_depth"].clone().cuda().requires_grad_()
+    sem = g[f"{tag}_sem"].clone().cuda().requires_grad_()
+    lc, ls, ld = ul.nerf_losses(image, sem, depth, gt_rgb.cuda(), labels.cuda(),
+                                gt_depth.cuda(), float(g[f"{tag}_uom"]),
+                                none_if_invalid=True)
+    assert (ls is None) == bool(g[f"{tag}_sem_is_none"])
+    total = ul.nerf_total_loss(lc, ls, ld)
+    total.backward()
+    assert abs(float(lc) - float(g[f"{tag}_loss_color"])) <= 1e-6
+    assert abs(float(ld) - float(g[f"{tag}_loss_depth"])) <= 1e-6
+    if ls is not None:
+        assert abs(float(ls) - float(g[f"{tag}_loss_sem"])) <= 2e-6 * abs(float(g[f"{tag}_loss_sem"]))
+    assert abs(float(total) - float(g[f"{tag}_total"])) <= 2e-6
+    assert maxabs(image.grad, g[f"{tag}_g_image"]) <= 1e-8
+    assert maxabs(depth.grad, g[f"{tag}_g_depth"]) <= 1e-8
+    gs = torch.zeros_like(sem) if sem.grad is None else sem.grad
+    assert maxabs(gs, g[f"{tag}_g_sem"]) <= 1e-6 * max(1.0, float(g[f"{tag}_g_sem"].abs().max()))

@@ -173,3 +173,43 @@ def test_semantics_meter():
     assert abs(miou - g["miou"]) < 1e-12
     assert abs(acc - g["total_acc"]) < 1e-12
     assert abs(cacc - g["class_avg_acc"]) < 1e-12
+
+
+# ---- G6: NeRF losses, from the reference's forward_nerf_train itself ---------
+def _g6_case(g, tag):
+    B, C, H, W = 2, 3, *g[f"{tag}_img_fp16"].shape[-2:]
+    bs, inds = int(g[f"{tag}_bs"]), g[f"{tag}_inds"]
+    img = g[f"{tag}_img_fp16"][[bs]]
+    gt_rgb = torch.gather(img.reshape(1, C, -1).permute(0, 2, 1), 1,
+                          torch.stack(C * [inds], -1))
+    labels = torch.gather(g[f"{tag}_seg"][[bs]].reshape(1, -1), 1, inds)
+    gt_depth = torch.gather(g[f"{tag}_depth_fp16"][[bs]].reshape(1, -1), 1, inds)
+    return gt_rgb, labels, gt_depth
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_nerf_losses_match_reference_forward_nerf_train(tag):
+    """oracle.losses.nerf_losses / nerf_total_loss against values and gradients
+    produced by the reference's own method (G6; case b: every ray invalid ->
+    loss_semantics None)."""
+    from oracle import losses as olosses
+    from tests.util import maxabs
+    g = load("g6_nerf_losses.npz")
+    gt_rgb, labels, gt_depth = _g6_case(g, tag)
+    image = g[f"{tag}_image"].clone().requires_grad_()
+    depth = g[f"{tag}_depth"].clone().requires_grad_()
+    sem = g[f"{tag}_sem"].clone().requires_grad_()
+    lc, ls, ld = olosses.nerf_losses(image, sem, depth, gt_rgb, labels, gt_depth,
+                                     float(g[f"{tag}_uom"]))
+    assert (ls is None) == bool(g[f"{tag}_sem_is_none"])
+    total = olosses.nerf_total_loss(lc, ls, ld)
+    total.backward()
+    assert abs(float(lc) - float(g[f"{tag}_loss_color"])) <= 1e-7
+    assert abs(float(ld) - float(g[f"{tag}_loss_depth"])) <= 1e-6
+    if ls is not None:
+        assert abs(float(ls) - float(g[f"{tag}_loss_sem"])) <= 1e-5
+    assert abs(float(total) - float(g[f"{tag}_total"])) <= 1e-6
+    assert maxabs(image.grad, g[f"{tag}_g_image"]) <= 1e-9
+    assert maxabs(depth.grad, g[f"{tag}_g_depth"]) <= 1e-9
+    gs = torch.zeros_like(sem) if sem.grad is None else sem.grad
+    assert maxabs(gs, g[f"{tag}_g_sem"]) <= 1e-7

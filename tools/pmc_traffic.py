@@ -1,7 +1,7 @@
 """Distil per-launch HBM traffic / MFMA busy of the bench-size launches of the
 two dominant kernels from the PMC summaries written by
-tools/refresh_profiles.sh.   python tools/pmc_traffic.py gpurun_out r01 >
-profiles/r01_pmc_traffic.json"""
+tools/refresh_profiles.sh.   python tools/pmc_traffic.py gpurun_out r02 >
+profiles/r02_pmc_traffic.json"""
 import json
 import re
 import sys
@@ -39,12 +39,17 @@ def main(d, tag):
     fetch = counters(f"{d}/{tag}_pmc1.txt")
     wr = counters(f"{d}/{tag}_pmc2.txt")
     sq = counters(f"{d}/{tag}_pmc3.txt")
+    try:
+        l2 = counters(f"{d}/{tag}_pmc4.txt")
+    except OSError:
+        l2 = {}
     res = {
+        "pretrain_steps": 200,
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                   "TCC_HIT_sum TCC_MISS_sum / --pmc SQ_* (three separate passes, "
                   "tools/refresh_profiles.sh) of `python3 bench.py --steps 2 "
-                  "--warmup 1 --no-cpu-baseline --no-train-bench --pretrain-steps "
-                  "20`; per-dispatch averages of the largest (bench-size: 61440 "
+                  "--warmup 1 --no-cpu-baseline --no-train-bench` (the default "
+                  "200 pretrain steps = the field bench.py times); per-dispatch averages of the largest (bench-size: 61440 "
                   "rays x 96 samples) launches",
         "units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are reported in KiB by "
                  "rocprofv3 and multiplied by 1024 here.  gfx950 note "
@@ -69,6 +74,14 @@ def main(d, tag):
             # the busy cycles of all 1024 SIMDs: busy / (cycles * 1024)
             e["mfma_busy_frac"] = (s[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) /
                                    (s[1]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
+        q = pick(l2, prefix)
+        if q:
+            # requests arriving at the L2 (all XCDs); one request = one 128-B
+            # line on gfx950's TCP->TCC path for these 8/16-byte gathers
+            e["l2_requests"] = int(q[1].get("TCC_REQ_sum", 0))
+            e["tcp_tcc_read_requests"] = int(q[1].get("TCP_TCC_READ_REQ_sum", 0))
+            e["l2_request_bytes"] = int(max(e["l2_requests"],
+                                            e["tcp_tcc_read_requests"]) * 128)
         res[key] = e
     print(json.dumps(res, indent=1))
 

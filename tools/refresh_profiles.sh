@@ -11,9 +11,12 @@ BENCH="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 timeout 900 rocprofv3 --kernel-trace -d /tmp/p0 -o p -- python3 $BENCH > $OUT/${TAG}_bench.log 2>&1
 BY_GRID=1 python3 tools/rocpd_summary.py /tmp/p0/*/p_results.db > $OUT/${TAG}_bench_kernel_trace.txt 2>/dev/null || \
 BY_GRID=1 python3 tools/rocpd_summary.py $(find /tmp/p0 -name "*.db" | head -1) > $OUT/${TAG}_bench_kernel_trace.txt
-SMALL="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-bench --pretrain-steps 20"
+# PMC passes on the SAME parameter state as the default bench run (200 pretrain
+# steps): the w > 1e-4 mask fraction, and with it the composite kernel's work
+# and traffic, depends on the field
+SMALL="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-bench"
 i=1
-for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
+for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE" "TCC_REQ_sum TCP_TCC_READ_REQ_sum"; do
   rm -rf /tmp/p$i
   timeout 900 rocprofv3 --kernel-trace --pmc $PMC -d /tmp/p$i -o p -- python3 $SMALL > $OUT/${TAG}_pmc$i.log 2>&1
   python3 tools/rocpd_summary.py $(find /tmp/p$i -name "*.db" | head -1) > $OUT/${TAG}_pmc$i.txt

@@ -115,11 +115,25 @@ def average_grads_(params: Iterable[torch.nn.Parameter]):
 def reduce_scatter_sum_(out: torch.Tensor, inp: torch.Tensor):
     """out[per] = sum over ranks of inp[rank*per:(rank+1)*per] (1-D,
     inp.numel() == world * out.numel())."""
+    if dist.get_backend() == "gloo" and inp.is_cuda:
+        # gloo (the 1-GPU test hook) has no reduce-scatter for device tensors:
+        # all-reduce a copy and keep this rank's slice.  RCCL takes the direct
+        # path below.
+        tmp = inp.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        r = dist.get_rank()
+        out.copy_(tmp[r * out.numel():(r + 1) * out.numel()])
+        return
     dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
 
 
 def all_gather_into_(out: torch.Tensor, inp: torch.Tensor):
     """out[rank*per:(rank+1)*per] = inp of that rank (1-D)."""
+    if dist.get_backend() == "gloo" and inp.is_cuda:
+        parts = [torch.empty_like(inp) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, inp)
+        out.copy_(torch.cat(parts))
+        return
     dist.all_gather_into_tensor(out, inp)
 
 

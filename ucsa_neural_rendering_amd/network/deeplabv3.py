@@ -142,19 +142,28 @@ class ASPPPooling(nn.Sequential):
                          nn.BatchNorm2d(cout), nn.ReLU())
 
     def forward(self, x):
+        """torchvision's forward (pool -> 1x1 conv -> BN -> ReLU -> bilinear
+        upsample), plus one zero-copy re-striding of the pooled map.
+
+        Diagnosed on MI355X / ROCm 7.2 (tests/scripts/aspp_probe.py,
+        aspp_probe2.py; each case in its own process): MIOpen's *NHWC,
+        16-bit* batch-norm TRAINING kernel segfaults on maps of one or two
+        pixels with small batches ([2,256,1,1], [3,256,1,1], [2,256,1,2] in
+        bf16 or fp16 crash; [4,256,1,1], [2,256,2,2], fp32, eval mode, the
+        NCHW kernel and the native (non-MIOpen) kernel are all fine).  A
+        [B,C,1,1] tensor is NCHW- and NHWC-contiguous at once and PyTorch picks
+        the kernel from its strides: a channels_last model hands BatchNorm the
+        conv output with strides (C,1,C,C) -> the NHWC kernel -> the crash at
+        batch 2 under bf16 autocast.  flatten/unflatten gives the same storage
+        the canonical strides (C,1,1,1), so the NCHW kernel runs, in the
+        input's own dtype -- no fp32 detour, no autocast switch."""
         size = x.shape[-2:]
-        dtype, cl = x.dtype, (x.dim() == 4 and not x.is_contiguous()
-                              and x.is_contiguous(memory_format=torch.channels_last))
-        # The pooled branch is a [B, C, 1, 1] tensor: negligible work, and its
-        # bf16 / NHWC batch-norm + upsample kernels crash on small maps
-        # (segfault seen with 48x64 inputs under bf16 autocast), so it always
-        # runs in fp32, NCHW, outside autocast.
-        with torch.autocast(x.device.type, enabled=False):
-            y = self[0](x).float().contiguous()
-            for mod in list(self)[1:]:
-                y = mod(y)
-            y = F.interpolate(y, size=size, mode="bilinear", align_corners=False)
-        y = y.to(dtype)
+        cl = (x.dim() == 4 and not x.is_contiguous()
+              and x.is_contiguous(memory_format=torch.channels_last))
+        y = self[1](self[0](x))                       # [B, cout, 1, 1]
+        y = y.flatten(1).unflatten(1, (y.shape[1], 1, 1))
+        y = self[3](self[2](y))
+        y = F.interpolate(y, size=size, mode="bilinear", align_corners=False)
         return y.contiguous(memory_format=torch.channels_last) if cl else y
 
 
@@ -217,7 +226,8 @@ class DeepLabV3(nn.Module):
         if path:
             sd = torch.load(path, map_location="cpu")
             sd = sd.get("state_dict", sd)
-            self.load_state_dict(sd, strict=False)
+            # strict: a key mismatch must not pass silently
+            self.load_state_dict(sd, strict=True)
         elif cfg_model.get("pretrained") or cfg_model.get("pretrained_backbone"):
             warnings.warn(
                 "pretrained / pretrained_backbone requested but no network "
