@@ -198,6 +198,35 @@ int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
                         float density_scale, uint32_t image_width, float* image,
                         float* depth, float* semantics, void* ws, void* stream);
 
+/* The same computation for INFERENCE as two dense kernels (no `src` /
+ * `weights` outputs): k_weights_compact (one wave per ray: merge, weights,
+ * mask, depth, survivors compacted into a global list) and k_shade_dense
+ * (colour + semantics nets over the survivor list with a software-pipelined
+ * operand fetch, per-ray sums in sample order).  Bit-identical outputs to
+ * ucsa_composite_fwd; what ucsa_render_fwd uses.  `workspace`:
+ * ucsa_composite_infer_workspace_bytes(N, T, t) bytes, caller-owned. */
+uint64_t ucsa_composite_infer_workspace_bytes(uint32_t N, uint32_t T, uint32_t t);
+int32_t ucsa_composite_infer(const float* rays_d, const float* norms,
+                             const float* z_c, const float* sigma_c,
+                             const float* h_c, const float* z_f,
+                             const float* sigma_f, const float* h_f,
+                             const float* packed_color, const float* packed_sem,
+                             uint32_t N, uint32_t T, uint32_t t,
+                             uint32_t n_classes, float density_scale,
+                             float* image, float* depth, float* semantics,
+                             void* workspace, void* stream);
+/* fp16-MFMA form (weights from ucsa_mlp_pack_f16) */
+int32_t ucsa_composite_infer_f16(const float* rays_d, const float* norms,
+                                 const float* z_c, const float* sigma_c,
+                                 const float* h_c, const float* z_f,
+                                 const float* sigma_f, const float* h_f,
+                                 const void* packed_color_half,
+                                 const void* packed_sem_half, uint32_t N,
+                                 uint32_t T, uint32_t t, uint32_t n_classes,
+                                 float density_scale, float* image,
+                                 float* depth, float* semantics,
+                                 void* workspace, void* stream);
+
 /* Pointwise colour / semantics queries: network.color() / network.semantics()
  * (reference network_tcnn_semantics.py:147-207).  dirs [M,3], geo_feat [M,15],
  * mask [M] uint8 or NULL; rgb [M,3] and/or probs [M,n_classes] (either may be

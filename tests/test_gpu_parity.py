@@ -391,3 +391,57 @@ def test_tile_order_kernel_equals_torch_ordering(ops, n, H, W, tile):
     assert torch.equal(got2.cpu().view(-1), want)
     big = torch.randint(0, H * W, (9000,), generator=g)
     assert torch.equal(ops.tile_order(big.cuda(), W, tile).cpu(), ops.tile_order(big, W, tile))
+
+
+# ---------------------------------------------------------------- split composite
+@pytest.mark.parametrize("N,T,t,half", [(1, 16, 16, False), (37, 16, 16, False),
+                                        (130, 32, 0, False), (700, 96, 96, False),
+                                        (50, 256, 256, False), (3000, 8, 8, False),
+                                        (700, 96, 96, True), (33, 16, 0, True)])
+def test_split_inference_composite_is_bit_identical_to_the_fused_kernel(ops, net, N, T, t, half):
+    """ucsa_composite_infer (k_weights_compact + k_shade_dense, what
+    ucsa_render_fwd uses) against ucsa_composite_fwd / _f16 (the fused kernel
+    the training path keeps) on the same staged inputs: same arithmetic in the
+    same order -> identical bits; rays that miss the box, rays without a
+    surviving sample and ragged last groups included."""
+    import ctypes as C
+    from ucsa_neural_rendering_amd._lib import check, lib
+    f = net._field_f16() if half else net._field()
+    o, d, norms = make_rays(N, 500 + N, inside=(N % 2 == 0))
+    o, d, norms = o.cuda(), d.cuda(), norms.cuda()
+    aabb = net._aabb_list(False)
+    near, far = ops.near_far_from_aabb(o, d, aabb)
+    zc = ops.sample_coarse(near, far, T)
+    sig = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
+    hc, sc = sig(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zc, aabb),
+                 f["packed_sigma"])
+    sc = sc.view(N, T).clone()
+    sc[::5] *= 1e-6          # rays whose weights never pass the mask
+    zf = hf = sf = None
+    if t:
+        g = torch.Generator().manual_seed(N)
+        zf = ops.resample(zc, sc, torch.rand(N, t, generator=g).cuda())
+        hf, sf = sig(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb),
+                     f["packed_sigma"])
+        sf = sf.view(N, t).clone()
+        sf[::5] *= 1e-6
+    if half:
+        image = torch.empty(N, 3, device="cuda")
+        depth = torch.empty(N, device="cuda")
+        sem = torch.empty(N, 40, device="cuda")
+        p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        check(lib().ucsa_composite_fwd_f16(
+            p(d), p(norms.view(-1)), p(zc), p(sc), p(hc), p(zf), p(sf), p(hf),
+            p(f["packed_color"]), p(f["packed_sem"]), N, T, t, 40, 1.0, p(image),
+            p(depth), p(sem), ops._stream()), "ucsa_composite_fwd_f16")
+        want = (image, depth, sem)
+    else:
+        want = ops.composite_fwd(d, norms, zc, sc, hc, zf, sf, hf, f["packed_color"],
+                                 f["packed_sem"], 40)
+    got = ops.composite_infer(d, norms, zc, sc, hc, zf, sf, hf, f["packed_color"],
+                              f["packed_sem"], 40, half=half)
+    torch.cuda.synchronize()
+    assert float(want[2].abs().sum()) > 0
+    assert int((want[2].abs().sum(-1) == 0).sum()) >= N // 6 or N < 6   # empty rays occur
+    for a, b, name in zip(got, want, ("image", "depth", "semantics")):
+        assert torch.equal(a, b), name

@@ -1,0 +1,639 @@
+// Inference composite as TWO dense kernels (SURVEY 8a rows a5 second half,
+// a6-a9; reference nr4seg/nerf/renderer_semantics.py:220-299 and
+// nr4seg/nerf/network_tcnn_semantics.py:147-207).
+//
+// Why split.  k_composite (composite.hip) runs per-ray sampling logic and the
+// MFMA shading in ONE wave: every group of 32 survivors waits on a chain of
+// dependent latencies (LDS list -> global h row -> three dependent MFMA layers
+// -> shuffles -> LDS tile -> ordered sums) with 3 waves per SIMD to hide them.
+// Measured (round 1): in fp16 mode the MFMA work falls 13x and the kernel only
+// 25-35 %: ~30 k cycles per wave and group, almost all of it waiting.  Here:
+//
+//  k_weights_compact  one wave per RAY, no MFMA state: merge of coarse+fine
+//      depths (binary-search ranks), alpha / transmittance by wave scan, mask
+//      w > 1e-4, depth, ballot+popcount compaction of the survivors into the
+//      ray's own region of a global list (w, row) -- 32 waves per CU, every
+//      access coalesced.
+//  k_shade_dense      each wave owns a range of rays whose survivors form one
+//      virtual list; it walks that list G entries at a time, REQUESTS the next
+//      group's entries / h rows / directions before shading the current one
+//      (software pipeline), runs the colour + semantics nets (fp32 16x16x4 or
+//      f16 16x16x32 MFMA), and sums w*rgb, w*p per ray in sample order through
+//      a 16-row LDS tile.
+//
+// The list costs 8 B per survivor each way (<= 0.1 ms per 61 440-ray chunk at
+// HBM rates).  The arithmetic -- k order of every contraction, expf vs
+// v_exp_f32, order of the per-ray sums -- is the fused kernel's, statement
+// for statement, so both paths give the same bits (tested).
+#include <cstdlib>
+
+#include "composite_common.h"
+
+extern __shared__ __attribute__((aligned(16))) float cs_smem[];
+
+struct WcArgs {
+  const float* norms;
+  const float* z_c;
+  const float* sigma_c;
+  const float* z_f;
+  const float* sigma_f;
+  uint32_t N, T, t;
+  float density_scale;
+  float* depth;
+  float* list_w;       // [N*S]
+  uint32_t* list_row;  // [N*S]
+  uint32_t* counts;    // [N]
+};
+
+#define WC_WAVES 4
+
+__global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t T = a.T, t = a.t, S = a.T + a.t;
+  const uint32_t r = blockIdx.x * WC_WAVES + wid;
+  if (r >= a.N) return;
+  float* zraw = cs_smem + (size_t)wid * 4 * S;
+  float* zm = zraw + S;
+  float* sgm = zm + S;
+  uint32_t* srcs = reinterpret_cast<uint32_t*>(sgm + S);
+  // ---- A1: raw depths (coarse then fine) ---------------------------------
+  const float* zc = a.z_c + (size_t)r * T;
+  const float* zf = a.z_f + (size_t)r * t;
+  for (uint32_t e = lane; e < S; e += 64) zraw[e] = e < T ? zc[e] : zf[e - T];
+  wave_lds_sync();
+  // ---- A2: rank in the stable sort of [coarse|fine] (composite.hip A2) ----
+  bool sorted_in = true;
+  for (uint32_t k = lane; k + 1 < T; k += 64)
+    sorted_in = sorted_in && (zraw[k] <= zraw[k + 1]);
+  for (uint32_t k = lane; k + 1 < t; k += 64)
+    sorted_in = sorted_in && (zraw[T + k] <= zraw[T + k + 1]);
+  sorted_in = __all(sorted_in);
+  for (uint32_t e = lane; e < S; e += 64) {
+    const float ze = zraw[e];
+    uint32_t rank;
+    if (!sorted_in) {
+      uint32_t c = 0;
+      for (uint32_t k = 0; k < S; ++k) {
+        const float zk = zraw[k];
+        c += (zk < ze || (zk == ze && k < e)) ? 1u : 0u;
+      }
+      rank = c;
+    } else if (e < T) {
+      uint32_t lo = 0, hi = t;  // #fine strictly below ze
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (zraw[T + mid] < ze) lo = mid + 1; else hi = mid;
+      }
+      rank = e + lo;
+    } else {
+      uint32_t lo = 0, hi = T;  // #coarse <= ze (coarse first on ties)
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (zraw[mid] <= ze) lo = mid + 1; else hi = mid;
+      }
+      rank = lo + (e - T);
+    }
+    const float sg = e < T ? a.sigma_c[(size_t)r * T + e]
+                           : a.sigma_f[(size_t)r * t + (e - T)];
+    zm[rank] = ze;
+    sgm[rank] = sg;
+    srcs[rank] = e;
+  }
+  wave_lds_sync();
+  // ---- A3: weights, mask, depth, compaction into the ray's region ---------
+  float carry = 1.0f, dsum = 0.0f;
+  uint32_t kept = 0;
+  const size_t base = (size_t)r * S;
+  for (uint32_t sbase = 0; sbase < S; sbase += 64) {
+    const uint32_t s = sbase + lane;
+    float alpha = 0.0f, zi = 0.0f;
+    if (s < S) {
+      zi = zm[s];
+      const float delta = (s + 1 < S) ? zm[s + 1] - zi : 1e10f;
+      alpha = 1.0f - expf(-delta * a.density_scale * sgm[s]);
+    }
+    const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
+    const float incl = wave_incl_scan_mul(fac, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float w = alpha * (carry * excl);
+    carry = carry * wave_bcast(incl, 63);
+    const bool keep = (s < S) && (w > 1e-4f);
+    if (keep) dsum += w * zi;
+    const unsigned long long bal = __ballot(keep);
+    if (keep) {
+      const uint32_t pos = kept + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      const uint32_t e = srcs[s];
+      a.list_w[base + pos] = w;
+      a.list_row[base + pos] = e < T ? (r * T + e) : (ROW_FINE | (r * t + (e - T)));
+    }
+    kept += (uint32_t)__popcll(bal);
+  }
+  dsum = wave_sum(dsum);
+  if (lane == 0) {
+    a.depth[r] = dsum / a.norms[r];
+    a.counts[r] = kept;
+  }
+}
+
+struct ShArgs {
+  const float* rays_d;
+  const float* h_c;
+  const float* h_f;
+  const float* packed_color;
+  const float* packed_sem;
+  const float* list_w;
+  const uint32_t* list_row;
+  const uint32_t* counts;
+  uint32_t N, S, C;
+  uint32_t rays_per_wave;  // <= 64
+  uint32_t contrib_stride;
+  float* image;
+  float* semantics;
+};
+
+template <int CBS>
+struct Pre {  // one group's operands, requested one group ahead
+  float ew[CBS];
+  uint32_t eray[CBS];
+  f32x4 hv[CBS];
+  float d[CBS][3];
+};
+
+template <int NRB_SEM, int CBS, bool HALF, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
+  constexpr uint32_t G = 16u * CBS;
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint32_t S = a.S, C = a.C;
+  const uint32_t cstride = a.contrib_stride;
+
+  constexpr uint32_t WC_FLOATS = HALF ? COLOR_H_FRAGS * 256 : 7168;
+  constexpr uint32_t WS_FLOATS = HALF ? SEM_H_FRAGS(NRB_SEM) * 256
+                                      : 1024 + NRB_SEM * 1024;
+  float* w_color = cs_smem;
+  float* w_sem = w_color + WC_FLOATS;
+  const uint32_t per_wave_floats = 16 * cstride + 64 + 68;
+  float* base = w_sem + WS_FLOATS + (size_t)wid * per_wave_floats;
+  float* contrib = base;                      // [16][cstride]
+  float* shpart = contrib + 16 * cstride;     // [64] colour-L1 SH part of a ray
+  uint32_t* offs = reinterpret_cast<uint32_t*>(shpart + 64);  // [rpw + 1]
+
+  for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
+    w_color[i] = a.packed_color[i];
+  for (uint32_t i = threadIdx.x; i < WS_FLOATS; i += blockDim.x)
+    w_sem[i] = a.packed_sem[i];
+  __syncthreads();
+
+  const uint64_t gwave = (uint64_t)blockIdx.x * WAVES + wid;
+  const uint64_t r_begin64 = gwave * a.rays_per_wave;
+  if (r_begin64 >= a.N) return;
+  const uint32_t r_begin = (uint32_t)r_begin64;
+  const uint32_t r_end = (r_begin + a.rays_per_wave < a.N)
+                             ? r_begin + a.rays_per_wave : a.N;
+  const uint32_t n_rays = r_end - r_begin;  // <= 64
+
+  // exclusive prefix of the survivor counts of this wave's rays
+  const uint32_t my_cnt = lane < n_rays ? a.counts[r_begin + lane] : 0u;
+  const uint32_t incl = wave_incl_scan_add_u32(my_cnt, lane);
+  if (lane < n_rays) offs[lane + 1] = incl;
+  if (lane == 0) offs[0] = 0u;
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+  // rays without a survivor: all-zero outputs
+  {
+    unsigned long long empty = __ballot(lane < n_rays && my_cnt == 0u);
+    while (empty) {
+      const uint32_t ri = (uint32_t)__ffsll((long long)empty) - 1u;
+      empty &= empty - 1ull;
+      const uint32_t ray = r_begin + ri;
+      if (lane < 3) a.image[(size_t)ray * 3 + lane] = 0.0f;
+      else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = 0.0f;
+    }
+  }
+  wave_lds_sync();
+  if (total == 0) return;
+
+  uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose sums sit in `acc`
+  uint32_t sh_ray = 0xFFFFFFFFu;   // ray whose SH part sits in `shpart`
+  float acc = 0.0f;                // lane c: running sum of channel c
+
+  auto flush_ray = [&](uint32_t ray) {
+    if (lane < 3) a.image[(size_t)ray * 3 + lane] = acc;
+    else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = acc;
+  };
+
+  // operands of the group starting at entry gb (entries past `total` are
+  // padded with the last real one at weight 0)
+  auto fetch = [&](uint32_t gb, Pre<CBS>& p) {
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      uint32_t e = gb + cb * 16 + j;
+      const bool live = e < total;
+      if (!live) e = total - 1;
+      uint32_t lo = 0, hi = n_rays;  // last ray index with offs[i] <= e
+      while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= e) lo = mid; else hi = mid;
+      }
+      const uint32_t ray = r_begin + lo;
+      const size_t idx = (size_t)ray * S + (e - offs[lo]);
+      const float w = a.list_w[idx];
+      const uint32_t row = a.list_row[idx];
+      p.ew[cb] = live ? w : 0.0f;
+      p.eray[cb] = ray;
+      const float* hp = ((row & ROW_FINE) ? a.h_f : a.h_c) +
+                        (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
+      p.hv[cb] = *reinterpret_cast<const f32x4*>(hp);
+      const float* dd = a.rays_d + (size_t)ray * 3;
+      p.d[cb][0] = dd[0];
+      p.d[cb][1] = dd[1];
+      p.d[cb][2] = dd[2];
+    }
+  };
+
+  // ---- nets + softmax + ordered per-ray sums on one fetched group ---------
+  auto shade = [&](const Pre<CBS>& p, uint32_t n) {
+    float geo[CBS][4];
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      geo[cb][0] = (g == 0) ? 1.0f : p.hv[cb][0];  // slot m==0 -> the "ones" pad
+      geo[cb][1] = p.hv[cb][1];
+      geo[cb][2] = p.hv[cb][2];
+      geo[cb][3] = p.hv[cb][3];
+    }
+    float rgb[CBS][3];
+    f32x4 lg[CBS][NRB_SEM];
+    if constexpr (!HALF) {
+      {  // colour net 32 -> 64 -> 64 -> 16 (composite.hip, same k order)
+        f32x4 acc1[CBS][4];
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          const uint32_t ray0 =
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)p.eray[cb]);
+          const bool uniform = __all(p.eray[cb] == ray0);
+          float sh[4];
+          if (!uniform || ray0 != sh_ray)
+            sh4_select(p.d[cb][0], p.d[cb][1], p.d[cb][2], g, sh);
+          if (uniform && ray0 != sh_ray) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+              f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks)
+                q = mfma16(w_color[(rb * 8 + ks) * 64 + lane], sh[ks], q);
+              if (j == 0) *reinterpret_cast<f32x4*>(shpart + 16 * rb + 4 * g) = q;
+            }
+            sh_ray = ray0;
+            wave_lds_sync();
+          }
+          if (uniform) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc1[cb][rb] = *reinterpret_cast<const f32x4*>(shpart + 16 * rb + 4 * g);
+          } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+              f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks)
+                q = mfma16(w_color[(rb * 8 + ks) * 64 + lane], sh[ks], q);
+              acc1[cb][rb] = q;
+            }
+          }
+        }
+#pragma unroll
+        for (int ks = 4; ks < 8; ++ks) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            const float wa = w_color[(rb * 8 + ks) * 64 + lane];
+#pragma unroll
+            for (int cb = 0; cb < CBS; ++cb)
+              acc1[cb][rb] = mfma16(wa, geo[cb][ks - 4], acc1[cb][rb]);
+          }
+        }
+        float hid[CBS][16];
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) chain_relu(acc1[cb], hid[cb]);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            const float wa = w_color[(COLOR_L1_FRAGS + rb * 16 + ks) * 64 + lane];
+#pragma unroll
+            for (int cb = 0; cb < CBS; ++cb)
+              acc1[cb][rb] = mfma16(wa, hid[cb][ks], acc1[cb][rb]);
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) chain_relu(acc1[cb], hid[cb]);
+        f32x4 o3[CBS];
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) o3[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const float wa =
+              w_color[(COLOR_L1_FRAGS + COLOR_L2_FRAGS + ks) * 64 + lane];
+#pragma unroll
+          for (int cb = 0; cb < CBS; ++cb) o3[cb] = mfma16(wa, hid[cb][ks], o3[cb]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[cb][c]));
+      }
+      {  // semantics net 16 -> 64 -> 16*NRB_SEM
+        f32x4 acc1[CBS][4];
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) acc1[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            const float wa = w_sem[(rb * 4 + ks) * 64 + lane];
+#pragma unroll
+            for (int cb = 0; cb < CBS; ++cb)
+              acc1[cb][rb] = mfma16(wa, geo[cb][ks], acc1[cb][rb]);
+          }
+        }
+        float hid[CBS][16];
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) chain_relu(acc1[cb], hid[cb]);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < NRB_SEM; ++rb) lg[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+          for (int rb = 0; rb < NRB_SEM; ++rb) {
+            const float wa = w_sem[(SEM_L1_FRAGS + rb * 16 + ks) * 64 + lane];
+#pragma unroll
+            for (int cb = 0; cb < CBS; ++cb)
+              lg[cb][rb] = mfma16(wa, hid[cb][ks], lg[cb][rb]);
+          }
+        }
+      }
+    } else {
+      // fp16 weights / layer inputs, fp32 accumulate: 24 MFMAs per column block
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        float sh[4];
+        sh4_select(p.d[cb][0], p.d[cb][1], p.d[cb][2], g, sh);
+        half8 b1, bs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          b1[r] = (_Float16)sh[r];
+          b1[4 + r] = (_Float16)geo[cb][r];
+          bs[r] = (_Float16)geo[cb][r];
+          bs[4 + r] = (_Float16)0.f;
+        }
+        f32x4 a1[4], a2[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
+        half8 h0 = chain_relu_h(a1[0], a1[1]), h1 = chain_relu_h(a1[2], a1[3]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
+          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2[rb]);
+        }
+        h0 = chain_relu_h(a2[0], a2[1]);
+        h1 = chain_relu_h(a2[2], a2[3]);
+        f32x4 o3 = mfma_h(frag_h(w_color, 12, lane), h0, z4);
+        o3 = mfma_h(frag_h(w_color, 13, lane), h1, o3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[c]));
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
+        h0 = chain_relu_h(a1[0], a1[1]);
+        h1 = chain_relu_h(a1[2], a1[3]);
+#pragma unroll
+        for (int rb = 0; rb < NRB_SEM; ++rb) {
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[cb][rb]);
+        }
+      }
+    }
+
+    // softmax + contributions + per-ray sums in sample order
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fmaxf(mx, lg[cb][rb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.0f;
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
+          const float ex = ok ? fast_exp(lg[cb][rb][r] - mx) : 0.0f;
+          lg[cb][rb][r] = ex;
+          sum += ex;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float wgt = p.ew[cb];
+      const float inv_sum = 1.0f / sum;
+      float* crow = contrib + j * cstride;
+      if (g == 0) {
+        crow[0] = wgt * rgb[cb][0];
+        crow[1] = wgt * rgb[cb][1];
+        crow[2] = wgt * rgb[cb][2];
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t cls = rb * 16 + 4 * g + r;
+          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] * inv_sum);
+        }
+      wave_lds_sync();
+      const uint32_t nb =
+          (n > (uint32_t)cb * 16) ? ((n - cb * 16 < 16) ? n - cb * 16 : 16) : 0;
+      float cv[16];
+      const uint32_t ch = lane < 3 + C ? lane : 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cv[e] = contrib[e * cstride + ch];
+      // the ray of entry e of this column block: lane e (g == 0) holds it
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if ((uint32_t)e < nb) {
+          const uint32_t ray = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], e);
+          if (ray != cur_ray) {
+            if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+            cur_ray = ray;
+            acc = 0.0f;
+          }
+          acc = acc + cv[e];
+        }
+      }
+      wave_lds_sync();
+    }
+  };
+
+  Pre<CBS> cur, nxt;
+  fetch(0u, cur);
+  for (uint32_t gb = 0; gb < total; gb += G) {
+    const bool more = gb + G < total;
+    if (more) fetch(gb + G, nxt);  // in flight while `cur` is shaded
+    const uint32_t n = (total - gb < G) ? total - gb : G;
+    shade(cur, n);
+    if (more) cur = nxt;
+  }
+  if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+}
+
+static inline uint32_t cs_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
+
+extern "C" uint64_t ucsa_composite_infer_workspace_bytes(uint32_t N, uint32_t T,
+                                                         uint32_t t) {
+  const uint64_t S = (uint64_t)T + t;
+  return (((uint64_t)N * S * 8 + 255) & ~255ull) + (((uint64_t)N * 4 + 255) & ~255ull);
+}
+
+template <int NRB, int CBS, bool H, int WAVES>
+static int32_t launch_shade(const ShArgs& a, uint32_t blocks, size_t smem,
+                            hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&k_shade_dense<NRB, CBS, H, WAVES>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return -(int32_t)e;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL((k_shade_dense<NRB, CBS, H, WAVES>), dim3(blocks),
+                     dim3(64 * WAVES), smem, s, a);
+  return ucsa_launch_status();
+}
+
+// Launch shapes (waves per workgroup, column blocks per group).  The register
+// budget follows from the workgroup size: 16 waves -> 128 VGPRs, 12 -> 168,
+// 8 -> 256.  UCSA_SHADE_VARIANT (0..2) selects another shape for experiments
+// (tools/composite_split_bench.py); results do not depend on it.
+static int shade_variant() {
+  const char* v = getenv("UCSA_SHADE_VARIANT");
+  return v ? atoi(v) : 0;
+}
+
+static int32_t composite_infer(bool half, const float* rays_d,
+                               const float* norms, const float* z_c,
+                               const float* sigma_c, const float* h_c,
+                               const float* z_f, const float* sigma_f,
+                               const float* h_f, const void* packed_color,
+                               const void* packed_sem, uint32_t N, uint32_t T,
+                               uint32_t t, uint32_t n_classes,
+                               float density_scale, float* image, float* depth,
+                               float* semantics, void* ws, void* stream) {
+  UCSA_CHECK_ARG(rays_d, 0);
+  UCSA_CHECK_ARG(norms, 1);
+  UCSA_CHECK_ARG(z_c && sigma_c && h_c, 2);
+  UCSA_CHECK_ARG(t == 0 || (z_f && sigma_f && h_f), 5);
+  UCSA_CHECK_ARG(packed_color && packed_sem, 8);
+  UCSA_CHECK_ARG(T >= 1 && (uint64_t)N * T < 0x80000000ull, 11);
+  UCSA_CHECK_ARG((uint64_t)N * t < 0x80000000ull && T + t <= 8192, 12);
+  UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 13);
+  UCSA_CHECK_ARG(image && depth && semantics, 15);
+  UCSA_CHECK_ARG(ws, 18);
+  if (N == 0) return 0;
+  const uint32_t S = T + t;
+  hipStream_t s = (hipStream_t)stream;
+  char* wp = (char*)ws;
+  float* list_w = (float*)wp;
+  uint32_t* list_row = (uint32_t*)(wp + (size_t)N * S * 4);
+  uint32_t* counts = (uint32_t*)(wp + (((size_t)N * S * 8 + 255) & ~(size_t)255));
+  // ---- A: weights + compaction, one wave per ray ---------------------------
+  {
+    WcArgs a{norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale,
+             depth, list_w, list_row, counts};
+    const size_t smem = (size_t)WC_WAVES * 4 * S * 4;
+    UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_weights_compact),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return -(int32_t)e;
+    UCSA_CLEAR_ERR();
+    hipLaunchKernelGGL(k_weights_compact, dim3(ucsa_div_up(N, WC_WAVES)),
+                       dim3(64 * WC_WAVES), smem, s, a);
+    const int32_t rc = ucsa_launch_status();
+    if (rc != 0) return rc;
+  }
+  // ---- B: dense shading of the survivor lists -------------------------------
+  const uint32_t nrb = cs_pad16(n_classes) / 16;
+  uint32_t cstride = 3 + n_classes;
+  if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
+  const int variant = shade_variant();
+  // fp16: 0 = (8 waves, 2 column blocks; 216 VGPRs: the 24 weight fragments
+  //          stay in registers), 1 = (8, 4), 2 = (16, 2; spills)
+  // fp32: 0 = (12 waves, 2 blocks; 166 VGPRs, no spills), 1 = (8, 2), 2 = (16, 1)
+  const uint32_t waves = half ? (variant == 2 ? 16u : 8u)
+                              : (variant == 0 ? 12u : (variant == 1 ? 8u : 16u));
+  const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
+                               : 7168 + 1024 + (size_t)nrb * 1024;
+  const size_t per_wave = 16 * (size_t)cstride + 64 + 68;
+  const size_t smem = (w_floats + waves * per_wave) * 4;
+  // enough waves to fill the chip twice over, whole rays per wave, <= 64 rays
+  const uint64_t total_waves = 256ull * 16 * 2;
+  uint32_t rpw = (uint32_t)((N + total_waves - 1) / total_waves);
+  const uint32_t rpw_min = S >= 128 ? 1u : (S >= 64 ? 2u : 4u);
+  if (rpw < rpw_min) rpw = rpw_min;
+  if (rpw > 64) rpw = 64;
+  const uint32_t blocks = ucsa_div_up(ucsa_div_up(N, rpw), waves);
+  ShArgs b{rays_d, h_c, h_f, (const float*)packed_color, (const float*)packed_sem,
+           list_w, list_row, counts, N, S, n_classes, rpw, cstride, image,
+           semantics};
+#define SH_GO(NRB)                                                             \
+  do {                                                                         \
+    if (half) {                                                                \
+      if (variant == 0) return launch_shade<NRB, 2, true, 8>(b, blocks, smem, s);  \
+      if (variant == 1) return launch_shade<NRB, 4, true, 8>(b, blocks, smem, s);  \
+      return launch_shade<NRB, 2, true, 16>(b, blocks, smem, s);               \
+    }                                                                          \
+    if (variant == 0) return launch_shade<NRB, 2, false, 12>(b, blocks, smem, s);  \
+    if (variant == 1) return launch_shade<NRB, 2, false, 8>(b, blocks, smem, s);   \
+    return launch_shade<NRB, 1, false, 16>(b, blocks, smem, s);                \
+  } while (0)
+  switch (nrb) {
+    case 1: SH_GO(1);
+    case 2: SH_GO(2);
+    case 3: SH_GO(3);
+    default: SH_GO(4);
+  }
+#undef SH_GO
+}
+
+extern "C" int32_t ucsa_composite_infer(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const float* packed_color,
+    const float* packed_sem, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, void* workspace, void* stream) {
+  return composite_infer(false, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+                         h_f, packed_color, packed_sem, N, T, t, n_classes,
+                         density_scale, image, depth, semantics, workspace,
+                         stream);
+}
+
+extern "C" int32_t ucsa_composite_infer_f16(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_half,
+    const void* packed_sem_half, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, void* workspace, void* stream) {
+  return composite_infer(true, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+                         h_f, packed_color_half, packed_sem_half, N, T, t,
+                         n_classes, density_scale, image, depth, semantics,
+                         workspace, stream);
+}

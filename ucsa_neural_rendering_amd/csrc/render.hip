@@ -9,6 +9,7 @@
 namespace {
 struct Ws {
   float *nears, *fars, *z_c, *z_f, *feat, *h_c, *sigma_c, *h_f, *sigma_f;
+  void* cmp;  // ucsa_composite_infer's survivor lists
   uint64_t bytes;
 };
 
@@ -34,6 +35,7 @@ Ws carve(void* base, uint32_t N, uint32_t T, uint32_t t, uint32_t L) {
   w.sigma_c = take(Mc);
   w.h_f = take(Mf ? Mf * 16 : 1);
   w.sigma_f = take(Mf ? Mf : 1);
+  w.cmp = take(ucsa_composite_infer_workspace_bytes(N, T, t) / 4 + 64);
   w.bytes = off;
   return w;
 }
@@ -92,10 +94,10 @@ extern "C" int32_t ucsa_render_fwd(
     UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * t, grid->n_levels,
                                 w.h_f, w.sigma_f, stream));
   }
-  UCSA_TRY(ucsa_composite_fwd(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
-                              w.sigma_f, w.h_f, packed_color, packed_sem, N, T,
-                              t, n_classes, density_scale, image, depth,
-                              semantics, nullptr, nullptr, stream));
+  UCSA_TRY(ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                w.sigma_f, w.h_f, packed_color, packed_sem, N,
+                                T, t, n_classes, density_scale, image, depth,
+                                semantics, w.cmp, stream));
   return 0;
 }
 
@@ -127,11 +129,11 @@ extern "C" int32_t ucsa_render_fwd_f16(
     UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * t,
                                     grid->n_levels, w.h_f, w.sigma_f, stream));
   }
-  UCSA_TRY(ucsa_composite_fwd_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
-                                  w.sigma_f, w.h_f, packed_color_half,
-                                  packed_sem_half, N, T, t, n_classes,
-                                  density_scale, image, depth, semantics,
-                                  stream));
+  UCSA_TRY(ucsa_composite_infer_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c,
+                                    w.z_f, w.sigma_f, w.h_f, packed_color_half,
+                                    packed_sem_half, N, T, t, n_classes,
+                                    density_scale, image, depth, semantics,
+                                    w.cmp, stream));
   return 0;
 }
 

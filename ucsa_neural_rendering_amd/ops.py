@@ -206,6 +206,32 @@ def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     return image, depth, sem
 
 
+def composite_infer(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                    packed_color, packed_sem, n_classes: int,
+                    density_scale: float = 1.0, half: bool = False):
+    """Inference composite as the dense kernel pair (ucsa_composite_infer):
+    same outputs as composite_fwd, bit for bit.  half=True: packed weights
+    from mlp_pack_f16."""
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    norms = _f32(norms, "norms").view(-1)
+    N, T = z_c.shape
+    t = 0 if z_f is None else z_f.shape[1]
+    dev = z_c.device
+    image = torch.empty(N, 3, device=dev)
+    depth = torch.empty(N, device=dev)
+    sem = torch.empty(N, n_classes, device=dev)
+    ws = _scratch_named("composite_infer",
+                        int(lib().ucsa_composite_infer_workspace_bytes(N, T, t)),
+                        dev)
+    fn = lib().ucsa_composite_infer_f16 if half else lib().ucsa_composite_infer
+    check(fn(_ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
+             _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(packed_color),
+             _ptr(packed_sem), N, T, t, n_classes, float(density_scale),
+             _ptr(image), _ptr(depth), _ptr(sem), _ptr(ws), _stream()),
+          "ucsa_composite_infer")
+    return image, depth, sem
+
+
 def point_shade(dirs, geo_feat, mask, packed_color, packed_sem, n_classes: int,
                 want_rgb: bool = True, want_probs: bool = True):
     geo_feat = _f32(geo_feat, "geo_feat").view(-1, 15)
