@@ -581,6 +581,11 @@ def main():
     from ucsa_neural_rendering_amd import ops
     prelog = {}
     net, scene_ds = build_field(dev, train_steps=args.pretrain_steps, log=prelog)
+    if dist:
+        # the pre-training is not bit-reproducible (float atomics in the grid
+        # backward): all ranks render / train rank 0's field
+        from ucsa_neural_rendering_amd import dist as udist_
+        udist_.broadcast_parameters_(net)
     net.hip_ray_chunk = 65536
     comm_dtype = {"fp32": None, "fp16": torch.float16,
                   "bf16": torch.bfloat16}[args.grad_comm_dtype]

@@ -147,6 +147,29 @@ int32_t ucsa_sigma_mlp_fwd(const float* feat, const float* packed_sigma,
                            uint32_t M, uint32_t n_levels, float* h,
                            float* sigma, void* stream);
 
+/* Encode + sigma MLP in ONE kernel for image-ordered rays (the pixels of full
+ * rows of an image `image_width` wide): the 32 features of a sample stay in
+ * LDS instead of travelling through HBM between ucsa_hashgrid_encode_rays_image
+ * and ucsa_sigma_mlp_fwd.  Same outputs, bit for bit: h [N*T,16], sigma [N*T].
+ * Replaces density() for a whole sample batch
+ * (reference network_tcnn_semantics.py:130-144).  n_levels must be 16. */
+int32_t ucsa_encode_sigma_rays_image(const ucsa_grid* grid, const float* table,
+                                     const float* packed_sigma,
+                                     const float* rays_o, const float* rays_d,
+                                     const float* z, const float* aabb_host,
+                                     uint32_t N, uint32_t T,
+                                     uint32_t image_width, float* h,
+                                     float* sigma, void* stream);
+/* fp16-MFMA form (weights from ucsa_mlp_pack_f16) */
+int32_t ucsa_encode_sigma_rays_image_f16(const ucsa_grid* grid,
+                                         const float* table,
+                                         const void* packed_sigma_half,
+                                         const float* rays_o,
+                                         const float* rays_d, const float* z,
+                                         const float* aabb_host, uint32_t N,
+                                         uint32_t T, uint32_t image_width,
+                                         float* h, float* sigma, void* stream);
+
 /* ---- hierarchical resampling ----------------------------------------------
  * Coarse weights -> pdf over interior bins -> inverse CDF at u.
  * Replaces renderer_semantics.py:182-207 and sample_pdf :10-46.

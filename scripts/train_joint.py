@@ -64,6 +64,8 @@ def train(exp, env, exp_cfg_path, env_cfg_path, args):
         # stratified-sampling noise and augmentations (DDP semantics; the
         # gradients are averaged inside the module)
         seed_everything(args.seed + rank)
+        udist.broadcast_parameters_(model.to(
+            f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"))
         torch.distributed.barrier()  # rank 0 has created the folder
     exp["seed"] = args.seed          # shared shuffling seed of the samplers
     datamodule = JointTrainDataModule(exp, env)

@@ -79,9 +79,8 @@ def main(d, tag):
             # requests arriving at the L2 (all XCDs); one request = one 128-B
             # line on gfx950's TCP->TCC path for these 8/16-byte gathers
             e["l2_requests"] = int(q[1].get("TCC_REQ_sum", 0))
-            e["tcp_tcc_read_requests"] = int(q[1].get("TCP_TCC_READ_REQ_sum", 0))
-            e["l2_request_bytes"] = int(max(e["l2_requests"],
-                                            e["tcp_tcc_read_requests"]) * 128)
+            e["l2_read_requests"] = int(q[1].get("TCC_READ_sum", 0))
+            e["l2_request_bytes"] = int(e["l2_requests"] * 128)
         res[key] = e
     print(json.dumps(res, indent=1))
 

@@ -75,6 +75,12 @@ SIGNATURES = {
     "ucsa_composite_fwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _u32, _u32, _u32, _u32, _f, _p, _p, _p,
                                        _p, _p, _p]),
+    "ucsa_encode_sigma_rays_image": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
+                                                 _p, C.POINTER(_f), _u32, _u32,
+                                                 _u32, _p, _p, _p]),
+    "ucsa_encode_sigma_rays_image_f16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p,
+                                                     _p, _p, C.POINTER(_f), _u32,
+                                                     _u32, _u32, _p, _p, _p]),
     "ucsa_composite_infer_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32]),
     "ucsa_composite_infer": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32, _f,
                                                       _p, _p, _p, _p, _p]),

@@ -3,6 +3,7 @@
 // kernels, with every intermediate in a caller-provided workspace.
 // Also: ucsa_version / ucsa_error_string.
 #include <cstdio>
+#include <cstdlib>
 
 #include "ucsa_common.h"
 
@@ -66,6 +67,13 @@ static int32_t encode(const ucsa_grid* grid, const float* table,
                                    T, feat, stream);
 }
 
+// image-ordered rays: encode + sigma MLP as one kernel unless
+// UCSA_FUSED_ENCODE=0 (A/B switch for measurements; same bits either way)
+static bool fused_encode() {
+  const char* v = getenv("UCSA_FUSED_ENCODE");
+  return !(v && v[0] == '0');
+}
+
 extern "C" int32_t ucsa_render_fwd(
     const ucsa_grid* grid, const float* table, const float* packed_sigma,
     const float* packed_color, const float* packed_sem, const float* rays_o,
@@ -82,17 +90,31 @@ extern "C" int32_t ucsa_render_fwd(
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
-                  image_width, w.feat, stream));
-  UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * T, grid->n_levels,
-                              w.h_c, w.sigma_c, stream));
+  const bool fuse = image_width && grid->n_levels == 16 && fused_encode();
+  if (fuse) {
+    UCSA_TRY(ucsa_encode_sigma_rays_image(grid, table, packed_sigma, rays_o,
+                                          rays_d, w.z_c, aabb_host, N, T,
+                                          image_width, w.h_c, w.sigma_c, stream));
+  } else {
+    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
+                    image_width, w.feat, stream));
+    UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * T, grid->n_levels,
+                                w.h_c, w.sigma_c, stream));
+  }
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
-                    image_width, w.feat, stream));
-    UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * t, grid->n_levels,
-                                w.h_f, w.sigma_f, stream));
+    if (fuse) {
+      UCSA_TRY(ucsa_encode_sigma_rays_image(grid, table, packed_sigma, rays_o,
+                                            rays_d, w.z_f, aabb_host, N, t,
+                                            image_width, w.h_f, w.sigma_f,
+                                            stream));
+    } else {
+      UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
+                      image_width, w.feat, stream));
+      UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * t, grid->n_levels,
+                                  w.h_f, w.sigma_f, stream));
+    }
   }
   UCSA_TRY(ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
                                 w.sigma_f, w.h_f, packed_color, packed_sem, N,
@@ -117,17 +139,32 @@ extern "C" int32_t ucsa_render_fwd_f16(
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
-                  image_width, w.feat, stream));
-  UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * T,
-                                  grid->n_levels, w.h_c, w.sigma_c, stream));
+  const bool fuse = image_width && grid->n_levels == 16 && fused_encode();
+  if (fuse) {
+    UCSA_TRY(ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma_half,
+                                              rays_o, rays_d, w.z_c, aabb_host,
+                                              N, T, image_width, w.h_c,
+                                              w.sigma_c, stream));
+  } else {
+    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
+                    image_width, w.feat, stream));
+    UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * T,
+                                    grid->n_levels, w.h_c, w.sigma_c, stream));
+  }
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
-                    image_width, w.feat, stream));
-    UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * t,
-                                    grid->n_levels, w.h_f, w.sigma_f, stream));
+    if (fuse) {
+      UCSA_TRY(ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma_half,
+                                                rays_o, rays_d, w.z_f, aabb_host,
+                                                N, t, image_width, w.h_f,
+                                                w.sigma_f, stream));
+    } else {
+      UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
+                      image_width, w.feat, stream));
+      UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * t,
+                                      grid->n_levels, w.h_f, w.sigma_f, stream));
+    }
   }
   UCSA_TRY(ucsa_composite_infer_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c,
                                     w.z_f, w.sigma_f, w.h_f, packed_color_half,

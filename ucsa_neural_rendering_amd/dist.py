@@ -101,6 +101,25 @@ def allreduce_grads_(params: Iterable[torch.nn.Parameter]):
     allreduce_sum_(grads)
 
 
+def broadcast_parameters_(module: torch.nn.Module, src: int = 0):
+    """Every rank takes rank `src`'s parameters and buffers (what DDP does at
+    construction).  Needed whenever the replicas were produced by a
+    non-deterministic computation -- e.g. a pre-training whose hash-grid
+    gradient uses float atomics -- before they are trained data-parallel."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return
+    gloo_cuda = dist.get_backend() == "gloo"
+    for t in list(module.parameters()) + list(module.buffers()):
+        if gloo_cuda and t.is_cuda:
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src)
+            t.data.copy_(h)
+        else:
+            dist.broadcast(t.data, src=src)
+        if isinstance(t, torch.nn.Parameter):
+            torch.autograd.graph.increment_version(t)
+
+
 def average_grads_(params: Iterable[torch.nn.Parameter]):
     """DDP semantics: SUM all-reduce of the gradients, then / world."""
     params = [p for p in params if p.grad is not None]

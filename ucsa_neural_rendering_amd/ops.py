@@ -137,6 +137,24 @@ def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
     return feat
 
 
+def encode_sigma_rays_image(grid: Grid, table, packed_sigma, rays_o, rays_d, z,
+                            aabb, image_width: int, half: bool = False):
+    """hashgrid_encode_rays(image_width=...) + sigma_mlp_fwd in one kernel
+    (features stay in LDS) -> h [N*T,16], sigma [N*T]; bit-identical."""
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    z = _f32(z, "z")
+    N, T = z.shape
+    h = torch.empty(N * T, 16, device=z.device)
+    sigma = torch.empty(N * T, device=z.device)
+    fn = (lib().ucsa_encode_sigma_rays_image_f16 if half
+          else lib().ucsa_encode_sigma_rays_image)
+    check(fn(C.byref(grid), _ptr(table), _ptr(packed_sigma), _ptr(rays_o),
+             _ptr(rays_d), _ptr(z), fvec(aabb), N, T, int(image_width), _ptr(h),
+             _ptr(sigma), _stream()), "ucsa_encode_sigma_rays_image")
+    return h, sigma
+
+
 def hashgrid_encode_points(grid: Grid, table, x):
     x = _f32(x, "x").view(-1, 3)
     M = x.shape[0]
