@@ -40,9 +40,14 @@ struct WcArgs {
   uint32_t N, T, t;
   float density_scale;
   float* depth;
-  float* list_w;       // [N*S]
+  float* list_w;       // [N*S]; wave w's entries start at w * rays_per_wave * S
   uint32_t* list_row;  // [N*S]
-  uint32_t* counts;    // [N]
+  uint32_t* list_ray;  // [N*S]
+  uint32_t* counts;    // [number of waves]
+  uint32_t rays_per_wave;
+  float* image;        // rays without a survivor get zeros here
+  float* semantics;
+  uint32_t C;
 };
 
 #define WC_WAVES 4
@@ -50,90 +55,103 @@ struct WcArgs {
 __global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t T = a.T, t = a.t, S = a.T + a.t;
-  const uint32_t r = blockIdx.x * WC_WAVES + wid;
-  if (r >= a.N) return;
+  const uint32_t gwave = blockIdx.x * WC_WAVES + wid;
+  const uint64_t r_begin64 = (uint64_t)gwave * a.rays_per_wave;
+  if (r_begin64 >= a.N) return;
+  const uint32_t r_begin = (uint32_t)r_begin64;
+  const uint32_t r_end = (r_begin + a.rays_per_wave < a.N)
+                             ? r_begin + a.rays_per_wave : a.N;
   float* zraw = cs_smem + (size_t)wid * 4 * S;
   float* zm = zraw + S;
   float* sgm = zm + S;
   uint32_t* srcs = reinterpret_cast<uint32_t*>(sgm + S);
-  // ---- A1: raw depths (coarse then fine) ---------------------------------
-  const float* zc = a.z_c + (size_t)r * T;
-  const float* zf = a.z_f + (size_t)r * t;
-  for (uint32_t e = lane; e < S; e += 64) zraw[e] = e < T ? zc[e] : zf[e - T];
-  wave_lds_sync();
-  // ---- A2: rank in the stable sort of [coarse|fine] (composite.hip A2) ----
-  bool sorted_in = true;
-  for (uint32_t k = lane; k + 1 < T; k += 64)
-    sorted_in = sorted_in && (zraw[k] <= zraw[k + 1]);
-  for (uint32_t k = lane; k + 1 < t; k += 64)
-    sorted_in = sorted_in && (zraw[T + k] <= zraw[T + k + 1]);
-  sorted_in = __all(sorted_in);
-  for (uint32_t e = lane; e < S; e += 64) {
-    const float ze = zraw[e];
-    uint32_t rank;
-    if (!sorted_in) {
-      uint32_t c = 0;
-      for (uint32_t k = 0; k < S; ++k) {
-        const float zk = zraw[k];
-        c += (zk < ze || (zk == ze && k < e)) ? 1u : 0u;
+  const size_t base = (size_t)r_begin * S;
+  uint32_t cnt = 0;  // entries written by this wave so far (wave-uniform)
+  for (uint32_t r = r_begin; r < r_end; ++r) {
+    // ---- A1: raw depths (coarse then fine) -------------------------------
+    const float* zc = a.z_c + (size_t)r * T;
+    const float* zf = a.z_f + (size_t)r * t;
+    for (uint32_t e = lane; e < S; e += 64) zraw[e] = e < T ? zc[e] : zf[e - T];
+    wave_lds_sync();
+    // ---- A2: rank in the stable sort of [coarse|fine] (composite.hip A2) --
+    bool sorted_in = true;
+    for (uint32_t k = lane; k + 1 < T; k += 64)
+      sorted_in = sorted_in && (zraw[k] <= zraw[k + 1]);
+    for (uint32_t k = lane; k + 1 < t; k += 64)
+      sorted_in = sorted_in && (zraw[T + k] <= zraw[T + k + 1]);
+    sorted_in = __all(sorted_in);
+    for (uint32_t e = lane; e < S; e += 64) {
+      const float ze = zraw[e];
+      uint32_t rank;
+      if (!sorted_in) {
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < S; ++k) {
+          const float zk = zraw[k];
+          c += (zk < ze || (zk == ze && k < e)) ? 1u : 0u;
+        }
+        rank = c;
+      } else if (e < T) {
+        uint32_t lo = 0, hi = t;  // #fine strictly below ze
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (zraw[T + mid] < ze) lo = mid + 1; else hi = mid;
+        }
+        rank = e + lo;
+      } else {
+        uint32_t lo = 0, hi = T;  // #coarse <= ze (coarse first on ties)
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (zraw[mid] <= ze) lo = mid + 1; else hi = mid;
+        }
+        rank = lo + (e - T);
       }
-      rank = c;
-    } else if (e < T) {
-      uint32_t lo = 0, hi = t;  // #fine strictly below ze
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (zraw[T + mid] < ze) lo = mid + 1; else hi = mid;
+      const float sg = e < T ? a.sigma_c[(size_t)r * T + e]
+                             : a.sigma_f[(size_t)r * t + (e - T)];
+      zm[rank] = ze;
+      sgm[rank] = sg;
+      srcs[rank] = e;
+    }
+    wave_lds_sync();
+    // ---- A3: weights, mask, depth, compaction -----------------------------
+    float carry = 1.0f, dsum = 0.0f;
+    uint32_t kept = 0;
+    for (uint32_t sbase = 0; sbase < S; sbase += 64) {
+      const uint32_t s = sbase + lane;
+      float alpha = 0.0f, zi = 0.0f;
+      if (s < S) {
+        zi = zm[s];
+        const float delta = (s + 1 < S) ? zm[s + 1] - zi : 1e10f;
+        alpha = 1.0f - expf(-delta * a.density_scale * sgm[s]);
       }
-      rank = e + lo;
-    } else {
-      uint32_t lo = 0, hi = T;  // #coarse <= ze (coarse first on ties)
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (zraw[mid] <= ze) lo = mid + 1; else hi = mid;
+      const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
+      const float incl = wave_incl_scan_mul(fac, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.0f;
+      const float w = alpha * (carry * excl);
+      carry = carry * wave_bcast(incl, 63);
+      const bool keep = (s < S) && (w > 1e-4f);
+      if (keep) dsum += w * zi;
+      const unsigned long long bal = __ballot(keep);
+      if (keep) {
+        const size_t pos =
+            base + cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        const uint32_t e = srcs[s];
+        a.list_w[pos] = w;
+        a.list_row[pos] = e < T ? (r * T + e) : (ROW_FINE | (r * t + (e - T)));
+        a.list_ray[pos] = r;
       }
-      rank = lo + (e - T);
+      cnt += (uint32_t)__popcll(bal);
+      kept += (uint32_t)__popcll(bal);
     }
-    const float sg = e < T ? a.sigma_c[(size_t)r * T + e]
-                           : a.sigma_f[(size_t)r * t + (e - T)];
-    zm[rank] = ze;
-    sgm[rank] = sg;
-    srcs[rank] = e;
-  }
-  wave_lds_sync();
-  // ---- A3: weights, mask, depth, compaction into the ray's region ---------
-  float carry = 1.0f, dsum = 0.0f;
-  uint32_t kept = 0;
-  const size_t base = (size_t)r * S;
-  for (uint32_t sbase = 0; sbase < S; sbase += 64) {
-    const uint32_t s = sbase + lane;
-    float alpha = 0.0f, zi = 0.0f;
-    if (s < S) {
-      zi = zm[s];
-      const float delta = (s + 1 < S) ? zm[s + 1] - zi : 1e10f;
-      alpha = 1.0f - expf(-delta * a.density_scale * sgm[s]);
+    dsum = wave_sum(dsum);
+    if (lane == 0) a.depth[r] = dsum / a.norms[r];
+    if (kept == 0) {  // nothing survived the mask: all-zero outputs
+      if (lane < 3) a.image[(size_t)r * 3 + lane] = 0.0f;
+      else if (lane < 3 + a.C) a.semantics[(size_t)r * a.C + (lane - 3)] = 0.0f;
     }
-    const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
-    const float incl = wave_incl_scan_mul(fac, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0f;
-    const float w = alpha * (carry * excl);
-    carry = carry * wave_bcast(incl, 63);
-    const bool keep = (s < S) && (w > 1e-4f);
-    if (keep) dsum += w * zi;
-    const unsigned long long bal = __ballot(keep);
-    if (keep) {
-      const uint32_t pos = kept + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      const uint32_t e = srcs[s];
-      a.list_w[base + pos] = w;
-      a.list_row[base + pos] = e < T ? (r * T + e) : (ROW_FINE | (r * t + (e - T)));
-    }
-    kept += (uint32_t)__popcll(bal);
+    wave_lds_sync();  // the next ray overwrites zraw / zm / sgm / srcs
   }
-  dsum = wave_sum(dsum);
-  if (lane == 0) {
-    a.depth[r] = dsum / a.norms[r];
-    a.counts[r] = kept;
-  }
+  if (lane == 0) a.counts[gwave] = cnt;
 }
 
 struct ShArgs {
@@ -144,12 +162,20 @@ struct ShArgs {
   const float* packed_sem;
   const float* list_w;
   const uint32_t* list_row;
+  const uint32_t* list_ray;
   const uint32_t* counts;
   uint32_t N, S, C;
-  uint32_t rays_per_wave;  // <= 64
+  uint32_t rays_per_wave;
   uint32_t contrib_stride;
   float* image;
   float* semantics;
+};
+
+template <int CBS>
+struct Ent {  // one group's list entries, requested two groups ahead
+  float w[CBS];
+  uint32_t row[CBS];
+  uint32_t ray[CBS];
 };
 
 template <int CBS>
@@ -173,11 +199,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
                                       : 1024 + NRB_SEM * 1024;
   float* w_color = cs_smem;
   float* w_sem = w_color + WC_FLOATS;
-  const uint32_t per_wave_floats = 16 * cstride + 64 + 68;
+  const uint32_t per_wave_floats = 16 * cstride + 64;
   float* base = w_sem + WS_FLOATS + (size_t)wid * per_wave_floats;
   float* contrib = base;                      // [16][cstride]
   float* shpart = contrib + 16 * cstride;     // [64] colour-L1 SH part of a ray
-  uint32_t* offs = reinterpret_cast<uint32_t*>(shpart + 64);  // [rpw + 1]
 
   for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
     w_color[i] = a.packed_color[i];
@@ -188,30 +213,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
   const uint64_t gwave = (uint64_t)blockIdx.x * WAVES + wid;
   const uint64_t r_begin64 = gwave * a.rays_per_wave;
   if (r_begin64 >= a.N) return;
-  const uint32_t r_begin = (uint32_t)r_begin64;
-  const uint32_t r_end = (r_begin + a.rays_per_wave < a.N)
-                             ? r_begin + a.rays_per_wave : a.N;
-  const uint32_t n_rays = r_end - r_begin;  // <= 64
-
-  // exclusive prefix of the survivor counts of this wave's rays
-  const uint32_t my_cnt = lane < n_rays ? a.counts[r_begin + lane] : 0u;
-  const uint32_t incl = wave_incl_scan_add_u32(my_cnt, lane);
-  if (lane < n_rays) offs[lane + 1] = incl;
-  if (lane == 0) offs[0] = 0u;
-  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-  // rays without a survivor: all-zero outputs
-  {
-    unsigned long long empty = __ballot(lane < n_rays && my_cnt == 0u);
-    while (empty) {
-      const uint32_t ri = (uint32_t)__ffsll((long long)empty) - 1u;
-      empty &= empty - 1ull;
-      const uint32_t ray = r_begin + ri;
-      if (lane < 3) a.image[(size_t)ray * 3 + lane] = 0.0f;
-      else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = 0.0f;
-    }
-  }
-  wave_lds_sync();
+  const uint32_t total = a.counts[gwave];
   if (total == 0) return;
+  const size_t lbase = (size_t)r_begin64 * S;
 
   uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose sums sit in `acc`
   uint32_t sh_ray = 0xFFFFFFFFu;   // ray whose SH part sits in `shpart`
@@ -222,29 +226,31 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
     else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = acc;
   };
 
-  // operands of the group starting at entry gb (entries past `total` are
-  // padded with the last real one at weight 0)
-  auto fetch = [&](uint32_t gb, Pre<CBS>& p) {
+  // stage 1: the list entries of the group starting at gb (entries past
+  // `total` are padded with the last real one at weight 0)
+  auto load_entries = [&](uint32_t gb, Ent<CBS>& en) {
 #pragma unroll
     for (int cb = 0; cb < CBS; ++cb) {
       uint32_t e = gb + cb * 16 + j;
       const bool live = e < total;
       if (!live) e = total - 1;
-      uint32_t lo = 0, hi = n_rays;  // last ray index with offs[i] <= e
-      while (lo + 1 < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (offs[mid] <= e) lo = mid; else hi = mid;
-      }
-      const uint32_t ray = r_begin + lo;
-      const size_t idx = (size_t)ray * S + (e - offs[lo]);
-      const float w = a.list_w[idx];
-      const uint32_t row = a.list_row[idx];
-      p.ew[cb] = live ? w : 0.0f;
-      p.eray[cb] = ray;
+      const float w = a.list_w[lbase + e];
+      en.w[cb] = live ? w : 0.0f;
+      en.row[cb] = a.list_row[lbase + e];
+      en.ray[cb] = a.list_ray[lbase + e];
+    }
+  };
+  // stage 2: h rows and ray directions of entries that have arrived
+  auto load_operands = [&](const Ent<CBS>& en, Pre<CBS>& p) {
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      p.ew[cb] = en.w[cb];
+      p.eray[cb] = en.ray[cb];
+      const uint32_t row = en.row[cb];
       const float* hp = ((row & ROW_FINE) ? a.h_f : a.h_c) +
                         (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
       p.hv[cb] = *reinterpret_cast<const f32x4*>(hp);
-      const float* dd = a.rays_d + (size_t)ray * 3;
+      const float* dd = a.rays_d + (size_t)en.ray[cb] * 3;
       p.d[cb][0] = dd[0];
       p.d[cb][1] = dd[1];
       p.d[cb][2] = dd[2];
@@ -484,14 +490,21 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
     }
   };
 
-  Pre<CBS> cur, nxt;
-  fetch(0u, cur);
+  // three-stage software pipeline: entries two groups ahead, operands one
+  // group ahead, so neither level of the dependent loads (list -> h row)
+  // stalls the in-order instruction stream of the wave
+  Ent<CBS> e1, e2;
+  Pre<CBS> p0, p1;
+  load_entries(0u, e1);
+  load_operands(e1, p0);
+  load_entries(G, e1);
   for (uint32_t gb = 0; gb < total; gb += G) {
-    const bool more = gb + G < total;
-    if (more) fetch(gb + G, nxt);  // in flight while `cur` is shaded
+    load_entries(gb + 2 * G, e2);
+    load_operands(e1, p1);
     const uint32_t n = (total - gb < G) ? total - gb : G;
-    shade(cur, n);
-    if (more) cur = nxt;
+    shade(p0, n);
+    p0 = p1;
+    e1 = e2;
   }
   if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
 }
@@ -501,7 +514,7 @@ static inline uint32_t cs_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
 extern "C" uint64_t ucsa_composite_infer_workspace_bytes(uint32_t N, uint32_t T,
                                                          uint32_t t) {
   const uint64_t S = (uint64_t)T + t;
-  return (((uint64_t)N * S * 8 + 255) & ~255ull) + (((uint64_t)N * 4 + 255) & ~255ull);
+  return (((uint64_t)N * S * 12 + 255) & ~255ull) + (((uint64_t)N * 4 + 255) & ~255ull);
 }
 
 template <int NRB, int CBS, bool H, int WAVES>
@@ -551,11 +564,29 @@ static int32_t composite_infer(bool half, const float* rays_d,
   char* wp = (char*)ws;
   float* list_w = (float*)wp;
   uint32_t* list_row = (uint32_t*)(wp + (size_t)N * S * 4);
-  uint32_t* counts = (uint32_t*)(wp + (((size_t)N * S * 8 + 255) & ~(size_t)255));
-  // ---- A: weights + compaction, one wave per ray ---------------------------
+  uint32_t* list_ray = (uint32_t*)(wp + (size_t)N * S * 8);
+  uint32_t* counts = (uint32_t*)(wp + (((size_t)N * S * 12 + 255) & ~(size_t)255));
+  const uint32_t nrb = cs_pad16(n_classes) / 16;
+  uint32_t cstride = 3 + n_classes;
+  if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
+  const int variant = shade_variant();
+  // fp16: 0 = (8 waves, 2 column blocks; the 24 weight fragments stay in
+  //          registers), 1 = (8, 4), 2 = (16, 2; spills)
+  // fp32: 0 = (12 waves, 2 blocks; no spills), 1 = (8, 2), 2 = (16, 1)
+  const uint32_t waves = half ? (variant == 2 ? 16u : 8u)
+                              : (variant == 0 ? 12u : (variant == 1 ? 8u : 16u));
+  // both kernels use the same ranges of whole rays per wave: enough waves to
+  // fill the chip twice over
+  const uint64_t total_waves = 256ull * 16 * 2;
+  uint32_t rpw = (uint32_t)((N + total_waves - 1) / total_waves);
+  const uint32_t rpw_min = S >= 128 ? 1u : (S >= 64 ? 2u : 4u);
+  if (rpw < rpw_min) rpw = rpw_min;
+  const uint32_t n_waves = ucsa_div_up(N, rpw);
+  // ---- A: weights + compaction ---------------------------------------------
   {
-    WcArgs a{norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale,
-             depth, list_w, list_row, counts};
+    WcArgs a{norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale, depth,
+             list_w, list_row, list_ray, counts, rpw, image, semantics,
+             n_classes};
     const size_t smem = (size_t)WC_WAVES * 4 * S * 4;
     UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
     hipError_t e = hipFuncSetAttribute(
@@ -563,35 +594,20 @@ static int32_t composite_infer(bool half, const float* rays_d,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return -(int32_t)e;
     UCSA_CLEAR_ERR();
-    hipLaunchKernelGGL(k_weights_compact, dim3(ucsa_div_up(N, WC_WAVES)),
+    hipLaunchKernelGGL(k_weights_compact, dim3(ucsa_div_up(n_waves, WC_WAVES)),
                        dim3(64 * WC_WAVES), smem, s, a);
     const int32_t rc = ucsa_launch_status();
     if (rc != 0) return rc;
   }
   // ---- B: dense shading of the survivor lists -------------------------------
-  const uint32_t nrb = cs_pad16(n_classes) / 16;
-  uint32_t cstride = 3 + n_classes;
-  if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
-  const int variant = shade_variant();
-  // fp16: 0 = (8 waves, 2 column blocks; 216 VGPRs: the 24 weight fragments
-  //          stay in registers), 1 = (8, 4), 2 = (16, 2; spills)
-  // fp32: 0 = (12 waves, 2 blocks; 166 VGPRs, no spills), 1 = (8, 2), 2 = (16, 1)
-  const uint32_t waves = half ? (variant == 2 ? 16u : 8u)
-                              : (variant == 0 ? 12u : (variant == 1 ? 8u : 16u));
   const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
                                : 7168 + 1024 + (size_t)nrb * 1024;
-  const size_t per_wave = 16 * (size_t)cstride + 64 + 68;
+  const size_t per_wave = 16 * (size_t)cstride + 64;
   const size_t smem = (w_floats + waves * per_wave) * 4;
-  // enough waves to fill the chip twice over, whole rays per wave, <= 64 rays
-  const uint64_t total_waves = 256ull * 16 * 2;
-  uint32_t rpw = (uint32_t)((N + total_waves - 1) / total_waves);
-  const uint32_t rpw_min = S >= 128 ? 1u : (S >= 64 ? 2u : 4u);
-  if (rpw < rpw_min) rpw = rpw_min;
-  if (rpw > 64) rpw = 64;
-  const uint32_t blocks = ucsa_div_up(ucsa_div_up(N, rpw), waves);
+  const uint32_t blocks = ucsa_div_up(n_waves, waves);
   ShArgs b{rays_d, h_c, h_f, (const float*)packed_color, (const float*)packed_sem,
-           list_w, list_row, counts, N, S, n_classes, rpw, cstride, image,
-           semantics};
+           list_w, list_row, list_ray, counts, N, S, n_classes, rpw, cstride,
+           image, semantics};
 #define SH_GO(NRB)                                                             \
   do {                                                                         \
     if (half) {                                                                \
