@@ -387,7 +387,17 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
         }
       }
     } else {
-      // fp16 weights / layer inputs, fp32 accumulate: 24 MFMAs per column block
+      // fp16 weights / layer inputs, fp32 accumulate: 24 MFMAs per column block.
+      // The 24 A fragments (96 VGPRs) are loop-invariant, and the compiler
+      // would keep them in registers for the whole kernel -- 216 VGPRs, two
+      // waves per SIMD, or spills under a smaller budget.  Reading them from
+      // LDS per group costs 24 ds_read_b128 (shared by the group's column
+      // blocks) and lets four waves per SIMD hide this kernel's latency
+      // chains; `zoff` (an opaque zero, re-made per group) keeps the loads
+      // inside the loop.
+      uint32_t zoff = 0;
+      if (WAVES > 8) asm volatile("" : "+v"(zoff));
+      const uint32_t wl = lane + zoff;
       const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cb = 0; cb < CBS; ++cb) {
@@ -403,27 +413,27 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
         }
         f32x4 a1[4], a2[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, wl), b1, z4);
         half8 h0 = chain_relu_h(a1[0], a1[1]), h1 = chain_relu_h(a1[2], a1[3]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
-          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2[rb]);
+          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, wl), h0, z4);
+          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, wl), h1, a2[rb]);
         }
         h0 = chain_relu_h(a2[0], a2[1]);
         h1 = chain_relu_h(a2[2], a2[3]);
-        f32x4 o3 = mfma_h(frag_h(w_color, 12, lane), h0, z4);
-        o3 = mfma_h(frag_h(w_color, 13, lane), h1, o3);
+        f32x4 o3 = mfma_h(frag_h(w_color, 12, wl), h0, z4);
+        o3 = mfma_h(frag_h(w_color, 13, wl), h1, o3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[c]));
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, wl), bs, z4);
         h0 = chain_relu_h(a1[0], a1[1]);
         h1 = chain_relu_h(a1[2], a1[3]);
 #pragma unroll
         for (int rb = 0; rb < NRB_SEM; ++rb) {
-          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
-          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[cb][rb]);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, wl), h0, z4);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, wl), h1, lg[cb][rb]);
         }
       }
     }
@@ -573,7 +583,9 @@ static int32_t composite_infer(bool half, const float* rays_d,
   // fp16: 0 = (8 waves, 2 column blocks; the 24 weight fragments stay in
   //          registers), 1 = (8, 4), 2 = (16, 2; spills)
   // fp32: 0 = (12 waves, 2 blocks; no spills), 1 = (8, 2), 2 = (16, 1)
-  const uint32_t waves = half ? (variant == 2 ? 16u : 8u)
+  //       3 = (16, 1), 4 = (12, 2)
+  const uint32_t waves = half ? ((variant == 2 || variant == 3) ? 16u
+                                 : (variant == 4 ? 12u : 8u))
                               : (variant == 0 ? 12u : (variant == 1 ? 8u : 16u));
   // both kernels use the same ranges of whole rays per wave: enough waves to
   // fill the chip twice over
@@ -613,6 +625,8 @@ static int32_t composite_infer(bool half, const float* rays_d,
     if (half) {                                                                \
       if (variant == 0) return launch_shade<NRB, 2, true, 8>(b, blocks, smem, s);  \
       if (variant == 1) return launch_shade<NRB, 4, true, 8>(b, blocks, smem, s);  \
+      if (variant == 3) return launch_shade<NRB, 1, true, 16>(b, blocks, smem, s); \
+      if (variant == 4) return launch_shade<NRB, 2, true, 12>(b, blocks, smem, s); \
       return launch_shade<NRB, 2, true, 16>(b, blocks, smem, s);               \
     }                                                                          \
     if (variant == 0) return launch_shade<NRB, 2, false, 12>(b, blocks, smem, s);  \

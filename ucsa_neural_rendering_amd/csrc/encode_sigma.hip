@@ -21,17 +21,18 @@
 //
 // Arithmetic: encode_level / encode_level_hashed and the MFMA chain of
 // k_sigma_mlp, unchanged -> h and sigma are bit-identical to the staged pair.
+#include <cstdlib>
+
 #include "hashgrid_common.h"
 #include "mfma_mlp_f16.h"
 
-#define ES_S 8                      // sample indices per workgroup
-#define ES_N (64 * ES_S)            // samples per workgroup
-#define ES_PLANE (ES_N + 8)         // 2*ES_PLANE = 16 mod 64: the four lane
-                                    // groups of an MFMA operand read hit
-                                    // disjoint bank windows
+// ES_S sample indices per workgroup (template: 8 -> 512 samples, 66.6 KB of
+// LDS, 2 workgroups per CU; 4 -> 256 samples, 33.8 KB, 4 per CU);
+// ES_PLANE = samples + 8: 2*ES_PLANE = 16 mod 64, so the four lane groups of
+// an MFMA operand read hit disjoint bank windows
 #define ES_UNROLL 4                 // column blocks in flight in the MLP phase
 
-template <bool HALF>
+template <bool HALF, int ES_S>
 __global__ void __launch_bounds__(256)
 k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
                      const float* __restrict__ rays_o,
@@ -41,6 +42,9 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
                      uint32_t n_blocks, const void* __restrict__ packed,
                      float* __restrict__ h, float* __restrict__ sigma) {
   extern __shared__ __attribute__((aligned(16))) float es_smem[];
+  constexpr uint32_t ES_N = 64 * ES_S, ES_PLANE = ES_N + 8;
+  constexpr uint32_t KPW = ES_S / 4;      // sample indices per wave and level
+  constexpr uint32_t CPW = ES_N / 64;     // column blocks per wave (MLP phase)
   float* f_s = es_smem;                                // [16][2][ES_PLANE]
   float* z_s = es_smem + 32 * ES_PLANE;                // [64][ES_S + 1]
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -60,7 +64,7 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
   };
   // depths of the tile, ray-major reads (32 B per ray)
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (uint32_t k = 0; k < ES_N / 256; ++k) {
     const uint32_t e = threadIdx.x + 256u * k;
     const uint32_t r = ray_of(e / ES_S), ss = e % ES_S;
     z_s[(e / ES_S) * (ES_S + 1) + ss] =
@@ -76,10 +80,10 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
     const float ox = o[0], oy = o[1], oz = o[2];
     const float dx = d[0], dy = d[1], dz = d[2];
     const float two_b = 2.0f * g.bound;
-    float x01[2], y01[2], z01[2];
+    float x01[KPW], y01[KPW], z01[KPW];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t ss = wid * 2 + k;
+    for (uint32_t k = 0; k < KPW; ++k) {
+      const uint32_t ss = wid * KPW + k;
       const float zz = z_s[lane * (ES_S + 1) + ss];
       const float px = clampf(ox + dx * zz, bb.lo[0], bb.hi[0]);
       const float py = clampf(oy + dy * zz, bb.lo[1], bb.hi[1]);
@@ -95,11 +99,11 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
       const uint32_t res = g.res[level], entries = g.entries[level],
                      hashed = g.hashed[level];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (uint32_t k = 0; k < KPW; ++k) {
         const float2 f = hashed
             ? encode_level_hashed(tab, x01[k], y01[k], z01[k], scale, entries)
             : encode_level(tab, x01[k], y01[k], z01[k], scale, res, entries, 0u);
-        const uint32_t sidx = lane * ES_S + wid * 2 + k;
+        const uint32_t sidx = lane * ES_S + wid * KPW + k;
         f_s[(level * 2 + 0) * ES_PLANE + sidx] = f.x;
         f_s[(level * 2 + 1) * ES_PLANE + sidx] = f.y;
       }
@@ -117,7 +121,7 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
       for (int ks = 0; ks < 8; ++ks) w1[rb][ks] = pk[(rb * 8 + ks) * 64 + lane];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) w2[ks] = pk[(SIGMA_L1_FRAGS + ks) * 64 + lane];
-    for (uint32_t c0 = wid * 8; c0 < wid * 8 + 8; c0 += ES_UNROLL) {
+    for (uint32_t c0 = wid * CPW; c0 < wid * CPW + CPW; c0 += ES_UNROLL) {
       float xin[ES_UNROLL][8];
 #pragma unroll
       for (int u = 0; u < ES_UNROLL; ++u) {
@@ -152,8 +156,8 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
 #pragma unroll
     for (int s = 0; s < 2; ++s) w2[s] = frag_h(packed, 4 + s, lane);
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) {
-      const uint32_t sidx = (wid * 8 + u) * 16 + j;
+    for (uint32_t u = 0; u < CPW; ++u) {
+      const uint32_t sidx = (wid * CPW + u) * 16 + j;
       half8 xin;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -193,25 +197,32 @@ static int32_t encode_sigma(bool half, const ucsa_grid* grid, const float* table
   const GridDev gd = ucsa_grid_dev(grid);
   const uint32_t rows = ucsa_div_up(N, image_width);
   const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
-  const uint32_t s_blocks = ucsa_div_up(T, ES_S);
+  // sample indices per workgroup: 4 by default, UCSA_ES_S=8 for the other shape
+  const char* ev = getenv("UCSA_ES_S");
+  const uint32_t es = (ev && ev[0] == '8') ? 8u : 4u;
+  const uint32_t s_blocks = ucsa_div_up(T, es);
   const uint32_t n_blocks = tiles * s_blocks;
   const uint32_t launch = (n_blocks + 7u) / 8u * 8u;
-  const size_t smem = (32 * (size_t)ES_PLANE + 64 * (ES_S + 1)) * 4;
+  const size_t smem = (32 * (size_t)(64 * es + 8) + 64 * (es + 1)) * 4;
   hipStream_t s = (hipStream_t)stream;
   const Aabb bb = ucsa_aabb(aabb_host);
-#define ES_LAUNCH(H)                                                          \
+#define ES_LAUNCH(H, SS)                                                      \
   do {                                                                        \
     hipError_t e = hipFuncSetAttribute(                                       \
-        reinterpret_cast<const void*>(&k_encode_sigma_tiled<H>),              \
+        reinterpret_cast<const void*>(&k_encode_sigma_tiled<H, SS>),          \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e != hipSuccess) return -(int32_t)e;                                  \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL(k_encode_sigma_tiled<H>, dim3(launch), dim3(256), smem, \
-                       s, gd, (const float2*)table, rays_o, rays_d, z, bb, T, \
-                       N, image_width, s_blocks, n_blocks, packed_sigma, h,   \
-                       sigma);                                                \
+    hipLaunchKernelGGL((k_encode_sigma_tiled<H, SS>), dim3(launch), dim3(256), \
+                       smem, s, gd, (const float2*)table, rays_o, rays_d, z,  \
+                       bb, T, N, image_width, s_blocks, n_blocks,             \
+                       packed_sigma, h, sigma);                               \
   } while (0)
-  if (half) ES_LAUNCH(true); else ES_LAUNCH(false);
+  if (half) {
+    if (es == 8) ES_LAUNCH(true, 8); else ES_LAUNCH(true, 4);
+  } else {
+    if (es == 8) ES_LAUNCH(false, 8); else ES_LAUNCH(false, 4);
+  }
 #undef ES_LAUNCH
   return ucsa_launch_status();
 }

@@ -67,11 +67,23 @@ static int32_t encode(const ucsa_grid* grid, const float* table,
                                    T, feat, stream);
 }
 
-// image-ordered rays: encode + sigma MLP as one kernel unless
-// UCSA_FUSED_ENCODE=0 (A/B switch for measurements; same bits either way)
+// image-ordered rays: encode + sigma MLP as ONE kernel only when
+// UCSA_FUSED_ENCODE=1.  Measured slower than the level-major staged pair
+// (profiles/r02_encode_sigma_fused.txt): kept as a switchable experiment; same
+// bits either way.
 static bool fused_encode() {
   const char* v = getenv("UCSA_FUSED_ENCODE");
-  return !(v && v[0] == '0');
+  return v && v[0] == '1';
+}
+
+// fp32 shading is MFMA-bound (352 fp32 MFMAs per 32 samples = 1.62 ms per
+// 61 440-ray chunk at 100 % of the pipe): the fused k_composite (2.3-2.4 ms)
+// beats the split pair there (2.5-2.8 ms); the split pair wins once the nets
+// run on f16 MFMA (UCSA_SPLIT_COMPOSITE=0/1 overrides either default).
+static bool split_composite(bool half) {
+  const char* v = getenv("UCSA_SPLIT_COMPOSITE");
+  if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
+  return half;
 }
 
 extern "C" int32_t ucsa_render_fwd(
@@ -116,10 +128,17 @@ extern "C" int32_t ucsa_render_fwd(
                                   w.h_f, w.sigma_f, stream));
     }
   }
-  UCSA_TRY(ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
-                                w.sigma_f, w.h_f, packed_color, packed_sem, N,
-                                T, t, n_classes, density_scale, image, depth,
-                                semantics, w.cmp, stream));
+  if (split_composite(false)) {
+    UCSA_TRY(ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                  w.sigma_f, w.h_f, packed_color, packed_sem, N,
+                                  T, t, n_classes, density_scale, image, depth,
+                                  semantics, w.cmp, stream));
+  } else {
+    UCSA_TRY(ucsa_composite_fwd(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                w.sigma_f, w.h_f, packed_color, packed_sem, N, T,
+                                t, n_classes, density_scale, image, depth,
+                                semantics, nullptr, nullptr, stream));
+  }
   return 0;
 }
 
@@ -166,11 +185,19 @@ extern "C" int32_t ucsa_render_fwd_f16(
                                       grid->n_levels, w.h_f, w.sigma_f, stream));
     }
   }
-  UCSA_TRY(ucsa_composite_infer_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c,
-                                    w.z_f, w.sigma_f, w.h_f, packed_color_half,
+  if (split_composite(true)) {
+    UCSA_TRY(ucsa_composite_infer_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c,
+                                      w.z_f, w.sigma_f, w.h_f, packed_color_half,
+                                      packed_sem_half, N, T, t, n_classes,
+                                      density_scale, image, depth, semantics,
+                                      w.cmp, stream));
+  } else {
+    UCSA_TRY(ucsa_composite_fwd_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                    w.sigma_f, w.h_f, packed_color_half,
                                     packed_sem_half, N, T, t, n_classes,
                                     density_scale, image, depth, semantics,
-                                    w.cmp, stream));
+                                    stream));
+  }
   return 0;
 }
 
