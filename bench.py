@@ -411,11 +411,13 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
     return n_rays / best, best, parity, ref, got, (o, d)
 
 
-def stage_times(net, o, d, nrm, u, iters=5, image_width=0):
+def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False):
     """Per-kernel durations of one chunk, measured with events on the stream
-    the kernels run on (torch's current stream)."""
+    the kernels run on (torch's current stream).  half=True: the fp16-MFMA
+    nets (sigma MLP f16, split composite f16)."""
     from ucsa_neural_rendering_amd import ops
-    f = net._field()
+    f = net._field_f16() if half else net._field()
+    sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
     aabb = net._aabb_list(False)
     N = o.shape[0]
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -432,22 +434,32 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0):
         feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zc, aabb,
                                         image_width=image_width)
         marks[2].record()
-        hc, sc = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
+        hc, sc = sigma_mlp(feat, f["packed_sigma"])
         marks[3].record()
         zf = ops.resample(zc, sc.view(N, T_COARSE), u)
         marks[4].record()
         feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb,
                                         image_width=image_width)
         marks[5].record()
-        hf, sf = ops.sigma_mlp_fwd(feat, f["packed_sigma"])
+        hf, sf = sigma_mlp(feat, f["packed_sigma"])
         marks[6].record()
-        img, dep, sem, src, w = ops.composite_fwd(
-            d, nrm, zc, sc.view(N, T_COARSE), hc, zf, sf.view(N, T_FINE), hf,
-            f["packed_color"], f["packed_sem"], N_CLASSES, 1.0, want_aux=True)
+        if half:
+            ops.composite_infer(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
+                                sf.view(N, T_FINE), hf, f["packed_color"],
+                                f["packed_sem"], N_CLASSES, 1.0, half=True)
+        elif it == 0:
+            w = ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
+                                  sf.view(N, T_FINE), hf, f["packed_color"],
+                                  f["packed_sem"], N_CLASSES, 1.0, want_aux=True)[4]
+        else:   # what ucsa_render_fwd launches for fp32: the fused kernel
+            ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
+                              sf.view(N, T_FINE), hf, f["packed_color"],
+                              f["packed_sem"], N_CLASSES, 1.0)
         marks[7].record()
         torch.cuda.synchronize()
         if it == 0:
-            rho = float((w > 1e-4).float().mean())
+            if not half:
+                rho = float((w > 1e-4).float().mean())
             continue
         for i, k in enumerate(names):
             acc[k] += marks[i].elapsed_time(marks[i + 1]) / iters
@@ -818,11 +830,32 @@ def main():
         dt16 = (time.perf_counter() - t1) / n16
         net.precision = "fp32"
         d16 = (out16["image"] - step(args.warmup + n16 - 1)["image"]).abs().max()
+        st16, _ = stage_times(net, o[0, :chunk].contiguous(), d[0, :chunk].contiguous(),
+                              nrm[0, :chunk, 0].contiguous(), u[:chunk],
+                              image_width=W, half=True)
+        cmp16_tf = mlp_flop / (st16["composite"] * 1e-3) / 1e12
+        sig16_tf = samples * 6144 / (0.5 * (st16["sigma_c"] + st16["sigma_f"]) * 1e-3) / 1e12
         result["f16_mlp_option"] = {
             "rays_per_s": H * W / dt16, "ms_per_view": dt16 * 1e3,
             "max_abs_image_diff_vs_fp32": float(d16),
-            "note": "precision='fp16': three MLPs on 16x16x32 f16 MFMA, fp32 "
-                    "accumulate; hash grid, sampling, compositing fp32"}
+            "stage_ms_per_chunk": st16,
+            "roofline_composite": {
+                "kernel": "k_weights_compact + k_shade_dense (colour+semantics "
+                          "MLPs on 16x16x32 f16 MFMA, fp32 accumulate)",
+                "bound": "mfma", "achieved": cmp16_tf, "peak": F16_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": cmp16_tf / F16_MFMA_PEAK_TF,
+                "launch_ms": st16["composite"], "sigma_mlp_tflops": sig16_tf,
+                "note": "the nets are 24 MFMAs per 16 samples here: the kernel "
+                        "is bound by the softmax / ordered per-ray sums (VALU, "
+                        "LDS) and by latency, not by the matrix pipe"},
+            "roofline_step_mfma_frac_of_fp16_dense_peak":
+                step_flop / (dt16 * 1e3) / 1e9 / F16_MFMA_PEAK_TF,
+            "note": "precision='fp16' (tiny-cuda-nn's own numerics, "
+                    "`nerf: {precision: fp16}`): three MLPs on 16x16x32 f16 MFMA "
+                    "with fp16 weights / layer inputs and fp32 accumulation; hash "
+                    "grid, sampling, compositing fp32.  Parity: tests/"
+                    "test_gpu_configs.py against the oracle with the same "
+                    "roundings emulated (3e-3)"}
         # The side measurements below (marcher, training, DeepLab, CPU
         # baseline) are single-GPU figures: at N > 1 the other ranks would only
         # wait for rank 0, so they run at N = 1 only.

@@ -61,6 +61,6 @@ for half in (False, True):
 '''
 
 if __name__ == "__main__":
-    for v in ("0", "3", "4"):
+    for v in ("0", "1"):
         env = dict(os.environ, UCSA_SHADE_VARIANT=v)
         subprocess.run([sys.executable, "-c", CHILD % (ROOT, v)], env=env, check=False)

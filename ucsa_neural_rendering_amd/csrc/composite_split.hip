@@ -542,7 +542,7 @@ static int32_t launch_shade(const ShArgs& a, uint32_t blocks, size_t smem,
 
 // Launch shapes (waves per workgroup, column blocks per group).  The register
 // budget follows from the workgroup size: 16 waves -> 128 VGPRs, 12 -> 168,
-// 8 -> 256.  UCSA_SHADE_VARIANT (0..2) selects another shape for experiments
+// 8 -> 256.  UCSA_SHADE_VARIANT selects another shape for experiments
 // (tools/composite_split_bench.py); results do not depend on it.
 static int shade_variant() {
   const char* v = getenv("UCSA_SHADE_VARIANT");
@@ -580,13 +580,17 @@ static int32_t composite_infer(bool half, const float* rays_d,
   uint32_t cstride = 3 + n_classes;
   if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
   const int variant = shade_variant();
-  // fp16: 0 = (8 waves, 2 column blocks; the 24 weight fragments stay in
-  //          registers), 1 = (8, 4), 2 = (16, 2; spills)
-  // fp32: 0 = (12 waves, 2 blocks; no spills), 1 = (8, 2), 2 = (16, 1)
-  //       3 = (16, 1), 4 = (12, 2)
-  const uint32_t waves = half ? ((variant == 2 || variant == 3) ? 16u
-                                 : (variant == 4 ? 12u : 8u))
-                              : (variant == 0 ? 12u : (variant == 1 ? 8u : 16u));
+  // (waves per workgroup, column blocks per group); measured on the bench's
+  // 61 440-ray chunk, k_weights_compact (0.13 ms) included:
+  // fp16: 0 = (16, 1): 0.94 ms  <- default: 120 VGPRs, 4 waves per SIMD
+  //       1 = (8, 2): 1.17 (216 VGPRs: the compiler keeps the 24 weight
+  //           fragments in registers), 2 = (8, 4): 1.31, 3 = (12, 2): 2.30
+  //           (spills), 4 = (16, 2): 3.7 (spills)
+  // fp32: 0 = (16, 1): 2.49, 1 = (12, 2): 2.85, 2 = (8, 2): 2.63 -- all behind
+  //       the fused k_composite (2.33), which ucsa_render_fwd keeps for fp32
+  const uint32_t waves = half ? ((variant == 0 || variant == 4) ? 16u
+                                 : (variant == 3 ? 12u : 8u))
+                              : (variant == 0 ? 16u : (variant == 1 ? 12u : 8u));
   // both kernels use the same ranges of whole rays per wave: enough waves to
   // fill the chip twice over
   const uint64_t total_waves = 256ull * 16 * 2;
@@ -623,15 +627,15 @@ static int32_t composite_infer(bool half, const float* rays_d,
 #define SH_GO(NRB)                                                             \
   do {                                                                         \
     if (half) {                                                                \
-      if (variant == 0) return launch_shade<NRB, 2, true, 8>(b, blocks, smem, s);  \
-      if (variant == 1) return launch_shade<NRB, 4, true, 8>(b, blocks, smem, s);  \
-      if (variant == 3) return launch_shade<NRB, 1, true, 16>(b, blocks, smem, s); \
-      if (variant == 4) return launch_shade<NRB, 2, true, 12>(b, blocks, smem, s); \
+      if (variant == 0) return launch_shade<NRB, 1, true, 16>(b, blocks, smem, s); \
+      if (variant == 1) return launch_shade<NRB, 2, true, 8>(b, blocks, smem, s);  \
+      if (variant == 2) return launch_shade<NRB, 4, true, 8>(b, blocks, smem, s);  \
+      if (variant == 3) return launch_shade<NRB, 2, true, 12>(b, blocks, smem, s); \
       return launch_shade<NRB, 2, true, 16>(b, blocks, smem, s);               \
     }                                                                          \
-    if (variant == 0) return launch_shade<NRB, 2, false, 12>(b, blocks, smem, s);  \
-    if (variant == 1) return launch_shade<NRB, 2, false, 8>(b, blocks, smem, s);   \
-    return launch_shade<NRB, 1, false, 16>(b, blocks, smem, s);                \
+    if (variant == 0) return launch_shade<NRB, 1, false, 16>(b, blocks, smem, s);  \
+    if (variant == 1) return launch_shade<NRB, 2, false, 12>(b, blocks, smem, s);  \
+    return launch_shade<NRB, 2, false, 8>(b, blocks, smem, s);                 \
   } while (0)
   switch (nrb) {
     case 1: SH_GO(1);

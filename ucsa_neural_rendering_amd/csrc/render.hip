@@ -7,6 +7,10 @@
 
 #include "ucsa_common.h"
 
+#ifndef UCSA_FUSED_ENCODE_DEFAULT
+#define UCSA_FUSED_ENCODE_DEFAULT 0
+#endif
+
 namespace {
 struct Ws {
   float *nears, *fars, *z_c, *z_f, *feat, *h_c, *sigma_c, *h_f, *sigma_f;
@@ -67,13 +71,13 @@ static int32_t encode(const ucsa_grid* grid, const float* table,
                                    T, feat, stream);
 }
 
-// image-ordered rays: encode + sigma MLP as ONE kernel only when
-// UCSA_FUSED_ENCODE=1.  Measured slower than the level-major staged pair
-// (profiles/r02_encode_sigma_fused.txt): kept as a switchable experiment; same
-// bits either way.
-static bool fused_encode() {
+// image-ordered rays: which passes run encode + sigma MLP as ONE kernel
+// (features through LDS, ucsa_encode_sigma_rays_image): UCSA_FUSED_ENCODE =
+// 0 none, 1 both, 2 the coarse pass only.  Same bits whatever the choice.
+static int fused_encode_mode() {
   const char* v = getenv("UCSA_FUSED_ENCODE");
-  return v && v[0] == '1';
+  if (v && v[0] >= '0' && v[0] <= '2') return v[0] - '0';
+  return UCSA_FUSED_ENCODE_DEFAULT;
 }
 
 // fp32 shading is MFMA-bound (352 fp32 MFMAs per 32 samples = 1.62 ms per
@@ -102,8 +106,8 @@ extern "C" int32_t ucsa_render_fwd(
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  const bool fuse = image_width && grid->n_levels == 16 && fused_encode();
-  if (fuse) {
+  const int fmode = image_width && grid->n_levels == 16 ? fused_encode_mode() : 0;
+  if (fmode != 0) {
     UCSA_TRY(ucsa_encode_sigma_rays_image(grid, table, packed_sigma, rays_o,
                                           rays_d, w.z_c, aabb_host, N, T,
                                           image_width, w.h_c, w.sigma_c, stream));
@@ -116,7 +120,7 @@ extern "C" int32_t ucsa_render_fwd(
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    if (fuse) {
+    if (fmode == 1) {
       UCSA_TRY(ucsa_encode_sigma_rays_image(grid, table, packed_sigma, rays_o,
                                             rays_d, w.z_f, aabb_host, N, t,
                                             image_width, w.h_f, w.sigma_f,
@@ -158,8 +162,8 @@ extern "C" int32_t ucsa_render_fwd_f16(
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  const bool fuse = image_width && grid->n_levels == 16 && fused_encode();
-  if (fuse) {
+  const int fmode = image_width && grid->n_levels == 16 ? fused_encode_mode() : 0;
+  if (fmode != 0) {
     UCSA_TRY(ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma_half,
                                               rays_o, rays_d, w.z_c, aabb_host,
                                               N, T, image_width, w.h_c,
@@ -173,7 +177,7 @@ extern "C" int32_t ucsa_render_fwd_f16(
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    if (fuse) {
+    if (fmode == 1) {
       UCSA_TRY(ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma_half,
                                                 rays_o, rays_d, w.z_f, aabb_host,
                                                 N, t, image_width, w.h_f,

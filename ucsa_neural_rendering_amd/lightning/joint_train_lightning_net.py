@@ -61,6 +61,10 @@ class JointTrainLightningNet(nn.Module):
             density_scale=1, num_semantic_classes=self.num_classes,
             seed=exp.get("nerf_seed"))
         self.nerf_model.march_training = self.cuda_ray
+        # `nerf: {precision: fp16}`: inference renders evaluate the three MLPs
+        # like tiny-cuda-nn does (fp16 weights / layer inputs, fp32 accumulate,
+        # 16x16x32 f16 MFMA); training and the default stay fp32
+        self.nerf_model.precision = str(nerf_cfg.get("precision", "fp32"))
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
         # (MIOpen's fast path on MI355X: 49 -> 34 ms per 8-image train step)
