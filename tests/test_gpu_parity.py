@@ -165,6 +165,17 @@ def test_resample_matches_oracle(ops, T, t):
     assert float(loose.float().mean()) <= 5e-3
     assert float(err.max()) <= 1.5 * widest_bin
     assert float(err.median()) <= 1e-6
+    # ... and the loose samples really are the ones the explanation above is
+    # about: they sit in (or next to) an EMPTY bin, i.e. a bin whose pdf is the
+    # 1e-5 floor -- weight below 1e-6 of the ray's total -- or on the
+    # degenerate all-zero-weight ray 0.
+    wi = w[:, 1:-1]
+    pdf_w = wi / (wi + 1e-5).sum(-1, keepdim=True)
+    bins = z[:, :-1] + 0.5 * deltas[:, :-1]
+    for r, k in loose.nonzero().tolist():
+        b = int(torch.searchsorted(bins[r].contiguous(), ref[r, k].clamp(bins[r, 0], bins[r, -1])))
+        lo, hi = max(0, b - 2), min(pdf_w.shape[1], b + 1)
+        assert r == 0 or float(pdf_w[r, lo:hi].min()) <= 1e-6, (r, k, float(err[r, k]))
 
 
 # ---------------------------------------------------------------- a3-a9

@@ -122,6 +122,11 @@ k_nerf_loss_grad(const float* __restrict__ rgb, const float* __restrict__ sem,
   } else {
     for (uint32_t k = 0; k < C; ++k) ds[k] = 0.f;
   }
+  // No pixel with depth: the reference's loss_depth is the mean of an EMPTY
+  // selection = NaN (logged as such, stats[2] / stats[5]), but its gradient is
+  // the scatter of an empty tensor = zeros, so the colour / semantics gradients
+  // stay finite and GradScaler does NOT skip the step (checked against torch in
+  // tests/test_gpu_losses_and_module.py).  Same here: d_depth = 0.
   const float gd = gt_depth[i];
   float dd = 0.f;
   if (gd != 0.f && n_valid > 0.f) {

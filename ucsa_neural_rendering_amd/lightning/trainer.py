@@ -120,9 +120,9 @@ class Trainer:
     def _loaders(self, dl):
         return dl if isinstance(dl, (list, tuple)) else [dl]
 
-    def _batches(self, loader):
+    def _batches(self, loader, limited=True):
         for i, b in enumerate(loader):
-            if self.limit_batches is not None and i >= self.limit_batches:
+            if limited and self.limit_batches is not None and i >= self.limit_batches:
                 break
             yield i, self._to_device(b)
 
@@ -157,8 +157,10 @@ class Trainer:
         getattr(model, f"on_{kind}_epoch_start")()
         outs = []
         with torch.no_grad():
+            # the predict pass writes the files the NEXT stage replays: it always
+            # covers every frame, whatever `limit_batches` (a smoke-run knob) says
             for li, loader in enumerate(self._loaders(dataloaders)):
-                for i, batch in self._batches(loader):
+                for i, batch in self._batches(loader, limited=kind != "predict"):
                     outs.append(getattr(model, f"{kind}_step")(batch, i, li))
         res = getattr(model, f"on_{kind}_epoch_end")()
         self._flush_logs()

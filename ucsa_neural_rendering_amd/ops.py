@@ -22,18 +22,27 @@ def _ptr(t: Optional[torch.Tensor]):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+def _raw_current_stream() -> int:
+    if _raw_stream is not None:
+        return int(_raw_stream(torch.cuda.current_device()))
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
 def _stream():
     # torch's current stream on the current device; the raw getter is ~20x
     # cheaper than torch.cuda.current_stream() (a training step makes ~17 calls)
-    if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_current_stream())
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.UcsaError(
             f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's current stream
+        raise _lib.UcsaError(
+            f"{name} is on {t.device} but the current device is cuda:"
+            f"{torch.cuda.current_device()}: call torch.cuda.set_device first")
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
@@ -398,7 +407,7 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
     ws = None
     if binned:
         need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(N, T, grid.n_levels))
-        key = z.device
+        key = (z.device, _raw_current_stream())   # one bin buffer per stream
         ws = _bwd_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=z.device)
@@ -417,7 +426,7 @@ def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
     ws = None
     if binned:
         need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(M, 1, grid.n_levels))
-        key = x.device
+        key = (x.device, _raw_current_stream())
         ws = _bwd_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=x.device)
