@@ -66,7 +66,14 @@ def parse():
                     help="Adam steps on the synthetic scene before timing "
                          "(SURVEY 8d: 200)")
     ap.add_argument("--no-train-bench", action="store_true")
-    ap.add_argument("--mode", choices=["render", "train", "cfg4"], default="render")
+    ap.add_argument("--mode", choices=["render", "train", "cfg3", "cfg4"],
+                    default="render")
+    ap.add_argument("--backbone", default="resnet50",
+                    help="cfg3: DeepLab backbone (BASELINE cfg3 says ResNet-50; "
+                         "the reference's model is resnet101)")
+    ap.add_argument("--seg-amp", default="", help="cfg3: '' (fp32, the reference) or bf16")
+    ap.add_argument("--nerf-precision", default="fp32", choices=["fp32", "fp16"],
+                    help="cfg3: nets of the no-grad full-frame renders")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="train legs: all-reduce + full Adam on every rank "
                          "instead of the sharded optimizer")
@@ -615,6 +622,8 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ucsa_neural_rendering_amd import ops
+    if args.mode == "cfg3":
+        return main_cfg3(args, dev, dist, world, rank, backend)
     prelog = {}
     net, scene_ds = build_field(dev, train_steps=args.pretrain_steps, log=prelog)
     if dist:
@@ -933,6 +942,86 @@ def main_train(args, net, scene_ds, dev, dist, world, rank, backend, prelog,
                    "mode": "train", "pretrain": prelog,
                    "optimizer": tr["optimizer"]},
         "train_dp": tr,
+    }
+    _finish(dist, rank, result)
+
+
+def main_cfg3(args, dev, dist, world, rank, backend):
+    """--mode cfg3: the joint training step of the LightningModule mirror
+    (reference training_step_joint, joint_train_lightning_net.py:363-471) at
+    BASELINE cfg3's batch: 8 new-scene frames of 320x240 per rank and step --
+    per frame one full no-grad render (256+256 samples, the reference's
+    behaviour: it feeds the augmentation / pseudo-label path) and one
+    4096-ray NeRF training step (fwd + bwd + Adam), then DeepLabV3 forward /
+    backward / Adam on the 8 augmented renders.  `value` = NeRF rays per
+    second through the step (rendered + trained), whole job."""
+    from ucsa_neural_rendering_amd import dist as udist
+    from ucsa_neural_rendering_amd.lightning import (JointTrainDataModule,
+                                                     JointTrainLightningNet, Trainer)
+    import tempfile
+    B, Hh, Ww = 8, 240, 320
+    exp = {
+        "general": {"name": "bench_cfg3", "clean_up_folder_if_exists": True,
+                    "checkpoint_load": ""},
+        "model": {"pretrained": False, "pretrained_backbone": False,
+                  "num_classes": N_CLASSES, "backbone": args.backbone,
+                  "amp": args.seg_amp},
+        "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
+        "trainer": {}, "data_module": {"batch_size": B},
+        "scenes": ["scene0000_00"],
+        "synthetic": {"n_views": 2 * B * max(1, world), "H": Hh, "W": Ww},
+        "nerf": {"n_rays": 4096, "num_steps": 256, "upsample_steps": 256,
+                 "precision": args.nerf_precision},
+        "nerf_seed": 123, "seed": 123,
+    }
+    tmp = tempfile.mkdtemp()
+    torch.manual_seed(123)
+    model = JointTrainLightningNet(exp, {"results": tmp, "scannet": tmp})
+    dm = JointTrainDataModule(exp)
+    dm.setup()
+    tr = Trainer(max_epochs=1, device=str(dev))
+    tr._attach(model)
+    if dist:
+        udist.broadcast_parameters_(model)
+        torch.manual_seed(123 + rank)
+    model.train()
+    model.joint_train = True
+    batches = [tr._to_device(b) for b in dm.train_dataloader_joint()]
+    n_b = len(batches)
+    for i in range(max(1, args.warmup)):
+        model.training_step(batches[i % n_b], 0)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.training_step(batches[i % n_b], 0)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    dt = elapsed / args.steps
+    rays = world * B * (Hh * Ww + 4096)
+    result = {
+        "metric": "rays/sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg3: joint step, 8 frames 320x240 per rank: 8 x (full "
+                               "no-grad render 256+256 + 4096-ray NeRF train step) + "
+                               f"DeepLabV3-{args.backbone} fwd/bwd/Adam on [8,3,240,320]",
+                   "mode": "cfg3", "backbone": args.backbone,
+                   "seg_precision": args.seg_amp or "fp32",
+                   "nerf_render_nets": args.nerf_precision,
+                   "nerf_rays_per_step_per_rank": B * (Hh * Ww + 4096),
+                   "seg_images_per_s": world * B / dt,
+                   "optimizer_nerf": type(model.optimizers()[1]).__name__},
+        "losses": {k: v for k, v in model.logged.items()},
     }
     _finish(dist, rank, result)
 

@@ -6,6 +6,10 @@ from ucsa_neural_rendering_amd.network import DeepLabV3
 from ucsa_neural_rendering_amd import losses as ul
 dev = torch.device("cuda", 0)
 B = 8
+# SEG_BENCHMARK=1: torch.backends.cudnn.benchmark (MIOpen's exhaustive find)
+torch.backends.cudnn.benchmark = os.environ.get("SEG_BENCHMARK", "0") == "1"
+print("cudnn.benchmark =", torch.backends.cudnn.benchmark, " MIOPEN_FIND_MODE =",
+      os.environ.get("MIOPEN_FIND_MODE"), flush=True)
 for backbone in ("resnet101", "resnet50"):
     for mode in ("fp32_nchw", "fp32_cl", "bf16_cl"):
         torch.manual_seed(0)
@@ -23,7 +27,7 @@ for backbone in ("resnet101", "resnet50"):
             opt.zero_grad(); loss.backward(); opt.step()
             return loss
         try:
-            for _ in range(3): step()
+            for _ in range(4): step()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(5): l = step()
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
