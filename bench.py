@@ -329,6 +329,7 @@ def seg_throughput(device, steps=5, B=8):
     from ucsa_neural_rendering_amd import losses as ul
     from ucsa_neural_rendering_amd.network import DeepLabV3
     out = {}
+    torch.backends.cudnn.benchmark = True   # MIOpen exhaustive find (as train_joint sets it)
     for mode in ("fp32", "bf16_channels_last"):
         torch.manual_seed(0)
         m = DeepLabV3({"pretrained": False, "pretrained_backbone": False,
@@ -844,6 +845,9 @@ def main():
                               image_width=W, half=True)
         cmp16_tf = mlp_flop / (st16["composite"] * 1e-3) / 1e12
         sig16_tf = samples * 6144 / (0.5 * (st16["sigma_c"] + st16["sigma_f"]) * 1e-3) / 1e12
+        # same workload with the three MLPs on f16 MFMA (tiny-cuda-nn's numerics);
+        # `value` stays the fp32 parity mode
+        result["value_fp16_nets"] = world * H * W / dt16 if world == 1 else None
         result["f16_mlp_option"] = {
             "rays_per_s": H * W / dt16, "ms_per_view": dt16 * 1e3,
             "max_abs_image_diff_vs_fp32": float(d16),
@@ -976,6 +980,7 @@ def main_cfg3(args, dev, dist, world, rank, backend):
     }
     tmp = tempfile.mkdtemp()
     torch.manual_seed(123)
+    torch.backends.cudnn.benchmark = True   # as scripts/train_joint.py sets it
     model = JointTrainLightningNet(exp, {"results": tmp, "scannet": tmp})
     dm = JointTrainDataModule(exp)
     dm.setup()
