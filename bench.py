@@ -138,13 +138,15 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
     return net.eval(), ds
 
 
-def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256):
+def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256,
+                     train_precision="fp32"):
     """cfg3's NeRF half at the reference's native sizes: 4096 rays x (256+256)
     samples, forward + backward + Adam per step."""
     from ucsa_neural_rendering_amd import losses as ul, ops
     from ucsa_neural_rendering_amd.nerf.optim import HipAdam
     import copy
     net = copy.deepcopy(net).train()
+    net.train_precision = train_precision
     opt = HipAdam(
         [{"name": "encoding", "params": list(net.encoder.parameters())},
          {"name": "net", "params": list(net.sigma_net.parameters()) +
@@ -885,6 +887,11 @@ def main():
                 result["march_option"] = {"error": repr(e), "failed": True}
         if extras and not args.no_train_bench:
             result["train"] = train_throughput(net, scene_ds, dev)
+            tf = train_throughput(net, scene_ds, dev, train_precision="fp16")
+            tf["workload"] += ("; colour / semantics nets forward + backward on f16 "
+                               "MFMA (`nerf: {train_precision: fp16}`), sigma net and "
+                               "grid fp32")
+            result["train_f16_nets"] = tf
             result["seg"] = seg_throughput(dev)
         if extras and not args.no_cpu_baseline:
             threads = effective_cores()

@@ -289,7 +289,8 @@ int32_t ucsa_composite_fwd_f16(const float* rays_d, const float* norms,
                                const void* packed_sem_half, uint32_t N,
                                uint32_t T, uint32_t t, uint32_t n_classes,
                                float density_scale, float* image, float* depth,
-                               float* semantics, void* stream);
+                               float* semantics, int32_t* src, float* weights,
+                               void* stream);
 int32_t ucsa_render_fwd_f16(const ucsa_grid* grid_host, const float* table,
                             const void* packed_sigma_half,
                             const void* packed_color_half,
@@ -336,6 +337,29 @@ int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
                            const float* packed_sigma_t, uint32_t M,
                            uint32_t n_levels, float* d_feat, float* partial,
                            void* stream);
+
+/* Transposed fp16 fragments for the f16 backward of the colour / semantics
+ * nets (kind = UCSA_MLP_COLOR or UCSA_MLP_SEM), and the backward itself:
+ * ucsa_composite_bwd with the two nets and their dX contractions on
+ * 16x16x32 f16 MFMA (the forward recompute reproduces ucsa_composite_fwd_f16;
+ * dW stays fp32).  `f16_scale` (a power of two, e.g. 1024): gradients entering
+ * the f16 MFMAs are multiplied by it and every output divided -- tiny-cuda-nn's
+ * loss scale; pass 1 when the incoming gradients already carry a GradScaler
+ * scale.  Partials: ucsa_composite_bwd_parts_f16(N) slots. */
+uint32_t ucsa_mlp_pack_t_f16_halves(int32_t kind, uint32_t n_classes);
+int32_t ucsa_mlp_pack_t_f16(int32_t kind, const float* params, void* packed_half,
+                            uint32_t n_classes, void* stream);
+uint32_t ucsa_composite_bwd_parts_f16(uint32_t N);
+int32_t ucsa_composite_bwd_f16(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const void* packed_color_half,
+    const void* packed_sem_half, const void* packed_color_t_half,
+    const void* packed_sem_t_half, const float* d_image, const float* d_depth,
+    const float* d_sem, uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes,
+    float density_scale, float f16_scale, float* G, float* d_h_c, float* d_h_f,
+    float* partial_color, float* partial_sem, void* stream);
 
 /* Backward of ucsa_hashgrid_encode_rays: adds into grad_table
  * [total_entries,2] (caller zeroes it).  Autograd of tcnn.Encoding.

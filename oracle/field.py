@@ -296,6 +296,9 @@ class OracleField:
                  seed: int | None = 123, grid_spec: GridSpec | None = None,
                  emulate_fp16: bool = False):
         self.emulate_fp16 = emulate_fp16
+        # per-net emulation ("sigma", "color", "sem"): the training mode
+        # train_precision="fp16" runs only the colour / semantics nets in fp16
+        self.emulate_fp16_nets = ()
         self.bound = float(bound)
         self.C = num_semantic_classes
         self.geo_feat_dim = geo_feat_dim
@@ -314,6 +317,9 @@ class OracleField:
             self.color_params = mlp_init(self.color_spec, g)
             self.sem_params = mlp_init(self.sem_spec, g)
 
+    def _emu(self, name: str) -> bool:
+        return bool(self.emulate_fp16) or name in getattr(self, "emulate_fp16_nets", ())
+
     def parameters(self):
         return [self.grid_params, self.sigma_params, self.color_params,
                 self.sem_params]
@@ -328,7 +334,7 @@ class OracleField:
         x01 = (x + self.bound) / (2 * self.bound)
         enc = hashgrid_encode(self.grid, x01, self.grid_params)
         h = mlp_forward(self.sigma_spec, enc, self.sigma_params,
-                        self.emulate_fp16)
+                        self._emu("sigma"))
         sigma = trunc_exp(h[:, 0])
         return {"sigma": sigma, "geo_feat": h[:, 1:]}
 
@@ -343,7 +349,7 @@ class OracleField:
         d01 = (d + 1) / 2
         h = torch.cat([sh4_encode(d01), geo_feat], dim=-1)
         h = torch.sigmoid(mlp_forward(self.color_spec, h, self.color_params,
-                                      self.emulate_fp16))
+                                      self._emu("color")))
         if mask is not None:
             rgbs[mask] = h
             return rgbs
@@ -357,7 +363,7 @@ class OracleField:
                 return out
             geo_feat = geo_feat[mask]
         h = mlp_forward(self.sem_spec, geo_feat, self.sem_params,
-                        self.emulate_fp16)
+                        self._emu("sem"))
         p = torch.softmax(h, dim=-1)
         if mask is not None:
             out[mask] = p

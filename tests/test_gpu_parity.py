@@ -446,7 +446,7 @@ def test_split_inference_composite_is_bit_identical_to_the_fused_kernel(ops, net
         check(lib().ucsa_composite_fwd_f16(
             p(d), p(norms.view(-1)), p(zc), p(sc), p(hc), p(zf), p(sf), p(hf),
             p(f["packed_color"]), p(f["packed_sem"]), N, T, t, 40, 1.0, p(image),
-            p(depth), p(sem), ops._stream()), "ucsa_composite_fwd_f16")
+            p(depth), p(sem), None, None, ops._stream()), "ucsa_composite_fwd_f16")
         want = (image, depth, sem)
     else:
         want = ops.composite_fwd(d, norms, zc, sc, hc, zf, sf, hf, f["packed_color"],

@@ -43,8 +43,7 @@ for _ in range(10):
     fn = lib().ucsa_composite_fwd_f16 if half else lib().ucsa_composite_fwd
     args = [p(d), p(nrm), p(zc), p(sc), p(hc), p(zf), p(sf), p(hf), p(f["packed_color"]),
             p(f["packed_sem"]), N, T, t, 40, 1.0, p(img), p(dep), p(sem)]
-    if not half:
-        args += [None, None]
+    args += [None, None]
     check(fn(*args, ops._stream()), "fused")
     ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, f["packed_color"], f["packed_sem"],
                         40, half=half)

@@ -99,7 +99,8 @@ SIGNATURES = {
     "ucsa_mlp_pack_f16": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_sigma_mlp_fwd_f16": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_composite_fwd_f16": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32,
-                                                        _f, _p, _p, _p, _p]),
+                                                        _f, _p, _p, _p, _p, _p,
+                                                        _p]),
     "ucsa_render_fwd_f16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                         _p, _p, C.POINTER(_f), _f, _p, _p,
                                         _u32, _u32, _u32, _u32, _f, _u32, _p,
@@ -122,6 +123,11 @@ SIGNATURES = {
     "ucsa_composite_bwd_parts": (C.c_uint32, [_u32]),
     "ucsa_composite_bwd": (C.c_int32, [_p] * 17 + [_u32, _u32, _u32, _u32, _f] +
                            [_p] * 6),
+    "ucsa_mlp_pack_t_f16_halves": (C.c_uint32, [C.c_int32, _u32]),
+    "ucsa_mlp_pack_t_f16": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
+    "ucsa_composite_bwd_parts_f16": (C.c_uint32, [_u32]),
+    "ucsa_composite_bwd_f16": (C.c_int32, [_p] * 17 + [_u32, _u32, _u32, _u32, _f,
+                                                        _f] + [_p] * 6),
     "ucsa_adam_step": (C.c_int32, [_p, _p, _p, _p, C.c_uint64, _u32, _f, _f,
                                    _f, _f, _f, _f, _p]),
     "ucsa_adam_step_scaled": (C.c_int32, [_p, _p, _p, _p, C.c_uint64, _u32,

@@ -785,12 +785,12 @@ extern "C" int32_t ucsa_composite_fwd_f16(
     const float* sigma_f, const float* h_f, const void* packed_color_half,
     const void* packed_sem_half, uint32_t N, uint32_t T, uint32_t t,
     uint32_t n_classes, float density_scale, float* image, float* depth,
-    float* semantics, void* stream) {
+    float* semantics, int32_t* src, float* weights, void* stream) {
   return composite_launch(true, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
                           h_f, (const float*)packed_color_half,
                           (const float*)packed_sem_half, N, T, t, n_classes,
-                          density_scale, image, depth, semantics, nullptr,
-                          nullptr, stream);
+                          density_scale, image, depth, semantics, src, weights,
+                          stream);
 }
 
 // ---------------------------------------------------------------------------

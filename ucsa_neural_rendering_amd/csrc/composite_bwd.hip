@@ -13,10 +13,14 @@
 //  k_weights_bwd : per ray, d_sigma from G by a forward transmittance scan and
 //                  a reverse suffix scan, times the trunc_exp backward
 //                  (reference nr4seg/nerf/activation.py:17-21), into d_h[:,0].
-#include "mfma_mlp.h"
+#include "mfma_mlp_f16.h"
 #include "wave_ops.h"
 
 #define CB_WAVES 4
+// Waves per workgroup of the f16 variant: the fp32 kernel needs ~480 registers
+// (1 wave per SIMD); the f16 one 214, and its LDS (48 KB of weights + 10 KB
+// per wave) lets 8 waves share a CU: 2 per SIMD.
+#define CB_WAVES_H 8
 #define CB_CAP 80  // 15 pending + one 64-sample chunk
 #define ROW_FINE 0x80000000u
 
@@ -57,7 +61,36 @@ struct ShadeBwdArgs {
   const float* t_all;
   uint32_t n_points;
   float w_min;
+  // HALF = true: gradients entering the f16 MFMAs are multiplied by f16_scale
+  // (a power of two) and everything that leaves the kernel is divided by it
+  float f16_scale;
 };
+
+// two accumulator blocks -> one 32-wide k-step operand, no ReLU (gradients)
+__device__ __forceinline__ half8 chain_h(f32x4 lo, f32x4 hi) {
+  half8 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v[r] = (_Float16)lo[r];
+    v[4 + r] = (_Float16)hi[r];
+  }
+  return v;
+}
+
+// what the f16 forward fed into the next layer: relu, rounded to fp16
+__device__ __forceinline__ f32x4 relu_q4(f32x4 v) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = (float)(_Float16)fmaxf(v[k], 0.f);
+  return r;
+}
+
+__device__ __forceinline__ f32x4 q4(f32x4 v) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = (float)(_Float16)v[k];
+  return r;
+}
 
 __device__ __forceinline__ void sh4_select_b(float dx, float dy, float dz,
                                              uint32_t g, f32x4& o) {
@@ -98,18 +131,30 @@ __device__ __forceinline__ f32x4 gate4(f32x4 pre, f32x4 v) {
   return r;
 }
 
-template <int NRB, bool MARCH>
-__global__ void __launch_bounds__(64 * CB_WAVES)
+// HALF: the colour / semantics nets and their dX contractions run on
+// 16x16x32 f16 MFMA (fp16 weights and layer inputs, fp32 accumulate) -- the
+// forward recompute reproduces k_composite<.., HALF = true> exactly, so the
+// ReLU gates and the activations entering dW are the forward's.  dW itself
+// stays on fp32 MFMA over the LDS tiles (fp32 gradients x fp16-rounded
+// activations, accumulated in fp32 registers as before).
+template <int NRB, bool MARCH, bool HALF>
+__global__ void __launch_bounds__(64 * (HALF ? CB_WAVES_H : CB_WAVES))
 k_shade_bwd(ShadeBwdArgs a) {
+  constexpr uint32_t NW = HALF ? CB_WAVES_H : CB_WAVES;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint32_t T = a.T, t = a.t, S = a.T + a.t, C = a.C;
+  constexpr int NS = (NRB + 1) / 2;  // half8 k-steps covering the class logits
 
-  float* w_color = cb_smem;                    // 7168
-  float* w_sem = w_color + 7168;               // 1024 + NRB*1024
-  float* wt_color = w_sem + 1024 + NRB * 1024; // 6144
-  float* wt_sem = wt_color + 6144;             // (16*NRB + 16) * 64
-  float* per_wave = wt_sem + (16 * NRB + 16) * 64;
+  constexpr uint32_t WC = HALF ? COLOR_H_FRAGS * 256 : 7168;
+  constexpr uint32_t WS = HALF ? SEM_H_FRAGS(NRB) * 256 : 1024 + NRB * 1024;
+  constexpr uint32_t WTC = HALF ? 14 * 256 : 6144;
+  constexpr uint32_t WTS = HALF ? (4 * NS + 2) * 256 : (16 * NRB + 16) * 64;
+  float* w_color = cb_smem;
+  float* w_sem = w_color + WC;
+  float* wt_color = w_sem + WS;
+  float* wt_sem = wt_color + WTC;
+  float* per_wave = wt_sem + WTS;
   const uint32_t per_wave_floats = 5 * CB_CAP + 2 * 16 * TILE_LD;
   float* base = per_wave + (size_t)wid * per_wave_floats;
   float* lw = base;
@@ -120,13 +165,14 @@ k_shade_bwd(ShadeBwdArgs a) {
   float* dy_tile = lz + CB_CAP;
   float* x_tile = dy_tile + 16 * TILE_LD;
 
-  for (uint32_t i = threadIdx.x; i < 7168; i += blockDim.x) w_color[i] = a.packed_color[i];
-  for (uint32_t i = threadIdx.x; i < 1024 + NRB * 1024; i += blockDim.x) w_sem[i] = a.packed_sem[i];
-  for (uint32_t i = threadIdx.x; i < 6144; i += blockDim.x) wt_color[i] = a.packed_color_t[i];
-  for (uint32_t i = threadIdx.x; i < (16 * NRB + 16) * 64; i += blockDim.x) wt_sem[i] = a.packed_sem_t[i];
+  for (uint32_t i = threadIdx.x; i < WC; i += blockDim.x) w_color[i] = a.packed_color[i];
+  for (uint32_t i = threadIdx.x; i < WS; i += blockDim.x) w_sem[i] = a.packed_sem[i];
+  for (uint32_t i = threadIdx.x; i < WTC; i += blockDim.x) wt_color[i] = a.packed_color_t[i];
+  for (uint32_t i = threadIdx.x; i < WTS; i += blockDim.x) wt_sem[i] = a.packed_sem_t[i];
   __syncthreads();
+  const float gs = HALF ? a.f16_scale : 1.0f, inv_gs = 1.0f / gs;
 
-  const uint64_t gwave = (uint64_t)blockIdx.x * CB_WAVES + wid;
+  const uint64_t gwave = (uint64_t)blockIdx.x * NW + wid;
   f32x4 dwc1[4][2], dwc2[4][4], dwc3[1][4], dws1[4][1], dws2[NRB][4];
   dw_zero(dwc1);
   dw_zero(dwc2);
@@ -154,7 +200,41 @@ k_shade_bwd(ShadeBwdArgs a) {
 
     // ------------------------- forward (recompute) ------------------------
     f32x4 a1c[4], a2c[4], o3[1], a1s[4], lg[NRB];
-    {
+    if constexpr (HALF) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      half8 b1, bs;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        b1[r] = (_Float16)sh[r];
+        b1[4 + r] = (_Float16)geo[r];
+        bs[r] = (_Float16)geo[r];
+        bs[4 + r] = (_Float16)0.f;
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a1c[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
+      half8 h0 = chain_relu_h(a1c[0], a1c[1]), h1 = chain_relu_h(a1c[2], a1c[3]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        a2c[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
+        a2c[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2c[rb]);
+      }
+      h0 = chain_relu_h(a2c[0], a2c[1]);
+      h1 = chain_relu_h(a2c[2], a2c[3]);
+      o3[0] = mfma_h(frag_h(w_color, 12, lane), h0, z4);
+      o3[0] = mfma_h(frag_h(w_color, 13, lane), h1, o3[0]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a1s[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
+      h0 = chain_relu_h(a1s[0], a1s[1]);
+      h1 = chain_relu_h(a1s[2], a1s[3]);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        lg[rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
+        lg[rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[rb]);
+      }
+      // the layer inputs the forward actually used (fp16-rounded): dW sees them
+      sh = q4(sh);
+      geo = q4(geo);
+    } else {
       float xin[8] = {sh[0], sh[1], sh[2], sh[3], geo[0], geo[1], geo[2], geo[3]};
       mfma_layer<8, 4>(xin, [&](int rb, int ks) { return w_color[(rb * 8 + ks) * 64 + lane]; }, a1c);
       float hid[16];
@@ -199,7 +279,7 @@ k_shade_bwd(ShadeBwdArgs a) {
       for (int c = 0; c < 3; ++c) {
         const float rgb = 1.0f / (1.0f + __expf(-o3[0][c]));
         dwsum += di[c] * rgb;
-        dy3[c] = wgt * di[c] * rgb * (1.0f - rgb);
+        dy3[c] = gs * (wgt * di[c] * rgb * (1.0f - rgb));
       }
       if (live) a.G[MARCH ? (size_t)smp : (size_t)ray * S + smp] = dwsum;
     }
@@ -222,18 +302,24 @@ k_shade_bwd(ShadeBwdArgs a) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dlg[rb][r] = lg[rb][r] * (dlg[rb][r] - dot);
+      for (int r = 0; r < 4; ++r) dlg[rb][r] = gs * (lg[rb][r] * (dlg[rb][r] - dot));
 
     // ------------------------- colour net backward ------------------------
     // L3: dW3 += dy3 (x) relu(a2c);  d_hid2 = W3^T dy3
     tile_store(dy_tile, g, j, 0, dy3);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) tile_store(x_tile, g, j, rb, relu4(a2c[rb]));
+    for (int rb = 0; rb < 4; ++rb)
+      tile_store(x_tile, g, j, rb, HALF ? relu_q4(a2c[rb]) : relu4(a2c[rb]));
     cb_sync();
     dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
     cb_sync();
     f32x4 dh2[4];
-    {
+    if constexpr (HALF) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      const half8 bd = chain_h(dy3, z4);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) dh2[rb] = mfma_h(frag_h(wt_color, rb, lane), bd, z4);
+    } else {
       float b[4] = {dy3[0], dy3[1], dy3[2], dy3[3]};
       mfma_layer<4, 4>(b, [&](int rb, int ks) { return wt_color[(rb * 4 + ks) * 64 + lane]; }, dh2);
     }
@@ -243,13 +329,21 @@ k_shade_bwd(ShadeBwdArgs a) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       tile_store(dy_tile, g, j, rb, dh2[rb]);
-      tile_store(x_tile, g, j, rb, relu4(a1c[rb]));
+      tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1c[rb]) : relu4(a1c[rb]));
     }
     cb_sync();
     dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
     cb_sync();
     f32x4 dh1[4];
-    {
+    if constexpr (HALF) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      const half8 d0 = chain_h(dh2[0], dh2[1]), d1 = chain_h(dh2[2], dh2[3]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        dh1[rb] = mfma_h(frag_h(wt_color, 4 + 2 * rb, lane), d0, z4);
+        dh1[rb] = mfma_h(frag_h(wt_color, 5 + 2 * rb, lane), d1, dh1[rb]);
+      }
+    } else {
       float b[16];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
@@ -272,7 +366,11 @@ k_shade_bwd(ShadeBwdArgs a) {
     dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
     cb_sync();
     f32x4 dslot[1];
-    {
+    if constexpr (HALF) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      dslot[0] = mfma_h(frag_h(wt_color, 12, lane), chain_h(dh1[0], dh1[1]), z4);
+      dslot[0] = mfma_h(frag_h(wt_color, 13, lane), chain_h(dh1[2], dh1[3]), dslot[0]);
+    } else {
       float b[16];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
@@ -285,12 +383,26 @@ k_shade_bwd(ShadeBwdArgs a) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) tile_store(dy_tile, g, j, rb, dlg[rb]);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) tile_store(x_tile, g, j, rb, relu4(a1s[rb]));
+    for (int rb = 0; rb < 4; ++rb)
+      tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1s[rb]) : relu4(a1s[rb]));
     cb_sync();
     dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
     cb_sync();
     f32x4 dhs[4];
-    {
+    if constexpr (HALF) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      half8 ld[NS];
+#pragma unroll
+      for (int sx = 0; sx < NS; ++sx)
+        ld[sx] = chain_h(dlg[2 * sx], (2 * sx + 1 < NRB) ? dlg[(2 * sx + 1 < NRB) ? 2 * sx + 1 : 0] : z4);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        dhs[rb] = z4;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx)
+          dhs[rb] = mfma_h(frag_h(wt_sem, NS * rb + sx, lane), ld[sx], dhs[rb]);
+      }
+    } else {
       float b[4 * NRB];
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb)
@@ -312,7 +424,11 @@ k_shade_bwd(ShadeBwdArgs a) {
     dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
     cb_sync();
     f32x4 dslot_s[1];
-    {
+    if constexpr (HALF) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS, lane), chain_h(dhs[0], dhs[1]), z4);
+      dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS + 1, lane), chain_h(dhs[2], dhs[3]), dslot_s[0]);
+    } else {
       float b[16];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
@@ -322,10 +438,10 @@ k_shade_bwd(ShadeBwdArgs a) {
     }
     if (live) {
       f32x4 out;
-      out[0] = (g == 0) ? 0.0f : dslot[0][0] + dslot_s[0][0];  // slot 0: k_weights_bwd
-      out[1] = dslot[0][1] + dslot_s[0][1];
-      out[2] = dslot[0][2] + dslot_s[0][2];
-      out[3] = dslot[0][3] + dslot_s[0][3];
+      out[0] = (g == 0) ? 0.0f : inv_gs * (dslot[0][0] + dslot_s[0][0]);  // slot 0: k_weights_bwd
+      out[1] = inv_gs * (dslot[0][1] + dslot_s[0][1]);
+      out[2] = inv_gs * (dslot[0][2] + dslot_s[0][2]);
+      out[3] = inv_gs * (dslot[0][3] + dslot_s[0][3]);
       *reinterpret_cast<f32x4*>((fine ? a.d_h_f : a.d_h_c) + hoff) = out;
     }
   };
@@ -426,6 +542,13 @@ k_shade_bwd(ShadeBwdArgs a) {
     if (cnt) shade16(cnt);
   }
   // per-wave partial gradients, tcnn layout
+  if constexpr (HALF) {
+    auto unscale = [&](auto& dw) {
+      for (auto& row : dw)
+        for (auto& v : row) v = v * inv_gs;
+    };
+    unscale(dwc1); unscale(dwc2); unscale(dwc3); unscale(dws1); unscale(dws2);
+  }
   float* pc = a.partial_color + (size_t)gwave * 7168;
   dw_store<4, 2>(pc, 32, lane, dwc1);
   dw_store<4, 4>(pc + 2048, 64, lane, dwc2);
@@ -437,12 +560,19 @@ k_shade_bwd(ShadeBwdArgs a) {
 
 static inline uint32_t cb_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
 
-static void shade_bwd_geometry(uint32_t N, uint32_t& rpw, uint32_t& blocks) {
-  const uint64_t total_waves = 256ull * CB_WAVES;
+static size_t shade_bwd_weight_floats(bool half, uint32_t nrb) {
+  if (half)
+    return (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb) + 14 + 4 * ((nrb + 1) / 2) + 2) * 256;
+  return 7168 + 1024 + (size_t)nrb * 1024 + 6144 + (16 * (size_t)nrb + 16) * 64;
+}
+
+static void shade_bwd_geometry(uint32_t N, uint32_t& rpw, uint32_t& blocks,
+                               uint32_t waves = CB_WAVES) {
+  const uint64_t total_waves = 256ull * waves;
   rpw = (uint32_t)((N + total_waves - 1) / total_waves);
   if (rpw < 2) rpw = 2;
   const uint32_t n_waves = ucsa_div_up(N, rpw);
-  blocks = ucsa_div_up(n_waves, CB_WAVES);
+  blocks = ucsa_div_up(n_waves, waves);
 }
 
 // number of per-wave partial slots the caller must provide
@@ -450,6 +580,12 @@ extern "C" uint32_t ucsa_composite_bwd_parts(uint32_t N) {
   uint32_t rpw, blocks;
   shade_bwd_geometry(N ? N : 1, rpw, blocks);
   return blocks * CB_WAVES;
+}
+
+extern "C" uint32_t ucsa_composite_bwd_parts_f16(uint32_t N) {
+  uint32_t rpw, blocks;
+  shade_bwd_geometry(N ? N : 1, rpw, blocks, CB_WAVES_H);
+  return blocks * CB_WAVES_H;
 }
 
 // ---------------------------------------------------------------------------
@@ -523,9 +659,9 @@ k_weights_bwd(const float* __restrict__ z_c, const float* __restrict__ z_f,
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int32_t ucsa_composite_bwd(
-    const float* rays_d, const float* norms, const float* z_c,
-    const float* sigma_c, const float* h_c, const float* z_f,
+static int32_t composite_bwd_impl(
+    bool half, float f16_scale, const float* rays_d, const float* norms,
+    const float* z_c, const float* sigma_c, const float* h_c, const float* z_f,
     const float* sigma_f, const float* h_f, const int32_t* src,
     const float* weights, const float* packed_color, const float* packed_sem,
     const float* packed_color_t, const float* packed_sem_t,
@@ -544,11 +680,13 @@ extern "C" int32_t ucsa_composite_bwd(
   UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 20);
   UCSA_CHECK_ARG(G && d_h_c && (t == 0 || d_h_f), 22);
   UCSA_CHECK_ARG(partial_color && partial_sem, 25);
+  UCSA_CHECK_ARG(!half || f16_scale > 0.f, 28);
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t nrb = cb_pad16(n_classes) / 16;
   uint32_t rpw, blocks;
-  shade_bwd_geometry(N, rpw, blocks);
+  const uint32_t waves = half ? CB_WAVES_H : CB_WAVES;
+  shade_bwd_geometry(N, rpw, blocks, waves);
   // d_h rows of samples outside the mask get no geo gradient
   hipError_t e = hipMemsetAsync(d_h_c, 0, (size_t)N * T * 16 * sizeof(float), s);
   if (e != hipSuccess) return -(int32_t)e;
@@ -559,26 +697,35 @@ extern "C" int32_t ucsa_composite_bwd(
   ShadeBwdArgs a{rays_d, norms, z_c, z_f, h_c, h_f, src, weights, d_image,
                  d_depth, d_sem, packed_color, packed_sem, packed_color_t,
                  packed_sem_t, N, T, t, n_classes, G, d_h_c, d_h_f,
-                 partial_color, partial_sem, rpw, nullptr, nullptr, 0u, 0.0f};
-  const size_t smem = (7168 + 1024 + (size_t)nrb * 1024 + 6144 +
-                       (16 * (size_t)nrb + 16) * 64 +
-                       (size_t)CB_WAVES * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
-#define LAUNCH(NRB)                                                           \
+                 partial_color, partial_sem, rpw, nullptr, nullptr, 0u, 0.0f,
+                 half ? f16_scale : 1.0f};
+  const size_t w_floats = shade_bwd_weight_floats(half, nrb);
+  const size_t smem = (w_floats +
+                       (size_t)waves * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
+#define LAUNCH(NRB, H)                                                        \
   do {                                                                        \
     hipError_t e2 = hipFuncSetAttribute(                                      \
-        reinterpret_cast<const void*>(&k_shade_bwd<NRB, false>),                     \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, false, H>),           \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e2 != hipSuccess) return -(int32_t)e2;                                \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL((k_shade_bwd<NRB, false>), dim3(blocks),               \
-                       dim3(64 * CB_WAVES),                                   \
-                       smem, s, a);                                           \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, false, H>), dim3(blocks),            \
+                       dim3(64 * waves), smem, s, a);                         \
   } while (0)
-  switch (nrb) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    default: LAUNCH(4); break;
+  if (half) {
+    switch (nrb) {
+      case 1: LAUNCH(1, true); break;
+      case 2: LAUNCH(2, true); break;
+      case 3: LAUNCH(3, true); break;
+      default: LAUNCH(4, true); break;
+    }
+  } else {
+    switch (nrb) {
+      case 1: LAUNCH(1, false); break;
+      case 2: LAUNCH(2, false); break;
+      case 3: LAUNCH(3, false); break;
+      default: LAUNCH(4, false); break;
+    }
   }
 #undef LAUNCH
   int32_t rc = ucsa_launch_status();
@@ -589,6 +736,43 @@ extern "C" int32_t ucsa_composite_bwd(
                      dim3(64 * WB_WAVES), smem2, s, z_c, z_f, sigma_c, sigma_f,
                      src, weights, G, N, T, t, density_scale, d_h_c, d_h_f);
   return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_composite_bwd(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const float* packed_color, const float* packed_sem,
+    const float* packed_color_t, const float* packed_sem_t,
+    const float* d_image, const float* d_depth, const float* d_sem, uint32_t N,
+    uint32_t T, uint32_t t, uint32_t n_classes, float density_scale, float* G,
+    float* d_h_c, float* d_h_f, float* partial_color, float* partial_sem,
+    void* stream) {
+  return composite_bwd_impl(false, 1.0f, rays_d, norms, z_c, sigma_c, h_c, z_f,
+                            sigma_f, h_f, src, weights, packed_color,
+                            packed_sem, packed_color_t, packed_sem_t, d_image,
+                            d_depth, d_sem, N, T, t, n_classes, density_scale,
+                            G, d_h_c, d_h_f, partial_color, partial_sem, stream);
+}
+
+extern "C" int32_t ucsa_composite_bwd_f16(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const void* packed_color_half,
+    const void* packed_sem_half, const void* packed_color_t_half,
+    const void* packed_sem_t_half, const float* d_image, const float* d_depth,
+    const float* d_sem, uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes,
+    float density_scale, float f16_scale, float* G, float* d_h_c, float* d_h_f,
+    float* partial_color, float* partial_sem, void* stream) {
+  return composite_bwd_impl(true, f16_scale, rays_d, norms, z_c, sigma_c, h_c,
+                            z_f, sigma_f, h_f, src, weights,
+                            (const float*)packed_color_half,
+                            (const float*)packed_sem_half,
+                            (const float*)packed_color_t_half,
+                            (const float*)packed_sem_t_half, d_image, d_depth,
+                            d_sem, N, T, t, n_classes, density_scale, G, d_h_c,
+                            d_h_f, partial_color, partial_sem, stream);
 }
 
 // ===========================================================================
@@ -678,18 +862,19 @@ extern "C" int32_t ucsa_march_train_bwd(
   ShadeBwdArgs a{rays_d, norms, nullptr, nullptr, h, nullptr, nullptr, w_all,
                  d_image, d_depth, d_sem, packed_color, packed_sem,
                  packed_color_t, packed_sem_t, N, 0u, 0u, n_classes, G, d_h,
-                 nullptr, partial_color, partial_sem, rpw, rays, t_all, M, w_min};
+                 nullptr, partial_color, partial_sem, rpw, rays, t_all, M, w_min,
+                 1.0f};
   const size_t smem = (7168 + 1024 + (size_t)nrb * 1024 + 6144 +
                        (16 * (size_t)nrb + 16) * 64 +
                        (size_t)CB_WAVES * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
 #define LAUNCH_M(NRB)                                                         \
   do {                                                                        \
     hipError_t e2 = hipFuncSetAttribute(                                      \
-        reinterpret_cast<const void*>(&k_shade_bwd<NRB, true>),               \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, true, false>),               \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
     if (e2 != hipSuccess) return -(int32_t)e2;                                \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL((k_shade_bwd<NRB, true>), dim3(blocks),                \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, true, false>), dim3(blocks),                \
                        dim3(64 * CB_WAVES), smem, s, a);                      \
   } while (0)
   switch (nrb) {

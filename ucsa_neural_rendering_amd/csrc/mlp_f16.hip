@@ -73,6 +73,74 @@ extern "C" int32_t ucsa_mlp_pack_f16(int32_t kind, const float* params,
   return ucsa_launch_status();
 }
 
+// ---------------------------------------------------------------------------
+// Transposed fp16 A fragments for dX = W^T dY of the colour / semantics nets
+// (training with precision="fp16": composite_bwd.hip, k_shade_bwd<.., HALF>).
+// Rows i of a fragment = neurons of the layer's INPUT (natural order, so the
+// result lands in the accumulator layout of the forward activations it
+// gates); k-slot (s, g, e) = the layer's OUTPUT neuron chain_col_h(s, g, e),
+// i.e. what lane (g, j) holds of dY after packing two accumulator blocks into
+// a half8 (chain without ReLU).
+//   colour: [L3^T 4 frags (k-slots e<4 = output row 4g+e, rest 0)
+//            | L2^T 8 (rb, s) | L1^T restricted to the 16 h-row slots: 2]  = 14
+//   sem   : [L2^T 4*NS (rb, s), NS = ceil(nrb/2), classes >= 16*nrb -> 0
+//            | L1^T (h-row slots) 2]
+// ---------------------------------------------------------------------------
+__global__ void k_mlp_pack_t_f16(int kind, const float* __restrict__ params,
+                                 _Float16* __restrict__ packed,
+                                 uint32_t n_total, uint32_t nrb) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total) return;
+  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u;
+  uint32_t f = idx >> 9;
+  const uint32_t g = l >> 4, i = l & 15u;
+  float v = 0.f;
+  if (kind == UCSA_MLP_COLOR) {
+    if (f < 4) {
+      if (e < 4) v = params[64 * 32 + 64 * 64 + (4u * g + e) * 64 + 16u * f + i];
+    } else if (f < 12) {
+      const uint32_t rb = (f - 4) >> 1, sidx = (f - 4) & 1u;
+      v = params[64 * 32 + chain_col_h(sidx, g, e) * 64 + 16u * rb + i];
+    } else {
+      const uint32_t col = i == 0 ? 31u : 15u + i;
+      v = params[chain_col_h(f - 12, g, e) * 32 + col];
+    }
+  } else {
+    const uint32_t ns = (nrb + 1u) / 2u;
+    if (f < 4 * ns) {
+      const uint32_t rb = f / ns, sidx = f % ns;
+      const uint32_t n = chain_col_h(sidx, g, e);
+      if (n < 16u * nrb) v = params[64 * 16 + n * 64 + 16u * rb + i];
+    } else {
+      const uint32_t col = i == 0 ? 15u : i - 1u;
+      v = params[chain_col_h(f - 4 * ns, g, e) * 16 + col];
+    }
+  }
+  packed[idx] = (_Float16)v;
+}
+
+extern "C" uint32_t ucsa_mlp_pack_t_f16_halves(int32_t kind, uint32_t n_classes) {
+  const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
+  const uint32_t frags = kind == UCSA_MLP_COLOR ? 14u : 4u * ((nrb + 1u) / 2u) + 2u;
+  return frags * 64 * 8;
+}
+
+extern "C" int32_t ucsa_mlp_pack_t_f16(int32_t kind, const float* params,
+                                       void* packed_half, uint32_t n_classes,
+                                       void* stream) {
+  UCSA_CHECK_ARG(kind == UCSA_MLP_COLOR || kind == UCSA_MLP_SEM, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed_half, 2);
+  UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
+  const uint32_t n_total = ucsa_mlp_pack_t_f16_halves(kind, n_classes);
+  const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack_t_f16, dim3(ucsa_div_up(n_total, 256)), dim3(256),
+                     0, (hipStream_t)stream, (int)kind, params,
+                     (_Float16*)packed_half, n_total, nrb);
+  return ucsa_launch_status();
+}
+
 // sigma MLP, fp16 inputs/weights, fp32 accumulate, fp32 outputs.
 // 6 MFMAs per 16 samples: load/store bound, 8 column blocks per iteration.
 #define SIGH_UNROLL 8

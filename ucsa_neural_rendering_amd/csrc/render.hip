@@ -200,7 +200,7 @@ extern "C" int32_t ucsa_render_fwd_f16(
                                     w.sigma_f, w.h_f, packed_color_half,
                                     packed_sem_half, N, T, t, n_classes,
                                     density_scale, image, depth, semantics,
-                                    stream));
+                                    nullptr, nullptr, stream));
   }
   return 0;
 }

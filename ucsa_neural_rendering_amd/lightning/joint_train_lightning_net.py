@@ -65,6 +65,11 @@ class JointTrainLightningNet(nn.Module):
         # like tiny-cuda-nn does (fp16 weights / layer inputs, fp32 accumulate,
         # 16x16x32 f16 MFMA); training and the default stay fp32
         self.nerf_model.precision = str(nerf_cfg.get("precision", "fp32"))
+        # `nerf: {train_precision: fp16}`: colour / semantics nets of the
+        # training pass on f16 MFMA too; the GradScaler's scale (reference :46)
+        # already protects the fp16 gradient operands, so no extra one
+        self.nerf_model.train_precision = str(nerf_cfg.get("train_precision", "fp32"))
+        self.nerf_model.f16_bwd_scale = float(nerf_cfg.get("f16_bwd_scale", 1.0))
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
         # (MIOpen's fast path on MI355X: 49 -> 34 ms per 8-image train step)

@@ -42,9 +42,18 @@ class _RenderFn(torch.autograd.Function):
             s_f = s_f.view(N, t)
         else:
             z_f = feat_f = h_f = s_f = None
+        # train_precision="fp16": the colour / semantics nets (forward and
+        # backward) on f16 MFMA; the sigma net and the hash grid stay fp32
+        half = net.train_precision == "fp16"
+        if half:
+            fh = net._field_f16(transposed=True)
+            f = dict(f, packed_color=fh["packed_color"], packed_sem=fh["packed_sem"],
+                     packed_color_t=fh["packed_color_t"],
+                     packed_sem_t=fh["packed_sem_t"])
         image, depth, sem, src, w = ops.composite_fwd(
             d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, f["packed_color"],
-            f["packed_sem"], C, ds, want_aux=True)
+            f["packed_sem"], C, ds, want_aux=True, half=half)
+        ctx.half = half
         ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t = net, f, aabb, T, t
         ctx.saved = (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f,
                      src, w)
@@ -61,7 +70,7 @@ class _RenderFn(torch.autograd.Function):
             d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, src, w, f["packed_color"],
             f["packed_sem"], f["packed_color_t"], f["packed_sem_t"],
             d_image.contiguous(), d_depth.contiguous(), d_sem.contiguous(), C,
-            ds)
+            ds, half=ctx.half, f16_scale=float(net.f16_bwd_scale))
         g_color = torch.empty_like(net.color_net.params)
         g_sem = torch.empty_like(net.semantics_net.params)
         ops.reduce_partials(pc, g_color, False)
@@ -206,11 +215,26 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             self._packed[name + "_h"] = (key, packed)
         return self._packed[name + "_h"][1]
 
-    def _field_f16(self):
-        return dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
-                    packed_sigma=self._pack_h("sigma", self.sigma_net),
-                    packed_color=self._pack_h("color", self.color_net),
-                    packed_sem=self._pack_h("sem", self.semantics_net))
+    def _pack_th(self, name: str, net: FullyFusedMLP):
+        p = net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get(name + "_th")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            packed = ops.mlp_pack_t_f16(net.kind, p, self.num_semantic_classes,
+                                        out=out)
+            self._packed[name + "_th"] = (key, packed)
+        return self._packed[name + "_th"][1]
+
+    def _field_f16(self, transposed: bool = False):
+        f = dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
+                 packed_sigma=self._pack_h("sigma", self.sigma_net),
+                 packed_color=self._pack_h("color", self.color_net),
+                 packed_sem=self._pack_h("sem", self.semantics_net))
+        if transposed:
+            f.update(packed_color_t=self._pack_th("color", self.color_net),
+                     packed_sem_t=self._pack_th("sem", self.semantics_net))
+        return f
 
     def _field(self, transposed: bool = False):
         f = dict(grid=self.encoder.grid, table=self.encoder.params.detach(),

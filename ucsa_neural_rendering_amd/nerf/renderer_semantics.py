@@ -62,6 +62,14 @@ class SemanticNeRFRenderer(nn.Module):
         # that evaluates the three MLPs like tiny-cuda-nn does (fp16 weights
         # and layer inputs, fp32 accumulation); training is always fp32
         self.precision = "fp32"
+        # training through run(): "fp32" (default, the parity path) or "fp16":
+        # colour / semantics nets forward AND backward on f16 MFMA (fp16
+        # weights / layer inputs / incoming gradients, fp32 accumulation, fp32
+        # weight gradients); sigma net and hash grid stay fp32.  f16_bwd_scale
+        # is tiny-cuda-nn's loss scale for the f16 gradient operands (set it to
+        # 1 when the incoming gradients already carry a GradScaler scale).
+        self.train_precision = "fp32"
+        self.f16_bwd_scale = 1024.0
         self._side_streams = []
         self._ws = None
         self._aabb_host = {}

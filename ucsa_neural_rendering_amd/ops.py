@@ -210,7 +210,8 @@ def resample(z, sigma, u, density_scale: float = 1.0):
 
 def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
                   packed_color, packed_sem, n_classes: int,
-                  density_scale: float = 1.0, want_aux: bool = False):
+                  density_scale: float = 1.0, want_aux: bool = False,
+                  half: bool = False):
     rays_d = _f32(rays_d, "rays_d").view(-1, 3)
     norms = _f32(norms, "norms").view(-1)
     N, T = z_c.shape
@@ -221,13 +222,12 @@ def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     sem = torch.empty(N, n_classes, device=dev)
     src = torch.empty(N, T + t, dtype=torch.int32, device=dev) if want_aux else None
     w = torch.empty(N, T + t, device=dev) if want_aux else None
-    check(lib().ucsa_composite_fwd(_ptr(rays_d), _ptr(norms), _ptr(z_c),
-                                   _ptr(sigma_c), _ptr(h_c), _ptr(z_f),
-                                   _ptr(sigma_f), _ptr(h_f), _ptr(packed_color),
-                                   _ptr(packed_sem), N, T, t, n_classes,
-                                   float(density_scale), _ptr(image),
-                                   _ptr(depth), _ptr(sem), _ptr(src), _ptr(w),
-                                   _stream()), "ucsa_composite_fwd")
+    fn = lib().ucsa_composite_fwd_f16 if half else lib().ucsa_composite_fwd
+    check(fn(_ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
+             _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(packed_color),
+             _ptr(packed_sem), N, T, t, n_classes, float(density_scale),
+             _ptr(image), _ptr(depth), _ptr(sem), _ptr(src), _ptr(w), _stream()),
+          "ucsa_composite_fwd")
     if want_aux:
         return image, depth, sem, src, w
     return image, depth, sem
@@ -437,11 +437,24 @@ def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
           "ucsa_hashgrid_bwd_points")
 
 
+def mlp_pack_t_f16(kind: int, params: torch.Tensor, n_classes: int = 0,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    params = _f32(params.detach(), "params")
+    n = int(lib().ucsa_mlp_pack_t_f16_halves(kind, n_classes))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float16, device=params.device)
+    check(lib().ucsa_mlp_pack_t_f16(kind, _ptr(params), _ptr(out), n_classes,
+                                    _stream()), "ucsa_mlp_pack_t_f16")
+    return out
+
+
 def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
                   weights, packed_color, packed_sem, packed_color_t,
                   packed_sem_t, d_image, d_depth, d_sem, n_classes: int,
-                  density_scale: float = 1.0):
-    """-> d_h_c [N*T,16], d_h_f [N*t,16] | None, partial_color, partial_sem."""
+                  density_scale: float = 1.0, half: bool = False,
+                  f16_scale: float = 1024.0):
+    """-> d_h_c [N*T,16], d_h_f [N*t,16] | None, partial_color, partial_sem.
+    half=True: packed weights from mlp_pack_f16 / mlp_pack_t_f16."""
     N, T = z_c.shape
     t = 0 if z_f is None else z_f.shape[1]
     dev = z_c.device
@@ -451,17 +464,22 @@ def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
     G = torch.empty(N, T + t, device=dev)
     d_h_c = torch.empty(N * T, 16, device=dev)
     d_h_f = torch.empty(N * t, 16, device=dev) if t else None
-    parts = int(lib().ucsa_composite_bwd_parts(N))
+    parts = int((lib().ucsa_composite_bwd_parts_f16 if half
+                 else lib().ucsa_composite_bwd_parts)(N))
     nrb = (n_classes + 15) // 16
     pc = torch.empty(parts, 7168, device=dev)
     ps = torch.empty(parts, 1024 + 1024 * nrb, device=dev)
-    check(lib().ucsa_composite_bwd(
-        _ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
-        _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(src), _ptr(weights),
-        _ptr(packed_color), _ptr(packed_sem), _ptr(packed_color_t),
-        _ptr(packed_sem_t), _ptr(d_image), _ptr(d_depth), _ptr(d_sem), N, T, t,
-        n_classes, float(density_scale), _ptr(G), _ptr(d_h_c), _ptr(d_h_f),
-        _ptr(pc), _ptr(ps), _stream()), "ucsa_composite_bwd")
+    head = (_ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
+            _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(src), _ptr(weights),
+            _ptr(packed_color), _ptr(packed_sem), _ptr(packed_color_t),
+            _ptr(packed_sem_t), _ptr(d_image), _ptr(d_depth), _ptr(d_sem), N, T,
+            t, n_classes, float(density_scale))
+    tail = (_ptr(G), _ptr(d_h_c), _ptr(d_h_f), _ptr(pc), _ptr(ps), _stream())
+    if half:
+        check(lib().ucsa_composite_bwd_f16(*head, float(f16_scale), *tail),
+              "ucsa_composite_bwd_f16")
+    else:
+        check(lib().ucsa_composite_bwd(*head, *tail), "ucsa_composite_bwd")
     return d_h_c, d_h_f, pc, ps
 
 
