@@ -7,5 +7,6 @@ dev = torch.device("cuda", 0)
 log = {}
 net, ds = bench.build_field(dev, train_steps=int(os.environ.get("PRE", "50")), log=log)
 print(log)
-r = bench.train_throughput(net, ds, dev, steps=int(os.environ.get("STEPS", "10")))
+r = bench.train_throughput(net, ds, dev, steps=int(os.environ.get("STEPS", "10")),
+                           train_precision=os.environ.get("TRAIN_PRECISION", "fp32"))
 print(r)

@@ -17,10 +17,12 @@
 #include "wave_ops.h"
 
 #define CB_WAVES 4
-// Waves per workgroup of the f16 variant: the fp32 kernel needs ~480 registers
-// (1 wave per SIMD); the f16 one 214, and its LDS (48 KB of weights + 10 KB
-// per wave) lets 8 waves share a CU: 2 per SIMD.
-#define CB_WAVES_H 8
+// Waves per workgroup of the f16 variant.  Measured: 8 waves (2 per SIMD, a
+// 256-register budget) spill ~100-160 registers into scratch inside the main
+// loop -- the 176 fp32 dW accumulators plus the activations of both nets do
+// not fit -- and end no faster than the fp32 kernel (1.43 vs 1.48 ms); 4 waves
+// (1 per SIMD, no spills) it is.
+#define CB_WAVES_H 4
 #define CB_CAP 80  // 15 pending + one 64-sample chunk
 #define ROW_FINE 0x80000000u
 
@@ -75,6 +77,16 @@ __device__ __forceinline__ half8 chain_h(f32x4 lo, f32x4 hi) {
     v[4 + r] = (_Float16)hi[r];
   }
   return v;
+}
+
+template <int OB, int IB>
+__device__ __forceinline__ void dw_scale(f32x4 (&dw)[OB][IB], float s) {
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dw[ob][ib][r] = dw[ob][ib][r] * s;
 }
 
 // what the f16 forward fed into the next layer: relu, rounded to fp16
@@ -543,11 +555,11 @@ k_shade_bwd(ShadeBwdArgs a) {
   }
   // per-wave partial gradients, tcnn layout
   if constexpr (HALF) {
-    auto unscale = [&](auto& dw) {
-      for (auto& row : dw)
-        for (auto& v : row) v = v * inv_gs;
-    };
-    unscale(dwc1); unscale(dwc2); unscale(dwc3); unscale(dws1); unscale(dws2);
+    dw_scale(dwc1, inv_gs);
+    dw_scale(dwc2, inv_gs);
+    dw_scale(dwc3, inv_gs);
+    dw_scale(dws1, inv_gs);
+    dw_scale(dws2, inv_gs);
   }
   float* pc = a.partial_color + (size_t)gwave * 7168;
   dw_store<4, 2>(pc, 32, lane, dwc1);
