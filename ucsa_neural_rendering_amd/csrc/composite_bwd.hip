@@ -194,21 +194,61 @@ k_shade_bwd(ShadeBwdArgs a) {
 
   uint32_t cnt = 0;
 
-  // ---- one block of up to 16 surviving samples ---------------------------
-  auto shade16 = [&](uint32_t n) {
+  // Operands of one block of <= 16 surviving samples.  With one wave per SIMD
+  // nothing hides a global load, so the NEXT block's operands (h row,
+  // direction, upstream gradients of its ray) are requested before the
+  // current block is shaded (same values, same arithmetic).
+  struct BlockOps {
+    bool live, fine;
+    float wgt, zz;
+    uint32_t ray, smp;
+    size_t hoff;
+    f32x4 geo;
+    float dir[3], di[3], dd, nrm;
+    float dsem[NRB * 4];
+  };
+  auto load_ops = [&](uint32_t first, uint32_t n, BlockOps& b) {
     uint32_t e = j;
-    const bool live = e < n;
-    if (!live) e = n - 1;
-    const float wgt = live ? lw[e] : 0.0f;
-    const uint32_t row = lrow[e], ray = lray[e], smp = lsmp[e];
-    const float zz = lz[e];
-    const bool fine = (row & ROW_FINE) != 0;
-    const size_t hoff = (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
-    f32x4 geo = *reinterpret_cast<const f32x4*>((fine ? a.h_f : a.h_c) + hoff);
+    b.live = e < n;
+    if (!b.live) e = n - 1;
+    e += first;
+    b.wgt = b.live ? lw[e] : 0.0f;
+    const uint32_t row = lrow[e];
+    b.ray = lray[e];
+    b.smp = lsmp[e];
+    b.zz = lz[e];
+    b.fine = (row & ROW_FINE) != 0;
+    b.hoff = (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
+    b.geo = *reinterpret_cast<const f32x4*>((b.fine ? a.h_f : a.h_c) + b.hoff);
+    const float* dptr = a.rays_d + (size_t)b.ray * 3;
+    b.dir[0] = dptr[0];
+    b.dir[1] = dptr[1];
+    b.dir[2] = dptr[2];
+    const float* di = a.d_image + (size_t)b.ray * 3;
+    b.di[0] = di[0];
+    b.di[1] = di[1];
+    b.di[2] = di[2];
+    b.dd = a.d_depth[b.ray];
+    b.nrm = a.norms[b.ray];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t cls = rb * 16 + 4 * g + r;
+        b.dsem[rb * 4 + r] = cls < C ? a.d_sem[(size_t)b.ray * C + cls] : 0.0f;
+      }
+  };
+
+  // ---- one block of up to 16 surviving samples ---------------------------
+  auto shade16 = [&](const BlockOps& b) {
+    const bool live = b.live, fine = b.fine;
+    const float wgt = b.wgt, zz = b.zz;
+    const uint32_t ray = b.ray, smp = b.smp;
+    const size_t hoff = b.hoff;
+    f32x4 geo = b.geo;
     if (g == 0) geo[0] = 1.0f;
-    const float* dptr = a.rays_d + (size_t)ray * 3;
     f32x4 sh;
-    sh4_select_b(dptr[0], dptr[1], dptr[2], g, sh);
+    sh4_select_b(b.dir[0], b.dir[1], b.dir[2], g, sh);
 
     // ------------------------- forward (recompute) ------------------------
     f32x4 a1c[4], a2c[4], o3[1], a1s[4], lg[NRB];
@@ -282,10 +322,10 @@ k_shade_bwd(ShadeBwdArgs a) {
     sum += __shfl_xor(sum, 32, 64);
 
     // ------------------------- upstream gradients -------------------------
-    const float* di = a.d_image + (size_t)ray * 3;
+    const float* di = b.di;
     f32x4 dy3 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (g == 0) {
-      float dwsum = a.d_depth[ray] * zz / a.norms[ray];
+      float dwsum = b.dd * zz / b.nrm;
       // image = sum_s w*rgb  ->  d_rgb = w*d_image, d_w += d_image . rgb
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -304,7 +344,7 @@ k_shade_bwd(ShadeBwdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const uint32_t cls = rb * 16 + 4 * g + r;
         const float p = lg[rb][r] / sum;
-        const float dp = cls < C ? wgt * a.d_sem[(size_t)ray * C + cls] : 0.0f;
+        const float dp = cls < C ? wgt * b.dsem[rb * 4 + r] : 0.0f;
         lg[rb][r] = p;
         dlg[rb][r] = dp;
         dot += p * dp;
@@ -458,24 +498,17 @@ k_shade_bwd(ShadeBwdArgs a) {
     }
   };
 
-  // shade the full blocks of 16 waiting in the list, keep the tail
+  // shade the full blocks of 16 waiting in the list (operands one block
+  // ahead), keep the tail
   auto drain16 = [&]() {
     uint32_t head = 0;
+    BlockOps cur, nxt;
+    if (cnt >= 16) load_ops(0u, 16u, cur);
     while (cnt - head >= 16) {
-      if (head) {
-        float tw = 0.f, tz = 0.f;
-        uint32_t tr = 0, ty = 0, ts = 0;
-        if (lane < 16) {
-          tw = lw[head + lane]; tr = lrow[head + lane]; ty = lray[head + lane];
-          ts = lsmp[head + lane]; tz = lz[head + lane];
-        }
-        cb_sync();
-        if (lane < 16) {
-          lw[lane] = tw; lrow[lane] = tr; lray[lane] = ty; lsmp[lane] = ts; lz[lane] = tz;
-        }
-        cb_sync();
-      }
-      shade16(16);
+      const bool more = cnt - head >= 32;
+      if (more) load_ops(head + 16, 16u, nxt);
+      shade16(cur);
+      if (more) cur = nxt;
       head += 16;
     }
     if (head) {
@@ -551,7 +584,11 @@ k_shade_bwd(ShadeBwdArgs a) {
       }
       }
     }
-    if (cnt) shade16(cnt);
+    if (cnt) {
+      BlockOps last;
+      load_ops(0u, cnt, last);
+      shade16(last);
+    }
   }
   // per-wave partial gradients, tcnn layout
   if constexpr (HALF) {
