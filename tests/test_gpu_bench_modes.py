@@ -1,0 +1,65 @@
+"""bench.py's multi-rank code paths, exercised with two ranks on ONE GPU
+(`UCSA_BENCH_BACKEND=gloo`, the test hook; the driver's real runs use RCCL,
+one rank per GPU): the default render line at N = 2 with its `train_dp`
+object, `--mode train` and `--mode cfg4 --gather`.  ``-m gpu``."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run2(extra, timeout=900):
+    env = dict(os.environ, UCSA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_default_render_line_at_two_ranks_carries_train_dp():
+    res = _run2(["--steps", "2", "--warmup", "1", "--pretrain-steps", "30"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["metric"] == "rays/sec"
+    assert res["value"] > 0 and res["roofline"]["bound"] == "hbm"
+    assert "cpu_baseline" not in res            # single-GPU legs run at N = 1 only
+    dp = res["train_dp"]
+    assert dp["collective_ranks"] == 2 and dp["replicas_identical"] is True
+    assert dp["optimizer"].startswith("ShardedHipAdam")
+    assert dp["allreduce_ms"] > 0 and dp["reduce_scatter_allgather_ms"] > 0
+    assert dp["rays_per_step_total"] == 2 * 4096
+
+
+@pytest.mark.parametrize("extra", [[], ["--replicated-adam"], ["--grad-comm-dtype", "fp16"]])
+def test_train_mode_two_ranks(extra):
+    res = _run2(["--mode", "train", "--steps", "3", "--warmup", "1",
+                 "--pretrain-steps", "30"] + extra)
+    dp = res["train_dp"]
+    assert res["config"]["mode"] == "train" and res["n_gpus"] == 2
+    assert dp["replicas_identical"] is True and dp["collective_ranks"] == 2
+    assert dp["final_loss"] == dp["final_loss"] and res["value"] == dp["rays_per_s"]
+    want = "HipAdam" if "--replicated-adam" in extra else "ShardedHipAdam"
+    assert dp["optimizer"].startswith(want)
+
+
+def test_cfg4_mode_two_ranks_with_gather():
+    res = _run2(["--mode", "cfg4", "--views", "4", "--warmup", "1", "--gather",
+                 "--pretrain-steps", "30"])
+    assert res["config"]["mode"] == "cfg4" and res["config"]["views_per_rank"] == 2
+    assert res["scaling"] == "strong" and res["value"] > 0
