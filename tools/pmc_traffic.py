@@ -59,7 +59,8 @@ def main(d, tag):
                  "the raw value is given and 2x raw is the upper bound",
     }
     for key, prefix in (("k_composite", "void k_composite<3, 2, false, false>"),
-                        ("k_hashgrid_encode_tiled", "k_hashgrid_encode_tiled")):
+                        ("k_hashgrid_encode_tiled", "k_hashgrid_encode_tiled"),
+                        ("k_shade_dense_f16", "void k_shade_dense<3, 1, true, 16>")):
         f, w, s = pick(fetch, prefix), pick(wr, prefix), pick(sq, prefix)
         if not (f and w):
             continue
@@ -69,6 +70,8 @@ def main(d, tag):
         hit, miss = w[1].get("TCC_HIT_sum", 0), w[1].get("TCC_MISS_sum", 0)
         if hit + miss:
             e["tcc_hit_rate"] = hit / (hit + miss)
+        if s and s[1].get("SQ_INSTS_VALU"):
+            e["valu_wave_instructions"] = int(s[1]["SQ_INSTS_VALU"])
         if s and s[1].get("GRBM_GUI_ACTIVE"):
             # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles, the MFMA counter
             # the busy cycles of all 1024 SIMDs: busy / (cycles * 1024)
