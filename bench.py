@@ -811,14 +811,14 @@ def main():
                         "frac": l2b / (e["launch_ms"] * 1e-3) / 1e9 / L2_PEAK_GBS,
                         "bytes_per_launch": l2b,
                         "source": "TCC request counter x 128-B lines (" + PMC_JSON + ")"}
-        except (OSError, KeyError, ValueError):
-            pass
                 if "k_shade_dense_f16" in pmc and "mfma_busy_frac" in pmc["k_shade_dense_f16"]:
                     result["pmc_k_shade_dense_f16"] = {
                         "mfma_pipe_busy_frac": pmc["k_shade_dense_f16"]["mfma_busy_frac"],
                         "valu_wave_instructions_per_launch":
                             pmc["k_shade_dense_f16"].get("valu_wave_instructions"),
                         "source": PMC_JSON}
+        except (OSError, KeyError, ValueError):
+            pass
         # "roofline" = the kernel with the largest share of the step
         enc_share = st["encode_c"] + st["encode_f"]
         dom = "roofline_encode" if enc_share >= st["composite"] else "roofline_composite"
