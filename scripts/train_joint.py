@@ -61,7 +61,15 @@ def train(exp, env, exp_cfg_path, env_cfg_path, args):
     # convolutions: measured 49.4 -> 44.4 ms per R-101 fp32 train step on
     # 8 x 240x320 (tools/seg_bench.py); `trainer: {cudnn_benchmark: false}`
     # keeps PyTorch's default (immediate mode)
+    bench_before = torch.backends.cudnn.benchmark
     torch.backends.cudnn.benchmark = bool(exp["trainer"].get("cudnn_benchmark", True))
+    try:
+        return _train(exp, env, args, rank, local_rank, world, model_path)
+    finally:  # a process-wide flag: hand it back as found
+        torch.backends.cudnn.benchmark = bench_before
+
+
+def _train(exp, env, args, rank, local_rank, world, model_path):
     model = JointTrainLightningNet(exp, env)
     if world > 1:
         # identical initial parameters on every rank (same seed above), then

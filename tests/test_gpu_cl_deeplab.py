@@ -20,7 +20,8 @@ def _exp():
         "model": {"pretrained": False, "pretrained_backbone": False, "num_classes": 40,
                   "backbone": "resnet50"},
         "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
-        "trainer": {"load_from_checkpoint": True, "resume_from_checkpoint": False},
+        "trainer": {"load_from_checkpoint": True, "resume_from_checkpoint": False,
+                    "cudnn_benchmark": False},
         "data_module": {"batch_size": 2, "output_size": (48, 64)},
         "scenes": ["scene0000_00"],
         "cl": {"active": False, "use_novel_viewpoints": False, "replay_buffer_size": 4},

@@ -138,7 +138,7 @@ def _module_worker(rank, world, port, root, sharded, ret):
             "model": {"pretrained": False, "pretrained_backbone": False,
                       "num_classes": 40, "backbone": "resnet50"},
             "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
-            "trainer": {"load_from_checkpoint": False},
+            "trainer": {"load_from_checkpoint": False, "cudnn_benchmark": False},
             "data_module": {"batch_size": 2},
             "scenes": ["scene0000_00"],
             "synthetic": {"n_views": 10, "H": 48, "W": 64},

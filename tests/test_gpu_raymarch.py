@@ -461,7 +461,9 @@ def _live_trained_gate(seed):
         # unfused segments == reference-style loop == fused with w_min 0, up
         # to the order of the fp32 sums (depth is a sum of up to ~1000 terms
         # of size <= 7: relative tolerance)
-        tol = 2e-4 * max(1.0, float(o_ref[k].abs().max()))
+        # (the sums grow with the points per ray, which depend on how foggy this
+        # chaotic training left the field: 2e-4 at <= 64 points, pro rata above)
+        tol = 2e-4 * max(1.0, pts / 64.0) * max(1.0, float(o_ref[k].abs().max()))
         assert float((o_unf[k] - o_ref[k]).abs().max()) <= tol
         assert float((o_all[k] - o_ref[k]).abs().max()) <= tol
         # the w > 1e-4 mask drops at most 1e-4 per sample
