@@ -600,6 +600,9 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
 
 
 def main():
+    if os.environ.get("UCSA_BENCH_WATCHDOG"):   # debugging aid: stacks of a stuck rank
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["UCSA_BENCH_WATCHDOG"]), exit=True)
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -22,20 +22,30 @@ def _port():
     return p
 
 
-def _run2(extra, timeout=900):
-    env = dict(os.environ, UCSA_BENCH_BACKEND="gloo")
+def _run2(extra, tmp_path, timeout=600):
+    """Output goes to FILES, not pipes: a helper process the ranks leave behind
+    for a while keeps an inherited pipe open, and `communicate()` would then
+    block until it is gone although torchrun itself exited after seconds."""
+    env = dict(os.environ, UCSA_BENCH_BACKEND="gloo", UCSA_BENCH_WATCHDOG="500")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env,
-                       cwd=ROOT)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stderr[-2000:])
+    out, err = tmp_path / "out.txt", tmp_path / "err.txt"
+    with open(out, "w") as fo, open(err, "w") as fe:
+        proc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                                env=env, cwd=ROOT)
+        try:
+            rc = proc.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            raise AssertionError("bench.py timed out:\n" + err.read_text()[-3000:])
+    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
     return json.loads(lines[0])
 
 
-def test_default_render_line_at_two_ranks_carries_train_dp():
-    res = _run2(["--steps", "2", "--warmup", "1", "--pretrain-steps", "30"])
+def test_default_render_line_at_two_ranks_carries_train_dp(tmp_path):
+    res = _run2(["--steps", "2", "--warmup", "1", "--pretrain-steps", "30"], tmp_path)
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["metric"] == "rays/sec"
     assert res["value"] > 0 and res["roofline"]["bound"] == "hbm"
     assert "cpu_baseline" not in res            # single-GPU legs run at N = 1 only
@@ -47,9 +57,9 @@ def test_default_render_line_at_two_ranks_carries_train_dp():
 
 
 @pytest.mark.parametrize("extra", [[], ["--replicated-adam"], ["--grad-comm-dtype", "fp16"]])
-def test_train_mode_two_ranks(extra):
+def test_train_mode_two_ranks(extra, tmp_path):
     res = _run2(["--mode", "train", "--steps", "3", "--warmup", "1",
-                 "--pretrain-steps", "30"] + extra)
+                 "--pretrain-steps", "30"] + extra, tmp_path)
     dp = res["train_dp"]
     assert res["config"]["mode"] == "train" and res["n_gpus"] == 2
     assert dp["replicas_identical"] is True and dp["collective_ranks"] == 2
@@ -58,8 +68,8 @@ def test_train_mode_two_ranks(extra):
     assert dp["optimizer"].startswith(want)
 
 
-def test_cfg4_mode_two_ranks_with_gather():
+def test_cfg4_mode_two_ranks_with_gather(tmp_path):
     res = _run2(["--mode", "cfg4", "--views", "4", "--warmup", "1", "--gather",
-                 "--pretrain-steps", "30"])
+                 "--pretrain-steps", "30"], tmp_path)
     assert res["config"]["mode"] == "cfg4" and res["config"]["views_per_rank"] == 2
     assert res["scaling"] == "strong" and res["value"] > 0
