@@ -338,6 +338,18 @@ int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
                            uint32_t n_levels, float* d_feat, float* partial,
                            void* stream);
 
+/* ucsa_hashgrid_bwd_rays with 8-byte bin records: the (entry, vx, vy) records
+ * of the fine levels carry their value pair as half2 x rec_scale (a power of
+ * two > 0) -- half the record traffic of both passes; sums stay fp32.  For
+ * the f16 training mode (tiny-cuda-nn accumulates its grid gradient from half2
+ * values too).  The workspace is mandatory. */
+int32_t ucsa_hashgrid_bwd_rays_h16(const ucsa_grid* grid, const float* rays_o,
+                                   const float* rays_d, const float* z,
+                                   const float* aabb_host, uint32_t N,
+                                   uint32_t T, const float* d_feat,
+                                   float* grad_table, void* workspace,
+                                   float rec_scale, void* stream);
+
 /* Transposed fp16 fragments for the f16 backward of the colour / semantics
  * nets (kind = UCSA_MLP_COLOR or UCSA_MLP_SEM), and the backward itself:
  * ucsa_composite_bwd with the two nets and their dX contractions on

@@ -375,3 +375,30 @@ def test_f16_training_reduces_the_loss_like_fp32():
         assert hist[-1] < 0.9 * hist[0], (prec, hist)
         finals[prec] = hist[-1]
     assert abs(finals["fp16"] - finals["fp32"]) <= 0.1 * finals["fp32"], finals
+
+
+def test_half_precision_bin_records_match_fp32_records(ops):
+    """ucsa_hashgrid_bwd_rays_h16 (8-byte records, half2 values x scale)
+    against the 16-byte-record path on the same inputs: every contribution is
+    rounded to fp16 (relative 5e-4, unbiased), sums stay fp32."""
+    from ucsa_neural_rendering_amd._lib import make_grid
+    dev = torch.device("cuda:0")
+    grid = make_grid(4.0)
+    g = torch.Generator().manual_seed(31)
+    N, T = 2000, 64
+    o = ((torch.rand(N, 3, generator=g) * 2 - 1) * 2.0)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    z = (torch.rand(N, T, generator=g) * 5 + 0.2).sort(-1).values
+    aabb = [-4.0, -4.0, -4.0, 4.0, 4.0, 4.0]
+    d_feat = torch.randn(grid.n_levels, N * T, 2, generator=g) * 1e-5   # unscaled-loss magnitudes
+    o, d, z, d_feat = o.to(dev).contiguous(), d.to(dev).contiguous(), z.to(dev).contiguous(), d_feat.to(dev)
+    total = int(grid.total_entries)
+    g32 = torch.zeros(total, 2, device=dev)
+    g16 = torch.zeros(total, 2, device=dev)
+    ops.hashgrid_bwd_rays(grid, o, d, z, aabb, d_feat, g32)
+    ops.hashgrid_bwd_rays(grid, o, d, z, aabb, d_feat, g16, rec_scale=1024.0 * 64)
+    torch.cuda.synchronize()
+    rel = float((g16 - g32).norm() / g32.norm())
+    print(f"half records: rel L2 {rel:.3e}")
+    assert rel <= 1e-3
+    assert torch.equal(g16 == 0, g32 == 0) or float(((g16 == 0) != (g32 == 0)).float().mean()) < 1e-4

@@ -286,14 +286,22 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
   }
 }
 
+// HREC: 8-byte records (entry index inside the bin | the value pair as half2,
+// multiplied by rec_scale) instead of 16-byte ones -- half the record traffic
+// of both passes.  Used by the f16 training mode only (train_precision="fp16":
+// tiny-cuda-nn itself accumulates its grid gradient from half2 values); the
+// sums in the accumulate pass stay fp32.
+template <bool HREC>
 __global__ void __launch_bounds__(256)
 k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                const float* __restrict__ rays_o,
                const float* __restrict__ rays_d, const float* __restrict__ zs,
                Aabb bb, uint32_t T, uint64_t M,
                const float2* __restrict__ d_feat,
-               uint32_t* __restrict__ gcount, float4* __restrict__ records,
-               float* __restrict__ grad_table) {
+               uint32_t* __restrict__ gcount, void* __restrict__ records_v,
+               float* __restrict__ grad_table, float rec_scale) {
+  float4* records = reinterpret_cast<float4*>(records_v);
+  uint2* records_h = reinterpret_cast<uint2*>(records_v);
   static_assert(BIN_COUNT == 256, "one thread per bin");
   __shared__ uint32_t hist[BIN_COUNT], base[BIN_COUNT], cursor[BIN_COUNT];
   __shared__ uint32_t it_cnt[BIN_COUNT], it_off[BIN_COUNT], wave_tot[4];
@@ -411,7 +419,16 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
       const uint32_t bin = __float_as_uint(r.w);
       const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
       if (pos < bg.cap) {
-        rec_level[(size_t)bin * bg.cap + pos] = make_float4(r.x, r.y, r.z, 0.f);
+        if constexpr (HREC) {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          h2 hv;
+          hv[0] = (_Float16)(r.y * rec_scale);
+          hv[1] = (_Float16)(r.z * rec_scale);
+          records_h[(size_t)level * BIN_COUNT * bg.cap + (size_t)bin * bg.cap + pos] =
+              make_uint2(__float_as_uint(r.x), __builtin_bit_cast(uint32_t, hv));
+        } else {
+          rec_level[(size_t)bin * bg.cap + pos] = make_float4(r.x, r.y, r.z, 0.f);
+        }
       } else {  // bin full: direct atomics keep the result exact
         const size_t idx = (size_t)bin * bsz + __float_as_uint(r.x);
         atomicAdd(gt + idx * 2, r.y);
@@ -427,11 +444,13 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
 
 extern __shared__ __attribute__((aligned(16))) float binacc_smem[];
 
+template <bool HREC>
 __global__ void __launch_bounds__(512)
 k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
                  const uint32_t* __restrict__ gcount,
-                 const float4* __restrict__ records,
-                 float* __restrict__ grad_table) {
+                 const void* __restrict__ records_v,
+                 float* __restrict__ grad_table, float inv_rec_scale) {
+  const float4* records = reinterpret_cast<const float4*>(records_v);
   const uint32_t level = level0 + blockIdx.y, bin = blockIdx.x;
   const uint32_t bsz = bg.bin_size[level];
   uint32_t n = gcount[level * BIN_COUNT + bin];
@@ -440,6 +459,29 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   float* acc = binacc_smem;  // [bsz][2]
   for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) acc[e] = 0.f;
   __syncthreads();
+  if constexpr (HREC) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const uint2* rec = reinterpret_cast<const uint2*>(records_v) +
+                       ((size_t)level * BIN_COUNT + bin) * bg.cap;
+    uint32_t i = threadIdx.x;
+    for (; i + 7 * 512 < n; i += 8 * 512) {   // 8 record loads in flight
+      uint2 r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = rec[i + k * 512];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const h2 hv = __builtin_bit_cast(h2, r[k].y);
+        lds_add_pair(&acc[2 * r[k].x], (float)hv[0] * inv_rec_scale,
+                     (float)hv[1] * inv_rec_scale);
+      }
+    }
+    for (; i < n; i += 512) {
+      const uint2 r = rec[i];
+      const h2 hv = __builtin_bit_cast(h2, r.y);
+      lds_add_pair(&acc[2 * r.x], (float)hv[0] * inv_rec_scale,
+                   (float)hv[1] * inv_rec_scale);
+    }
+  } else {
   const float4* rec = records + ((size_t)level * BIN_COUNT + bin) * bg.cap;
   // 4 record loads in flight per thread before the LDS adds
   uint32_t i = threadIdx.x;
@@ -454,6 +496,7 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   for (; i < n; i += 512) {
     const float4 r = rec[i];
     lds_add_pair(&acc[2 * __float_as_uint(r.x)], r.y, r.z);
+  }
   }
   __syncthreads();
   const uint32_t first = bin * bsz;
@@ -500,7 +543,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    const float* aabb_host, uint32_t N,
                                    uint32_t T, const float* d_feat,
                                    float* grad_table, void* workspace,
-                                   void* stream) {
+                                   void* stream, float rec_scale = 0.0f) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
   // Binning pays where updates are spread over the whole slab (hashed levels
@@ -526,13 +569,27 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
       if (bg.bin_size[l] > max_bsz) max_bsz = bg.bin_size[l];
     const uint32_t nl = grid->n_levels - n_lo;
     UCSA_CLEAR_ERR();
-    hipLaunchKernelGGL(k_grid_bwd_bin, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
-                       dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o,
-                       rays_d, z, bb, T, M, (const float2*)d_feat, gcount,
-                       records, grad_table);
-    hipLaunchKernelGGL(k_grid_bwd_accum, dim3(BIN_COUNT, nl), dim3(512),
-                       (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
-                       gd, bg, n_lo, gcount, records, grad_table);
+    if (rec_scale > 0.0f) {
+      hipLaunchKernelGGL(k_grid_bwd_bin<true>,
+                         dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
+                         (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
+                         T, M, (const float2*)d_feat, gcount, (void*)records,
+                         grad_table, rec_scale);
+      hipLaunchKernelGGL(k_grid_bwd_accum<true>, dim3(BIN_COUNT, nl), dim3(512),
+                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
+                         gd, bg, n_lo, gcount, (const void*)records, grad_table,
+                         1.0f / rec_scale);
+    } else {
+      hipLaunchKernelGGL(k_grid_bwd_bin<false>,
+                         dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
+                         (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
+                         T, M, (const float2*)d_feat, gcount, (void*)records,
+                         grad_table, 1.0f);
+      hipLaunchKernelGGL(k_grid_bwd_accum<false>, dim3(BIN_COUNT, nl), dim3(512),
+                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
+                         gd, bg, n_lo, gcount, (const void*)records, grad_table,
+                         1.0f);
+    }
     const int32_t rc = ucsa_launch_status();
     if (rc) return rc;
   }
@@ -581,6 +638,28 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
   UCSA_CHECK_ARG(grad_table, 8);
   return hashgrid_bwd_launch(grid, rays_o, rays_d, z, aabb_host, N, T, d_feat,
                              grad_table, workspace, stream);
+}
+
+// The same with 8-byte bin records: value pairs stored as half2 x rec_scale
+// (rec_scale > 0; a power of two).  Requires the workspace.
+extern "C" int32_t ucsa_hashgrid_bwd_rays_h16(const ucsa_grid* grid,
+                                              const float* rays_o,
+                                              const float* rays_d,
+                                              const float* z,
+                                              const float* aabb_host, uint32_t N,
+                                              uint32_t T, const float* d_feat,
+                                              float* grad_table, void* workspace,
+                                              float rec_scale, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(rays_o && rays_d && z, 1);
+  UCSA_CHECK_ARG(aabb_host, 4);
+  UCSA_CHECK_ARG(d_feat, 7);
+  UCSA_CHECK_ARG(grad_table, 8);
+  UCSA_CHECK_ARG(workspace, 9);
+  UCSA_CHECK_ARG(rec_scale > 0.0f, 10);
+  return hashgrid_bwd_launch(grid, rays_o, rays_d, z, aabb_host, N, T, d_feat,
+                             grad_table, workspace, stream, rec_scale);
 }
 
 extern "C" int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid,

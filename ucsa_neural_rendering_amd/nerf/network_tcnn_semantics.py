@@ -80,12 +80,17 @@ class _RenderFn(torch.autograd.Function):
         d_feat, part = ops.sigma_mlp_bwd(feat_c, d_h_c, f["packed_sigma"],
                                          f["packed_sigma_t"])
         ops.reduce_partials(part, g_sigma, False)
-        ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid)
+        # f16 training mode: 8-byte bin records (half2 values under the same
+        # loss scale as the nets' gradient operands)
+        rs = float(net.f16_bwd_scale) if (ctx.half and net.f16_grid_records) else 0.0
+        ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid,
+                              rec_scale=rs)
         if t > 0:
             d_feat, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
                                              f["packed_sigma_t"])
             ops.reduce_partials(part, g_sigma, True)
-            ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat, g_grid)
+            ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat, g_grid,
+                                  rec_scale=rs)
         ctx.saved = None
         return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
 

@@ -70,6 +70,9 @@ class SemanticNeRFRenderer(nn.Module):
         # 1 when the incoming gradients already carry a GradScaler scale).
         self.train_precision = "fp32"
         self.f16_bwd_scale = 1024.0
+        # with train_precision="fp16": the hash-grid backward's bin records
+        # carry half2 values (8 instead of 16 bytes per record)
+        self.f16_grid_records = True
         self._side_streams = []
         self._ws = None
         self._aabb_host = {}

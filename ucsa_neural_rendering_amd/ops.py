@@ -400,9 +400,11 @@ _bwd_ws = {}
 
 
 def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
-                      binned: bool = True):
+                      binned: bool = True, rec_scale: float = 0.0):
     """Adds the table gradient.  binned=True: two-pass LDS-binned algorithm
-    (workspace cached per device); False: direct float atomics."""
+    (workspace cached per device); False: direct float atomics.
+    rec_scale > 0 (binned only): 8-byte bin records, values as half2 x
+    rec_scale (the f16 training mode)."""
     N, T = z.shape
     ws = None
     if binned:
@@ -412,6 +414,12 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=z.device)
             _bwd_ws[key] = ws
+    if rec_scale > 0.0 and ws is not None:
+        check(lib().ucsa_hashgrid_bwd_rays_h16(
+            C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
+            _ptr(d_feat), _ptr(grad_table), _ptr(ws), float(rec_scale), _stream()),
+            "ucsa_hashgrid_bwd_rays_h16")
+        return
     check(lib().ucsa_hashgrid_bwd_rays(C.byref(grid), _ptr(rays_o),
                                        _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
                                        _ptr(d_feat), _ptr(grad_table),
