@@ -72,8 +72,12 @@ def parse():
                     help="cfg3: DeepLab backbone (BASELINE cfg3 says ResNet-50; "
                          "the reference's model is resnet101)")
     ap.add_argument("--seg-amp", default="", help="cfg3: '' (fp32, the reference) or bf16")
-    ap.add_argument("--nerf-precision", default="fp32", choices=["fp32", "fp16"],
-                    help="cfg3: nets of the no-grad full-frame renders")
+    ap.add_argument("--nerf-precision", default="bf16x3",
+                    choices=["fp32", "bf16x3", "fp16"],
+                    help="arithmetic of the three MLPs in the no-grad renders: "
+                         "bf16x3 (default; fp32-grade on the bf16 MFMA pipe, "
+                         "csrc/mfma_mlp_x3.h), fp32 (f32-input MFMA, an exact "
+                         "fmaf chain), fp16 (tiny-cuda-nn's own numerics)")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="train legs: all-reduce + full Adam on every rank "
                          "instead of the sharded optimizer")
@@ -421,13 +425,77 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
     return n_rays / best, best, parity, ref, got, (o, d)
 
 
-def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False):
+MLP_ARITHMETIC = {
+    "bf16x3": "fp32-grade on the bf16 MFMA pipe: every fp32 weight and layer "
+              "input split exactly into three bf16 terms, six partial products "
+              "per product (v_mfma_f32_16x16x32_bf16), fp32 accumulation "
+              "(csrc/mfma_mlp_x3.h); within 1-2 ulp of the f32-input MFMA mode "
+              "(f32_mfma_option.max_abs_image_diff_vs_value_mode)",
+    "fp32": "f32-input MFMA (v_mfma_f32_16x16x4_f32): bit for bit a k-ordered "
+            "fmaf chain",
+    "fp16": "tiny-cuda-nn's own numerics: fp16 weights / layer inputs, fp32 "
+            "accumulation (v_mfma_f32_16x16x32_f16)",
+}
+
+
+def composite_roofline(mode, mlp_tf, sig_tf, launch_ms):
+    """MFMA roofline object of the colour + semantics stage (algorithmic flop
+    of the masked samples / launch time)."""
+    if mode == "fp32":
+        return {
+            "kernel": "k_composite (colour+semantics MLPs, fp32 MFMA)",
+            "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF,
+            "frac_of_fp16_dense_peak": mlp_tf / F16_MFMA_PEAK_TF,
+            "launch_ms": launch_ms, "traffic": None, "sigma_mlp_tflops": sig_tf,
+            "note": "peak = fp32-input MFMA (the instruction this mode issues, "
+                    "1/16 of the 16-bit rate; it runs at the vector FMA rate "
+                    "and, measured, does not overlap with VALU work at all: "
+                    "kernel time = MFMA busy + VALU issue); "
+                    "frac_of_fp16_dense_peak is the same achieved rate against "
+                    "SURVEY 8d's 2.5 PF line"}
+    if mode == "bf16x3":
+        return {
+            "kernel": "k_weights_compact + k_shade_dense<bf16x3> (colour + "
+                      "semantics MLPs, six bf16 MFMA passes per fp32 product)",
+            "bound": "mfma", "achieved": mlp_tf, "peak": F16_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": mlp_tf / F16_MFMA_PEAK_TF,
+            "issued_mfma_tflops": mlp_tf * 6 * 22528 / 19584,
+            "issued_frac": mlp_tf * 6 * 22528 / 19584 / F16_MFMA_PEAK_TF,
+            "frac_of_fp32_mfma_peak": mlp_tf / F32_MFMA_PEAK_TF,
+            "launch_ms": launch_ms, "traffic": None, "sigma_mlp_tflops": sig_tf,
+            "note": "achieved = ALGORITHMIC fp32 flop of the masked samples / "
+                    "launch time against the 2.5 PF 16-bit dense line "
+                    "(SURVEY 8d); issued_* counts the six bf16 passes and the "
+                    "padding (144 MFMAs per 16 samples).  Measured (PMC, "
+                    "profiles/r02_shade_x3_pmc.txt): kernel time = MFMA-busy "
+                    "cycles + VALU issue cycles, the two do not overlap on a "
+                    "SIMD shared by several waves"}
+    return {
+        "kernel": "k_weights_compact + k_shade_dense<f16> (colour+semantics "
+                  "MLPs on 16x16x32 f16 MFMA, fp32 accumulate)",
+        "bound": "mfma", "achieved": mlp_tf, "peak": F16_MFMA_PEAK_TF,
+        "unit": "TFLOP/s", "frac": mlp_tf / F16_MFMA_PEAK_TF,
+        "launch_ms": launch_ms, "traffic": None, "sigma_mlp_tflops": sig_tf,
+        "note": "the nets are 24 MFMAs per 16 samples here: the kernel is "
+                "bound by VALU issue (softmax, conversions, ordered per-ray "
+                "sums), not by the matrix pipe"}
+
+
+def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
+                mode=None):
     """Per-kernel durations of one chunk, measured with events on the stream
-    the kernels run on (torch's current stream).  half=True: the fp16-MFMA
-    nets (sigma MLP f16, split composite f16)."""
+    the kernels run on (torch's current stream), launched the way
+    ucsa_render_fwd[_f16|_x3] launches them.  mode: "fp32" (f32-input MFMA,
+    fused composite), "fp16" / "bf16x3" (sigma MLP and the split composite
+    pair on the 16-bit MFMA pipe)."""
     from ucsa_neural_rendering_amd import ops
-    f = net._field_f16() if half else net._field()
-    sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
+    mode = mode or ("fp16" if half else "fp32")
+    half = mode == "fp16"
+    x3 = mode == "bf16x3"
+    f = net._field_f16() if half else (net._field_x3() if x3 else net._field())
+    sigma_mlp = (ops.sigma_mlp_fwd_f16 if half else
+                 ops.sigma_mlp_fwd_x3 if x3 else ops.sigma_mlp_fwd)
     aabb = net._aabb_list(False)
     N = o.shape[0]
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -453,14 +521,15 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False):
         marks[5].record()
         hf, sf = sigma_mlp(feat, f["packed_sigma"])
         marks[6].record()
-        if half:
+        if it == 0:   # the weights, for the masked fraction rho
+            f32 = net._field()
+            w = ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
+                                  sf.view(N, T_FINE), hf, f32["packed_color"],
+                                  f32["packed_sem"], N_CLASSES, 1.0, want_aux=True)[4]
+        elif half or x3:
             ops.composite_infer(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
                                 sf.view(N, T_FINE), hf, f["packed_color"],
-                                f["packed_sem"], N_CLASSES, 1.0, half=True)
-        elif it == 0:
-            w = ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
-                                  sf.view(N, T_FINE), hf, f["packed_color"],
-                                  f["packed_sem"], N_CLASSES, 1.0, want_aux=True)[4]
+                                f["packed_sem"], N_CLASSES, 1.0, half=half, x3=x3)
         else:   # what ucsa_render_fwd launches for fp32: the fused kernel
             ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
                               sf.view(N, T_FINE), hf, f["packed_color"],
@@ -468,8 +537,7 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False):
         marks[7].record()
         torch.cuda.synchronize()
         if it == 0:
-            if not half:
-                rho = float((w > 1e-4).float().mean())
+            rho = float((w > 1e-4).float().mean())
             continue
         for i, k in enumerate(names):
             acc[k] += marks[i].elapsed_time(marks[i + 1]) / iters
@@ -662,6 +730,7 @@ def main():
                               num_steps=T_COARSE, upsample_steps=T_FINE,
                               rng_u=u, image_width=W)
 
+    net.precision = args.nerf_precision
     for i in range(args.warmup):
         step(i)
     if dist:
@@ -691,7 +760,7 @@ def main():
         st, rho = stage_times(net, o[0, :chunk].contiguous(),
                               d[0, :chunk].contiguous(),
                               nrm[0, :chunk, 0].contiguous(), u[:chunk],
-                              image_width=W)
+                              image_width=W, mode=args.nerf_precision)
         # --- roofline of the dominant kernel: hash-grid encode -------------
         # algorithmic bytes per sample: L * 8 corners * F * 4 B
         samples = chunk * T_COARSE
@@ -735,6 +804,7 @@ def main():
                 "pretrain": prelog,
                 "masked_fraction_rho": rho,
                 "sharding": "views round-robin over ranks, no data-path collective",
+                "mlp_arithmetic": MLP_ARITHMETIC[args.nerf_precision],
             },
             "roofline_encode": {
                 "kernel": "k_hashgrid_encode_tiled",
@@ -753,21 +823,8 @@ def main():
                         "works on is L2/MALL resident; what binds the kernel is "
                         "the L2->L1 path of divergent gathers (binding_resource)",
             },
-            "roofline_composite": {
-                "kernel": "k_composite (colour+semantics MLPs, fp32 MFMA)",
-                "bound": "mfma",
-                "achieved": mlp_tf,
-                "peak": F32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s",
-                "frac": mlp_tf / F32_MFMA_PEAK_TF,
-                "frac_of_fp16_dense_peak": mlp_tf / F16_MFMA_PEAK_TF,
-                "launch_ms": st["composite"],
-                "traffic": None,
-                "sigma_mlp_tflops": sig_tf,
-                "note": "peak = fp32-input MFMA (the instruction the parity mode "
-                        "issues, 1/16 of the fp16 rate); frac_of_fp16_dense_peak "
-                        "is the same achieved rate against SURVEY 8d's 2.5 PF line",
-            },
+            "roofline_composite": composite_roofline(args.nerf_precision, mlp_tf,
+                                                     sig_tf, st["composite"]),
             "roofline_step": {
                 "what": "one 640x480 view end to end (ms_per_step)",
                 "hbm": {"algorithmic_bytes_fp32_table": step_bytes_fp32,
@@ -793,8 +850,16 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, PMC_JSON)))
             if int(pmc.get("pretrain_steps", -1)) == int(args.pretrain_steps):
-                for key, kn in (("roofline_composite", "k_composite"),
+                cmp_kernel = {"fp32": "k_composite", "bf16x3": "k_shade_dense_x3",
+                              "fp16": "k_shade_dense_f16"}[args.nerf_precision]
+                for key, kn in (("roofline_composite", cmp_kernel),
                                 ("roofline_encode", "k_hashgrid_encode_tiled")):
+                    if kn not in pmc or "fetch_bytes" not in pmc[kn]:
+                        if kn in pmc and "mfma_busy_frac" in pmc[kn]:
+                            result[key]["mfma_pipe_busy_frac"] = pmc[kn]["mfma_busy_frac"]
+                            result[key]["valu_issue_frac"] = pmc[kn].get("valu_issue_frac")
+                            result[key]["pmc_source"] = PMC_JSON
+                        continue
                     tr = pmc[kn]["fetch_bytes"] + pmc[kn]["write_bytes"]
                     r = result[key]
                     r["traffic"] = tr
@@ -837,49 +902,49 @@ def main():
                              "miou": meter.measure()[0],
                              "note": "novel 640x480 view vs analytic GT after "
                                      "the pre-training above"}
-        # inference-only option: MLPs on fp16 MFMA (tcnn's numerics); never the
-        # headline `value` (the parity path is fp32)
-        net.precision = "fp16"
-        for i in range(2):
-            step(i)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n16 = min(5, args.steps)
-        for i in range(n16):
-            out16 = step(args.warmup + i)
-        torch.cuda.synchronize()
-        dt16 = (time.perf_counter() - t1) / n16
-        net.precision = "fp32"
-        d16 = (out16["image"] - step(args.warmup + n16 - 1)["image"]).abs().max()
-        st16, _ = stage_times(net, o[0, :chunk].contiguous(), d[0, :chunk].contiguous(),
-                              nrm[0, :chunk, 0].contiguous(), u[:chunk],
-                              image_width=W, half=True)
-        cmp16_tf = mlp_flop / (st16["composite"] * 1e-3) / 1e12
-        sig16_tf = samples * 6144 / (0.5 * (st16["sigma_c"] + st16["sigma_f"]) * 1e-3) / 1e12
-        # same workload with the three MLPs on f16 MFMA (tiny-cuda-nn's numerics);
-        # `value` stays the fp32 parity mode
-        result["value_fp16_nets"] = world * H * W / dt16 if world == 1 else None
-        result["f16_mlp_option"] = {
-            "rays_per_s": H * W / dt16, "ms_per_view": dt16 * 1e3,
-            "max_abs_image_diff_vs_fp32": float(d16),
-            "stage_ms_per_chunk": st16,
-            "roofline_composite": {
-                "kernel": "k_weights_compact + k_shade_dense (colour+semantics "
-                          "MLPs on 16x16x32 f16 MFMA, fp32 accumulate)",
-                "bound": "mfma", "achieved": cmp16_tf, "peak": F16_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": cmp16_tf / F16_MFMA_PEAK_TF,
-                "launch_ms": st16["composite"], "sigma_mlp_tflops": sig16_tf,
-                "note": "the nets are 24 MFMAs per 16 samples here: the kernel "
-                        "is bound by the softmax / ordered per-ray sums (VALU, "
-                        "LDS) and by latency, not by the matrix pipe"},
-            "roofline_step_mfma_frac_of_fp16_dense_peak":
-                step_flop / (dt16 * 1e3) / 1e9 / F16_MFMA_PEAK_TF,
-            "note": "precision='fp16' (tiny-cuda-nn's own numerics, "
-                    "`nerf: {precision: fp16}`): three MLPs on 16x16x32 f16 MFMA "
-                    "with fp16 weights / layer inputs and fp32 accumulation; hash "
-                    "grid, sampling, compositing fp32.  Parity: tests/"
-                    "test_gpu_configs.py against the oracle with the same "
-                    "roundings emulated (3e-3)"}
+        # the same workload in the other arithmetic modes of the three MLPs
+        # (never the headline `value`, which is --nerf-precision's mode)
+        ref_img = step(args.warmup + args.steps - 1)["image"]
+        n_alt = min(5, args.steps)
+        for alt in ("fp32", "bf16x3", "fp16"):
+            if alt == args.nerf_precision:
+                continue
+            net.precision = alt
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_alt):
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t1) / n_alt
+            diff = (step(args.warmup + args.steps - 1)["image"] - ref_img).abs().max()
+            sta, _ = stage_times(net, o[0, :chunk].contiguous(),
+                                 d[0, :chunk].contiguous(),
+                                 nrm[0, :chunk, 0].contiguous(), u[:chunk],
+                                 image_width=W, mode=alt)
+            cmp_tf = mlp_flop / (sta["composite"] * 1e-3) / 1e12
+            sga_tf = samples * 6144 / (0.5 * (sta["sigma_c"] + sta["sigma_f"]) * 1e-3) / 1e12
+            key = {"fp32": "f32_mfma_option", "bf16x3": "bf16x3_option",
+                   "fp16": "f16_mlp_option"}[alt]
+            vkey = {"fp32": "value_f32_mfma_nets", "bf16x3": "value_bf16x3_nets",
+                    "fp16": "value_fp16_nets"}[alt]
+            result[vkey] = world * H * W / dta if world == 1 else None
+            result[key] = {
+                "rays_per_s": H * W / dta, "ms_per_view": dta * 1e3,
+                "max_abs_image_diff_vs_value_mode": float(diff),
+                "stage_ms_per_chunk": sta,
+                "roofline_composite": composite_roofline(alt, cmp_tf, sga_tf,
+                                                         sta["composite"]),
+                "roofline_step_mfma_frac_of_fp16_dense_peak":
+                    step_flop / (dta * 1e3) / 1e9 / F16_MFMA_PEAK_TF,
+                "mlp_arithmetic": MLP_ARITHMETIC[alt],
+                "select": "`nerf: {precision: %s}` / --nerf-precision %s" % (alt, alt)}
+        if "f16_mlp_option" in result:
+            result["f16_mlp_option"]["note"] = (
+                "parity of this mode: tests/test_gpu_configs.py against the "
+                "oracle with tiny-cuda-nn's roundings emulated (3e-3)")
+        net.precision = args.nerf_precision
         # The side measurements below (marcher, training, DeepLab, CPU
         # baseline) are single-GPU figures: at N > 1 the other ranks would only
         # wait for rank 0, so they run at N = 1 only.

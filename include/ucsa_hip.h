@@ -270,6 +270,45 @@ int32_t ucsa_point_shade_h(const float* dirs, const float* h,
                            uint32_t n_classes, float* rgb, float* probs,
                            void* stream);
 
+/* ================= bf16x3: fp32-grade nets on the bf16 MFMA pipe ============ */
+/* Every fp32 weight and layer input is split exactly into three bf16 terms and
+ * each product is accumulated in fp32 from six bf16 partial products
+ * (csrc/mfma_mlp_x3.h): ordinary fp32 round-off, NOT bit-identical to the
+ * f32-input MFMA of the entry points above, 144 16-cycle MFMAs per 16 samples
+ * instead of 176 32-cycle ones.  Same call sites as the fp32 forms
+ * (reference network_tcnn_semantics.py:147-207, renderer_semantics.py:238-299).
+ * packed_*_x3: ucsa_mlp_pack_x3_bytes(kind, n_classes) bytes from
+ * ucsa_mlp_pack_x3. */
+uint32_t ucsa_mlp_pack_x3_bytes(int32_t kind, uint32_t n_classes);
+int32_t ucsa_mlp_pack_x3(int32_t kind, const float* params, void* packed_x3,
+                         uint32_t n_classes, void* stream);
+/* density() nets of a sample batch (cf. ucsa_sigma_mlp_fwd) */
+int32_t ucsa_sigma_mlp_fwd_x3(const float* feat, const void* packed_sigma_x3,
+                              uint32_t M, uint32_t n_levels, float* h,
+                              float* sigma, void* stream);
+/* run() as one enqueue (cf. ucsa_render_fwd; same workspace) */
+int32_t ucsa_render_fwd_x3(const ucsa_grid* grid, const float* table,
+                           const void* packed_sigma_x3,
+                           const void* packed_color_x3,
+                           const void* packed_sem_x3, const float* rays_o,
+                           const float* rays_d, const float* norms,
+                           const float* aabb_host, float min_near,
+                           const float* t_rand, const float* u, uint32_t N,
+                           uint32_t T, uint32_t t, uint32_t n_classes,
+                           float density_scale, uint32_t image_width,
+                           float* image, float* depth, float* semantics,
+                           void* workspace, void* stream);
+int32_t ucsa_composite_infer_x3(const float* rays_d, const float* norms,
+                                const float* z_c, const float* sigma_c,
+                                const float* h_c, const float* z_f,
+                                const float* sigma_f, const float* h_f,
+                                const void* packed_color_x3,
+                                const void* packed_sem_x3, uint32_t N,
+                                uint32_t T, uint32_t t, uint32_t n_classes,
+                                float density_scale, float* image,
+                                float* depth, float* semantics,
+                                void* workspace, void* stream);
+
 /* ======================= fp16-MFMA inference option ======================== */
 /* tiny-cuda-nn evaluates the three MLPs with fp16 weights / layer inputs and
  * fp32 accumulation; the entry points below do the same (16x16x32 f16 MFMA)

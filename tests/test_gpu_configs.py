@@ -139,6 +139,21 @@ def test_cfg2_bench_path_640x480_staged_image_ordered(which):
         ref = oren.run(fld, o.cpu()[:, sel], d.cpu()[:, sel], nrm.cpu()[:, sel], AABB4,
                        num_steps=T, upsample_steps=t, u=u.cpu()[sel], return_aux=True)
     _check(res, ref, sel, tag=f"cfg2[{which}]")
+    # bench.py's default arithmetic (bf16x3, fp32-grade on the bf16 MFMA pipe):
+    # the same fp32 tolerances against the oracle, and 1e-6 to the exact chain
+    net.precision = "bf16x3"
+    with torch.no_grad():
+        res3 = net.render(o, d, nrm, staged=True, perturb=False, num_steps=T,
+                          upsample_steps=t, rng_u=u, image_width=W)
+    net.precision = "fp32"
+    _check(res3, ref, sel, tag=f"cfg2[{which}, bf16x3]")
+    for k in ("image", "semantics"):
+        # (a weight within an ulp of the 1e-4 mask threshold may flip between
+        # the two modes and move a pixel by up to 1e-4 x |value|: statistics)
+        e = (res3[k][0] - res[k][0]).abs().max(-1)[0]
+        print(f"cfg2[{which}] bf16x3 vs f32 MFMA, {k}: p99.9 "
+              f"{float(e.quantile(0.999)):.2e} max {float(e.max()):.2e}")
+        assert float(e.quantile(0.999)) <= 2e-5 and float(e.max()) <= 3e-4, k
     # the fp16-MFMA option on the same path, against the oracle emulating
     # tcnn's roundings (fp16 weights / layer inputs, fp32 accumulate)
     import copy

@@ -194,12 +194,19 @@ def _hip_render(net, g, chunk=None, staged=None):
     return {k: v.cpu() for k, v in res.items()}
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
-def test_render_matches_reference_fixture(net, tag):
-    """Fixtures = the REFERENCE renderer run on the restated field."""
+def test_render_matches_reference_fixture(net, tag, precision):
+    """Fixtures = the REFERENCE renderer run on the restated field.  Same
+    fp32 tolerance for the f32-input MFMA nets and for bf16x3 (three-term
+    bf16 operands, six partial products: fp32-grade)."""
     g = load_golden(f"g5{tag}_run_field.npz")
     net.train(not bool(g["staged"]))
-    res = _hip_render(net, g)
+    net.precision = precision
+    try:
+        res = _hip_render(net, g)
+    finally:
+        net.precision = "fp32"
     net.eval()
     assert maxabs(res["image"], g["image"]) <= 1e-4
     assert maxabs(res["semantics"], g["semantics"]) <= 1e-4
@@ -485,3 +492,77 @@ def test_fused_encode_sigma_is_bit_identical_to_the_staged_pair(H, W, T, half):
                                          aabb, W, half=half)
     torch.cuda.synchronize()
     assert torch.equal(h0, h1) and torch.equal(s0, s1)
+
+
+# ------------------------------------------------- bf16x3: fp32-grade nets
+def _nets_fp64(fld, d, h):
+    """Colour and semantics nets of samples (d [M,3], h [M,16]) in fp64."""
+    geo = h[:, 1:].double()
+    d01 = (d.double() + 1) / 2
+    x = torch.cat([ofield.sh4_encode(d01), geo], dim=-1)
+    rgb = torch.sigmoid(ofield.mlp_forward(fld.color_spec, x, fld.color_params.double()))
+    p = torch.softmax(ofield.mlp_forward(fld.sem_spec, geo, fld.sem_params.double()), -1)
+    return rgb, p
+
+
+@pytest.mark.parametrize("scale", [1.0, 6.0])
+def test_bf16x3_nets_are_fp32_grade(ops, scale):
+    """Per-sample colours / class probabilities of the bf16x3 shading kernel
+    against an fp64 evaluation, next to the f32-input MFMA kernel's error
+    against the same truth: one sample per ray (T = 1, t = 0) with a huge
+    density makes the composite return the nets' outputs themselves."""
+    import copy
+    fld = copy.copy(lively_oracle_field())
+    g = torch.Generator().manual_seed(7)
+    # larger weights than a trained field has: hidden activations of O(10),
+    # logits of O(scale * 10)
+    fld.color_params = fld.color_params * scale
+    fld.sem_params = fld.sem_params * scale
+    M = 4096 + 37
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    h = torch.randn(M, 16, generator=g) * 1.5
+    rgb64, p64 = _nets_fp64(fld, d, h)
+    dev = torch.device("cuda:0")
+    z = torch.ones(M, 1, device=dev)
+    sig = torch.full((M, 1), 50.0, device=dev)   # alpha = 1 - exp(-1e10 * 50) = 1
+    nrm = torch.ones(M, device=dev)
+    cp, sp = fld.color_params.to(dev), fld.sem_params.to(dev)
+    args = (d.to(dev), nrm, z, sig, h.to(dev), None, None, None)
+    f32 = ops.composite_infer(*args, ops.mlp_pack(1, cp), ops.mlp_pack(2, sp, 40), 40)
+    x3 = ops.composite_infer(*args, ops.mlp_pack_x3(1, cp), ops.mlp_pack_x3(2, sp, 40),
+                             40, x3=True)
+    f16 = ops.composite_infer(*args, ops.mlp_pack_f16(1, cp), ops.mlp_pack_f16(2, sp, 40),
+                              40, half=True)
+    torch.cuda.synchronize()
+    err = lambda got, ref: float((got.cpu().double() - ref).abs().max())
+    e32 = (err(f32[0], rgb64), err(f32[2], p64))
+    ex3 = (err(x3[0], rgb64), err(x3[2], p64))
+    e16 = (err(f16[0], rgb64), err(f16[2], p64))
+    print(f"scale {scale}: max |. - fp64|  f32 MFMA rgb {e32[0]:.2e} p {e32[1]:.2e} | "
+          f"bf16x3 rgb {ex3[0]:.2e} p {ex3[1]:.2e} | f16 rgb {e16[0]:.2e} p {e16[1]:.2e}")
+    for a, b in zip(ex3, e32):
+        assert a <= max(2.0 * b, 3e-7), (ex3, e32)        # as good as the exact chain
+    assert max(ex3) <= 0.05 * max(e16)                    # and far from fp16's error
+    # the two fp32-grade kernels agree to within their own distances to the truth
+    assert maxabs(x3[0], f32[0]) <= max(1e-6, 2 * (e32[0] + ex3[0]))
+    assert maxabs(x3[2], f32[2]) <= max(1e-6, 2 * (e32[1] + ex3[1]))
+
+
+def test_bf16x3_sigma_mlp_is_fp32_grade(ops):
+    fld = lively_oracle_field()
+    g = torch.Generator().manual_seed(11)
+    M = 5000
+    feat = torch.randn(16, M, 2, generator=g) * 0.5       # [L, M, F], as the encoder writes
+    x = feat.permute(1, 0, 2).reshape(M, 32).double()
+    h64 = ofield.mlp_forward(fld.sigma_spec, x, fld.sigma_params.double())
+    dev = torch.device("cuda:0")
+    sp = fld.sigma_params.to(dev)
+    h32, s32 = ops.sigma_mlp_fwd(feat.to(dev), ops.mlp_pack(0, sp))
+    hx3, sx3 = ops.sigma_mlp_fwd_x3(feat.to(dev), ops.mlp_pack_x3(0, sp))
+    torch.cuda.synchronize()
+    e32 = float((h32.cpu().double() - h64).abs().max())
+    ex3 = float((hx3.cpu().double() - h64).abs().max())
+    print(f"sigma MLP: max |h - fp64|  f32 MFMA {e32:.2e}  bf16x3 {ex3:.2e}")
+    assert ex3 <= max(2.0 * e32, 3e-7)
+    rel = ((sx3 - s32).abs() / s32.abs().clamp_min(1e-30)).max()
+    assert float(rel) <= 5e-6                              # sigma = exp(h0)

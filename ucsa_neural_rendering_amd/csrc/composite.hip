@@ -297,7 +297,7 @@ k_composite(CmpArgs a) {
       for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[cb][c]));  // rows 0..2 live in g==0
+          rgb[cb][c] = fast_sigmoid(o3[cb][c]);  // rows 0..2 live in g==0
     }
 
     // ---------------- semantics net: 16 -> 64 -> 16*NRB_SEM --------------
@@ -366,7 +366,7 @@ k_composite(CmpArgs a) {
         f32x4 o3 = mfma_h(frag_h(w_color, 12, lane), h0, z4);
         o3 = mfma_h(frag_h(w_color, 13, lane), h1, o3);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[c]));
+        for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
         h0 = chain_relu_h(a1[0], a1[1]);
@@ -403,7 +403,7 @@ k_composite(CmpArgs a) {
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
       const float wgt = ew[cb];
-      const float inv_sum = 1.0f / sum;
+      const float ws = wgt * fast_rcp(sum);
       float* crow = contrib + j * cstride;
       if (g == 0) {
         crow[0] = wgt * rgb[cb][0];
@@ -415,7 +415,7 @@ k_composite(CmpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const uint32_t cls = rb * 16 + 4 * g + r;
-          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] * inv_sum);
+          if (cls < C) crow[3 + cls] = lg[cb][rb][r] * ws;
         }
       wave_lds_sync();
       const uint32_t nb = (n > (uint32_t)cb * 16) ? ((n - cb * 16 < 16) ? n - cb * 16 : 16) : 0;

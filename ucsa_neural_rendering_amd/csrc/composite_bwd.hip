@@ -93,7 +93,7 @@ __device__ __forceinline__ void dw_scale(f32x4 (&dw)[OB][IB], float s) {
 __device__ __forceinline__ f32x4 relu_q4(f32x4 v) {
   f32x4 r;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) r[k] = (float)(_Float16)fmaxf(v[k], 0.f);
+  for (int k = 0; k < 4; ++k) r[k] = (float)(_Float16)relu1(v[k]);
   return r;
 }
 

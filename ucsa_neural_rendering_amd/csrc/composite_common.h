@@ -17,6 +17,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 // kernel as libm expf (measured), and the outputs are probabilities / colours
 // compared at 1e-4.  The weights (phase A) keep expf: they decide the mask.
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+// ... and the hardware reciprocal (v_rcp_f32, 1 ulp) for the sigmoid and the
+// softmax normalisation: an IEEE division is an 11-instruction sequence, four
+// of them per sample were ~9 % of the shading kernel's VALU work.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return fast_rcp(1.0f + fast_exp(-x));
+}
 
 __device__ __forceinline__ void sh4_select(float dx, float dy, float dz,
                                            uint32_t g, float (&o)[4]) {

@@ -28,10 +28,12 @@
 #include <cstdlib>
 
 #include "composite_common.h"
+#include "mfma_mlp_x3.h"
 
 extern __shared__ __attribute__((aligned(16))) float cs_smem[];
 
 struct WcArgs {
+  const float* rays_d;
   const float* norms;
   const float* z_c;
   const float* sigma_c;
@@ -48,6 +50,7 @@ struct WcArgs {
   float* image;        // rays without a survivor get zeros here
   float* semantics;
   uint32_t C;
+  float* sh;           // [N,16] SH basis of the ray direction (null: not wanted)
 };
 
 #define WC_WAVES 4
@@ -145,6 +148,13 @@ __global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
     }
     dsum = wave_sum(dsum);
     if (lane == 0) a.depth[r] = dsum / a.norms[r];
+    if (a.sh && lane < 16) {  // the 16 SH values of the ray, once per ray
+      const float* dd = a.rays_d + (size_t)r * 3;
+      float sh[4];
+      sh4_select(dd[0], dd[1], dd[2], lane >> 2, sh);
+      const uint32_t q = lane & 3u;
+      a.sh[(size_t)r * 16 + lane] = q == 0 ? sh[0] : (q == 1 ? sh[1] : (q == 2 ? sh[2] : sh[3]));
+    }
     if (kept == 0) {  // nothing survived the mask: all-zero outputs
       if (lane < 3) a.image[(size_t)r * 3 + lane] = 0.0f;
       else if (lane < 3 + a.C) a.semantics[(size_t)r * a.C + (lane - 3)] = 0.0f;
@@ -166,9 +176,9 @@ struct ShArgs {
   const uint32_t* counts;
   uint32_t N, S, C;
   uint32_t rays_per_wave;
-  uint32_t contrib_stride;
   float* image;
   float* semantics;
+  const float* sh;  // [N,16] from k_weights_compact (16-bit MFMA modes)
 };
 
 template <int CBS>
@@ -183,26 +193,33 @@ struct Pre {  // one group's operands, requested one group ahead
   float ew[CBS];
   uint32_t eray[CBS];
   f32x4 hv[CBS];
-  float d[CBS][3];
+  float d[CBS][3];  // f32-input MFMA mode: the ray direction
+  f32x4 shv[CBS];   // 16-bit MFMA modes: this lane's four SH values of the ray
 };
 
-template <int NRB_SEM, int CBS, bool HALF, int WAVES>
+// PREC: 0 = f32-input MFMA, 1 = f16 MFMA (tiny-cuda-nn's numerics), 2 = bf16x3
+// (fp32-grade on the bf16 MFMA pipe, mfma_mlp_x3.h)
+template <int NRB_SEM, int CBS, int PREC, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
+  constexpr bool HALF = PREC == 1;
   constexpr uint32_t G = 16u * CBS;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint32_t S = a.S, C = a.C;
-  const uint32_t cstride = a.contrib_stride;
+  constexpr uint32_t CSTRIDE = 16 * NRB_SEM + 4;
 
-  constexpr uint32_t WC_FLOATS = HALF ? COLOR_H_FRAGS * 256 : 7168;
-  constexpr uint32_t WS_FLOATS = HALF ? SEM_H_FRAGS(NRB_SEM) * 256
-                                      : 1024 + NRB_SEM * 1024;
+  constexpr uint32_t WC_FLOATS = PREC == 2   ? COLOR_H_FRAGS * 768
+                                 : PREC == 1 ? COLOR_H_FRAGS * 256
+                                             : 7168;
+  constexpr uint32_t WS_FLOATS = PREC == 2   ? SEM_H_FRAGS(NRB_SEM) * 768
+                                 : PREC == 1 ? SEM_H_FRAGS(NRB_SEM) * 256
+                                             : 1024 + NRB_SEM * 1024;
   float* w_color = cs_smem;
   float* w_sem = w_color + WC_FLOATS;
-  const uint32_t per_wave_floats = 16 * cstride + 64;
+  constexpr uint32_t per_wave_floats = 16 * CSTRIDE + 64;
   float* base = w_sem + WS_FLOATS + (size_t)wid * per_wave_floats;
-  float* contrib = base;                      // [16][cstride]
-  float* shpart = contrib + 16 * cstride;     // [64] colour-L1 SH part of a ray
+  float* contrib = base;                      // [16][CSTRIDE]
+  float* shpart = contrib + 16 * CSTRIDE;     // [64] colour-L1 SH part of a ray
 
   for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
     w_color[i] = a.packed_color[i];
@@ -213,7 +230,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
   const uint64_t gwave = (uint64_t)blockIdx.x * WAVES + wid;
   const uint64_t r_begin64 = gwave * a.rays_per_wave;
   if (r_begin64 >= a.N) return;
-  const uint32_t total = a.counts[gwave];
+  const uint32_t total =
+      (uint32_t)__builtin_amdgcn_readfirstlane((int)a.counts[gwave]);
   if (total == 0) return;
   const size_t lbase = (size_t)r_begin64 * S;
 
@@ -221,9 +239,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
   uint32_t sh_ray = 0xFFFFFFFFu;   // ray whose SH part sits in `shpart`
   float acc = 0.0f;                // lane c: running sum of channel c
 
+  // lane c < C sums class c, lanes C..C+2 sum r, g, b
+  const uint32_t choff = lane < C ? lane : (lane < C + 3 ? 16 * NRB_SEM + (lane - C) : 0u);
   auto flush_ray = [&](uint32_t ray) {
-    if (lane < 3) a.image[(size_t)ray * 3 + lane] = acc;
-    else if (lane < 3 + C) a.semantics[(size_t)ray * C + (lane - 3)] = acc;
+    if (lane < C) a.semantics[(size_t)ray * C + lane] = acc;
+    else if (lane < C + 3) a.image[(size_t)ray * 3 + (lane - C)] = acc;
   };
 
   // stage 1: the list entries of the group starting at gb (entries past
@@ -250,10 +270,15 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
       const float* hp = ((row & ROW_FINE) ? a.h_f : a.h_c) +
                         (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
       p.hv[cb] = *reinterpret_cast<const f32x4*>(hp);
-      const float* dd = a.rays_d + (size_t)en.ray[cb] * 3;
-      p.d[cb][0] = dd[0];
-      p.d[cb][1] = dd[1];
-      p.d[cb][2] = dd[2];
+      if constexpr (PREC == 0) {
+        const float* dd = a.rays_d + (size_t)en.ray[cb] * 3;
+        p.d[cb][0] = dd[0];
+        p.d[cb][1] = dd[1];
+        p.d[cb][2] = dd[2];
+      } else {
+        p.shv[cb] = *reinterpret_cast<const f32x4*>(
+            a.sh + (size_t)en.ray[cb] * 16 + 4 * g);
+      }
     }
   };
 
@@ -269,7 +294,89 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
     }
     float rgb[CBS][3];
     f32x4 lg[CBS][NRB_SEM];
-    if constexpr (!HALF) {
+    if constexpr (PREC == 2) {
+      // six bf16 partial products per fp32 product: 144 MFMAs (16 cycles
+      // each) per column block instead of 176 f32-input ones (32 cycles).
+      // Layer-major: a weight fragment (three terms, 3 ds_read_b128) is read
+      // once per group and used by all its column blocks.
+      uint32_t zoff = 0;
+      asm volatile("" : "+v"(zoff));  // keep the 72 fragments in LDS
+      const uint32_t wl = lane + zoff;
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      X3 b1[CBS];
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        split_pair(p.shv[cb][0], p.shv[cb][1], b1[cb], 0);
+        split_pair(p.shv[cb][2], p.shv[cb][3], b1[cb], 1);
+        split_pair(geo[cb][0], geo[cb][1], b1[cb], 2);
+        split_pair(geo[cb][2], geo[cb][3], b1[cb], 3);
+      }
+      f32x4 a1[CBS][4], a2[CBS][4];
+      X3 h0[CBS], h1[CBS];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const W3 w = frag_x3(w_color, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a1[cb][rb] = mfma_x3(w, b1[cb], z4);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
+        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const W3 wa = frag_x3(w_color, 4 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = mfma_x3(wa, h0[cb], z4);
+        const W3 wb = frag_x3(w_color, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = mfma_x3(wb, h1[cb], a2[cb][rb]);
+      }
+      // semantics L1 reads the h-row slots of b1: its fragments carry zeros
+      // in the SH slots' place (k-slots e >= 4 of the f16 layout <-> e < 4)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const W3 w = frag_x3(w_sem, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          X3 bs;
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+            bs.t[term] = u32x4{b1[cb].t[term][2], b1[cb].t[term][3], 0u, 0u};
+          a1[cb][rb] = mfma_x3(w, bs, z4);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = chain_relu_x3(a2[cb][0], a2[cb][1]);
+        h1[cb] = chain_relu_x3(a2[cb][2], a2[cb][3]);
+      }
+      {
+        const W3 wa = frag_x3(w_color, 12, wl), wb = frag_x3(w_color, 13, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          f32x4 o3 = mfma_x3(wa, h0[cb], z4);
+          o3 = mfma_x3(wb, h1[cb], o3);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
+        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb) {
+        const W3 wa = frag_x3(w_sem, 4 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wa, h0[cb], z4);
+        const W3 wb = frag_x3(w_sem, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wb, h1[cb], lg[cb][rb]);
+      }
+    } else if constexpr (!HALF) {
       {  // colour net 32 -> 64 -> 64 -> 16 (composite.hip, same k order)
         f32x4 acc1[CBS][4];
 #pragma unroll
@@ -350,7 +457,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
         for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[cb][c]));
+            rgb[cb][c] = fast_sigmoid(o3[cb][c]);
       }
       {  // semantics net 16 -> 64 -> 16*NRB_SEM
         f32x4 acc1[CBS][4];
@@ -401,12 +508,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
       const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cb = 0; cb < CBS; ++cb) {
-        float sh[4];
-        sh4_select(p.d[cb][0], p.d[cb][1], p.d[cb][2], g, sh);
         half8 b1, bs;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          b1[r] = (_Float16)sh[r];
+          b1[r] = (_Float16)p.shv[cb][r];
           b1[4 + r] = (_Float16)geo[cb][r];
           bs[r] = (_Float16)geo[cb][r];
           bs[4 + r] = (_Float16)0.f;
@@ -425,7 +530,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
         f32x4 o3 = mfma_h(frag_h(w_color, 12, wl), h0, z4);
         o3 = mfma_h(frag_h(w_color, 13, wl), h1, o3);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[cb][c] = 1.0f / (1.0f + fast_exp(-o3[c]));
+        for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, wl), bs, z4);
         h0 = chain_relu_h(a1[0], a1[1]);
@@ -438,7 +543,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
       }
     }
 
-    // softmax + contributions + per-ray sums in sample order
+    // softmax + contributions + per-ray sums in sample order.  Row of entry j
+    // in the LDS tile: [16*NRB_SEM class slots | r g b | pad], CSTRIDE floats
+    // (an odd number of 16-byte chunks: the b128 stores of 8 lanes land in
+    // distinct bank groups); padded classes carry zeros.
 #pragma unroll
     for (int cb = 0; cb < CBS; ++cb) {
       float mx = -INFINITY;
@@ -462,38 +570,51 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
       const float wgt = p.ew[cb];
-      const float inv_sum = 1.0f / sum;
-      float* crow = contrib + j * cstride;
+      const float ws = wgt * fast_rcp(sum);
+      float* crow = contrib + j * CSTRIDE;
       if (g == 0) {
-        crow[0] = wgt * rgb[cb][0];
-        crow[1] = wgt * rgb[cb][1];
-        crow[2] = wgt * rgb[cb][2];
+        crow[16 * NRB_SEM + 0] = wgt * rgb[cb][0];
+        crow[16 * NRB_SEM + 1] = wgt * rgb[cb][1];
+        crow[16 * NRB_SEM + 2] = wgt * rgb[cb][2];
       }
 #pragma unroll
-      for (int rb = 0; rb < NRB_SEM; ++rb)
+      for (int rb = 0; rb < NRB_SEM; ++rb) {
+        f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t cls = rb * 16 + 4 * g + r;
-          if (cls < C) crow[3 + cls] = wgt * (lg[cb][rb][r] * inv_sum);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = lg[cb][rb][r] * ws;
+        *reinterpret_cast<f32x4*>(crow + rb * 16 + 4 * g) = v;
+      }
       wave_lds_sync();
       const uint32_t nb =
           (n > (uint32_t)cb * 16) ? ((n - cb * 16 < 16) ? n - cb * 16 : 16) : 0;
       float cv[16];
-      const uint32_t ch = lane < 3 + C ? lane : 0;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) cv[e] = contrib[e * cstride + ch];
-      // the ray of entry e of this column block: lane e (g == 0) holds it
+      for (int e = 0; e < 16; ++e) cv[e] = contrib[e * CSTRIDE + choff];
+      // the ray of entry e of this column block: lane e (g == 0) holds it; the
+      // list is sorted by ray, so first == last means one ray for all 16
+      const uint32_t ray_a = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], 0);
+      const uint32_t ray_z = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], 15);
+      if (nb == 16 && ray_a == ray_z) {
+        if (ray_a != cur_ray) {
+          if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+          cur_ray = ray_a;
+          acc = 0.0f;
+        }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        if ((uint32_t)e < nb) {
-          const uint32_t ray = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], e);
-          if (ray != cur_ray) {
-            if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
-            cur_ray = ray;
-            acc = 0.0f;
+        for (int e = 0; e < 16; ++e) acc = acc + cv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if ((uint32_t)e < nb) {
+            const uint32_t ray =
+                (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], e);
+            if (ray != cur_ray) {
+              if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+              cur_ray = ray;
+              acc = 0.0f;
+            }
+            acc = acc + cv[e];
           }
-          acc = acc + cv[e];
         }
       }
       wave_lds_sync();
@@ -524,10 +645,11 @@ static inline uint32_t cs_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
 extern "C" uint64_t ucsa_composite_infer_workspace_bytes(uint32_t N, uint32_t T,
                                                          uint32_t t) {
   const uint64_t S = (uint64_t)T + t;
-  return (((uint64_t)N * S * 12 + 255) & ~255ull) + (((uint64_t)N * 4 + 255) & ~255ull);
+  return (((uint64_t)N * S * 12 + 255) & ~255ull) + (((uint64_t)N * 4 + 255) & ~255ull) +
+         (uint64_t)N * 64;
 }
 
-template <int NRB, int CBS, bool H, int WAVES>
+template <int NRB, int CBS, int H, int WAVES>
 static int32_t launch_shade(const ShArgs& a, uint32_t blocks, size_t smem,
                             hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(
@@ -549,7 +671,7 @@ static int shade_variant() {
   return v ? atoi(v) : 0;
 }
 
-static int32_t composite_infer(bool half, const float* rays_d,
+static int32_t composite_infer(int prec, const float* rays_d,
                                const float* norms, const float* z_c,
                                const float* sigma_c, const float* h_c,
                                const float* z_f, const float* sigma_f,
@@ -570,15 +692,17 @@ static int32_t composite_infer(bool half, const float* rays_d,
   UCSA_CHECK_ARG(ws, 18);
   if (N == 0) return 0;
   const uint32_t S = T + t;
+  const bool half = prec == 1;
   hipStream_t s = (hipStream_t)stream;
   char* wp = (char*)ws;
   float* list_w = (float*)wp;
   uint32_t* list_row = (uint32_t*)(wp + (size_t)N * S * 4);
   uint32_t* list_ray = (uint32_t*)(wp + (size_t)N * S * 8);
   uint32_t* counts = (uint32_t*)(wp + (((size_t)N * S * 12 + 255) & ~(size_t)255));
+  float* sh = prec == 0 ? nullptr
+                        : (float*)((char*)counts + (((size_t)N * 4 + 255) & ~(size_t)255));
   const uint32_t nrb = cs_pad16(n_classes) / 16;
-  uint32_t cstride = 3 + n_classes;
-  if ((cstride & 1u) == 0) cstride += 1;  // odd stride: conflict-free rows
+  const uint32_t cstride = 16 * nrb + 4;  // k_shade_dense's CSTRIDE
   const int variant = shade_variant();
   // (waves per workgroup, column blocks per group); measured on the bench's
   // 61 440-ray chunk, k_weights_compact (0.13 ms) included:
@@ -588,9 +712,11 @@ static int32_t composite_infer(bool half, const float* rays_d,
   //           (spills), 4 = (16, 2): 3.7 (spills)
   // fp32: 0 = (16, 1): 2.49, 1 = (12, 2): 2.85, 2 = (8, 2): 2.63 -- all behind
   //       the fused k_composite (2.33), which ucsa_render_fwd keeps for fp32
-  const uint32_t waves = half ? ((variant == 0 || variant == 4) ? 16u
-                                 : (variant == 3 ? 12u : 8u))
-                              : (variant == 0 ? 16u : (variant == 1 ? 12u : 8u));
+  // bf16x3: 0 = (16, 1), 1 = (8, 2), 2 = (12, 2), 3 = (12, 1), 4 = (8, 4)
+  const uint32_t waves =
+      prec == 2 ? (variant == 0 ? 16u : ((variant == 2 || variant == 3) ? 12u : 8u))
+      : half    ? ((variant == 0 || variant == 4) ? 16u : (variant == 3 ? 12u : 8u))
+                : (variant == 0 ? 16u : (variant == 1 ? 12u : 8u));
   // both kernels use the same ranges of whole rays per wave: enough waves to
   // fill the chip twice over
   const uint64_t total_waves = 256ull * 16 * 2;
@@ -600,9 +726,9 @@ static int32_t composite_infer(bool half, const float* rays_d,
   const uint32_t n_waves = ucsa_div_up(N, rpw);
   // ---- A: weights + compaction ---------------------------------------------
   {
-    WcArgs a{norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale, depth,
-             list_w, list_row, list_ray, counts, rpw, image, semantics,
-             n_classes};
+    WcArgs a{rays_d, norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale,
+             depth, list_w, list_row, list_ray, counts, rpw, image, semantics,
+             n_classes, sh};
     const size_t smem = (size_t)WC_WAVES * 4 * S * 4;
     UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
     hipError_t e = hipFuncSetAttribute(
@@ -616,26 +742,35 @@ static int32_t composite_infer(bool half, const float* rays_d,
     if (rc != 0) return rc;
   }
   // ---- B: dense shading of the survivor lists -------------------------------
-  const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
-                               : 7168 + 1024 + (size_t)nrb * 1024;
+  const size_t w_floats =
+      prec == 2 ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 768
+      : half    ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
+                : 7168 + 1024 + (size_t)nrb * 1024;
   const size_t per_wave = 16 * (size_t)cstride + 64;
   const size_t smem = (w_floats + waves * per_wave) * 4;
   const uint32_t blocks = ucsa_div_up(n_waves, waves);
   ShArgs b{rays_d, h_c, h_f, (const float*)packed_color, (const float*)packed_sem,
-           list_w, list_row, list_ray, counts, N, S, n_classes, rpw, cstride,
-           image, semantics};
+           list_w, list_row, list_ray, counts, N, S, n_classes, rpw, image,
+           semantics, sh};
 #define SH_GO(NRB)                                                             \
   do {                                                                         \
-    if (half) {                                                                \
-      if (variant == 0) return launch_shade<NRB, 1, true, 16>(b, blocks, smem, s); \
-      if (variant == 1) return launch_shade<NRB, 2, true, 8>(b, blocks, smem, s);  \
-      if (variant == 2) return launch_shade<NRB, 4, true, 8>(b, blocks, smem, s);  \
-      if (variant == 3) return launch_shade<NRB, 2, true, 12>(b, blocks, smem, s); \
-      return launch_shade<NRB, 2, true, 16>(b, blocks, smem, s);               \
+    if (prec == 2) {                                                           \
+      if (variant == 0) return launch_shade<NRB, 1, 2, 16>(b, blocks, smem, s); \
+      if (variant == 1) return launch_shade<NRB, 2, 2, 8>(b, blocks, smem, s);  \
+      if (variant == 2) return launch_shade<NRB, 2, 2, 12>(b, blocks, smem, s); \
+      if (variant == 3) return launch_shade<NRB, 1, 2, 12>(b, blocks, smem, s); \
+      return launch_shade<NRB, 4, 2, 8>(b, blocks, smem, s);                   \
     }                                                                          \
-    if (variant == 0) return launch_shade<NRB, 1, false, 16>(b, blocks, smem, s);  \
-    if (variant == 1) return launch_shade<NRB, 2, false, 12>(b, blocks, smem, s);  \
-    return launch_shade<NRB, 2, false, 8>(b, blocks, smem, s);                 \
+    if (half) {                                                                \
+      if (variant == 0) return launch_shade<NRB, 1, 1, 16>(b, blocks, smem, s); \
+      if (variant == 1) return launch_shade<NRB, 2, 1, 8>(b, blocks, smem, s);  \
+      if (variant == 2) return launch_shade<NRB, 4, 1, 8>(b, blocks, smem, s);  \
+      if (variant == 3) return launch_shade<NRB, 2, 1, 12>(b, blocks, smem, s); \
+      return launch_shade<NRB, 2, 1, 16>(b, blocks, smem, s);                  \
+    }                                                                          \
+    if (variant == 0) return launch_shade<NRB, 1, 0, 16>(b, blocks, smem, s);  \
+    if (variant == 1) return launch_shade<NRB, 2, 0, 12>(b, blocks, smem, s);  \
+    return launch_shade<NRB, 2, 0, 8>(b, blocks, smem, s);                     \
   } while (0)
   switch (nrb) {
     case 1: SH_GO(1);
@@ -653,7 +788,7 @@ extern "C" int32_t ucsa_composite_infer(
     const float* packed_sem, uint32_t N, uint32_t T, uint32_t t,
     uint32_t n_classes, float density_scale, float* image, float* depth,
     float* semantics, void* workspace, void* stream) {
-  return composite_infer(false, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+  return composite_infer(0, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
                          h_f, packed_color, packed_sem, N, T, t, n_classes,
                          density_scale, image, depth, semantics, workspace,
                          stream);
@@ -666,8 +801,21 @@ extern "C" int32_t ucsa_composite_infer_f16(
     const void* packed_sem_half, uint32_t N, uint32_t T, uint32_t t,
     uint32_t n_classes, float density_scale, float* image, float* depth,
     float* semantics, void* workspace, void* stream) {
-  return composite_infer(true, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+  return composite_infer(1, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
                          h_f, packed_color_half, packed_sem_half, N, T, t,
                          n_classes, density_scale, image, depth, semantics,
                          workspace, stream);
+}
+
+extern "C" int32_t ucsa_composite_infer_x3(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_x3,
+    const void* packed_sem_x3, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, void* workspace, void* stream) {
+  return composite_infer(2, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                         packed_color_x3, packed_sem_x3, N, T, t, n_classes,
+                         density_scale, image, depth, semantics, workspace,
+                         stream);
 }

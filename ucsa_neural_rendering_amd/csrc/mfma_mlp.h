@@ -24,12 +24,20 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ReLU as ONE instruction (v_max_i32 on the bit pattern: a float is negative
+// iff its bit pattern is a negative integer; -0 -> +0).  fmaxf(x, 0) costs two
+// (the compiler first quiets a possible signalling NaN with v_max_f32 x, x).
+__device__ __forceinline__ float relu1(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   f32x4 r;
-  r[0] = fmaxf(v[0], 0.f);
-  r[1] = fmaxf(v[1], 0.f);
-  r[2] = fmaxf(v[2], 0.f);
-  r[3] = fmaxf(v[3], 0.f);
+  r[0] = relu1(v[0]);
+  r[1] = relu1(v[1]);
+  r[2] = relu1(v[2]);
+  r[3] = relu1(v[3]);
   return r;
 }
 
@@ -64,7 +72,7 @@ __device__ __forceinline__ void chain_relu(const f32x4 (&acc)[4],
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xin[rb * 4 + r] = fmaxf(acc[rb][r], 0.f);
+    for (int r = 0; r < 4; ++r) xin[rb * 4 + r] = relu1(acc[rb][r]);
 }
 
 // ---------------------------------------------------------------------------

@@ -16,15 +16,21 @@ __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// two accumulator blocks (ReLU) -> one 32-wide k-step operand
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// two accumulator blocks (ReLU) -> one 32-wide k-step operand.  Rounding is
+// monotonic and keeps the sign, so the ReLU runs AFTER the conversion, on the
+// packed halves (v_pk_max_i16 on the bit patterns: one instruction per pair).
 __device__ __forceinline__ half8 chain_relu_h(f32x4 lo, f32x4 hi) {
   half8 v;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    v[r] = (_Float16)fmaxf(lo[r], 0.f);
-    v[4 + r] = (_Float16)fmaxf(hi[r], 0.f);
+    v[r] = (_Float16)lo[r];
+    v[4 + r] = (_Float16)hi[r];
   }
-  return v;
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(
+      half8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
 }
 
 // A fragment f of a packed fp16 weight buffer (16 B per lane)

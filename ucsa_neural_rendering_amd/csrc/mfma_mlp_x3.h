@@ -1,0 +1,92 @@
+// "bf16x3": fp32-grade contraction of the three MLPs on the dense bf16 MFMA
+// pipe (v_mfma_f32_16x16x32_bf16, 16x the rate of the f32-input form).
+//
+// Every fp32 operand is split EXACTLY into three bf16 terms,
+//     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1
+// (round to nearest even, v_cvt_pk_bf16_f32; both differences are exact in
+// fp32 and the last one has at most 8 significant bits), and a product x*w is
+// accumulated in fp32 from the six partial products of order <= 2:
+//     x2*w0 + x1*w1 + x0*w2 + x1*w0 + x0*w1 + x0*w0      (smallest first).
+// Each partial product of two bf16 values is exact in fp32; what is dropped
+// (x1*w2 + x2*w1 + x2*w2) is at most 2^-23 |x*w|, the size of the rounding of
+// the fp32 product itself, and unbiased.  The same scheme is what "fp32 matmul precision =
+// highest" means on bf16 matrix units elsewhere (six bf16 passes).  It is NOT
+// bit-identical to the k-ordered fmaf chain of the f32-input MFMA; both sit
+// at ordinary fp32 round-off from an fp64 evaluation
+// (tests/test_gpu_parity.py::test_bf16x3_*).
+//
+// Fragment layout: as mfma_mlp_f16.h (lane l = 16g+j holds k-slots 8g+e,
+// e = 0..7, of row / column j), one 16-byte fragment per term:
+// packed[(f * 3 + term) * 64 + lane].
+#pragma once
+#include "mfma_mlp_f16.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct X3 {  // 8 values, three bf16 terms each (2 values per dword)
+  u32x4 t[3];
+};
+
+__device__ __forceinline__ f32x4 mfma_b(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+      __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> two bf16 (round to nearest even) in one dword, a in the low half
+__device__ __forceinline__ uint32_t bf16_pair(float a, float b) {
+  return __builtin_bit_cast(uint32_t,
+                            __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float pair_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float pair_hi(uint32_t u) {
+  return __uint_as_float(u & 0xFFFF0000u);
+}
+
+// exact three-term split of two values into dword `d` of each term
+__device__ __forceinline__ void split_pair(float a, float b, X3& x, int d) {
+  const uint32_t p0 = bf16_pair(a, b);
+  const float ra = a - pair_lo(p0), rb = b - pair_hi(p0);
+  const uint32_t p1 = bf16_pair(ra, rb);
+  const float sa = ra - pair_lo(p1), sb = rb - pair_hi(p1);
+  x.t[0][d] = p0;
+  x.t[1][d] = p1;
+  x.t[2][d] = bf16_pair(sa, sb);
+}
+
+// two accumulator blocks (ReLU) -> one 32-wide k-step operand
+__device__ __forceinline__ X3 chain_relu_x3(f32x4 lo, f32x4 hi) {
+  X3 x;
+  split_pair(relu1(lo[0]), relu1(lo[1]), x, 0);
+  split_pair(relu1(lo[2]), relu1(lo[3]), x, 1);
+  split_pair(relu1(hi[0]), relu1(hi[1]), x, 2);
+  split_pair(relu1(hi[2]), relu1(hi[3]), x, 3);
+  return x;
+}
+
+struct W3 {  // one A fragment, three terms
+  u32x4 t[3];
+};
+
+__device__ __forceinline__ W3 frag_x3(const void* packed, int f, uint32_t lane) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(packed) + (f * 3) * 64 + lane;
+  W3 w;
+  w.t[0] = p[0];
+  w.t[1] = p[64];
+  w.t[2] = p[128];
+  return w;
+}
+
+// acc += W * x, six partial products, smallest magnitude first
+__device__ __forceinline__ f32x4 mfma_x3(const W3& w, const X3& x, f32x4 acc) {
+  acc = mfma_b(w.t[2], x.t[0], acc);
+  acc = mfma_b(w.t[1], x.t[1], acc);
+  acc = mfma_b(w.t[0], x.t[2], acc);
+  acc = mfma_b(w.t[1], x.t[0], acc);
+  acc = mfma_b(w.t[0], x.t[1], acc);
+  acc = mfma_b(w.t[0], x.t[0], acc);
+  return acc;
+}

@@ -1,20 +1,18 @@
 // fp16-MFMA inference option: weight packing and the sigma MLP.
 // (call sites: reference nr4seg/nerf/network_tcnn_semantics.py:48-58,133-139;
 // tiny-cuda-nn itself computes these nets in fp16 with fp32 accumulation.)
-#include "mfma_mlp_f16.h"
+#include "mfma_mlp_x3.h"
 
 __device__ __forceinline__ uint32_t chain_col_h(uint32_t s, uint32_t g,
                                                 uint32_t e) {
   return 16u * (2u * s + (e >> 2)) + 4u * g + (e & 3u);
 }
 
-__global__ void k_mlp_pack_f16(int kind, const float* __restrict__ params,
-                               _Float16* __restrict__ packed, uint32_t n_total,
-                               uint32_t nrb) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_total) return;
-  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u;
-  uint32_t f = idx >> 9;
+// the weight at k-slot e of lane l of A fragment f (both 16-bit layouts)
+__device__ __forceinline__ float pack_h_value(int kind,
+                                              const float* __restrict__ params,
+                                              uint32_t f, uint32_t l,
+                                              uint32_t e) {
   const uint32_t g = l >> 4, i = l & 15u;
   float v = 0.f;
   if (kind == UCSA_MLP_SIGMA) {
@@ -46,7 +44,31 @@ __global__ void k_mlp_pack_f16(int kind, const float* __restrict__ params,
       v = params[64 * 16 + (rb * 16 + i) * 64 + chain_col_h(s, g, e)];
     }
   }
-  packed[idx] = (_Float16)v;
+  return v;
+}
+
+__global__ void k_mlp_pack_f16(int kind, const float* __restrict__ params,
+                               _Float16* __restrict__ packed, uint32_t n_total) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total) return;
+  packed[idx] =
+      (_Float16)pack_h_value(kind, params, idx >> 9, (idx >> 3) & 63u, idx & 7u);
+}
+
+// bf16x3 (mfma_mlp_x3.h): the same fragments, each weight as three bf16 terms
+// w = w0 + w1 + w2 (exact), fragment (f, term) at [(f * 3 + term) * 64 + lane]
+__global__ void k_mlp_pack_x3(int kind, const float* __restrict__ params,
+                              uint16_t* __restrict__ packed, uint32_t n_total) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total) return;
+  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u, f = idx >> 9;
+  float r = pack_h_value(kind, params, f, l, e);
+#pragma unroll
+  for (uint32_t term = 0; term < 3; ++term) {
+    const uint32_t bits = bf16_pair(r, 0.f) & 0xFFFFu;
+    packed[((f * 3 + term) * 64 + l) * 8 + e] = (uint16_t)bits;
+    r -= __uint_as_float(bits << 16);
+  }
 }
 
 extern "C" uint32_t ucsa_mlp_pack_f16_halves(int32_t kind, uint32_t n_classes) {
@@ -65,11 +87,29 @@ extern "C" int32_t ucsa_mlp_pack_f16(int32_t kind, const float* params,
   UCSA_CHECK_ARG(packed_half, 2);
   UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
   const uint32_t n_total = ucsa_mlp_pack_f16_halves(kind, n_classes);
-  const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_mlp_pack_f16, dim3(ucsa_div_up(n_total, 256)), dim3(256),
                      0, (hipStream_t)stream, (int)kind, params,
-                     (_Float16*)packed_half, n_total, nrb);
+                     (_Float16*)packed_half, n_total);
+  return ucsa_launch_status();
+}
+
+extern "C" uint32_t ucsa_mlp_pack_x3_bytes(int32_t kind, uint32_t n_classes) {
+  return ucsa_mlp_pack_f16_halves(kind, n_classes) * 2u * 3u;
+}
+
+extern "C" int32_t ucsa_mlp_pack_x3(int32_t kind, const float* params,
+                                    void* packed_x3, uint32_t n_classes,
+                                    void* stream) {
+  UCSA_CHECK_ARG(kind >= 0 && kind <= 2, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed_x3, 2);
+  UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
+  const uint32_t n_total = ucsa_mlp_pack_f16_halves(kind, n_classes);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack_x3, dim3(ucsa_div_up(n_total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (int)kind, params, (uint16_t*)packed_x3,
+                     n_total);
   return ucsa_launch_status();
 }
 
@@ -203,6 +243,71 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_f16(const float* feat,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp_f16, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_half,
+                     (uint64_t)M, h, sigma);
+  return ucsa_launch_status();
+}
+
+// sigma MLP on the bf16 MFMA pipe with three-term operands (mfma_mlp_x3.h):
+// fp32-grade h and sigma, 36 16-cycle MFMAs per 16 samples instead of 48
+// 32-cycle f32-input ones.
+#define SIGX_UNROLL 4
+
+__global__ void __launch_bounds__(256)
+k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
+               uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  W3 w1[4], w2[2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) w1[rb] = frag_x3(packed, rb, lane);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) w2[s] = frag_x3(packed, 4 + s, lane);
+  const uint64_t span = 16 * SIGX_UNROLL;
+  for (uint64_t base = wave * span; base < M; base += nwaves * span) {
+    float2 raw[SIGX_UNROLL][4];
+#pragma unroll
+    for (int sb = 0; sb < SIGX_UNROLL; ++sb) {
+      uint64_t m = base + sb * 16 + j;
+      if (m >= M) m = M - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) raw[sb][q] = feat[(uint64_t)(4 * q + g) * M + m];
+    }
+#pragma unroll
+    for (int sb = 0; sb < SIGX_UNROLL; ++sb) {
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      X3 xin;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split_pair(raw[sb][q].x, raw[sb][q].y, xin, q);
+      f32x4 a1[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_x3(w1[rb], xin, z4);
+      f32x4 out = mfma_x3(w2[0], chain_relu_x3(a1[0], a1[1]), z4);
+      out = mfma_x3(w2[1], chain_relu_x3(a1[2], a1[3]), out);
+      const uint64_t m = base + sb * 16 + j;
+      if (m < M) {
+        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out;
+        if (g == 0) sigma[m] = expf(out[0]);
+      }
+    }
+  }
+}
+
+extern "C" int32_t ucsa_sigma_mlp_fwd_x3(const float* feat,
+                                         const void* packed_sigma_x3, uint32_t M,
+                                         uint32_t n_levels, float* h,
+                                         float* sigma, void* stream) {
+  UCSA_CHECK_ARG(feat, 0);
+  UCSA_CHECK_ARG(packed_sigma_x3, 1);
+  UCSA_CHECK_ARG(n_levels == 16, 3);
+  UCSA_CHECK_ARG(h && sigma, 4);
+  if (M == 0) return 0;
+  const uint32_t need = ucsa_div_up(M, 16 * SIGX_UNROLL * 4);
+  const uint32_t blocks = need < 4096u ? need : 4096u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp_x3, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)feat, packed_sigma_x3,
                      (uint64_t)M, h, sigma);
   return ucsa_launch_status();
 }

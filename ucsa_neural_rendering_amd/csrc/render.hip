@@ -80,14 +80,92 @@ static int fused_encode_mode() {
   return UCSA_FUSED_ENCODE_DEFAULT;
 }
 
-// fp32 shading is MFMA-bound (352 fp32 MFMAs per 32 samples = 1.62 ms per
-// 61 440-ray chunk at 100 % of the pipe): the fused k_composite (2.3-2.4 ms)
-// beats the split pair there (2.5-2.8 ms); the split pair wins once the nets
-// run on f16 MFMA (UCSA_SPLIT_COMPOSITE=0/1 overrides either default).
-static bool split_composite(bool half) {
+// Which composite: the f32-input MFMA is bound by the matrix pipe itself (352
+// MFMAs per 32 samples = 1.62 ms per 61 440-ray chunk at 100 % of the pipe)
+// and the fused k_composite (2.25 ms) beats the split pair there (2.5-2.8 ms);
+// the split pair wins once the nets run on the 16-bit MFMA pipe (f16, bf16x3).
+// UCSA_SPLIT_COMPOSITE=0/1 overrides (bf16x3 exists as the split pair only).
+static bool split_composite(int prec) {
+  if (prec == 2) return true;
   const char* v = getenv("UCSA_SPLIT_COMPOSITE");
   if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
-  return half;
+  return prec == 1;
+}
+
+// prec: 0 = f32-input MFMA nets (packed by ucsa_mlp_pack), 1 = f16 MFMA
+// (ucsa_mlp_pack_f16), 2 = bf16x3 (ucsa_mlp_pack_x3)
+static int32_t render_impl(int prec, const ucsa_grid* grid, const float* table,
+                           const void* packed_sigma, const void* packed_color,
+                           const void* packed_sem, const float* rays_o,
+                           const float* rays_d, const float* norms,
+                           const float* aabb_host, float min_near,
+                           const float* t_rand, const float* u, uint32_t N,
+                           uint32_t T, uint32_t t, uint32_t n_classes,
+                           float density_scale, uint32_t image_width,
+                           float* image, float* depth, float* semantics,
+                           void* ws, void* stream) {
+  UCSA_CHECK_ARG(grid, 0);
+  UCSA_CHECK_ARG(ws, 21);
+  UCSA_CHECK_ARG(t == 0 || u, 11);
+  if (N == 0) return 0;
+  const Ws w = carve(ws, N, T, t, grid->n_levels);
+  UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
+                                   w.nears, w.fars, stream));
+  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
+  // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
+  auto density = [&](const float* z, uint32_t n, bool fused, float* h,
+                     float* sigma) -> int32_t {
+    if (fused && prec == 0)
+      return ucsa_encode_sigma_rays_image(grid, table, (const float*)packed_sigma,
+                                          rays_o, rays_d, z, aabb_host, N, n,
+                                          image_width, h, sigma, stream);
+    if (fused && prec == 1)
+      return ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma, rays_o,
+                                              rays_d, z, aabb_host, N, n,
+                                              image_width, h, sigma, stream);
+    UCSA_TRY(encode(grid, table, rays_o, rays_d, z, aabb_host, N, n, image_width,
+                    w.feat, stream));
+    if (prec == 0)
+      return ucsa_sigma_mlp_fwd(w.feat, (const float*)packed_sigma, N * n,
+                                grid->n_levels, h, sigma, stream);
+    if (prec == 1)
+      return ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma, N * n, grid->n_levels,
+                                    h, sigma, stream);
+    return ucsa_sigma_mlp_fwd_x3(w.feat, packed_sigma, N * n, grid->n_levels, h,
+                                 sigma, stream);
+  };
+  const int fmode =
+      image_width && grid->n_levels == 16 && prec != 2 ? fused_encode_mode() : 0;
+  UCSA_TRY(density(w.z_c, T, fmode != 0, w.h_c, w.sigma_c));
+  if (t > 0) {
+    UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
+                           stream));
+    UCSA_TRY(density(w.z_f, t, fmode == 1, w.h_f, w.sigma_f));
+  }
+  if (split_composite(prec)) {
+    auto fn = prec == 2   ? ucsa_composite_infer_x3
+              : prec == 1 ? ucsa_composite_infer_f16
+                          : (decltype(&ucsa_composite_infer_x3))nullptr;
+    if (prec == 0)
+      return ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                  w.sigma_f, w.h_f, (const float*)packed_color,
+                                  (const float*)packed_sem, N, T, t, n_classes,
+                                  density_scale, image, depth, semantics, w.cmp,
+                                  stream);
+    return fn(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f, w.sigma_f, w.h_f,
+              packed_color, packed_sem, N, T, t, n_classes, density_scale, image,
+              depth, semantics, w.cmp, stream);
+  }
+  if (prec == 1)
+    return ucsa_composite_fwd_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                                  w.sigma_f, w.h_f, packed_color, packed_sem, N,
+                                  T, t, n_classes, density_scale, image, depth,
+                                  semantics, nullptr, nullptr, stream);
+  return ucsa_composite_fwd(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
+                            w.sigma_f, w.h_f, (const float*)packed_color,
+                            (const float*)packed_sem, N, T, t, n_classes,
+                            density_scale, image, depth, semantics, nullptr,
+                            nullptr, stream);
 }
 
 extern "C" int32_t ucsa_render_fwd(
@@ -98,52 +176,10 @@ extern "C" int32_t ucsa_render_fwd(
     uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
     uint32_t image_width, float* image, float* depth, float* semantics,
     void* ws, void* stream) {
-  UCSA_CHECK_ARG(grid, 0);
-  UCSA_CHECK_ARG(ws, 21);
-  UCSA_CHECK_ARG(t == 0 || u, 11);
-  if (N == 0) return 0;
-  const Ws w = carve(ws, N, T, t, grid->n_levels);
-  UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
-                                   w.nears, w.fars, stream));
-  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  const int fmode = image_width && grid->n_levels == 16 ? fused_encode_mode() : 0;
-  if (fmode != 0) {
-    UCSA_TRY(ucsa_encode_sigma_rays_image(grid, table, packed_sigma, rays_o,
-                                          rays_d, w.z_c, aabb_host, N, T,
-                                          image_width, w.h_c, w.sigma_c, stream));
-  } else {
-    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
-                    image_width, w.feat, stream));
-    UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * T, grid->n_levels,
-                                w.h_c, w.sigma_c, stream));
-  }
-  if (t > 0) {
-    UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
-                           stream));
-    if (fmode == 1) {
-      UCSA_TRY(ucsa_encode_sigma_rays_image(grid, table, packed_sigma, rays_o,
-                                            rays_d, w.z_f, aabb_host, N, t,
-                                            image_width, w.h_f, w.sigma_f,
-                                            stream));
-    } else {
-      UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
-                      image_width, w.feat, stream));
-      UCSA_TRY(ucsa_sigma_mlp_fwd(w.feat, packed_sigma, N * t, grid->n_levels,
-                                  w.h_f, w.sigma_f, stream));
-    }
-  }
-  if (split_composite(false)) {
-    UCSA_TRY(ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
-                                  w.sigma_f, w.h_f, packed_color, packed_sem, N,
-                                  T, t, n_classes, density_scale, image, depth,
-                                  semantics, w.cmp, stream));
-  } else {
-    UCSA_TRY(ucsa_composite_fwd(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
-                                w.sigma_f, w.h_f, packed_color, packed_sem, N, T,
-                                t, n_classes, density_scale, image, depth,
-                                semantics, nullptr, nullptr, stream));
-  }
-  return 0;
+  return render_impl(0, grid, table, packed_sigma, packed_color, packed_sem,
+                     rays_o, rays_d, norms, aabb_host, min_near, t_rand, u, N, T,
+                     t, n_classes, density_scale, image_width, image, depth,
+                     semantics, ws, stream);
 }
 
 extern "C" int32_t ucsa_render_fwd_f16(
@@ -154,55 +190,23 @@ extern "C" int32_t ucsa_render_fwd_f16(
     uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
     uint32_t image_width, float* image, float* depth, float* semantics,
     void* ws, void* stream) {
-  UCSA_CHECK_ARG(grid, 0);
-  UCSA_CHECK_ARG(ws, 21);
-  UCSA_CHECK_ARG(t == 0 || u, 11);
-  if (N == 0) return 0;
-  const Ws w = carve(ws, N, T, t, grid->n_levels);
-  UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
-                                   w.nears, w.fars, stream));
-  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  const int fmode = image_width && grid->n_levels == 16 ? fused_encode_mode() : 0;
-  if (fmode != 0) {
-    UCSA_TRY(ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma_half,
-                                              rays_o, rays_d, w.z_c, aabb_host,
-                                              N, T, image_width, w.h_c,
-                                              w.sigma_c, stream));
-  } else {
-    UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_c, aabb_host, N, T,
-                    image_width, w.feat, stream));
-    UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * T,
-                                    grid->n_levels, w.h_c, w.sigma_c, stream));
-  }
-  if (t > 0) {
-    UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
-                           stream));
-    if (fmode == 1) {
-      UCSA_TRY(ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma_half,
-                                                rays_o, rays_d, w.z_f, aabb_host,
-                                                N, t, image_width, w.h_f,
-                                                w.sigma_f, stream));
-    } else {
-      UCSA_TRY(encode(grid, table, rays_o, rays_d, w.z_f, aabb_host, N, t,
-                      image_width, w.feat, stream));
-      UCSA_TRY(ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma_half, N * t,
-                                      grid->n_levels, w.h_f, w.sigma_f, stream));
-    }
-  }
-  if (split_composite(true)) {
-    UCSA_TRY(ucsa_composite_infer_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c,
-                                      w.z_f, w.sigma_f, w.h_f, packed_color_half,
-                                      packed_sem_half, N, T, t, n_classes,
-                                      density_scale, image, depth, semantics,
-                                      w.cmp, stream));
-  } else {
-    UCSA_TRY(ucsa_composite_fwd_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
-                                    w.sigma_f, w.h_f, packed_color_half,
-                                    packed_sem_half, N, T, t, n_classes,
-                                    density_scale, image, depth, semantics,
-                                    nullptr, nullptr, stream));
-  }
-  return 0;
+  return render_impl(1, grid, table, packed_sigma_half, packed_color_half,
+                     packed_sem_half, rays_o, rays_d, norms, aabb_host, min_near,
+                     t_rand, u, N, T, t, n_classes, density_scale, image_width,
+                     image, depth, semantics, ws, stream);
+}
+
+extern "C" int32_t ucsa_render_fwd_x3(
+    const ucsa_grid* grid, const float* table, const void* packed_sigma_x3,
+    const void* packed_color_x3, const void* packed_sem_x3, const float* rays_o,
+    const float* rays_d, const float* norms, const float* aabb_host,
+    float min_near, const float* t_rand, const float* u, uint32_t N, uint32_t T,
+    uint32_t t, uint32_t n_classes, float density_scale, uint32_t image_width,
+    float* image, float* depth, float* semantics, void* ws, void* stream) {
+  return render_impl(2, grid, table, packed_sigma_x3, packed_color_x3,
+                     packed_sem_x3, rays_o, rays_d, norms, aabb_host, min_near,
+                     t_rand, u, N, T, t, n_classes, density_scale, image_width,
+                     image, depth, semantics, ws, stream);
 }
 
 extern "C" int32_t ucsa_version(void) { return UCSA_VERSION; }

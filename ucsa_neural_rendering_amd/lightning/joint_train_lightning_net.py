@@ -61,10 +61,14 @@ class JointTrainLightningNet(nn.Module):
             density_scale=1, num_semantic_classes=self.num_classes,
             seed=exp.get("nerf_seed"))
         self.nerf_model.march_training = self.cuda_ray
-        # `nerf: {precision: fp16}`: inference renders evaluate the three MLPs
-        # like tiny-cuda-nn does (fp16 weights / layer inputs, fp32 accumulate,
-        # 16x16x32 f16 MFMA); training and the default stay fp32
-        self.nerf_model.precision = str(nerf_cfg.get("precision", "fp32"))
+        # `nerf: {precision: ...}`: arithmetic of the three MLPs in the no-grad
+        # renders.  "bf16x3" (default): fp32-grade on the bf16 MFMA pipe (three
+        # bf16 terms per operand, six partial products, fp32 accumulation:
+        # within 1-2 ulp of "fp32", a quarter less time per view); "fp32": the
+        # f32-input MFMA (an exact fmaf chain, the training forward's kernels);
+        # "fp16": like tiny-cuda-nn (fp16 weights / layer inputs, fp32
+        # accumulate).  Training stays fp32 unless train_precision says so.
+        self.nerf_model.precision = str(nerf_cfg.get("precision", "bf16x3"))
         # `nerf: {train_precision: fp16}`: colour / semantics nets of the
         # training pass on f16 MFMA too; the GradScaler's scale (reference :46)
         # already protects the fp16 gradient operands, so no extra one

@@ -231,6 +231,24 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             self._packed[name + "_th"] = (key, packed)
         return self._packed[name + "_th"][1]
 
+    def _pack_x3(self, name: str, net: FullyFusedMLP):
+        p = net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get(name + "_x3")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            packed = ops.mlp_pack_x3(net.kind, p, self.num_semantic_classes,
+                                     out=out)
+            self._packed[name + "_x3"] = (key, packed)
+        return self._packed[name + "_x3"][1]
+
+    def _field_x3(self):
+        """Weights as three bf16 terms each (csrc/mfma_mlp_x3.h)."""
+        return dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
+                    packed_sigma=self._pack_x3("sigma", self.sigma_net),
+                    packed_color=self._pack_x3("color", self.color_net),
+                    packed_sem=self._pack_x3("sem", self.semantics_net))
+
     def _field_f16(self, transposed: bool = False):
         f = dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
                  packed_sigma=self._pack_h("sigma", self.sigma_net),

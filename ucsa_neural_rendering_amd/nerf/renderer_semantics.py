@@ -58,9 +58,15 @@ class SemanticNeRFRenderer(nn.Module):
         # measured on MI355X: no gain (every kernel already fills the chip),
         # so one stream by default
         self.hip_streams = 1
-        # "fp32" (default, the parity path) or "fp16": inference-only option
-        # that evaluates the three MLPs like tiny-cuda-nn does (fp16 weights
-        # and layer inputs, fp32 accumulation); training is always fp32
+        # inference (no-grad render) arithmetic of the three MLPs:
+        #   "fp32"   f32-input MFMA, bit for bit a k-ordered fmaf chain (the
+        #            same kernels arithmetic as the training forward);
+        #   "bf16x3" fp32-grade on the bf16 MFMA pipe: every operand split
+        #            exactly into three bf16 terms, six partial products per
+        #            product, fp32 accumulation (csrc/mfma_mlp_x3.h) -- within
+        #            1-2 ulp of "fp32", ~25 % less time per view;
+        #   "fp16"   what tiny-cuda-nn does (fp16 weights and layer inputs,
+        #            fp32 accumulation).
         self.precision = "fp32"
         # training through run(): "fp32" (default, the parity path) or "fp16":
         # colour / semantics nets forward AND backward on f16 MFMA (fp16
@@ -268,8 +274,10 @@ class SemanticNeRFRenderer(nn.Module):
             }
         aabb = self._aabb_list(self.training)
         nears, fars = ops.near_far_from_aabb(o, d, aabb, min_near)
-        if self.precision not in ("fp32", "fp16"):
-            raise ValueError(f"precision must be fp32 or fp16, got {self.precision}")
+        if self.precision not in ("fp32", "fp16", "bf16x3"):
+            raise ValueError("precision must be fp32, bf16x3 or fp16, got "
+                             f"{self.precision}")
+        # (the marcher has no bf16x3 kernels: that mode shades in fp32 here)
         half = self.precision == "fp16" and schedule == "segments" and fused_shade
         f = self._field_f16() if half else self._field()
         sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
@@ -447,11 +455,15 @@ class SemanticNeRFRenderer(nn.Module):
 
     def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near,
                    image_width=0):
-        if self.precision not in ("fp32", "fp16"):
-            raise ValueError(f"precision must be fp32 or fp16, got {self.precision}")
-        half = self.precision == "fp16"
-        f = self._field_f16() if half else self._field()
-        render = ops.render_fwd_f16 if half else ops.render_fwd
+        if self.precision not in ("fp32", "fp16", "bf16x3"):
+            raise ValueError("precision must be fp32, bf16x3 or fp16, got "
+                             f"{self.precision}")
+        if self.precision == "fp16":
+            f, render = self._field_f16(), ops.render_fwd_f16
+        elif self.precision == "bf16x3":
+            f, render = self._field_x3(), ops.render_fwd_x3
+        else:
+            f, render = self._field(), ops.render_fwd
         N = o.shape[0]
         C = self.num_semantic_classes
         dev = o.device

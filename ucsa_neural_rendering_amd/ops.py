@@ -235,10 +235,12 @@ def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
 
 def composite_infer(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
                     packed_color, packed_sem, n_classes: int,
-                    density_scale: float = 1.0, half: bool = False):
+                    density_scale: float = 1.0, half: bool = False,
+                    x3: bool = False):
     """Inference composite as the dense kernel pair (ucsa_composite_infer):
     same outputs as composite_fwd, bit for bit.  half=True: packed weights
-    from mlp_pack_f16."""
+    from mlp_pack_f16.  x3=True: bf16x3 nets (fp32-grade, weights from
+    mlp_pack_x3; not bit-identical to the f32-input MFMA)."""
     rays_d = _f32(rays_d, "rays_d").view(-1, 3)
     norms = _f32(norms, "norms").view(-1)
     N, T = z_c.shape
@@ -250,7 +252,8 @@ def composite_infer(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     ws = _scratch_named("composite_infer",
                         int(lib().ucsa_composite_infer_workspace_bytes(N, T, t)),
                         dev)
-    fn = lib().ucsa_composite_infer_f16 if half else lib().ucsa_composite_infer
+    fn = (lib().ucsa_composite_infer_x3 if x3 else
+          lib().ucsa_composite_infer_f16 if half else lib().ucsa_composite_infer)
     check(fn(_ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
              _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(packed_color),
              _ptr(packed_sem), N, T, t, n_classes, float(density_scale),
@@ -327,6 +330,19 @@ def mlp_pack_f16(kind: int, params: torch.Tensor, n_classes: int = 0,
     return out
 
 
+def mlp_pack_x3(kind: int, params: torch.Tensor, n_classes: int = 0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weights as three bf16 terms per value in MFMA fragment order
+    (csrc/mfma_mlp_x3.h)."""
+    params = _f32(params.detach(), "params")
+    n = int(lib().ucsa_mlp_pack_x3_bytes(kind, n_classes))
+    if out is None:
+        out = torch.empty(n // 2, dtype=torch.bfloat16, device=params.device)
+    check(lib().ucsa_mlp_pack_x3(kind, _ptr(params), _ptr(out), n_classes,
+                                 _stream()), "ucsa_mlp_pack_x3")
+    return out
+
+
 def sigma_mlp_fwd_f16(feat, packed_sigma_half):
     L, M, _ = feat.shape
     h = torch.empty(M, 16, device=feat.device)
@@ -349,6 +365,31 @@ def render_fwd_f16(grid: Grid, table, packed_sigma_h, packed_color_h,
         float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
         float(density_scale), int(image_width), _ptr(image), _ptr(depth),
         _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_f16")
+
+
+def sigma_mlp_fwd_x3(feat, packed_sigma_x3):
+    L, M, _ = feat.shape
+    h = torch.empty(M, 16, device=feat.device)
+    sigma = torch.empty(M, device=feat.device)
+    check(lib().ucsa_sigma_mlp_fwd_x3(_ptr(feat), _ptr(packed_sigma_x3), M, L,
+                                      _ptr(h), _ptr(sigma), _stream()),
+          "ucsa_sigma_mlp_fwd_x3")
+    return h, sigma
+
+
+def render_fwd_x3(grid: Grid, table, packed_sigma_x3, packed_color_x3,
+                  packed_sem_x3, rays_o, rays_d, norms, aabb, min_near: float,
+                  t_rand, u, T: int, t: int, n_classes: int,
+                  density_scale: float, image, depth, semantics,
+                  ws: torch.Tensor, image_width: int = 0):
+    """run() with the three nets as bf16x3 (fp32-grade on the bf16 MFMA pipe)."""
+    N = rays_o.shape[0]
+    check(lib().ucsa_render_fwd_x3(
+        C.byref(grid), _ptr(table), _ptr(packed_sigma_x3), _ptr(packed_color_x3),
+        _ptr(packed_sem_x3), _ptr(rays_o), _ptr(rays_d), _ptr(norms), fvec(aabb),
+        float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
+        float(density_scale), int(image_width), _ptr(image), _ptr(depth),
+        _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_x3")
 
 
 # ============================ training (backward) ===========================
