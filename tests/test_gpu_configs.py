@@ -148,12 +148,16 @@ def test_cfg2_bench_path_640x480_staged_image_ordered(which):
     net.precision = "fp32"
     _check(res3, ref, sel, tag=f"cfg2[{which}, bf16x3]")
     for k in ("image", "semantics"):
-        # (a weight within an ulp of the 1e-4 mask threshold may flip between
-        # the two modes and move a pixel by up to 1e-4 x |value|: statistics)
+        # The nets of the two modes agree to ~1e-7 (test_bf16x3_nets_are_fp32_
+        # grade); a whole view also passes the two step functions of the path
+        # (mask w > 1e-4, sample_pdf's denom < 1e-5, see _check): a 1e-6
+        # relative difference in sigma moves a fine sample across an empty bin
+        # on a fraction of a percent of the rays.  Hence statistics.
         e = (res3[k][0] - res[k][0]).abs().max(-1)[0]
-        print(f"cfg2[{which}] bf16x3 vs f32 MFMA, {k}: p99.9 "
-              f"{float(e.quantile(0.999)):.2e} max {float(e.max()):.2e}")
-        assert float(e.quantile(0.999)) <= 2e-5 and float(e.max()) <= 3e-4, k
+        print(f"cfg2[{which}] bf16x3 vs f32 MFMA, {k}: median {float(e.median()):.2e} "
+              f"p99 {float(e.quantile(0.99)):.2e} p99.9 {float(e.quantile(0.999)):.2e} "
+              f"max {float(e.max()):.2e}")
+        assert float(e.median()) <= 2e-6 and float(e.max()) <= 3e-4, k
     # the fp16-MFMA option on the same path, against the oracle emulating
     # tcnn's roundings (fp16 weights / layer inputs, fp32 accumulate)
     import copy

@@ -60,7 +60,8 @@ def main(d, tag):
     }
     for key, prefix in (("k_composite", "void k_composite<3, 2, false, false>"),
                         ("k_hashgrid_encode_tiled", "k_hashgrid_encode_tiled"),
-                        ("k_shade_dense_f16", "void k_shade_dense<3, 1, true, 16>")):
+                        ("k_shade_dense_f16", "void k_shade_dense<3, 1, 1, 16>"),
+                        ("k_shade_dense_x3", "void k_shade_dense<3, 1, 2, 16>")):
         f, w, s = pick(fetch, prefix), pick(wr, prefix), pick(sq, prefix)
         if not (f and w):
             continue
@@ -77,6 +78,11 @@ def main(d, tag):
             # the busy cycles of all 1024 SIMDs: busy / (cycles * 1024)
             e["mfma_busy_frac"] = (s[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) /
                                    (s[1]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
+        if s and s[1].get("GRBM_GUI_ACTIVE") and s[1].get("SQ_ACTIVE_INST_VALU"):
+            # quad-cycles in which a SIMD issues a VALU-class instruction (MFMA
+            # issue slots included) / SIMD cycles
+            e["valu_issue_frac"] = (s[1]["SQ_ACTIVE_INST_VALU"] * 4.0 /
+                                    (s[1]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
         q = pick(l2, prefix)
         if q:
             # requests arriving at the L2 (all XCDs); one request = one 128-B

@@ -16,7 +16,7 @@ BY_GRID=1 python3 tools/rocpd_summary.py $(find /tmp/p0 -name "*.db" | head -1) 
 # and traffic, depends on the field
 SMALL="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-bench"
 i=1
-for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE" "TCC_REQ_sum TCC_READ_sum"; do
+for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "TCC_REQ_sum TCC_READ_sum"; do
   rm -rf /tmp/p$i
   timeout 900 rocprofv3 --kernel-trace --pmc $PMC -d /tmp/p$i -o p -- python3 $SMALL > $OUT/${TAG}_pmc$i.log 2>&1
   python3 tools/rocpd_summary.py $(find /tmp/p$i -name "*.db" | head -1) > $OUT/${TAG}_pmc$i.txt

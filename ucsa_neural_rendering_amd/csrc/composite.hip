@@ -387,9 +387,9 @@ k_composite(CmpArgs a) {
       for (int rb = 0; rb < NRB_SEM; ++rb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fmaxf(mx, lg[cb][rb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fast_max(mx, lg[cb][rb][r]);
+      mx = fast_max(mx, __shfl_xor(mx, 16, 64));
+      mx = fast_max(mx, __shfl_xor(mx, 32, 64));
       float sum = 0.0f;
 #pragma unroll
       for (int rb = 0; rb < NRB_SEM; ++rb)

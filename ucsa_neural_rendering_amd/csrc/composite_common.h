@@ -20,6 +20,11 @@ __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 // ... and the hardware reciprocal (v_rcp_f32, 1 ulp) for the sigmoid and the
 // softmax normalisation: an IEEE division is an 11-instruction sequence, four
 // of them per sample were ~9 % of the shading kernel's VALU work.
+// max of two finite-or-infinite floats as ONE instruction (v_med3_f32 with +inf
+// as the third operand); fmaxf costs two (it first quiets a signalling NaN)
+__device__ __forceinline__ float fast_max(float a, float b) {
+  return __builtin_amdgcn_fmed3f(a, b, __builtin_inff());
+}
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) {
   return fast_rcp(1.0f + fast_exp(-x));

@@ -554,9 +554,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
       for (int rb = 0; rb < NRB_SEM; ++rb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fmaxf(mx, lg[cb][rb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fast_max(mx, lg[cb][rb][r]);
+      mx = fast_max(mx, __shfl_xor(mx, 16, 64));
+      mx = fast_max(mx, __shfl_xor(mx, 32, 64));
       float sum = 0.0f;
 #pragma unroll
       for (int rb = 0; rb < NRB_SEM; ++rb)
@@ -624,18 +624,20 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
   // three-stage software pipeline: entries two groups ahead, operands one
   // group ahead, so neither level of the dependent loads (list -> h row)
   // stalls the in-order instruction stream of the wave
+  // (two groups per trip, the two register sets alternating: no copies)
   Ent<CBS> e1, e2;
   Pre<CBS> p0, p1;
   load_entries(0u, e1);
   load_operands(e1, p0);
   load_entries(G, e1);
-  for (uint32_t gb = 0; gb < total; gb += G) {
+  for (uint32_t gb = 0; gb < total; gb += 2 * G) {
     load_entries(gb + 2 * G, e2);
     load_operands(e1, p1);
-    const uint32_t n = (total - gb < G) ? total - gb : G;
-    shade(p0, n);
-    p0 = p1;
-    e1 = e2;
+    shade(p0, (total - gb < G) ? total - gb : G);
+    if (gb + G >= total) break;
+    load_entries(gb + 3 * G, e1);
+    load_operands(e2, p0);
+    shade(p1, (total - gb - G < G) ? total - gb - G : G);
   }
   if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
 }
@@ -712,9 +714,11 @@ static int32_t composite_infer(int prec, const float* rays_d,
   //           (spills), 4 = (16, 2): 3.7 (spills)
   // fp32: 0 = (16, 1): 2.49, 1 = (12, 2): 2.85, 2 = (8, 2): 2.63 -- all behind
   //       the fused k_composite (2.33), which ucsa_render_fwd keeps for fp32
-  // bf16x3: 0 = (16, 1), 1 = (8, 2), 2 = (12, 2), 3 = (12, 1), 4 = (8, 4)
+  // bf16x3: 0 = (8, 2): 1.57 ms  <- default (a weight fragment, three terms,
+  //           read once for both column blocks), 1 = (16, 1): 1.60,
+  //           2 = (12, 2): 1.80, 3 = (12, 1): 1.74, 4 = (8, 4): 1.90
   const uint32_t waves =
-      prec == 2 ? (variant == 0 ? 16u : ((variant == 2 || variant == 3) ? 12u : 8u))
+      prec == 2 ? (variant == 1 ? 16u : ((variant == 2 || variant == 3) ? 12u : 8u))
       : half    ? ((variant == 0 || variant == 4) ? 16u : (variant == 3 ? 12u : 8u))
                 : (variant == 0 ? 16u : (variant == 1 ? 12u : 8u));
   // both kernels use the same ranges of whole rays per wave: enough waves to
@@ -755,8 +759,8 @@ static int32_t composite_infer(int prec, const float* rays_d,
 #define SH_GO(NRB)                                                             \
   do {                                                                         \
     if (prec == 2) {                                                           \
-      if (variant == 0) return launch_shade<NRB, 1, 2, 16>(b, blocks, smem, s); \
-      if (variant == 1) return launch_shade<NRB, 2, 2, 8>(b, blocks, smem, s);  \
+      if (variant == 0) return launch_shade<NRB, 2, 2, 8>(b, blocks, smem, s);  \
+      if (variant == 1) return launch_shade<NRB, 1, 2, 16>(b, blocks, smem, s); \
       if (variant == 2) return launch_shade<NRB, 2, 2, 12>(b, blocks, smem, s); \
       if (variant == 3) return launch_shade<NRB, 1, 2, 12>(b, blocks, smem, s); \
       return launch_shade<NRB, 4, 2, 8>(b, blocks, smem, s);                   \
