@@ -78,6 +78,11 @@ def parse():
                          "bf16x3 (default; fp32-grade on the bf16 MFMA pipe, "
                          "csrc/mfma_mlp_x3.h), fp32 (f32-input MFMA, an exact "
                          "fmaf chain), fp16 (tiny-cuda-nn's own numerics)")
+    ap.add_argument("--seg-find", action="store_true",
+                    help="DeepLab legs with torch.backends.cudnn.benchmark (MIOpen's "
+                         "exhaustive solver search, what scripts/train_joint.py "
+                         "uses): several minutes of search on a fresh box, "
+                         "49 -> 44 ms per R-101 fp32 step")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="train legs: all-reduce + full Adam on every rank "
                          "instead of the sharded optimizer")
@@ -90,6 +95,16 @@ def parse():
     ap.add_argument("--gather", action="store_true",
                     help="cfg4: gather the images on rank 0 inside the timed region")
     return ap.parse_args()
+
+
+_T0 = time.perf_counter()
+
+
+def _tick(what):
+    """Wall-clock log of the sections of a run (stderr; the JSON line stays
+    alone on stdout)."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f} s] {what}", file=sys.stderr,
+          flush=True)
 
 
 def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
@@ -326,7 +341,7 @@ def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
     return res
 
 
-def seg_throughput(device, steps=5, B=8):
+def seg_throughput(device, steps=5, B=8, find=False):
     """cfg3's segmentation half: DeepLabV3-ResNet-101 forward + backward +
     Adam on [8,3,240,320] uniform-random images / labels, with the
     reference's CE-on-softmax loss through ucsa_seg_tail.  fp32 like the
@@ -335,7 +350,11 @@ def seg_throughput(device, steps=5, B=8):
     from ucsa_neural_rendering_amd import losses as ul
     from ucsa_neural_rendering_amd.network import DeepLabV3
     out = {}
-    torch.backends.cudnn.benchmark = True   # MIOpen exhaustive find (as train_joint sets it)
+    # MIOpen exhaustive find, as scripts/train_joint.py sets it: minutes of
+    # search on a fresh box, so the default bench run measures immediate mode
+    before = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = bool(find)
+    out["miopen_find"] = bool(find)
     for mode in ("fp32", "bf16_channels_last"):
         torch.manual_seed(0)
         m = DeepLabV3({"pretrained": False, "pretrained_backbone": False,
@@ -369,6 +388,7 @@ def seg_throughput(device, steps=5, B=8):
         torch.cuda.empty_cache()
     out["workload"] = ("DeepLabV3-ResNet-101 train step, batch 8 x 3x240x320, "
                        "CE-on-softmax loss, Adam")
+    torch.backends.cudnn.benchmark = before
     return out
 
 
@@ -410,7 +430,7 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
     aabb = torch.tensor([-4.0, -4, -4, 4, 4, 4])
     best = None
     with torch.no_grad():
-        for it in range(2):
+        for it in range(1):   # one pass is ~25 s of CPU work already
             t0 = time.perf_counter()
             ref = oren.run(fld, o, d, nrm, aabb, num_steps=T_COARSE,
                            upsample_steps=T_FINE, u=u)
@@ -699,7 +719,9 @@ def main():
     if args.mode == "cfg3":
         return main_cfg3(args, dev, dist, world, rank, backend)
     prelog = {}
+    _tick("imports, device")
     net, scene_ds = build_field(dev, train_steps=args.pretrain_steps, log=prelog)
+    _tick("field pre-trained")
     if dist:
         # the pre-training is not bit-reproducible (float atomics in the grid
         # backward): all ranks render / train rank 0's field
@@ -951,6 +973,7 @@ def main():
         extras = world == 1
         # occupancy-grid marching on the same parameters:
         # never the headline `value` (cfg2 is defined at 192 samples/ray)
+        _tick("render modes measured")
         if extras:
             try:
                 result["march_option"] = march_option(net, scene_ds, rays,
@@ -959,6 +982,7 @@ def main():
                 import traceback
                 traceback.print_exc(file=sys.stderr)
                 result["march_option"] = {"error": repr(e), "failed": True}
+        _tick("marcher option done")
         if extras and not args.no_train_bench:
             result["train"] = train_throughput(net, scene_ds, dev)
             tf = train_throughput(net, scene_ds, dev, train_precision="fp16")
@@ -966,7 +990,9 @@ def main():
                                "MFMA (`nerf: {train_precision: fp16}`), sigma net and "
                                "grid fp32")
             result["train_f16_nets"] = tf
-            result["seg"] = seg_throughput(dev)
+            _tick("training legs done")
+            result["seg"] = seg_throughput(dev, find=args.seg_find)
+            _tick("DeepLab leg done")
         if extras and not args.no_cpu_baseline:
             threads = effective_cores()
             v, dt, parity, ref, got, (co, cd) = cpu_baseline(
@@ -984,9 +1010,10 @@ def main():
                 "cores": threads,
                 "kind": "port",
                 "sample": f"{args.cpu_rays} random rays of view 0, same "
-                          f"T={T_COARSE}/t={T_FINE}, best of 2 ({dt:.1f} s each)",
+                          f"T={T_COARSE}/t={T_FINE}, one pass ({dt:.1f} s)",
             }
             result["speedup_vs_cpu"] = value / v
+            _tick("CPU baseline done")
     if world > 1:
         # the data-parallel training step with its gradient collectives: all
         # ranks take part; rank 0 reports it next to the render line
@@ -1122,6 +1149,7 @@ def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
     intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
     mine = udist.shard_round_robin(args.views, rank, world)
     poses = _slerp_loop_poses(args.views, seed=999)[mine].to(dev)
+    net.precision = args.nerf_precision
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     u = torch.rand(H * W, T_FINE, device=dev, generator=g)
 
@@ -1169,6 +1197,7 @@ def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
                                "get_rays + render per view",
                    "mode": "cfg4", "views_per_rank": len(mine),
                    "gather_to_rank0": bool(args.gather), "pretrain": prelog,
+                   "mlp_arithmetic": MLP_ARITHMETIC[args.nerf_precision],
                    "total_s": elapsed},
     }
     _finish(dist, rank, result)
