@@ -60,4 +60,11 @@ for v in ("0", "1", "2", "3", "4"):
     print("x3 variant %s: %.3f ms; max |x3 - fp32| image %.3e depth %.3e sem %.3e ; f16: image %.3e sem %.3e" % (
         v, ms, (out[0] - ref[0]).abs().max(), (out[1] - ref[1]).abs().max(), (out[2] - ref[2]).abs().max(),
         (h16[0] - ref[0]).abs().max(), (h16[2] - ref[2]).abs().max()), flush=True)
+for v in ("0", "1", "2", "3"):
+    os.environ["UCSA_SHADE_VARIANT"] = v
+    fn = lambda: ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, fh["packed_color"], fh["packed_sem"], 40, half=True)
+    out = fn()
+    torch.cuda.synchronize()
+    print("f16 variant %s: %.3f ms; identical to variant 0: %s" % (
+        v, timed(fn), torch.equal(out[0], h16[0]) and torch.equal(out[2], h16[2])), flush=True)
 os.environ.pop("UCSA_SHADE_VARIANT")

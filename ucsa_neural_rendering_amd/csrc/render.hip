@@ -143,18 +143,16 @@ static int32_t render_impl(int prec, const ucsa_grid* grid, const float* table,
     UCSA_TRY(density(w.z_f, t, fmode == 1, w.h_f, w.sigma_f));
   }
   if (split_composite(prec)) {
-    auto fn = prec == 2   ? ucsa_composite_infer_x3
-              : prec == 1 ? ucsa_composite_infer_f16
-                          : (decltype(&ucsa_composite_infer_x3))nullptr;
     if (prec == 0)
       return ucsa_composite_infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
                                   w.sigma_f, w.h_f, (const float*)packed_color,
                                   (const float*)packed_sem, N, T, t, n_classes,
                                   density_scale, image, depth, semantics, w.cmp,
                                   stream);
-    return fn(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f, w.sigma_f, w.h_f,
-              packed_color, packed_sem, N, T, t, n_classes, density_scale, image,
-              depth, semantics, w.cmp, stream);
+    const auto infer = prec == 2 ? ucsa_composite_infer_x3 : ucsa_composite_infer_f16;
+    return infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f, w.sigma_f, w.h_f,
+                 packed_color, packed_sem, N, T, t, n_classes, density_scale,
+                 image, depth, semantics, w.cmp, stream);
   }
   if (prec == 1)
     return ucsa_composite_fwd_f16(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f,
