@@ -13,8 +13,7 @@
 //  k_weights_bwd : per ray, d_sigma from G by a forward transmittance scan and
 //                  a reverse suffix scan, times the trunc_exp backward
 //                  (reference nr4seg/nerf/activation.py:17-21), into d_h[:,0].
-#include "mfma_mlp_f16.h"
-#include "wave_ops.h"
+#include "composite_common.h"
 
 #define CB_WAVES 4
 // Waves per workgroup of the f16 variant.  Measured: 8 waves (2 per SIMD, a
@@ -305,9 +304,9 @@ k_shade_bwd(ShadeBwdArgs a) {
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fmaxf(mx, lg[rb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fast_max(mx, lg[rb][r]);
+    mx = fast_max(mx, __shfl_xor(mx, 16, 64));
+    mx = fast_max(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.0f;
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
@@ -320,6 +319,7 @@ k_shade_bwd(ShadeBwdArgs a) {
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
+    const float inv_sum = fast_rcp(sum);  // as the forward
 
     // ------------------------- upstream gradients -------------------------
     const float* di = b.di;
@@ -329,7 +329,7 @@ k_shade_bwd(ShadeBwdArgs a) {
       // image = sum_s w*rgb  ->  d_rgb = w*d_image, d_w += d_image . rgb
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float rgb = 1.0f / (1.0f + __expf(-o3[0][c]));
+        const float rgb = fast_sigmoid(o3[0][c]);  // as the forward
         dwsum += di[c] * rgb;
         dy3[c] = gs * (wgt * di[c] * rgb * (1.0f - rgb));
       }
@@ -343,7 +343,7 @@ k_shade_bwd(ShadeBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const uint32_t cls = rb * 16 + 4 * g + r;
-        const float p = lg[rb][r] / sum;
+        const float p = lg[rb][r] * inv_sum;
         const float dp = cls < C ? wgt * b.dsem[rb * 4 + r] : 0.0f;
         lg[rb][r] = p;
         dlg[rb][r] = dp;
