@@ -891,6 +891,8 @@ def main():
                         r["tcc_hit_rate"] = pmc[kn]["tcc_hit_rate"]
                     if key == "roofline_composite" and "mfma_busy_frac" in pmc[kn]:
                         r["mfma_pipe_busy_frac"] = pmc[kn]["mfma_busy_frac"]
+                    if "valu_issue_frac" in pmc[kn]:
+                        r["valu_issue_frac"] = pmc[kn]["valu_issue_frac"]
                 e = result["roofline_encode"]
                 if "l2_request_bytes" in pmc["k_hashgrid_encode_tiled"]:
                     l2b = pmc["k_hashgrid_encode_tiled"]["l2_request_bytes"]
