@@ -15,8 +15,13 @@ template <int TYPE>
 __device__ __forceinline__ void mf(f32x4& acc, const f32x4& a, const f32x4& b) {
   if constexpr (TYPE == 0)
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a[0]), "v"(b[0]));
-  else
+  else if constexpr (TYPE == 1)
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a2 = {a[0], a[1]}, b2 = {b[0], b[1]};
+    asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a2), "v"(b2));
+  }
 }
 __device__ __forceinline__ void va(float& x, float y, float z) {
   asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(y), "v"(z));
@@ -95,5 +100,6 @@ int main() {
   all<1, 3>("bf16 16x16x32", out);
   all<1, 6>("bf16 16x16x32", out);
   all<0, 3>("f32 16x16x4", out);
+  all<2, 3>("bf16 16x16x16 (K = 16)", out);
   return 0;
 }
