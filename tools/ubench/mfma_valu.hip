@@ -17,6 +17,10 @@ __device__ __forceinline__ void mf(f32x4& acc, const f32x4& a, const f32x4& b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a[0]), "v"(b[0]));
   else if constexpr (TYPE == 1)
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else if constexpr (TYPE == 3)  // K = 32, accumulator in AGPRs
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else if constexpr (TYPE == 4)  // K = 32, accumulator and A operand in AGPRs
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "v"(b));
   else {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 a2 = {a[0], a[1]}, b2 = {b[0], b[1]};
@@ -101,5 +105,7 @@ int main() {
   all<1, 6>("bf16 16x16x32", out);
   all<0, 3>("f32 16x16x4", out);
   all<2, 3>("bf16 16x16x16 (K = 16)", out);
+  all<3, 3>("bf16 16x16x32, accumulators in AGPRs", out);
+  all<4, 3>("bf16 16x16x32, accumulators and A in AGPRs", out);
   return 0;
 }
