@@ -566,3 +566,42 @@ def test_bf16x3_sigma_mlp_is_fp32_grade(ops):
     assert ex3 <= max(2.0 * e32, 3e-7)
     rel = ((sx3 - s32).abs() / s32.abs().clamp_min(1e-30)).max()
     assert float(rel) <= 5e-6                              # sigma = exp(h0)
+
+
+@pytest.mark.parametrize("C", [3, 21, 40, 61])
+def test_composite_modes_agree_for_every_class_count(ops, C):
+    """fused f32-MFMA kernel, split pair (bit-identical to it) and the bf16x3
+    split pair (fp32-grade) for 1 .. 4 row blocks of classes, ragged groups,
+    rays without survivors and rays missing the box."""
+    g = torch.Generator().manual_seed(100 + C)
+    N, T, t = 77, 24, 40
+    dev = torch.device("cuda:0")
+    spec = ofield.MLPSpec(15, C, 64, 1)
+    sem_params = ofield.mlp_init(spec, g).to(dev)
+    color_params = ofield.mlp_init(ofield.MLPSpec(31, 3, 64, 2), g).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(dev)
+    nrm = (1 + torch.rand(N, generator=g)).to(dev)
+    zc = torch.sort(torch.rand(N, T, generator=g) * 5 + 0.2, dim=-1)[0].to(dev)
+    zf = torch.sort(torch.rand(N, t, generator=g) * 5 + 0.2, dim=-1)[0].to(dev)
+    sc = (torch.rand(N, T, generator=g) * 3).to(dev)
+    sf = (torch.rand(N, t, generator=g) * 3).to(dev)
+    sc[::9] = 0.0
+    sf[::9] = 0.0           # empty rays: only the closing sample carries weight
+    sc[4::11] = float("nan")
+    sf[4::11] = float("nan")  # NaN weights: no survivor at all
+    hc = torch.randn(N * T, 16, generator=g).to(dev)
+    hf = torch.randn(N * t, 16, generator=g).to(dev)
+    pc, ps = ops.mlp_pack(1, color_params), ops.mlp_pack(2, sem_params, C)
+    fused = ops.composite_fwd(d, nrm, zc, sc, hc, zf, sf, hf, pc, ps, C)
+    split = ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, pc, ps, C)
+    x3 = ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, ops.mlp_pack_x3(1, color_params),
+                             ops.mlp_pack_x3(2, sem_params, C), C, x3=True)
+    torch.cuda.synchronize()
+    nn = lambda a: torch.nan_to_num(a, nan=-7.0)
+    for a, b, c, name in zip(fused, split, x3, ("image", "depth", "semantics")):
+        assert a.shape[-1] == (3 if name == "image" else C) or name == "depth"
+        assert torch.equal(nn(a), nn(b)), name
+        assert maxabs(nn(c), nn(a)) <= 2e-6, name
+    assert float(fused[2][4::11].abs().sum()) == 0.0 and float(x3[2][4::11].abs().sum()) == 0.0
+    ok = torch.isfinite(fused[2]).all(-1)
+    assert torch.allclose(fused[2][ok].sum(-1), x3[2][ok].sum(-1), atol=1e-5)
