@@ -214,10 +214,11 @@ def test_render_matches_reference_fixture(net, tag, precision):
     assert float(rel.max()) <= 2e-4
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("N,T,t,perturb", [(1, 16, 16, False), (37, 16, 16, True),
                                            (130, 32, 0, False), (64, 96, 96, True),
                                            (50, 256, 256, False)])
-def test_render_matches_oracle_edge_shapes(net, fld, N, T, t, perturb):
+def test_render_matches_oracle_edge_shapes(net, fld, N, T, t, perturb, precision):
     o, d, norms = make_rays(N, 100 + N)
     g = torch.Generator().manual_seed(N)
     t_rand = torch.rand(N, T, generator=g) if perturb else None
@@ -225,10 +226,14 @@ def test_render_matches_oracle_edge_shapes(net, fld, N, T, t, perturb):
     with torch.no_grad():
         ref = oren.run(fld, o[None], d[None], norms[None], AABB4, num_steps=T,
                        upsample_steps=t, t_rand=t_rand, u=u if t else None)
-        res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
-                         perturb=perturb, num_steps=T, upsample_steps=t,
-                         rng_t=None if t_rand is None else t_rand.cuda(),
-                         rng_u=u.cuda() if t else None)
+        net.precision = precision
+        try:
+            res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                             perturb=perturb, num_steps=T, upsample_steps=t,
+                             rng_t=None if t_rand is None else t_rand.cuda(),
+                             rng_u=u.cuda() if t else None)
+        finally:
+            net.precision = "fp32"
     assert res["image"].shape == (1, N, 3) and res["depth"].shape == (1, N)
     assert res["semantics"].shape == (1, N, 40)
     assert maxabs(res["image"], ref["image"]) <= 1e-4
