@@ -83,6 +83,9 @@ def parse():
                          "exhaustive solver search, what scripts/train_joint.py "
                          "uses): several minutes of search on a fresh box, "
                          "49 -> 44 ms per R-101 fp32 step")
+    ap.add_argument("--no-seg-find", action="store_true",
+                    help="cfg3: immediate-mode MIOpen solvers instead of the "
+                         "module's default exhaustive search (profiling runs)")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="train legs: all-reduce + full Adam on every rank "
                          "instead of the sharded optimizer")
@@ -964,6 +967,32 @@ def main():
                     step_flop / (dta * 1e3) / 1e9 / F16_MFMA_PEAK_TF,
                 "mlp_arithmetic": MLP_ARITHMETIC[alt],
                 "select": "`nerf: {precision: %s}` / --nerf-precision %s" % (alt, alt)}
+        # fp16 nets AND the hash grid read from an fp16 copy of the table: what
+        # tiny-cuda-nn stores and computes with (`nerf: {precision: fp16,
+        # fp16_table: true}`)
+        net.precision, net.fp16_table = "fp16", True
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_alt):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - t1) / n_alt
+        diff_h = (step(args.warmup + args.steps - 1)["image"] - ref_img).abs().max()
+        net.fp16_table = False
+        result["value_fp16_nets_fp16_table"] = world * H * W / dth if world == 1 else None
+        result["fp16_table_option"] = {
+            "rays_per_s": H * W / dth, "ms_per_view": dth * 1e3,
+            "max_abs_image_diff_vs_value_mode": float(diff_h),
+            "note": "fp16 nets + half2 hash table (26 MB instead of 52 MB; fp32 "
+                    "master copy with the optimizer): 4-byte entries let one "
+                    "16-byte access serve an aligned group of four x-neighbours, "
+                    "5 instead of 6 accesses per sample and hashed level; parity: "
+                    "features bit-identical to the fp32 kernels on the rounded "
+                    "table, render vs the oracle with rounded table + fp16 nets "
+                    "(tests/test_gpu_parity.py::test_fp16_table_*)",
+            "select": "`nerf: {precision: fp16, fp16_table: true}`"}
         if "f16_mlp_option" in result:
             result["f16_mlp_option"]["note"] = (
                 "parity of this mode: tests/test_gpu_configs.py against the "
@@ -1090,7 +1119,7 @@ def main_cfg3(args, dev, dist, world, rank, backend):
     }
     tmp = tempfile.mkdtemp()
     torch.manual_seed(123)
-    torch.backends.cudnn.benchmark = True   # as scripts/train_joint.py sets it
+    torch.backends.cudnn.benchmark = not args.no_seg_find   # default: as scripts/train_joint.py sets it
     model = JointTrainLightningNet(exp, {"results": tmp, "scannet": tmp})
     dm = JointTrainDataModule(exp)
     dm.setup()

@@ -270,6 +270,39 @@ int32_t ucsa_point_shade_h(const float* dirs, const float* h,
                            uint32_t n_classes, float* rgb, float* probs,
                            void* stream);
 
+/* ============================ fp16 hash table ============================== */
+/* tiny-cuda-nn stores the hash grid in fp16 (fp32 master copy in the optimizer).
+ * Optional here: `table_half` = the fp32 table rounded to half
+ * (ucsa_cast_f32_to_f16; half2 entries, same level offsets).  Values are
+ * widened on load and interpolated in fp32, so the features equal the fp32
+ * kernels' on the rounded table bit for bit; 4-byte entries let one 16-byte
+ * access serve four x-neighbours (5 instead of 6 accesses per sample and
+ * hashed level).  image_width = 0: ray-ordered samples, else as
+ * ucsa_hashgrid_encode_rays_image.  Call site: reference
+ * network_tcnn_semantics.py:36-46,133-134. */
+int32_t ucsa_cast_f32_to_f16(const float* src, void* dst_half, uint64_t n,
+                             void* stream);
+int32_t ucsa_hashgrid_encode_rays_h16(const ucsa_grid* grid,
+                                      const void* table_half,
+                                      const float* rays_o, const float* rays_d,
+                                      const float* z, const float* aabb_host,
+                                      uint32_t N, uint32_t T,
+                                      uint32_t image_width, float* feat,
+                                      void* stream);
+/* ucsa_render_fwd_f16 reading the fp16 table */
+int32_t ucsa_render_fwd_f16_h16(const ucsa_grid* grid, const void* table_half,
+                                const void* packed_sigma_half,
+                                const void* packed_color_half,
+                                const void* packed_sem_half,
+                                const float* rays_o, const float* rays_d,
+                                const float* norms, const float* aabb_host,
+                                float min_near, const float* t_rand,
+                                const float* u, uint32_t N, uint32_t T,
+                                uint32_t t, uint32_t n_classes,
+                                float density_scale, uint32_t image_width,
+                                float* image, float* depth, float* semantics,
+                                void* workspace, void* stream);
+
 /* ================= bf16x3: fp32-grade nets on the bf16 MFMA pipe ============ */
 /* Every fp32 weight and layer input is split exactly into three bf16 terms and
  * each product is accumulated in fp32 from six bf16 partial products

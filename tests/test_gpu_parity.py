@@ -610,3 +610,57 @@ def test_composite_modes_agree_for_every_class_count(ops, C):
     assert float(fused[2][4::11].abs().sum()) == 0.0 and float(x3[2][4::11].abs().sum()) == 0.0
     ok = torch.isfinite(fused[2]).all(-1)
     assert torch.allclose(fused[2][ok].sum(-1), x3[2][ok].sum(-1), atol=1e-5)
+
+
+# ------------------------------------------------------ fp16 hash table option
+@pytest.mark.parametrize("H,W,T", [(16, 24, 16), (40, 64, 33), (96, 640, 24)])
+def test_fp16_table_features_equal_the_fp32_kernels_on_the_rounded_table(ops, H, W, T):
+    """ucsa_hashgrid_encode_rays_h16 (half2 entries, group-of-four loads) against
+    the fp32-table kernels fed the same values: widening is exact and the
+    interpolation arithmetic is shared, so the features are bit-identical --
+    ray-ordered and image-ordered, dense and hashed levels."""
+    fld = lively_oracle_field()
+    net = hip_network_from_oracle(fld).eval()
+    f = net._field()
+    table_h = ops.table_to_half(f["table"])
+    table_r = table_h.float()
+    assert not torch.equal(table_r, f["table"])          # the rounding is real
+    N = H * W
+    o, d, _ = make_rays(N, 21)
+    o, d = o.cuda(), d.cuda()
+    aabb = net._aabb_list(False)
+    near, far = ops.near_far_from_aabb(o, d, aabb)
+    z = ops.sample_coarse(near, far, T)
+    for width in (0, W):
+        a = ops.hashgrid_encode_rays(f["grid"], table_h, o, d, z, aabb, image_width=width)
+        b = ops.hashgrid_encode_rays(f["grid"], table_r, o, d, z, aabb, image_width=width)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), width
+
+
+def test_fp16_table_render_matches_the_oracle_with_the_rounded_table():
+    """precision='fp16' + fp16_table: tiny-cuda-nn's storage and arithmetic.
+    Oracle: fp16-rounded table values, fp16-emulating nets."""
+    import copy
+    fld = lively_oracle_field()
+    net = hip_network_from_oracle(fld).eval()
+    f16 = copy.copy(fld)
+    f16.emulate_fp16 = True
+    f16.grid_params = fld.grid_params.half().float()
+    N, T, t = 96, 32, 32
+    o, d, norms = make_rays(N, 33)
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand(N, t, generator=g)
+    net.precision, net.fp16_table = "fp16", True
+    try:
+        with torch.no_grad():
+            ref = oren.run(f16, o[None], d[None], norms[None], AABB4, num_steps=T,
+                           upsample_steps=t, u=u)
+            res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                             num_steps=T, upsample_steps=t, rng_u=u.cuda())
+    finally:
+        net.precision, net.fp16_table = "fp32", False
+    assert maxabs(res["image"], ref["image"]) <= 3e-3
+    assert maxabs(res["semantics"], ref["semantics"]) <= 3e-3
+    rel = (res["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-3)
+    assert float(rel.max()) <= 3e-3

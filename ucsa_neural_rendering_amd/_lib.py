@@ -95,6 +95,14 @@ SIGNATURES = {
     "ucsa_point_shade_h": (C.c_int32, [_p, _p, _p, _p, _p, _u32, _u32, _p, _p,
                                        _p]),
     # ---- fp16-MFMA inference option ----
+    "ucsa_cast_f32_to_f16": (C.c_int32, [_p, _p, C.c_uint64, _p]),
+    "ucsa_hashgrid_encode_rays_h16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
+                                                  C.POINTER(_f), _u32, _u32, _u32,
+                                                  _p, _p]),
+    "ucsa_render_fwd_f16_h16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
+                                            _p, _p, C.POINTER(_f), _f, _p, _p,
+                                            _u32, _u32, _u32, _u32, _f, _u32, _p,
+                                            _p, _p, _p, _p]),
     "ucsa_mlp_pack_x3_bytes": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_x3": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_sigma_mlp_fwd_x3": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),

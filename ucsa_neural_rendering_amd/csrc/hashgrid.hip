@@ -45,10 +45,10 @@ __device__ __forceinline__ void sample_x01(const GridDev& g,
 // Coarse levels [0, n_coarse): cells span several samples of a ray, gathers
 // hit L1/L2, and a per-level launch would be all fixed cost (~25 us each,
 // measured) -- so one thread walks all of them.
-template <bool FROM_RAYS>
+template <bool FROM_RAYS, typename TT = float2>
 __global__ void __launch_bounds__(256)
 k_hashgrid_encode_coarse(GridDev g, uint32_t n_coarse,
-                         const float2* __restrict__ table,
+                         const TT* __restrict__ table,
                          const float* __restrict__ rays_o,
                          const float* __restrict__ rays_d,
                          const float* __restrict__ zs, Aabb bb, uint32_t T,
@@ -66,10 +66,10 @@ k_hashgrid_encode_coarse(GridDev g, uint32_t n_coarse,
 }
 
 // Fine levels [level0, n_levels): level-major (see file header).
-template <bool FROM_RAYS>
+template <bool FROM_RAYS, typename TT = float2>
 __global__ void __launch_bounds__(256)
 k_hashgrid_encode(GridDev g, uint32_t level0,
-                  const float2* __restrict__ table,
+                  const TT* __restrict__ table,
                   const float* __restrict__ rays_o,
                   const float* __restrict__ rays_d,
                   const float* __restrict__ zs, Aabb bb, uint32_t T,
@@ -102,9 +102,10 @@ k_hashgrid_encode(GridDev g, uint32_t level0,
 // (64 B of z, 128 B of features per ray).  Arithmetic per sample is unchanged:
 // the features are bit-identical to k_hashgrid_encode's.
 #define TILE_S 16
+template <typename TT = float2>
 __global__ void __launch_bounds__(256)
 k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
-                        const float2* __restrict__ table,
+                        const TT* __restrict__ table,
                         const float* __restrict__ rays_o,
                         const float* __restrict__ rays_d,
                         const float* __restrict__ zs, Aabb bb, uint32_t T,
@@ -140,7 +141,7 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
     const float ox = o[0], oy = o[1], oz = o[2];
     const float dx = d[0], dy = d[1], dz = d[2];
     const float two_b = 2.0f * g.bound;
-    const float2* tab = table + g.offset[level];
+    const TT* tab = table + g.offset[level];
     const float scale = g.scale[level];
     const uint32_t res = g.res[level], entries = g.entries[level],
                    hashed = g.hashed[level];
@@ -178,8 +179,8 @@ static uint32_t coarse_levels(const ucsa_grid* grid) {
   return n;
 }
 
-template <bool FROM_RAYS>
-static int32_t launch_encode(const ucsa_grid* grid, const float* table,
+template <bool FROM_RAYS, typename TT = float2>
+static int32_t launch_encode(const ucsa_grid* grid, const void* table,
                              const float* a, const float* b, const float* z,
                              Aabb bb, uint32_t T, uint64_t M, float* feat,
                              void* stream) {
@@ -188,14 +189,14 @@ static int32_t launch_encode(const ucsa_grid* grid, const float* table,
   const dim3 blk(256);
   UCSA_CLEAR_ERR();
   if (nc > 0)
-    hipLaunchKernelGGL(k_hashgrid_encode_coarse<FROM_RAYS>,
+    hipLaunchKernelGGL((k_hashgrid_encode_coarse<FROM_RAYS, TT>),
                        dim3(ucsa_div_up(M, 256)), blk, 0, (hipStream_t)stream,
-                       gd, nc, (const float2*)table, a, b, z, bb, T, M,
+                       gd, nc, (const TT*)table, a, b, z, bb, T, M,
                        (float2*)feat);
   if (nc < grid->n_levels)
-    hipLaunchKernelGGL(k_hashgrid_encode<FROM_RAYS>,
+    hipLaunchKernelGGL((k_hashgrid_encode<FROM_RAYS, TT>),
                        dim3(ucsa_div_up(M, 256), grid->n_levels - nc), blk, 0,
-                       (hipStream_t)stream, gd, nc, (const float2*)table, a, b,
+                       (hipStream_t)stream, gd, nc, (const TT*)table, a, b,
                        z, bb, T, M, (float2*)feat);
   return ucsa_launch_status();
 }
@@ -217,7 +218,8 @@ extern "C" int32_t ucsa_hashgrid_encode_rays(
 }
 
 // image_width > 0: rays are the pixels of full rows of an image that wide
-static int32_t launch_encode_image(const ucsa_grid* grid, const float* table,
+template <typename TT = float2>
+static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
                                    const float* rays_o, const float* rays_d,
                                    const float* z, Aabb bb, uint32_t N,
                                    uint32_t T, uint32_t image_width,
@@ -230,17 +232,17 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const float* table,
   const uint64_t M = (uint64_t)N * T;
   UCSA_CLEAR_ERR();
   if (nc > 0)
-    hipLaunchKernelGGL(k_hashgrid_encode_coarse<true>, dim3(ucsa_div_up(M, 256)),
+    hipLaunchKernelGGL((k_hashgrid_encode_coarse<true, TT>), dim3(ucsa_div_up(M, 256)),
                        dim3(256), 0, (hipStream_t)stream, gd, nc,
-                       (const float2*)table, rays_o, rays_d, z, bb, T, M,
+                       (const TT*)table, rays_o, rays_d, z, bb, T, M,
                        (float2*)feat);
   if (nc < grid->n_levels) {
     const uint32_t rows = ucsa_div_up(N, image_width);
     const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
     const uint32_t s_blocks = ucsa_div_up(T, TILE_S);
-    hipLaunchKernelGGL(k_hashgrid_encode_tiled,
+    hipLaunchKernelGGL(k_hashgrid_encode_tiled<TT>,
                        dim3(tiles * s_blocks, grid->n_levels - nc), dim3(256), 0,
-                       (hipStream_t)stream, gd, nc, (const float2*)table, rays_o,
+                       (hipStream_t)stream, gd, nc, (const TT*)table, rays_o,
                        rays_d, z, bb, T, N, image_width, s_blocks,
                        (float2*)feat);
   }
@@ -262,6 +264,46 @@ extern "C" int32_t ucsa_hashgrid_encode_rays_image(
   return launch_encode_image(grid, table, rays_o, rays_d, z,
                              ucsa_aabb(aabb_host), N, T, image_width, feat,
                              stream);
+}
+
+// fp16 table (4-byte half2 entries, `table_half` = the fp32 table rounded to
+// half, ucsa_cast_f32_to_f16): features = the fp32 kernels' on the rounded
+// values, bit for bit.  image_width = 0: ray-ordered samples.
+extern "C" int32_t ucsa_hashgrid_encode_rays_h16(
+    const ucsa_grid* grid, const void* table_half, const float* rays_o,
+    const float* rays_d, const float* z, const float* aabb_host, uint32_t N,
+    uint32_t T, uint32_t image_width, float* feat, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(table_half && ((uintptr_t)table_half & 15u) == 0, 1);
+  UCSA_CHECK_ARG(rays_o && rays_d && z, 2);
+  UCSA_CHECK_ARG(aabb_host, 5);
+  UCSA_CHECK_ARG(feat, 9);
+  if ((uint64_t)N * T == 0) return 0;
+  if (image_width)
+    return launch_encode_image<ucsa_half2>(grid, table_half, rays_o, rays_d, z,
+                                           ucsa_aabb(aabb_host), N, T,
+                                           image_width, feat, stream);
+  return launch_encode<true, ucsa_half2>(grid, table_half, rays_o, rays_d, z,
+                                         ucsa_aabb(aabb_host), T,
+                                         (uint64_t)N * T, feat, stream);
+}
+
+__global__ void k_cast_f32_to_f16(const float* __restrict__ src,
+                                  _Float16* __restrict__ dst, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (_Float16)src[i];
+}
+
+extern "C" int32_t ucsa_cast_f32_to_f16(const float* src, void* dst_half,
+                                        uint64_t n, void* stream) {
+  UCSA_CHECK_ARG(src, 0);
+  UCSA_CHECK_ARG(dst_half, 1);
+  if (n == 0) return 0;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_cast_f32_to_f16, dim3((uint32_t)((n + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, src, (_Float16*)dst_half, n);
+  return ucsa_launch_status();
 }
 
 extern "C" int32_t ucsa_hashgrid_encode_points(const ucsa_grid* grid,

@@ -59,10 +59,16 @@ extern "C" uint64_t ucsa_render_workspace_bytes(uint32_t N, uint32_t T,
   } while (0)
 
 // image_width > 0: image-ordered rays -> tile-ordered gather (same features)
-static int32_t encode(const ucsa_grid* grid, const float* table,
-                      const float* rays_o, const float* rays_d, const float* z,
-                      const float* aabb_host, uint32_t N, uint32_t T,
-                      uint32_t image_width, float* feat, void* stream) {
+static int32_t encode(const ucsa_grid* grid, const void* table_any,
+                      bool table_half, const float* rays_o, const float* rays_d,
+                      const float* z, const float* aabb_host, uint32_t N,
+                      uint32_t T, uint32_t image_width, float* feat,
+                      void* stream) {
+  if (table_half)
+    return ucsa_hashgrid_encode_rays_h16(grid, table_any, rays_o, rays_d, z,
+                                         aabb_host, N, T, image_width, feat,
+                                         stream);
+  const float* table = (const float*)table_any;
   if (image_width)
     return ucsa_hashgrid_encode_rays_image(grid, table, rays_o, rays_d, z,
                                            aabb_host, N, T, image_width, feat,
@@ -94,7 +100,8 @@ static bool split_composite(int prec) {
 
 // prec: 0 = f32-input MFMA nets (packed by ucsa_mlp_pack), 1 = f16 MFMA
 // (ucsa_mlp_pack_f16), 2 = bf16x3 (ucsa_mlp_pack_x3)
-static int32_t render_impl(int prec, const ucsa_grid* grid, const float* table,
+static int32_t render_impl(int prec, const ucsa_grid* grid,
+                           const void* table_any, bool table_half,
                            const void* packed_sigma, const void* packed_color,
                            const void* packed_sem, const float* rays_o,
                            const float* rays_d, const float* norms,
@@ -109,6 +116,7 @@ static int32_t render_impl(int prec, const ucsa_grid* grid, const float* table,
   UCSA_CHECK_ARG(t == 0 || u, 11);
   if (N == 0) return 0;
   const Ws w = carve(ws, N, T, t, grid->n_levels);
+  const float* table = table_half ? nullptr : (const float*)table_any;
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
@@ -123,8 +131,8 @@ static int32_t render_impl(int prec, const ucsa_grid* grid, const float* table,
       return ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma, rays_o,
                                               rays_d, z, aabb_host, N, n,
                                               image_width, h, sigma, stream);
-    UCSA_TRY(encode(grid, table, rays_o, rays_d, z, aabb_host, N, n, image_width,
-                    w.feat, stream));
+    UCSA_TRY(encode(grid, table_any, table_half, rays_o, rays_d, z, aabb_host, N,
+                    n, image_width, w.feat, stream));
     if (prec == 0)
       return ucsa_sigma_mlp_fwd(w.feat, (const float*)packed_sigma, N * n,
                                 grid->n_levels, h, sigma, stream);
@@ -134,8 +142,8 @@ static int32_t render_impl(int prec, const ucsa_grid* grid, const float* table,
     return ucsa_sigma_mlp_fwd_x3(w.feat, packed_sigma, N * n, grid->n_levels, h,
                                  sigma, stream);
   };
-  const int fmode =
-      image_width && grid->n_levels == 16 && prec != 2 ? fused_encode_mode() : 0;
+  const int fmode = image_width && grid->n_levels == 16 && prec != 2 && !table_half
+                        ? fused_encode_mode() : 0;
   UCSA_TRY(density(w.z_c, T, fmode != 0, w.h_c, w.sigma_c));
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
@@ -174,7 +182,7 @@ extern "C" int32_t ucsa_render_fwd(
     uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
     uint32_t image_width, float* image, float* depth, float* semantics,
     void* ws, void* stream) {
-  return render_impl(0, grid, table, packed_sigma, packed_color, packed_sem,
+  return render_impl(0, grid, table, false, packed_sigma, packed_color, packed_sem,
                      rays_o, rays_d, norms, aabb_host, min_near, t_rand, u, N, T,
                      t, n_classes, density_scale, image_width, image, depth,
                      semantics, ws, stream);
@@ -188,10 +196,27 @@ extern "C" int32_t ucsa_render_fwd_f16(
     uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
     uint32_t image_width, float* image, float* depth, float* semantics,
     void* ws, void* stream) {
-  return render_impl(1, grid, table, packed_sigma_half, packed_color_half,
+  return render_impl(1, grid, table, false, packed_sigma_half, packed_color_half,
                      packed_sem_half, rays_o, rays_d, norms, aabb_host, min_near,
                      t_rand, u, N, T, t, n_classes, density_scale, image_width,
                      image, depth, semantics, ws, stream);
+}
+
+// fp16 nets AND fp16 table (what tiny-cuda-nn stores and computes with)
+extern "C" int32_t ucsa_render_fwd_f16_h16(
+    const ucsa_grid* grid, const void* table_half, const void* packed_sigma_half,
+    const void* packed_color_half, const void* packed_sem_half,
+    const float* rays_o, const float* rays_d, const float* norms,
+    const float* aabb_host, float min_near, const float* t_rand, const float* u,
+    uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
+    uint32_t image_width, float* image, float* depth, float* semantics,
+    void* ws, void* stream) {
+  UCSA_CHECK_ARG(table_half, 1);
+  return render_impl(1, grid, table_half, true, packed_sigma_half,
+                     packed_color_half, packed_sem_half, rays_o, rays_d, norms,
+                     aabb_host, min_near, t_rand, u, N, T, t, n_classes,
+                     density_scale, image_width, image, depth, semantics, ws,
+                     stream);
 }
 
 extern "C" int32_t ucsa_render_fwd_x3(
@@ -201,7 +226,7 @@ extern "C" int32_t ucsa_render_fwd_x3(
     float min_near, const float* t_rand, const float* u, uint32_t N, uint32_t T,
     uint32_t t, uint32_t n_classes, float density_scale, uint32_t image_width,
     float* image, float* depth, float* semantics, void* ws, void* stream) {
-  return render_impl(2, grid, table, packed_sigma_x3, packed_color_x3,
+  return render_impl(2, grid, table, false, packed_sigma_x3, packed_color_x3,
                      packed_sem_x3, rays_o, rays_d, norms, aabb_host, min_near,
                      t_rand, u, N, T, t, n_classes, density_scale, image_width,
                      image, depth, semantics, ws, stream);

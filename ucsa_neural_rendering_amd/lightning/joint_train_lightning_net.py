@@ -69,6 +69,9 @@ class JointTrainLightningNet(nn.Module):
         # "fp16": like tiny-cuda-nn (fp16 weights / layer inputs, fp32
         # accumulate).  Training stays fp32 unless train_precision says so.
         self.nerf_model.precision = str(nerf_cfg.get("precision", "bf16x3"))
+        # `nerf: {fp16_table: true}` (with precision: fp16): the renders read the
+        # hash grid from an fp16 copy of the table, as tiny-cuda-nn stores it
+        self.nerf_model.fp16_table = bool(nerf_cfg.get("fp16_table", False))
         # `nerf: {train_precision: fp16}`: colour / semantics nets of the
         # training pass on f16 MFMA too; the GradScaler's scale (reference :46)
         # already protects the fp16 gradient operands, so no extra one

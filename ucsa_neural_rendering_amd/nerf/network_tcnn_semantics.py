@@ -242,6 +242,17 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             self._packed[name + "_x3"] = (key, packed)
         return self._packed[name + "_x3"][1]
 
+    def _table_half(self):
+        """fp16 copy of the hash table (what tiny-cuda-nn stores), refreshed
+        when the fp32 parameters change."""
+        p = self.encoder.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get("table_h16")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            self._packed["table_h16"] = (key, ops.table_to_half(p, out=out))
+        return self._packed["table_h16"][1]
+
     def _field_x3(self):
         """Weights as three bf16 terms each (csrc/mfma_mlp_x3.h)."""
         return dict(grid=self.encoder.grid, table=self.encoder.params.detach(),

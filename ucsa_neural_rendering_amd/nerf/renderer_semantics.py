@@ -68,6 +68,11 @@ class SemanticNeRFRenderer(nn.Module):
         #   "fp16"   what tiny-cuda-nn does (fp16 weights and layer inputs,
         #            fp32 accumulation).
         self.precision = "fp32"
+        # with precision="fp16": also read the hash grid from an fp16 copy of
+        # the table, as tiny-cuda-nn stores it (fp32 master with the
+        # optimizer); off by default -- the fp16 mode's parity fixtures are
+        # stated for the fp32 table
+        self.fp16_table = False
         # training through run(): "fp32" (default, the parity path) or "fp16":
         # colour / semantics nets forward AND backward on f16 MFMA (fp16
         # weights / layer inputs / incoming gradients, fp32 accumulation, fp32
@@ -460,6 +465,9 @@ class SemanticNeRFRenderer(nn.Module):
                              f"{self.precision}")
         if self.precision == "fp16":
             f, render = self._field_f16(), ops.render_fwd_f16
+            if self.fp16_table:
+                f = dict(f, table=self._table_half())
+                render = ops.render_fwd_f16_h16
         elif self.precision == "bf16x3":
             f, render = self._field_x3(), ops.render_fwd_x3
         else:

@@ -132,6 +132,12 @@ def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
     z = _f32(z, "z")
     N, T = z.shape
     feat = torch.empty(grid.n_levels, N * T, 2, device=z.device)
+    if table.dtype == torch.float16:   # fp16 table (table_to_half)
+        check(lib().ucsa_hashgrid_encode_rays_h16(
+            C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
+            fvec(aabb), N, T, int(image_width), _ptr(feat), _stream()),
+            "ucsa_hashgrid_encode_rays_h16")
+        return feat
     if image_width:
         check(lib().ucsa_hashgrid_encode_rays_image(
             C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
@@ -365,6 +371,32 @@ def render_fwd_f16(grid: Grid, table, packed_sigma_h, packed_color_h,
         float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
         float(density_scale), int(image_width), _ptr(image), _ptr(depth),
         _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_f16")
+
+
+def table_to_half(table: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """fp32 hash table -> the fp16 copy the *_h16 entry points read."""
+    table = _f32(table.detach(), "table")
+    if out is None:
+        out = torch.empty(table.numel(), dtype=torch.float16, device=table.device)
+    check(lib().ucsa_cast_f32_to_f16(_ptr(table), _ptr(out), table.numel(),
+                                     _stream()), "ucsa_cast_f32_to_f16")
+    return out
+
+
+def render_fwd_f16_h16(grid: Grid, table_half, packed_sigma_h, packed_color_h,
+                       packed_sem_h, rays_o, rays_d, norms, aabb, min_near: float,
+                       t_rand, u, T: int, t: int, n_classes: int,
+                       density_scale: float, image, depth, semantics,
+                       ws: torch.Tensor, image_width: int = 0):
+    """render_fwd_f16 reading the fp16 table (table_to_half)."""
+    N = rays_o.shape[0]
+    assert table_half.dtype == torch.float16
+    check(lib().ucsa_render_fwd_f16_h16(
+        C.byref(grid), _ptr(table_half), _ptr(packed_sigma_h), _ptr(packed_color_h),
+        _ptr(packed_sem_h), _ptr(rays_o), _ptr(rays_d), _ptr(norms), fvec(aabb),
+        float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
+        float(density_scale), int(image_width), _ptr(image), _ptr(depth),
+        _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_f16_h16")
 
 
 def sigma_mlp_fwd_x3(feat, packed_sigma_x3):
