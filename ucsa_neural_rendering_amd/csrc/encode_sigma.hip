@@ -79,7 +79,7 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
     const float* d = rays_d + (size_t)rr * 3;
     const float ox = o[0], oy = o[1], oz = o[2];
     const float dx = d[0], dy = d[1], dz = d[2];
-    const float two_b = 2.0f * g.bound;
+    const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
     float x01[KPW], y01[KPW], z01[KPW];
 #pragma unroll
     for (uint32_t k = 0; k < KPW; ++k) {
@@ -88,9 +88,9 @@ k_encode_sigma_tiled(GridDev g, const float2* __restrict__ table,
       const float px = clampf(ox + dx * zz, bb.lo[0], bb.hi[0]);
       const float py = clampf(oy + dy * zz, bb.lo[1], bb.hi[1]);
       const float pz = clampf(oz + dz * zz, bb.lo[2], bb.hi[2]);
-      x01[k] = (px + g.bound) / two_b;
-      y01[k] = (py + g.bound) / two_b;
-      z01[k] = (pz + g.bound) / two_b;
+      x01[k] = to_unit(px, g.bound, two_b, inv);
+      y01[k] = to_unit(py, g.bound, two_b, inv);
+      z01[k] = to_unit(pz, g.bound, two_b, inv);
     }
 #pragma unroll 4
     for (uint32_t level = 0; level < 16; ++level) {

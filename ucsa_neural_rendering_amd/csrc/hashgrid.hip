@@ -36,10 +36,10 @@ __device__ __forceinline__ void sample_x01(const GridDev& g,
     py = x[1];
     pz = x[2];
   }
-  const float two_b = 2.0f * g.bound;
-  x01 = (px + g.bound) / two_b;
-  y01 = (py + g.bound) / two_b;
-  z01 = (pz + g.bound) / two_b;
+  const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
+  x01 = to_unit(px, g.bound, two_b, inv);
+  y01 = to_unit(py, g.bound, two_b, inv);
+  z01 = to_unit(pz, g.bound, two_b, inv);
 }
 
 // Coarse levels [0, n_coarse): cells span several samples of a ray, gathers
@@ -140,7 +140,7 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
     const float* d = rays_d + (size_t)ray * 3;
     const float ox = o[0], oy = o[1], oz = o[2];
     const float dx = d[0], dy = d[1], dz = d[2];
-    const float two_b = 2.0f * g.bound;
+    const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
     const TT* tab = table + g.offset[level];
     const float scale = g.scale[level];
     const uint32_t res = g.res[level], entries = g.entries[level],
@@ -153,8 +153,9 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
       const float px = clampf(ox + dx * zz, bb.lo[0], bb.hi[0]);
       const float py = clampf(oy + dy * zz, bb.lo[1], bb.hi[1]);
       const float pz = clampf(oz + dz * zz, bb.lo[2], bb.hi[2]);
-      const float x01 = (px + g.bound) / two_b, y01 = (py + g.bound) / two_b,
-                  z01 = (pz + g.bound) / two_b;
+      const float x01 = to_unit(px, g.bound, two_b, inv),
+                  y01 = to_unit(py, g.bound, two_b, inv),
+                  z01 = to_unit(pz, g.bound, two_b, inv);
       f_s[lane][ss] = hashed
           ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
           : encode_level(tab, x01, y01, z01, scale, res, entries, 0u);

@@ -29,8 +29,16 @@ __device__ __forceinline__ uint32_t grid_index_b(uint32_t x, uint32_t y,
   return hashed ? (idx & (entries - 1)) : (idx % entries);
 }
 
+// (same one-instruction clamp and exact-reciprocal position as the forward,
+// hashgrid_common.h: the backward must land in the forward's cells)
 __device__ __forceinline__ float clampf_b(float v, float lo, float hi) {
-  return fminf(fmaxf(v, lo), hi);
+  return __builtin_amdgcn_fmed3f(v, lo, hi);
+}
+__device__ __forceinline__ float unit_inv_b(float two_b) {
+  return (__float_as_uint(two_b) & 0x007FFFFFu) == 0u ? 1.0f / two_b : 0.0f;
+}
+__device__ __forceinline__ float to_unit_b(float p, float bound, float two_b, float inv) {
+  return inv != 0.0f ? (p + bound) * inv : (p + bound) / two_b;
 }
 
 // Run-combining: lanes of a wave are consecutive samples of a ray, so on the
@@ -151,7 +159,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
   float* gt = grad_table + (size_t)g.offset[level] * 2;
   const uint32_t res = g.res[level], entries = g.entries[level],
                  hashed = g.hashed[level];
-  const float two_b = 2.0f * g.bound;
+  const float two_b = 2.0f * g.bound, inv_b = unit_inv_b(two_b);
   const float scale = g.scale[level];
   if (RUNRED) {
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) {
@@ -185,9 +193,9 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
       py = xp[1];
       pz = xp[2];
     }
-    const float x = (px + g.bound) / two_b * scale + 0.5f;
-    const float y = (py + g.bound) / two_b * scale + 0.5f;
-    const float z = (pz + g.bound) / two_b * scale + 0.5f;
+    const float x = to_unit_b(px, g.bound, two_b, inv_b) * scale + 0.5f;
+    const float y = to_unit_b(py, g.bound, two_b, inv_b) * scale + 0.5f;
+    const float z = to_unit_b(pz, g.bound, two_b, inv_b) * scale + 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
     const float wx = x - fx0, wy = y - fy0, wz = z - fz0;
     const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
@@ -259,7 +267,7 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
                                             const Aabb& bb, uint32_t T,
                                             uint64_t m, uint32_t (&gi)[3],
                                             float (&wf)[3]) {
-  const float two_b = 2.0f * g.bound;
+  const float two_b = 2.0f * g.bound, inv_b = unit_inv_b(two_b);
   const float scale = g.scale[level];
   float pos[3];
   if (zs) {
@@ -279,7 +287,7 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float p = pos[a];
-    const float x = (p + g.bound) / two_b * scale + 0.5f;
+    const float x = to_unit_b(p, g.bound, two_b, inv_b) * scale + 0.5f;
     const float f0 = floorf(x);
     wf[a] = x - f0;
     gi[a] = (uint32_t)(int32_t)f0;

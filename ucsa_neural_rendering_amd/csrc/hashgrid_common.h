@@ -31,6 +31,23 @@ __device__ __forceinline__ float2 tab_load(const ucsa_half2* __restrict__ tab, u
   return make_float2((float)v[0], (float)v[1]);
 }
 
+// entries i and i + 1 with one access (4-byte alignment is all the hardware
+// asks of a global load)
+typedef float ucsa_f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 ucsa_half4_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void tab_load_pair(const float2* __restrict__ tab, uint32_t i,
+                                              float2& a, float2& b) {
+  const ucsa_f32x4_u p = *reinterpret_cast<const ucsa_f32x4_u*>(tab + i);
+  a = make_float2(p[0], p[1]);
+  b = make_float2(p[2], p[3]);
+}
+__device__ __forceinline__ void tab_load_pair(const ucsa_half2* __restrict__ tab,
+                                              uint32_t i, float2& a, float2& b) {
+  const ucsa_half4_u p = *reinterpret_cast<const ucsa_half4_u*>(tab + i);
+  a = make_float2((float)p[0], (float)p[1]);
+  b = make_float2((float)p[2], (float)p[3]);
+}
+
 // Trilinear gather of one level at x01 (already in [0,1]).
 template <typename TT>
 __device__ __forceinline__ float2 encode_level(const TT* __restrict__ tab,
@@ -45,11 +62,27 @@ __device__ __forceinline__ float2 encode_level(const TT* __restrict__ tab,
   const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
                  gz = (uint32_t)(int32_t)fz0;
   float2 v[8];
+  if (!hashed) {
+    // dense level: idx(x0 + 1) = idx(x0) + 1, so the x-pair is one (possibly
+    // unaligned) double-width access -- 4 instead of 8 per sample
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint32_t ix = gx + (c & 1), iy = gy + ((c >> 1) & 1),
-                   iz = gz + ((c >> 2) & 1);
-    v[c] = tab_load(tab, grid_index(ix, iy, iz, res, entries, hashed));
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lin = gx + (gy + (q & 1)) * res + (gz + (q >> 1)) * res * res;
+      const uint32_t i0 = lin % entries;
+      if (i0 + 1u < entries) {
+        tab_load_pair(tab, i0, v[2 * q], v[2 * q + 1]);
+      } else {  // the pair wraps around the end of the level's slab
+        v[2 * q] = tab_load(tab, i0);
+        v[2 * q + 1] = tab_load(tab, (lin + 1u) % entries);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t ix = gx + (c & 1), iy = gy + ((c >> 1) & 1),
+                     iz = gz + ((c >> 2) & 1);
+      v[c] = tab_load(tab, grid_index(ix, iy, iz, res, entries, hashed));
+    }
   }
   float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
@@ -65,8 +98,23 @@ __device__ __forceinline__ float2 encode_level(const TT* __restrict__ tab,
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {
-  // torch.min(torch.max(v, lo), hi)
-  return fminf(fmaxf(v, lo), hi);
+  // torch.min(torch.max(v, lo), hi) for lo <= hi and a finite v, as ONE
+  // instruction (v_med3_f32); fminf(fmaxf()) is four (each first quiets a
+  // possible signalling NaN)
+  return __builtin_amdgcn_fmed3f(v, lo, hi);
+}
+
+// x01 = (p + bound) / (2 * bound) as the oracle computes it.  For a
+// power-of-two 2 * bound (bound = 4 here) the division equals the
+// multiplication by its reciprocal bit for bit, and an IEEE division is an
+// 11-instruction sequence, three of them per sample and LEVEL (the level-major
+// launch recomputes the position per level): `inv` is 1 / (2 * bound) then,
+// 0 otherwise (wave-uniform).
+__device__ __forceinline__ float unit_inv(float two_b) {
+  return (__float_as_uint(two_b) & 0x007FFFFFu) == 0u ? 1.0f / two_b : 0.0f;
+}
+__device__ __forceinline__ float to_unit(float p, float bound, float two_b, float inv) {
+  return inv != 0.0f ? (p + bound) * inv : (p + bound) / two_b;
 }
 
 // Hashed level with x-pair loads.  Random 8-byte gathers run at the TCP's
@@ -88,16 +136,31 @@ __device__ __forceinline__ float2 encode_level_hashed(
   const uint32_t mask = entries - 1;
   const bool odd = (gx & 1u) != 0;
   float2 v[8];
+  // all accesses of the sample are requested before the first one is used
+  // (separate destination registers: no wait between them)
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  uint32_t i0[4], i1[4];
+  f32x4_t pr[4];
+  f32x2_t ex[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const uint32_t h = ((gy + (q & 1)) * PRIME_Y) ^ ((gz + (q >> 1)) * PRIME_Z);
-    const uint32_t i0 = (gx ^ h) & mask;
-    const float4 pr = *reinterpret_cast<const float4*>(tab + (i0 & ~1u));
-    const bool hi = (i0 & 1u) != 0;
-    v[2 * q] = hi ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
-    float2 other = hi ? make_float2(pr.x, pr.y) : make_float2(pr.z, pr.w);
-    if (odd) other = tab[((gx + 1u) ^ h) & mask];
-    v[2 * q + 1] = other;
+    i0[q] = (gx ^ h) & mask;
+    i1[q] = ((gx + 1u) ^ h) & mask;
+    pr[q] = *reinterpret_cast<const f32x4_t*>(tab + (i0[q] & ~1u));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ex[q] = f32x2_t{0.f, 0.f};
+    if (odd) ex[q] = *reinterpret_cast<const f32x2_t*>(tab + i1[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool hi = (i0[q] & 1u) != 0;
+    v[2 * q] = hi ? make_float2(pr[q][2], pr[q][3]) : make_float2(pr[q][0], pr[q][1]);
+    const float mx = hi ? pr[q][0] : pr[q][2], my = hi ? pr[q][1] : pr[q][3];
+    v[2 * q + 1] = odd ? make_float2(ex[q][0], ex[q][1]) : make_float2(mx, my);
   }
   float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
@@ -127,21 +190,36 @@ __device__ __forceinline__ float2 encode_level_hashed(
                  gz = (uint32_t)(int32_t)fz0;
   const uint32_t mask = entries - 1;
   const bool split = (gx & 3u) == 3u;  // x0 + 1 starts the next group
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   float2 v[8];
+  uint32_t i0[4], i1[4], ex[4];
+  u32x4_t grp[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const uint32_t h = ((gy + (q & 1)) * PRIME_Y) ^ ((gz + (q >> 1)) * PRIME_Z);
-    const uint32_t i0 = (gx ^ h) & mask, i1 = ((gx + 1u) ^ h) & mask;
-    const ucsa_half8 grp = *reinterpret_cast<const ucsa_half8*>(tab + (i0 & ~3u));
-    auto pick = [&](uint32_t k) {
-      const _Float16 a = k & 2u ? (k & 1u ? grp[6] : grp[4]) : (k & 1u ? grp[2] : grp[0]);
-      const _Float16 b = k & 2u ? (k & 1u ? grp[7] : grp[5]) : (k & 1u ? grp[3] : grp[1]);
-      return make_float2((float)a, (float)b);
-    };
-    v[2 * q] = pick(i0 & 3u);
-    float2 other = pick(i1 & 3u);
-    if (split) other = tab_load(tab, i1);
-    v[2 * q + 1] = other;
+    i0[q] = (gx ^ h) & mask;
+    i1[q] = ((gx + 1u) ^ h) & mask;
+    grp[q] = *reinterpret_cast<const u32x4_t*>(tab + (i0[q] & ~3u));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ex[q] = 0u;
+    if (split) ex[q] = *reinterpret_cast<const uint32_t*>(tab + i1[q]);
+  }
+  auto sel4 = [](const u32x4_t& g4, uint32_t k) {  // entry k of the group: 3 selects
+    const uint32_t lo = (k & 1u) ? g4[1] : g4[0];
+    const uint32_t hi = (k & 1u) ? g4[3] : g4[2];
+    return (k & 2u) ? hi : lo;
+  };
+  auto widen = [](uint32_t u) {
+    const ucsa_half2 h2 = __builtin_bit_cast(ucsa_half2, u);
+    return make_float2((float)h2[0], (float)h2[1]);
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[2 * q] = widen(sel4(grp[q], i0[q] & 3u));
+    const uint32_t mate = sel4(grp[q], i1[q] & 3u);
+    v[2 * q + 1] = widen(split ? ex[q] : mate);
   }
   float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
