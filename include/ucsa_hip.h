@@ -271,13 +271,15 @@ int32_t ucsa_point_shade_h(const float* dirs, const float* h,
                            void* stream);
 
 /* ============================ fp16 hash table ============================== */
-/* tiny-cuda-nn stores the hash grid in fp16 (fp32 master copy in the optimizer).
- * Optional here: `table_half` = the fp32 table rounded to half
- * (ucsa_cast_f32_to_f16; half2 entries, same level offsets).  Values are
- * widened on load and interpolated in fp32, so the features equal the fp32
- * kernels' on the rounded table bit for bit; 4-byte entries let one 16-byte
- * access serve four x-neighbours (5 instead of 6 accesses per sample and
- * hashed level).  image_width = 0: ray-ordered samples, else as
+/* tiny-cuda-nn stores the hash grid in fp16 (fp32 master copy in the optimizer)
+ * and its encoding emits fp16 features.  Optional here: `table_half` = the
+ * fp32 table rounded to half (ucsa_cast_f32_to_f16; half2 entries, same level
+ * offsets); `feat_half` [L][N*T] half2.  Values are widened on load and
+ * interpolated in fp32, so the features equal the fp32 kernels' on the
+ * rounded table, rounded to half once (where ucsa_sigma_mlp_fwd_f16 would
+ * round them anyway); 4-byte entries let one 16-byte access serve four
+ * x-neighbours (5 instead of 6 accesses per sample and hashed level).
+ * image_width = 0: ray-ordered samples, else as
  * ucsa_hashgrid_encode_rays_image.  Call site: reference
  * network_tcnn_semantics.py:36-46,133-134. */
 int32_t ucsa_cast_f32_to_f16(const float* src, void* dst_half, uint64_t n,
@@ -287,8 +289,13 @@ int32_t ucsa_hashgrid_encode_rays_h16(const ucsa_grid* grid,
                                       const float* rays_o, const float* rays_d,
                                       const float* z, const float* aabb_host,
                                       uint32_t N, uint32_t T,
-                                      uint32_t image_width, float* feat,
+                                      uint32_t image_width, void* feat_half,
                                       void* stream);
+/* ucsa_sigma_mlp_fwd_f16 on fp16 features (same h / sigma) */
+int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
+                                 const void* packed_sigma_half, uint32_t M,
+                                 uint32_t n_levels, float* h, float* sigma,
+                                 void* stream);
 /* ucsa_render_fwd_f16 reading the fp16 table */
 int32_t ucsa_render_fwd_f16_h16(const ucsa_grid* grid, const void* table_half,
                                 const void* packed_sigma_half,

@@ -615,10 +615,12 @@ def test_composite_modes_agree_for_every_class_count(ops, C):
 # ------------------------------------------------------ fp16 hash table option
 @pytest.mark.parametrize("H,W,T", [(16, 24, 16), (40, 64, 33), (96, 640, 24)])
 def test_fp16_table_features_equal_the_fp32_kernels_on_the_rounded_table(ops, H, W, T):
-    """ucsa_hashgrid_encode_rays_h16 (half2 entries, group-of-four loads) against
-    the fp32-table kernels fed the same values: widening is exact and the
-    interpolation arithmetic is shared, so the features are bit-identical --
-    ray-ordered and image-ordered, dense and hashed levels."""
+    """ucsa_hashgrid_encode_rays_h16 (half2 entries, group-of-four loads, fp16
+    features) against the fp32-table kernels fed the same values: widening is
+    exact and the interpolation arithmetic is shared, so its features are the
+    fp32 kernels' rounded to half, bit for bit -- ray-ordered and image-ordered,
+    dense and hashed levels; and the f16 sigma MLP gives the same h / sigma
+    from either."""
     fld = lively_oracle_field()
     net = hip_network_from_oracle(fld).eval()
     f = net._field()
@@ -635,7 +637,12 @@ def test_fp16_table_features_equal_the_fp32_kernels_on_the_rounded_table(ops, H,
         a = ops.hashgrid_encode_rays(f["grid"], table_h, o, d, z, aabb, image_width=width)
         b = ops.hashgrid_encode_rays(f["grid"], table_r, o, d, z, aabb, image_width=width)
         torch.cuda.synchronize()
-        assert torch.equal(a, b), width
+        assert a.dtype == torch.float16 and torch.equal(a, b.half()), width
+        ps = net._field_f16()["packed_sigma"]
+        ha, sa = ops.sigma_mlp_fwd_f16(a, ps)
+        hb, sb = ops.sigma_mlp_fwd_f16(b, ps)
+        torch.cuda.synchronize()
+        assert torch.equal(ha, hb) and torch.equal(sa, sb), width
 
 
 def test_fp16_table_render_matches_the_oracle_with_the_rounded_table():

@@ -28,6 +28,22 @@ __device__ __forceinline__ void feat_store(float2* dst, float2 v) {
 #endif
 }
 
+// fp16 features (tiny-cuda-nn's all-half encoding): rounded where they are
+// produced instead of where the f16 sigma MLP consumes them -- the same values
+__device__ __forceinline__ void feat_store(ucsa_half2* dst, float2 v) {
+  const ucsa_half2 h = {(_Float16)v.x, (_Float16)v.y};
+  __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, h),
+                              reinterpret_cast<uint32_t*>(dst));
+}
+__device__ __forceinline__ void feat_store(ucsa_half2* dst, ucsa_half2 h) {
+  __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, h),
+                              reinterpret_cast<uint32_t*>(dst));
+}
+__device__ __forceinline__ void to_feat(float2& d, float2 v) { d = v; }
+__device__ __forceinline__ void to_feat(ucsa_half2& d, float2 v) {
+  d = ucsa_half2{(_Float16)v.x, (_Float16)v.y};
+}
+
 template <bool FROM_RAYS>
 __device__ __forceinline__ void sample_x01(const GridDev& g,
                                            const float* __restrict__ rays_o,
@@ -60,14 +76,14 @@ __device__ __forceinline__ void sample_x01(const GridDev& g,
 // Coarse levels [0, n_coarse): cells span several samples of a ray, gathers
 // hit L1/L2, and a per-level launch would be all fixed cost (~25 us each,
 // measured) -- so one thread walks all of them.
-template <bool FROM_RAYS, typename TT = float2>
+template <bool FROM_RAYS, typename TT = float2, typename FT = float2>
 __global__ void __launch_bounds__(256)
 k_hashgrid_encode_coarse(GridDev g, uint32_t n_coarse,
                          const TT* __restrict__ table,
                          const float* __restrict__ rays_o,
                          const float* __restrict__ rays_d,
                          const float* __restrict__ zs, Aabb bb, uint32_t T,
-                         uint64_t M, float2* __restrict__ feat) {
+                         uint64_t M, FT* __restrict__ feat) {
   const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   float x01, y01, z01;
@@ -81,14 +97,14 @@ k_hashgrid_encode_coarse(GridDev g, uint32_t n_coarse,
 }
 
 // Fine levels [level0, n_levels): level-major (see file header).
-template <bool FROM_RAYS, typename TT = float2>
+template <bool FROM_RAYS, typename TT = float2, typename FT = float2>
 __global__ void __launch_bounds__(256)
 k_hashgrid_encode(GridDev g, uint32_t level0,
                   const TT* __restrict__ table,
                   const float* __restrict__ rays_o,
                   const float* __restrict__ rays_d,
                   const float* __restrict__ zs, Aabb bb, uint32_t T,
-                  uint64_t M, float2* __restrict__ feat) {
+                  uint64_t M, FT* __restrict__ feat) {
   const uint32_t level = level0 + blockIdx.y;
   const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -117,7 +133,7 @@ k_hashgrid_encode(GridDev g, uint32_t level0,
 // (64 B of z, 128 B of features per ray).  Arithmetic per sample is unchanged:
 // the features are bit-identical to k_hashgrid_encode's.
 #define TILE_S 16
-template <typename TT = float2>
+template <typename TT = float2, typename FT = float2>
 __global__ void __launch_bounds__(256)
 k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
                         const TT* __restrict__ table,
@@ -125,9 +141,9 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
                         const float* __restrict__ rays_d,
                         const float* __restrict__ zs, Aabb bb, uint32_t T,
                         uint32_t N, uint32_t W, uint32_t s_blocks,
-                        float2* __restrict__ feat) {
+                        FT* __restrict__ feat) {
   __shared__ float z_s[64][TILE_S + 1];
-  __shared__ float2 f_s[64][TILE_S + 1];
+  __shared__ FT f_s[64][TILE_S + 1];
   const uint32_t level = level0 + blockIdx.y;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
@@ -171,9 +187,9 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
       const float x01 = to_unit(px, g.bound, two_b, inv),
                   y01 = to_unit(py, g.bound, two_b, inv),
                   z01 = to_unit(pz, g.bound, two_b, inv);
-      f_s[lane][ss] = hashed
-          ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
-          : encode_level(tab, x01, y01, z01, scale, res, entries, 0u);
+      to_feat(f_s[lane][ss],
+              hashed ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
+                     : encode_level(tab, x01, y01, z01, scale, res, entries, 0u));
     }
   }
   __syncthreads();
@@ -196,25 +212,25 @@ static uint32_t coarse_levels(const ucsa_grid* grid) {
   return n;
 }
 
-template <bool FROM_RAYS, typename TT = float2>
+template <bool FROM_RAYS, typename TT = float2, typename FT = float2>
 static int32_t launch_encode(const ucsa_grid* grid, const void* table,
                              const float* a, const float* b, const float* z,
-                             Aabb bb, uint32_t T, uint64_t M, float* feat,
+                             Aabb bb, uint32_t T, uint64_t M, void* feat,
                              void* stream) {
   const GridDev gd = ucsa_grid_dev(grid);
   const uint32_t nc = coarse_levels(grid);
   const dim3 blk(256);
   UCSA_CLEAR_ERR();
   if (nc > 0)
-    hipLaunchKernelGGL((k_hashgrid_encode_coarse<FROM_RAYS, TT>),
+    hipLaunchKernelGGL((k_hashgrid_encode_coarse<FROM_RAYS, TT, FT>),
                        dim3(ucsa_div_up(M, 256)), blk, 0, (hipStream_t)stream,
                        gd, nc, (const TT*)table, a, b, z, bb, T, M,
-                       (float2*)feat);
+                       (FT*)feat);
   if (nc < grid->n_levels)
-    hipLaunchKernelGGL((k_hashgrid_encode<FROM_RAYS, TT>),
+    hipLaunchKernelGGL((k_hashgrid_encode<FROM_RAYS, TT, FT>),
                        dim3(ucsa_div_up(M, 256), grid->n_levels - nc), blk, 0,
                        (hipStream_t)stream, gd, nc, (const TT*)table, a, b,
-                       z, bb, T, M, (float2*)feat);
+                       z, bb, T, M, (FT*)feat);
   return ucsa_launch_status();
 }
 
@@ -235,12 +251,12 @@ extern "C" int32_t ucsa_hashgrid_encode_rays(
 }
 
 // image_width > 0: rays are the pixels of full rows of an image that wide
-template <typename TT = float2>
+template <typename TT = float2, typename FT = float2>
 static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
                                    const float* rays_o, const float* rays_d,
                                    const float* z, Aabb bb, uint32_t N,
                                    uint32_t T, uint32_t image_width,
-                                   float* feat, void* stream) {
+                                   void* feat, void* stream) {
   const GridDev gd = ucsa_grid_dev(grid);
   // every level goes through the tiled kernel: on the coarse ones a whole tile
   // sits in one or two cells (measured 0.84 ms vs 0.93 ms with levels 0-5 in
@@ -249,19 +265,19 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
   const uint64_t M = (uint64_t)N * T;
   UCSA_CLEAR_ERR();
   if (nc > 0)
-    hipLaunchKernelGGL((k_hashgrid_encode_coarse<true, TT>), dim3(ucsa_div_up(M, 256)),
+    hipLaunchKernelGGL((k_hashgrid_encode_coarse<true, TT, FT>), dim3(ucsa_div_up(M, 256)),
                        dim3(256), 0, (hipStream_t)stream, gd, nc,
                        (const TT*)table, rays_o, rays_d, z, bb, T, M,
-                       (float2*)feat);
+                       (FT*)feat);
   if (nc < grid->n_levels) {
     const uint32_t rows = ucsa_div_up(N, image_width);
     const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
     const uint32_t s_blocks = ucsa_div_up(T, TILE_S);
-    hipLaunchKernelGGL(k_hashgrid_encode_tiled<TT>,
+    hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
                        dim3(tiles * s_blocks, grid->n_levels - nc), dim3(256), 0,
                        (hipStream_t)stream, gd, nc, (const TT*)table, rays_o,
                        rays_d, z, bb, T, N, image_width, s_blocks,
-                       (float2*)feat);
+                       (FT*)feat);
   }
   return ucsa_launch_status();
 }
@@ -283,13 +299,15 @@ extern "C" int32_t ucsa_hashgrid_encode_rays_image(
                              stream);
 }
 
-// fp16 table (4-byte half2 entries, `table_half` = the fp32 table rounded to
-// half, ucsa_cast_f32_to_f16): features = the fp32 kernels' on the rounded
-// values, bit for bit.  image_width = 0: ray-ordered samples.
+// tiny-cuda-nn's all-half encoding: fp16 table (4-byte half2 entries,
+// `table_half` = the fp32 table rounded to half, ucsa_cast_f32_to_f16) and
+// fp16 features [L][N*T] half2 = the fp32 kernels' features on the rounded
+// table, rounded to half (interpolation in fp32).  image_width = 0:
+// ray-ordered samples.
 extern "C" int32_t ucsa_hashgrid_encode_rays_h16(
     const ucsa_grid* grid, const void* table_half, const float* rays_o,
     const float* rays_d, const float* z, const float* aabb_host, uint32_t N,
-    uint32_t T, uint32_t image_width, float* feat, void* stream) {
+    uint32_t T, uint32_t image_width, void* feat, void* stream) {
   UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
                      grid->n_levels <= UCSA_MAX_LEVELS, 0);
   UCSA_CHECK_ARG(table_half && ((uintptr_t)table_half & 15u) == 0, 1);
@@ -298,12 +316,12 @@ extern "C" int32_t ucsa_hashgrid_encode_rays_h16(
   UCSA_CHECK_ARG(feat, 9);
   if ((uint64_t)N * T == 0) return 0;
   if (image_width)
-    return launch_encode_image<ucsa_half2>(grid, table_half, rays_o, rays_d, z,
-                                           ucsa_aabb(aabb_host), N, T,
-                                           image_width, feat, stream);
-  return launch_encode<true, ucsa_half2>(grid, table_half, rays_o, rays_d, z,
-                                         ucsa_aabb(aabb_host), T,
-                                         (uint64_t)N * T, feat, stream);
+    return launch_encode_image<ucsa_half2, ucsa_half2>(
+        grid, table_half, rays_o, rays_d, z, ucsa_aabb(aabb_host), N, T,
+        image_width, feat, stream);
+  return launch_encode<true, ucsa_half2, ucsa_half2>(
+      grid, table_half, rays_o, rays_d, z, ucsa_aabb(aabb_host), T,
+      (uint64_t)N * T, feat, stream);
 }
 
 __global__ void k_cast_f32_to_f16(const float* __restrict__ src,

@@ -185,8 +185,21 @@ extern "C" int32_t ucsa_mlp_pack_t_f16(int32_t kind, const float* params,
 // 6 MFMAs per 16 samples: load/store bound, 8 column blocks per iteration.
 #define SIGH_UNROLL 8
 
+typedef _Float16 sig_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void feat_to_h(const float2 v, _Float16& a, _Float16& b) {
+  a = (_Float16)v.x;
+  b = (_Float16)v.y;
+}
+__device__ __forceinline__ void feat_to_h(const sig_half2 v, _Float16& a, _Float16& b) {
+  a = v[0];
+  b = v[1];
+}
+
+// FT: float2 features (rounded to half here) or half2 features (already
+// rounded by ucsa_hashgrid_encode_rays_h16): the same operands either way
+template <typename FT>
 __global__ void __launch_bounds__(256)
-k_sigma_mlp_f16(const float2* __restrict__ feat, const void* __restrict__ packed,
+k_sigma_mlp_f16(const FT* __restrict__ feat, const void* __restrict__ packed,
                 uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
@@ -206,9 +219,10 @@ k_sigma_mlp_f16(const float2* __restrict__ feat, const void* __restrict__ packed
       if (m >= M) m = M - 1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float2 v = feat[(uint64_t)(4 * q + g) * M + m];
-        xin[sb][2 * q] = (_Float16)v.x;
-        xin[sb][2 * q + 1] = (_Float16)v.y;
+        _Float16 fa, fb;
+        feat_to_h(feat[(uint64_t)(4 * q + g) * M + m], fa, fb);
+        xin[sb][2 * q] = fa;
+        xin[sb][2 * q + 1] = fb;
       }
     }
 #pragma unroll
@@ -241,9 +255,28 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_f16(const float* feat,
   const uint32_t need = ucsa_div_up(M, 16 * SIGH_UNROLL * 4);
   const uint32_t blocks = need < 2048u ? need : 2048u;
   UCSA_CLEAR_ERR();
-  hipLaunchKernelGGL(k_sigma_mlp_f16, dim3(blocks), dim3(256), 0,
+  hipLaunchKernelGGL(k_sigma_mlp_f16<float2>, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_half,
                      (uint64_t)M, h, sigma);
+  return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
+                                            const void* packed_sigma_half,
+                                            uint32_t M, uint32_t n_levels,
+                                            float* h, float* sigma,
+                                            void* stream) {
+  UCSA_CHECK_ARG(feat_half, 0);
+  UCSA_CHECK_ARG(packed_sigma_half, 1);
+  UCSA_CHECK_ARG(n_levels == 16, 3);
+  UCSA_CHECK_ARG(h && sigma, 4);
+  if (M == 0) return 0;
+  const uint32_t need = ucsa_div_up(M, 16 * SIGH_UNROLL * 4);
+  const uint32_t blocks = need < 2048u ? need : 2048u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp_f16<sig_half2>, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const sig_half2*)feat_half,
+                     packed_sigma_half, (uint64_t)M, h, sigma);
   return ucsa_launch_status();
 }
 

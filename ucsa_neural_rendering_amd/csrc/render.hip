@@ -100,6 +100,8 @@ static bool split_composite(int prec) {
 
 // prec: 0 = f32-input MFMA nets (packed by ucsa_mlp_pack), 1 = f16 MFMA
 // (ucsa_mlp_pack_f16), 2 = bf16x3 (ucsa_mlp_pack_x3)
+// (table_half is only offered together with the f16 nets: its encoder emits
+// fp16 features, which only the f16 sigma MLP reads)
 static int32_t render_impl(int prec, const ucsa_grid* grid,
                            const void* table_any, bool table_half,
                            const void* packed_sigma, const void* packed_color,
@@ -136,6 +138,9 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
     if (prec == 0)
       return ucsa_sigma_mlp_fwd(w.feat, (const float*)packed_sigma, N * n,
                                 grid->n_levels, h, sigma, stream);
+    if (prec == 1 && table_half)  // the h16 encoder wrote fp16 features
+      return ucsa_sigma_mlp_fwd_f16_h(w.feat, packed_sigma, N * n,
+                                      grid->n_levels, h, sigma, stream);
     if (prec == 1)
       return ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma, N * n, grid->n_levels,
                                     h, sigma, stream);

@@ -131,13 +131,15 @@ def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
     rays_d = _f32(rays_d, "rays_d").view(-1, 3)
     z = _f32(z, "z")
     N, T = z.shape
-    feat = torch.empty(grid.n_levels, N * T, 2, device=z.device)
-    if table.dtype == torch.float16:   # fp16 table (table_to_half)
+    if table.dtype == torch.float16:   # fp16 table (table_to_half) -> fp16 features
+        feat = torch.empty(grid.n_levels, N * T, 2, dtype=torch.float16,
+                           device=z.device)
         check(lib().ucsa_hashgrid_encode_rays_h16(
             C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
             fvec(aabb), N, T, int(image_width), _ptr(feat), _stream()),
             "ucsa_hashgrid_encode_rays_h16")
         return feat
+    feat = torch.empty(grid.n_levels, N * T, 2, device=z.device)
     if image_width:
         check(lib().ucsa_hashgrid_encode_rays_image(
             C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
@@ -353,6 +355,11 @@ def sigma_mlp_fwd_f16(feat, packed_sigma_half):
     L, M, _ = feat.shape
     h = torch.empty(M, 16, device=feat.device)
     sigma = torch.empty(M, device=feat.device)
+    if feat.dtype == torch.float16:   # features of the fp16-table encoder
+        check(lib().ucsa_sigma_mlp_fwd_f16_h(_ptr(feat), _ptr(packed_sigma_half),
+                                             M, L, _ptr(h), _ptr(sigma),
+                                             _stream()), "ucsa_sigma_mlp_fwd_f16_h")
+        return h, sigma
     check(lib().ucsa_sigma_mlp_fwd_f16(_ptr(feat), _ptr(packed_sigma_half), M,
                                        L, _ptr(h), _ptr(sigma), _stream()),
           "ucsa_sigma_mlp_fwd_f16")
