@@ -533,14 +533,14 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
         zc = ops.sample_coarse(near, far, T_COARSE)
         marks[1].record()
         feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zc, aabb,
-                                        image_width=image_width)
+                                        image_width=image_width, half_features=half)
         marks[2].record()
         hc, sc = sigma_mlp(feat, f["packed_sigma"])
         marks[3].record()
         zf = ops.resample(zc, sc.view(N, T_COARSE), u)
         marks[4].record()
         feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb,
-                                        image_width=image_width)
+                                        image_width=image_width, half_features=half)
         marks[5].record()
         hf, sf = sigma_mlp(feat, f["packed_sigma"])
         marks[6].record()

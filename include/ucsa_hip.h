@@ -291,6 +291,15 @@ int32_t ucsa_hashgrid_encode_rays_h16(const ucsa_grid* grid,
                                       uint32_t N, uint32_t T,
                                       uint32_t image_width, void* feat_half,
                                       void* stream);
+/* fp32 table, fp16 features (for ucsa_sigma_mlp_fwd_f16_h: same h / sigma as
+ * ucsa_hashgrid_encode_rays[_image] + ucsa_sigma_mlp_fwd_f16, half the
+ * feature traffic) */
+int32_t ucsa_hashgrid_encode_rays_hf(const ucsa_grid* grid, const float* table,
+                                     const float* rays_o, const float* rays_d,
+                                     const float* z, const float* aabb_host,
+                                     uint32_t N, uint32_t T,
+                                     uint32_t image_width, void* feat_half,
+                                     void* stream);
 /* ucsa_sigma_mlp_fwd_f16 on fp16 features (same h / sigma) */
 int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
                                  const void* packed_sigma_half, uint32_t M,

@@ -643,6 +643,14 @@ def test_fp16_table_features_equal_the_fp32_kernels_on_the_rounded_table(ops, H,
         hb, sb = ops.sigma_mlp_fwd_f16(b, ps)
         torch.cuda.synchronize()
         assert torch.equal(ha, hb) and torch.equal(sa, sb), width
+        # fp32 table, fp16 features: the fp32 features rounded at the source
+        c32 = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb, image_width=width)
+        c16 = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb,
+                                       image_width=width, half_features=True)
+        h32, s32 = ops.sigma_mlp_fwd_f16(c32, ps)
+        h16, s16 = ops.sigma_mlp_fwd_f16(c16, ps)
+        torch.cuda.synchronize()
+        assert torch.equal(c16, c32.half()) and torch.equal(h32, h16) and torch.equal(s32, s16)
 
 
 def test_fp16_table_render_matches_the_oracle_with_the_rounded_table():

@@ -99,6 +99,9 @@ SIGNATURES = {
     "ucsa_hashgrid_encode_rays_h16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
                                                   C.POINTER(_f), _u32, _u32, _u32,
                                                   _p, _p]),
+    "ucsa_hashgrid_encode_rays_hf": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
+                                                 C.POINTER(_f), _u32, _u32, _u32,
+                                                 _p, _p]),
     "ucsa_sigma_mlp_fwd_f16_h": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_render_fwd_f16_h16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                             _p, _p, C.POINTER(_f), _f, _p, _p,

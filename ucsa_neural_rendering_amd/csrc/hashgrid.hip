@@ -324,6 +324,28 @@ extern "C" int32_t ucsa_hashgrid_encode_rays_h16(
       (uint64_t)N * T, feat, stream);
 }
 
+// fp32 table, fp16 features: what ucsa_sigma_mlp_fwd_f16 would round on load,
+// rounded at the source (half the feature round trip through HBM)
+extern "C" int32_t ucsa_hashgrid_encode_rays_hf(
+    const ucsa_grid* grid, const float* table, const float* rays_o,
+    const float* rays_d, const float* z, const float* aabb_host, uint32_t N,
+    uint32_t T, uint32_t image_width, void* feat_half, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(table, 1);
+  UCSA_CHECK_ARG(rays_o && rays_d && z, 2);
+  UCSA_CHECK_ARG(aabb_host, 5);
+  UCSA_CHECK_ARG(feat_half, 9);
+  if ((uint64_t)N * T == 0) return 0;
+  if (image_width)
+    return launch_encode_image<float2, ucsa_half2>(
+        grid, table, rays_o, rays_d, z, ucsa_aabb(aabb_host), N, T, image_width,
+        feat_half, stream);
+  return launch_encode<true, float2, ucsa_half2>(
+      grid, table, rays_o, rays_d, z, ucsa_aabb(aabb_host), T, (uint64_t)N * T,
+      feat_half, stream);
+}
+
 __global__ void k_cast_f32_to_f16(const float* __restrict__ src,
                                   _Float16* __restrict__ dst, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -133,6 +133,13 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
       return ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma, rays_o,
                                               rays_d, z, aabb_host, N, n,
                                               image_width, h, sigma, stream);
+    if (prec == 1 && !table_half) {  // f16 nets: fp16 features at the source
+      UCSA_TRY(ucsa_hashgrid_encode_rays_hf(grid, table, rays_o, rays_d, z,
+                                            aabb_host, N, n, image_width, w.feat,
+                                            stream));
+      return ucsa_sigma_mlp_fwd_f16_h(w.feat, packed_sigma, N * n,
+                                      grid->n_levels, h, sigma, stream);
+    }
     UCSA_TRY(encode(grid, table_any, table_half, rays_o, rays_d, z, aabb_host, N,
                     n, image_width, w.feat, stream));
     if (prec == 0)
@@ -141,9 +148,6 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
     if (prec == 1 && table_half)  // the h16 encoder wrote fp16 features
       return ucsa_sigma_mlp_fwd_f16_h(w.feat, packed_sigma, N * n,
                                       grid->n_levels, h, sigma, stream);
-    if (prec == 1)
-      return ucsa_sigma_mlp_fwd_f16(w.feat, packed_sigma, N * n, grid->n_levels,
-                                    h, sigma, stream);
     return ucsa_sigma_mlp_fwd_x3(w.feat, packed_sigma, N * n, grid->n_levels, h,
                                  sigma, stream);
   };

@@ -124,9 +124,11 @@ def sample_coarse(nears, fars, T: int, t_rand=None):
 
 
 def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
-                         image_width: int = 0):
+                         image_width: int = 0, half_features: bool = False):
     """-> feat [L, N*T, 2] (level-major).  image_width > 0: the rays are the
-    pixels of full image rows (tile-ordered gather, same result)."""
+    pixels of full image rows (tile-ordered gather, same result).  An fp16
+    table (table_to_half) or half_features=True gives fp16 features (for
+    sigma_mlp_fwd_f16)."""
     rays_o = _f32(rays_o, "rays_o").view(-1, 3)
     rays_d = _f32(rays_d, "rays_d").view(-1, 3)
     z = _f32(z, "z")
@@ -138,6 +140,14 @@ def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
             C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
             fvec(aabb), N, T, int(image_width), _ptr(feat), _stream()),
             "ucsa_hashgrid_encode_rays_h16")
+        return feat
+    if half_features:
+        feat = torch.empty(grid.n_levels, N * T, 2, dtype=torch.float16,
+                           device=z.device)
+        check(lib().ucsa_hashgrid_encode_rays_hf(
+            C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z),
+            fvec(aabb), N, T, int(image_width), _ptr(feat), _stream()),
+            "ucsa_hashgrid_encode_rays_hf")
         return feat
     feat = torch.empty(grid.n_levels, N * T, 2, device=z.device)
     if image_width:
