@@ -314,6 +314,10 @@ extern "C" int32_t ucsa_hashgrid_encode_rays_h16(
   UCSA_CHECK_ARG(rays_o && rays_d && z, 2);
   UCSA_CHECK_ARG(aabb_host, 5);
   UCSA_CHECK_ARG(feat, 9);
+  // the group-of-four gather reads 16 aligned bytes: hashed levels must start
+  // on a multiple of four entries (ucsa_grid_init rounds every level to x8)
+  for (uint32_t l = 0; l < grid->n_levels; ++l)
+    UCSA_CHECK_ARG(!grid->level[l].hashed || (grid->level[l].offset & 3u) == 0, 0);
   if ((uint64_t)N * T == 0) return 0;
   if (image_width)
     return launch_encode_image<ucsa_half2, ucsa_half2>(
