@@ -59,7 +59,7 @@ def main(d, tag):
                  "the raw value is given and 2x raw is the upper bound",
     }
     for key, prefix in (("k_composite", "void k_composite<3, 2, false, false>"),
-                        ("k_hashgrid_encode_tiled", "k_hashgrid_encode_tiled"),
+                        ("k_hashgrid_encode_tiled", "void k_hashgrid_encode_tiled<HIP_vector_t"),
                         ("k_shade_dense_f16", "void k_shade_dense<3, 1, 1, 16>"),
                         ("k_shade_dense_x3", "void k_shade_dense<3, 2, 2, 8>")):
         f, w, s = pick(fetch, prefix), pick(wr, prefix), pick(sq, prefix)
