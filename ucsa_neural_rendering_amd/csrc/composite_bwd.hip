@@ -145,9 +145,12 @@ __device__ __forceinline__ f32x4 gate4(f32x4 pre, f32x4 v) {
 // HALF: the colour / semantics nets and their dX contractions run on
 // 16x16x32 f16 MFMA (fp16 weights and layer inputs, fp32 accumulate) -- the
 // forward recompute reproduces k_composite<.., HALF = true> exactly, so the
-// ReLU gates and the activations entering dW are the forward's.  dW itself
-// stays on fp32 MFMA over the LDS tiles (fp32 gradients x fp16-rounded
-// activations, accumulated in fp32 registers as before).
+// ReLU gates and the activations entering dW are the forward's.  dW runs on
+// the f16 pipe too (dw_accumulate_h: one 16x16x16 f16 MFMA per weight tile and
+// 16 samples; gradients under the loss scale and the forward's fp16 layer
+// inputs, accumulated in fp32 registers for the whole kernel) -- as f32-input
+// MFMAs the 176 weight-gradient k-steps per 16 samples were four fifths of
+// this variant's matrix work and ran on the vector ALU.
 template <int NRB, bool MARCH, bool HALF>
 __global__ void __launch_bounds__(64 * (HALF ? CB_WAVES_H : CB_WAVES))
 k_shade_bwd(ShadeBwdArgs a) {
@@ -363,7 +366,8 @@ k_shade_bwd(ShadeBwdArgs a) {
     for (int rb = 0; rb < 4; ++rb)
       tile_store(x_tile, g, j, rb, HALF ? relu_q4(a2c[rb]) : relu4(a2c[rb]));
     cb_sync();
-    dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
+    if constexpr (HALF) dw_accumulate_h<1, 4>(dy_tile, x_tile, lane, dwc3);
+    else dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
     cb_sync();
     f32x4 dh2[4];
     if constexpr (HALF) {
@@ -384,7 +388,8 @@ k_shade_bwd(ShadeBwdArgs a) {
       tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1c[rb]) : relu4(a1c[rb]));
     }
     cb_sync();
-    dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
+    if constexpr (HALF) dw_accumulate_h<4, 4>(dy_tile, x_tile, lane, dwc2);
+    else dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
     cb_sync();
     f32x4 dh1[4];
     if constexpr (HALF) {
@@ -415,7 +420,8 @@ k_shade_bwd(ShadeBwdArgs a) {
       x_tile[j * TILE_LD + (m == 0 ? 31u : 15u + m)] = geo[r];
     }
     cb_sync();
-    dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
+    if constexpr (HALF) dw_accumulate_h<4, 2>(dy_tile, x_tile, lane, dwc1);
+    else dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
     cb_sync();
     f32x4 dslot[1];
     if constexpr (HALF) {
@@ -438,7 +444,8 @@ k_shade_bwd(ShadeBwdArgs a) {
     for (int rb = 0; rb < 4; ++rb)
       tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1s[rb]) : relu4(a1s[rb]));
     cb_sync();
-    dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
+    if constexpr (HALF) dw_accumulate_h<NRB, 4>(dy_tile, x_tile, lane, dws2);
+    else dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
     cb_sync();
     f32x4 dhs[4];
     if constexpr (HALF) {
@@ -473,7 +480,8 @@ k_shade_bwd(ShadeBwdArgs a) {
       x_tile[j * TILE_LD + (m == 0 ? 15u : m - 1u)] = geo[r];
     }
     cb_sync();
-    dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
+    if constexpr (HALF) dw_accumulate_h<4, 1>(dy_tile, x_tile, lane, dws1);
+    else dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
     cb_sync();
     f32x4 dslot_s[1];
     if constexpr (HALF) {

@@ -43,3 +43,36 @@ __device__ __forceinline__ half8 frag_h(const void* packed, int f,
 #define SIGMA_H_FRAGS 6
 #define COLOR_H_FRAGS 14
 #define SEM_H_FRAGS(nrb) (4 + 2 * (nrb))
+
+// dW[ob][ib] += dY_tile^T X_tile over the 16 samples of the tile on the f16
+// pipe: ONE v_mfma_f32_16x16x16_f16 per 16x16 weight tile instead of four
+// f32-input k-steps (which run on the vector ALU at 32 cycles each).  Lane
+// (k = lane >> 4, i = lane & 15) holds samples 4k .. 4k+3 of neuron 16*ob + i
+// (A) resp. 16*ib + i (B) -- the same LDS words as the f32 form reads, four
+// per operand, rounded to half (dY carries the loss scale; X is what the f16
+// forward fed into the layer).  fp32 accumulation across the whole kernel.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+template <int OB, int IB>
+__device__ __forceinline__ void dw_accumulate_h(const float* dy_tile,
+                                                const float* x_tile,
+                                                uint32_t lane,
+                                                f32x4 (&dw)[OB][IB]) {
+  const uint32_t i = lane & 15u, k = lane >> 4;
+  half4 a[OB], b[IB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      a[ob][e] = (_Float16)dy_tile[(4 * k + e) * TILE_LD + 16 * ob + i];
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      b[ib][e] = (_Float16)x_tile[(4 * k + e) * TILE_LD + 16 * ib + i];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+      dw[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[ob], b[ib], dw[ob][ib], 0, 0, 0);
+}
