@@ -463,6 +463,9 @@ class SemanticNeRFRenderer(nn.Module):
         if self.precision not in ("fp32", "fp16", "bf16x3"):
             raise ValueError("precision must be fp32, bf16x3 or fp16, got "
                              f"{self.precision}")
+        if self.fp16_table and self.precision != "fp16":
+            raise ValueError("fp16_table needs precision='fp16' (its encoder emits "
+                             "fp16 features, which only the f16 sigma MLP reads)")
         if self.precision == "fp16":
             f, render = self._field_f16(), ops.render_fwd_f16
             if self.fp16_table:
