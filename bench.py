@@ -505,6 +505,57 @@ def composite_roofline(mode, mlp_tf, sig_tf, launch_ms):
                 "sums), not by the matrix pipe"}
 
 
+def mlp_error_vs_fp64(net, dev, M=16384):
+    """Max error of the colour / class-probability outputs of the three
+    shading arithmetics against an fp64 evaluation of the same nets (torch,
+    double, on the device): M random samples, one per ray, through
+    ucsa_composite_infer with T = 1 and a huge density (weight 1), so the
+    composite returns the nets' outputs themselves.  Shows in the bench line
+    that bf16x3 is as close to fp64 as the exact f32-input MFMA chain."""
+    from ucsa_neural_rendering_amd import ops
+    C = N_CLASSES
+    g = torch.Generator(device=dev).manual_seed(11)
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev, generator=g), dim=-1)
+    h = torch.randn(M, 16, device=dev, generator=g)
+    cp, sp = net.color_net.params.detach(), net.semantics_net.params.detach()
+    # fp64 reference: SH-4 of the direction mapped as the reference does
+    x, y, z = [(((d[:, i].double() + 1) / 2) * 2 - 1) for i in range(3)]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    sh = torch.stack([
+        torch.full_like(x, 0.28209479177387814), -0.48860251190291987 * y,
+        0.48860251190291987 * z, -0.48860251190291987 * x, 1.0925484305920792 * xy,
+        -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z,
+        0.45704579946446572 * y * (1.0 - 5.0 * z2), 0.3731763325901154 * z * (5.0 * z2 - 3.0),
+        0.45704579946446572 * x * (1.0 - 5.0 * z2), 1.4453057213202769 * z * (x2 - y2),
+        0.59004358992664352 * x * (-x2 + 3.0 * y2)], dim=-1)
+    geo = h[:, 1:].double()
+    one = torch.ones(M, 1, dtype=torch.float64, device=dev)
+    cpd, spd = cp.double(), sp.double()
+    w1, w2, w3 = cpd[:2048].view(64, 32), cpd[2048:6144].view(64, 64), cpd[6144:7168].view(16, 64)
+    xin = torch.cat([sh, geo, one], -1)
+    rgb64 = torch.sigmoid(torch.relu(torch.relu(xin @ w1.t()) @ w2.t()) @ w3.t())[:, :3]
+    out_pad = (C + 15) // 16 * 16
+    s1, s2 = spd[:1024].view(64, 16), spd[1024:1024 + out_pad * 64].view(out_pad, 64)
+    p64 = torch.softmax((torch.relu(torch.cat([geo, one], -1) @ s1.t()) @ s2.t())[:, :C], -1)
+    zc = torch.ones(M, 1, device=dev)
+    sg = torch.full((M, 1), 50.0, device=dev)
+    nrm = torch.ones(M, device=dev)
+    args = (d, nrm, zc, sg, h, None, None, None)
+    res = {}
+    for name, pc, ps, kw in (
+            ("f32_mfma", ops.mlp_pack(1, cp), ops.mlp_pack(2, sp, C), {}),
+            ("bf16x3", ops.mlp_pack_x3(1, cp), ops.mlp_pack_x3(2, sp, C), {"x3": True}),
+            ("fp16", ops.mlp_pack_f16(1, cp), ops.mlp_pack_f16(2, sp, C), {"half": True})):
+        img, _, sem = ops.composite_infer(*args, pc, ps, C, **kw)
+        res[name] = {"rgb": float((img.double() - rgb64).abs().max()),
+                     "class_probability": float((sem.double() - p64).abs().max())}
+    res["note"] = ("max |kernel - fp64| over %d random samples on the benchmarked "
+                   "field's colour / semantics nets" % M)
+    return res
+
+
 def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
                 mode=None):
     """Per-kernel durations of one chunk, measured with events on the stream
@@ -1004,6 +1055,7 @@ def main():
         extras = world == 1
         # occupancy-grid marching on the same parameters:
         # never the headline `value` (cfg2 is defined at 192 samples/ray)
+        result["mlp_error_vs_fp64"] = mlp_error_vs_fp64(net, dev)
         _tick("render modes measured")
         if extras:
             try:
