@@ -151,10 +151,13 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
   const uint32_t s0 = sb * TILE_S;
   const uint64_t M = (uint64_t)N * T;
+  FT* feat_level = feat + (uint64_t)level * M;  // wave-uniform
+  // (32-bit indices: the host checks N * T < 2^31; rows beyond the last one
+  // give r >= N)
   auto ray_of = [&](uint32_t l) -> uint32_t {
     const uint32_t px = tx * 8 + (l & 7u), py = ty * 8 + (l >> 3);
-    const uint64_t r = (uint64_t)py * W + px;
-    return (px < W && r < N) ? (uint32_t)r : 0xFFFFFFFFu;
+    const uint32_t r = py * W + px;
+    return (px < W && r < N) ? r : 0xFFFFFFFFu;
   };
   // depths of the tile, ray-major reads
 #pragma unroll
@@ -162,13 +165,13 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
     const uint32_t e = threadIdx.x + 256u * k;
     const uint32_t r = ray_of(e / TILE_S), ss = e % TILE_S;
     if (r != 0xFFFFFFFFu && s0 + ss < T)
-      z_s[e / TILE_S][ss] = zs[(uint64_t)r * T + s0 + ss];
+      z_s[e / TILE_S][ss] = zs[r * T + s0 + ss];
   }
   __syncthreads();
   const uint32_t ray = ray_of(lane);
   if (ray != 0xFFFFFFFFu) {
-    const float* o = rays_o + (size_t)ray * 3;
-    const float* d = rays_d + (size_t)ray * 3;
+    const float* o = rays_o + ray * 3u;
+    const float* d = rays_d + ray * 3u;
     const float ox = o[0], oy = o[1], oz = o[2];
     const float dx = d[0], dy = d[1], dz = d[2];
     const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
@@ -198,8 +201,7 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
     const uint32_t e = threadIdx.x + 256u * k;
     const uint32_t r = ray_of(e / TILE_S), ss = e % TILE_S;
     if (r != 0xFFFFFFFFu && s0 + ss < T)
-      feat_store(feat + (uint64_t)level * M + (uint64_t)r * T + s0 + ss,
-                 f_s[e / TILE_S][ss]);
+      feat_store(feat_level + (r * T + s0 + ss), f_s[e / TILE_S][ss]);
   }
 }
 
@@ -263,6 +265,8 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
   // k_hashgrid_encode_coarse, 5.9 M samples)
   const uint32_t nc = 0;
   const uint64_t M = (uint64_t)N * T;
+  UCSA_CHECK_ARG(M < 0x80000000ull && N < 0x40000000u &&
+                     (uint64_t)N + 8ull * image_width < 0xFFFFFFFFull, 6);
   UCSA_CLEAR_ERR();
   if (nc > 0)
     hipLaunchKernelGGL((k_hashgrid_encode_coarse<true, TT, FT>), dim3(ucsa_div_up(M, 256)),
