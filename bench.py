@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=49152)
+    ap.add_argument("--cpu-rays", type=int, default=16384,
+                    help="rays per pass of the CPU baseline (3 passes, median)")
     ap.add_argument("--pretrain-steps", type=int, default=200,
                     help="Adam steps on the synthetic scene before timing "
                          "(SURVEY 8d: 200)")
@@ -431,21 +432,21 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
     o, d, nrm = o[:, sel], d[:, sel], nrm[:, sel]
     u = torch.rand(n_rays, T_FINE, generator=g)
     aabb = torch.tensor([-4.0, -4, -4, 4, 4, 4])
-    best = None
+    times = []
     with torch.no_grad():
-        for it in range(1):   # one pass is ~25 s of CPU work already
+        for it in range(3):   # >= 3 repeats, median (~8 s per pass)
             t0 = time.perf_counter()
             ref = oren.run(fld, o, d, nrm, aabb, num_steps=T_COARSE,
                            upsample_steps=T_FINE, u=u)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+            times.append(time.perf_counter() - t0)
+        best = sorted(times)[1]
         # the same rays / uniforms through the HIP path: parity + matched PSNR
         dev = net.encoder.params.device
         got = net.render(o.to(dev), d.to(dev), nrm.to(dev), num_steps=T_COARSE,
                          upsample_steps=T_FINE, rng_u=u.to(dev))
     parity = {k: float((got[k].cpu() - ref[k]).abs().max())
               for k in ("image", "depth", "semantics")}
-    return n_rays / best, best, parity, ref, got, (o, d)
+    return n_rays / best, times, parity, ref, got, (o, d)
 
 
 MLP_ARITHMETIC = {
@@ -741,11 +742,78 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
     return res
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start
+    the N ranks as a CHILD `python -m torch.distributed.run` and relay its
+    stdout / exit code.  This process never touches the GPU (no torch.cuda
+    call that initialises HIP happens before this point;
+    ``torch.cuda.device_count()`` does not) -- a process that has initialised
+    the GPU must not exec or be replaced, so the ranks are children and the
+    parent only waits.  The reference's DDP site: scripts/train_joint.py:137-142
+    (Lightning spawns the ranks there)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("UCSA_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit(
+            f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s). One rank "
+            "per GPU over RCCL needs that many; UCSA_BENCH_BACKEND=gloo runs all "
+            "ranks on cuda:0 (code-path check on a 1-GPU box, not a measurement)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["UCSA_BENCH_LAUNCHER"] = "self"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    _tick("self-launch: " + " ".join(cmd[1:]))
+    # stdout through a FILE, not a pipe: helper processes the ranks leave
+    # behind for a while would keep an inherited pipe open past torchrun's exit
+    import tempfile
+    with tempfile.TemporaryFile("w+") as fo:
+        proc = subprocess.Popen(cmd, env=env, stdout=fo, stdin=subprocess.DEVNULL)
+        rc = proc.wait()
+        fo.seek(0)
+        sys.stdout.write(fo.read())   # rank 0's JSON line (stderr passed through)
+        sys.stdout.flush()
+    return rc
+
+
+def dist_record(dist, world, rank, backend, dev, args):
+    """What actually ran: world size as torch.distributed sees it, backend,
+    the device of every rank.  Fails loudly when the process group has a
+    different number of ranks than --gpus."""
+    launcher = os.environ.get("UCSA_BENCH_LAUNCHER", "torchrun" if world > 1 else "none")
+    if dist is None:
+        return {"world_size": 1, "backend": None, "launcher": launcher,
+                "devices": [f"{dev} ({torch.cuda.get_device_name(dev)})"]}
+    ws = dist.get_world_size()
+    if ws != args.gpus:
+        raise SystemExit(f"process group has {ws} ranks, --gpus {args.gpus}")
+    mine = (rank, str(dev), torch.cuda.get_device_name(dev))
+    devs = [None] * ws
+    dist.all_gather_object(devs, mine)
+    if backend == "nccl" and len({d for _, d, _ in devs}) != ws:
+        raise SystemExit(f"RCCL ranks share a device: {devs}")
+    devs = [f"rank {r}: {d} ({n})" for r, d, n in devs]
+    return {"world_size": ws, "backend": dist.get_backend() + (" (RCCL)" if backend == "nccl" else ""),
+            "launcher": launcher, "devices": devs}
+
+
+_DIST_RECORD = None
+
+
 def main():
     if os.environ.get("UCSA_BENCH_WATCHDOG"):   # debugging aid: stacks of a stuck rank
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["UCSA_BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -767,7 +835,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    global _DIST_RECORD
+    _DIST_RECORD = dist_record(dist, world, rank, backend, dev, args)
 
     from ucsa_neural_rendering_amd import ops
     if args.mode == "cfg3":
@@ -880,6 +951,11 @@ def main():
                 "pretrain": prelog,
                 "masked_fraction_rho": rho,
                 "sharding": "views round-robin over ranks, no data-path collective",
+                "timed_region": "net.render() of one view per step (rows a2-a10); "
+                                "ray generation (a1, ucsa_get_rays, ~10 us per view) "
+                                "runs BEFORE the timed region: its outputs are the "
+                                "HBM-resident inputs of the step (bench.py --mode cfg4 "
+                                "times get_rays + render per view)",
                 "mlp_arithmetic": MLP_ARITHMETIC[args.nerf_precision],
             },
             "roofline_encode": {
@@ -963,8 +1039,11 @@ def main():
                         "valu_wave_instructions_per_launch":
                             pmc["k_shade_dense_f16"].get("valu_wave_instructions"),
                         "source": PMC_JSON}
-        except (OSError, KeyError, ValueError):
-            pass
+        except OSError as e:
+            raise SystemExit(f"bench.py: {PMC_JSON} (the committed PMC passes the "
+                             f"roofline's `traffic` comes from) is missing: {e}")
+        except (KeyError, ValueError) as e:
+            raise SystemExit(f"bench.py: {PMC_JSON} is malformed: {e!r}")
         # "roofline" = the kernel with the largest share of the step
         enc_share = st["encode_c"] + st["encode_f"]
         dom = "roofline_encode" if enc_share >= st["composite"] else "roofline_composite"
@@ -1093,7 +1172,9 @@ def main():
                 "cores": threads,
                 "kind": "port",
                 "sample": f"{args.cpu_rays} random rays of view 0, same "
-                          f"T={T_COARSE}/t={T_FINE}, one pass ({dt:.1f} s)",
+                          f"T={T_COARSE}/t={T_FINE}; median of 3 passes ("
+                          + ", ".join(f"{x:.1f}" for x in dt) + " s)",
+                "pass_seconds": dt,
             }
             result["speedup_vs_cpu"] = value / v
             _tick("CPU baseline done")
@@ -1106,6 +1187,7 @@ def main():
         if rank == 0:
             result["train_dp"] = tr
     if rank == 0:
+        result["distributed"] = _DIST_RECORD
         print(json.dumps(result))
     if dist:
         dist.barrier()
@@ -1114,6 +1196,7 @@ def main():
 
 def _finish(dist, rank, result):
     if rank == 0:
+        result["distributed"] = _DIST_RECORD
         print(json.dumps(result))
     if dist:
         dist.barrier()
@@ -1222,28 +1305,36 @@ def main_cfg3(args, dev, dist, world, rank, backend):
     _finish(dist, rank, result)
 
 
-def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
-    """--mode cfg4: `--views` novel 640x480 views round-robin over the ranks
-    (BASELINE cfg4: 512), parameters replicated, no data-path collective;
-    `--gather` additionally collects the images on rank 0 inside the timed
-    region (the only collective a render job can need)."""
+def cfg4_job(net, n_views, rank, world, dev, dist=None, backend="nccl", warmup=1,
+             gather=False, precision="bf16x3", keep=()):
+    """BASELINE cfg4's render job: `n_views` novel 640x480 views round-robin
+    over the ranks (this rank renders views rank, rank+world, ...), per view
+    get_rays (a1) + staged render at 96+96 samples, parameters replicated, no
+    data-path collective.  Returns (max-over-ranks seconds, views of this
+    rank, {view index: rays + outputs} for the indices in `keep` that this
+    rank rendered -- used by tests/test_gpu_configs.py for the oracle spot
+    checks).  Reference: forward_nerf_test, joint_train_lightning_net.py:225-257."""
     from ucsa_neural_rendering_amd import dist as udist, ops
     from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
     intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
-    mine = udist.shard_round_robin(args.views, rank, world)
-    poses = _slerp_loop_poses(args.views, seed=999)[mine].to(dev)
-    net.precision = args.nerf_precision
+    mine = udist.shard_round_robin(n_views, rank, world)
+    poses = _slerp_loop_poses(n_views, seed=999)[mine].to(dev)
+    net.precision = precision
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     u = torch.rand(H * W, T_FINE, device=dev, generator=g)
+    kept_views = {}
 
-    def view(i):
+    def view(i, record=False):
         o, d, nrm = ops.get_rays(poses[i:i + 1], intr, H, W)   # a1 inside the job
         with torch.no_grad():
-            return net.render(o, d, nrm, staged=True, perturb=False,
-                              num_steps=T_COARSE, upsample_steps=T_FINE,
-                              rng_u=u, image_width=W)
+            out = net.render(o, d, nrm, staged=True, perturb=False,
+                             num_steps=T_COARSE, upsample_steps=T_FINE,
+                             rng_u=u, image_width=W)
+        if record:
+            kept_views[mine[i]] = dict(o=o, d=d, nrm=nrm, u=u, **out)
+        return out
 
-    for i in range(min(args.warmup, len(mine))):
+    for i in range(min(warmup, len(mine))):
         view(i)
     if dist:
         dist.barrier()
@@ -1251,14 +1342,14 @@ def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
     t0 = time.perf_counter()
     kept = []
     for i in range(len(mine)):
-        out = view(i)
-        if args.gather:
+        out = view(i, record=mine[i] in keep)
+        if gather:
             kept.append((out["image"][0] * 255).to(torch.uint8))
-    if args.gather and dist:
+    if gather and dist:
         loc = torch.stack(kept) if kept else torch.empty(0, H * W, 3, dtype=torch.uint8, device=dev)
         if backend != "nccl":
             loc = loc.cpu()
-        sizes = [len(udist.shard_round_robin(args.views, r, world)) for r in range(world)]
+        sizes = [len(udist.shard_round_robin(n_views, r, world)) for r in range(world)]
         udist.gather_rows(loc, sizes)
     torch.cuda.synchronize()
     if dist:
@@ -1269,6 +1360,17 @@ def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
                           device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    return elapsed, mine, kept_views
+
+
+def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
+    """--mode cfg4: `--views` novel 640x480 views round-robin over the ranks
+    (BASELINE cfg4: 512), parameters replicated, no data-path collective;
+    `--gather` additionally collects the images on rank 0 inside the timed
+    region (the only collective a render job can need)."""
+    elapsed, mine, _ = cfg4_job(net, args.views, rank, world, dev, dist, backend,
+                                warmup=args.warmup, gather=args.gather,
+                                precision=args.nerf_precision)
     result = {
         "metric": "rays/sec", "value": args.views * H * W / elapsed,
         "unit": "rays/s", "n_gpus": world, "steps": args.views,

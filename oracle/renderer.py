@@ -120,6 +120,9 @@ def run(field,
                            order.unsqueeze(-1).expand_as(geo_all))
         aux["new_z"] = new_z
         aux["order"] = order
+        aux["z_mid_coarse"] = z_mid      # bins / weights / u of the inverse CDF:
+        aux["w_coarse"] = w              # tests use them to tell which fine
+        aux["u"] = u                     # samples sit on sample_pdf's denom step
 
     _, weights = alpha_weights(z, sigma, density_scale)
     mask = weights > 1e-4  # same mask for colour and semantics (:249-250)

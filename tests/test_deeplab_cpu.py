@@ -32,12 +32,38 @@ def test_state_dict_keys_are_torchvision_compatible():
     assert sd["_model.classifier.0.project.0.weight"].shape == (256, 1280, 1, 1)
     assert sd["_model.classifier.4.weight"].shape == (40, 256, 1, 1)
     n_params = sum(p.numel() for p in m.parameters())
-    assert 58e6 < n_params < 62e6  # DeepLabV3-R101 without aux head (~58.6-61 M)
+    # 21-class figure below + 19 more output channels of the last 1x1 (256 w + 1 b each)
+    assert n_params == 58_630_997 + 19 * 257
     # dilation pattern: layer3/4 keep stride 1 with dilation 2 / 4
     b = m._model.backbone
     assert b.layer3[0].conv2.stride == (1, 1) and b.layer3[1].conv2.dilation == (2, 2)
     assert b.layer4[0].conv2.dilation == (2, 2) and b.layer4[1].conv2.dilation == (4, 4)
     assert b.layer2[0].conv2.stride == (2, 2)
+
+
+def test_parameter_counts_equal_torchvisions_exactly():
+    """torchvision's published parameter counts (its model documentation,
+    21 classes, aux head included): deeplabv3_resnet101 60 996 202,
+    deeplabv3_resnet50 42 004 074; resnet101 44 549 160 and resnet50
+    25 557 032 with their 2 049 000-parameter fc layer.  The reference builds
+    the model with ``aux_loss=None`` semantics of a pretrained=False call and
+    drops the aux head from checkpoints (scripts/train_joint.py:116-128); the
+    aux FCNHead(1024, 21) is 3x3 1024->256 (2 359 296) + BN (512) + 1x1
+    256->21 with bias (5 397) = 2 365 205.  An architecture slip (a block
+    count, a width, a bias, the ASPP branch set) changes these numbers."""
+    aux = 1024 * 256 * 9 + 2 * 256 + 256 * 21 + 21
+    assert aux == 2_365_205
+    for backbone, full, resnet in (("resnet101", 60_996_202, 44_549_160),
+                                   ("resnet50", 42_004_074, 25_557_032)):
+        m = DeepLabV3({"pretrained": False, "pretrained_backbone": False,
+                       "num_classes": 21, "backbone": backbone})
+        n = sum(p.numel() for p in m.parameters())
+        nb = sum(p.numel() for p in m._model.backbone.parameters())
+        nc = sum(p.numel() for p in m._model.classifier.parameters())
+        assert n == full - aux, (backbone, n)
+        assert nb == resnet - 2_049_000, (backbone, nb)      # no fc
+        assert nc == 16_130_837, (backbone, nc)              # DeepLabHead(2048, 21)
+    assert 60_996_202 - aux == 58_630_997 and 42_004_074 - aux == 39_638_869
 
 
 def test_forward_backward_shapes_resnet50_small_input():

@@ -178,7 +178,8 @@ def _opt_problem():
     return [big0, s1, s2], tgt
 
 
-def _sharded_trajectory(rank, world, sharded, scaler_on, comm_dtype=None):
+def _sharded_trajectory(rank, world, sharded, scaler_on, comm_dtype=None,
+                        init_scale=64.0, loss_gain=1.0):
     from ucsa_neural_rendering_amd import ops
     from ucsa_neural_rendering_amd.nerf import optim as uoptim
     _cpu_adam_ops(ops)
@@ -193,13 +194,15 @@ def _sharded_trajectory(rank, world, sharded, scaler_on, comm_dtype=None):
                                     comm_dtype=comm_dtype, **kw)
     else:
         opt = uoptim.HipAdam(groups, **kw)
-    scaler = uoptim.CollectiveGradScaler("cpu", enabled=scaler_on, init_scale=64.0)
+    scaler = uoptim.CollectiveGradScaler("cpu", enabled=scaler_on,
+                                         init_scale=init_scale)
     gen = torch.Generator().manual_seed(100 + rank)           # per-rank data
     hist = []
     for it in range(6):
         opt.zero_grad()
         noise = [torch.randn(t.shape, generator=gen) * 0.1 for t in tgt]
         loss = sum((((p - t - n) ** 2).mean() for p, t, n in zip(ps, tgt, noise)))
+        loss = loss * loss_gain
         if it == 2 and rank == 1 and scaler_on:
             loss = loss * float("inf")                         # one rank overflows
         scaler.scale(loss).backward()
@@ -264,6 +267,54 @@ def test_sharded_adam_fp16_gradient_payload_stays_close():
     for x, y in zip(a[0][0], b[0][0]):
         assert float((x - y).abs().max()) <= 5e-3
     assert a[0][3] < b[0][3]                                   # fewer bytes on the links
+
+
+def _traj_fp16_big(rank, world):
+    # gradients of O(1..10) under the reference's scale 2^16: 6.5e4..6.5e5
+    # as fp32, beyond fp16's 65504
+    return _sharded_trajectory(rank, world, True, True, torch.float16,
+                               init_scale=65536.0, loss_gain=4099.0)
+
+
+def _traj_fp32_big(rank, world):
+    return _sharded_trajectory(rank, world, True, True, None,
+                               init_scale=65536.0, loss_gain=4099.0)
+
+
+def _traj_fp16_plain_tiny(rank, world):
+    # no scaler, gradients of ~1e-9: would flush to zero in a bare fp16 cast
+    return _sharded_trajectory(rank, world, True, False, torch.float16,
+                               loss_gain=1e-6)
+
+
+def _traj_fp32_plain_tiny(rank, world):
+    return _sharded_trajectory(rank, world, True, False, None, loss_gain=1e-6)
+
+
+def test_fp16_payload_cannot_overflow_after_the_inf_check():
+    """the scaler's inf check runs on the fp32, still-scaled
+    gradients; a bare cast to fp16 of a value above 65504 (or a sum over the
+    ranks passing it) would put inf into Adam AFTER found_inf was computed.
+    The payload is range-normalised by the collective max|g|: parameters stay
+    finite, equal on the ranks, and close to the fp32-payload trajectory; the
+    only skipped step is the deliberately overflowed one."""
+    a = spawn(_traj_fp16_big)
+    b = spawn(_traj_fp32_big)
+    for x, y in zip(a[0][0], a[1][0]):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+    for x, y in zip(a[0][0], b[0][0]):
+        assert float((x - y).abs().max()) <= 5e-3
+    assert a[0][1] == b[0][1]                                  # same scale history
+    assert a[0][1][1] == 65536.0 and a[0][1][2] == 32768.0
+
+
+def test_fp16_payload_without_scaler_keeps_tiny_gradients():
+    a = spawn(_traj_fp16_plain_tiny)
+    b = spawn(_traj_fp32_plain_tiny)
+    init, _ = _opt_problem()
+    for x, y, x0 in zip(a[0][0], b[0][0], init):
+        assert float((y - x0).abs().max()) > 1e-3              # Adam did move
+        assert float((x - y).abs().max()) <= 5e-3
 
 
 def _gms(rank, world):

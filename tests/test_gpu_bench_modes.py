@@ -73,3 +73,24 @@ def test_cfg4_mode_two_ranks_with_gather(tmp_path):
                  "--pretrain-steps", "30"], tmp_path)
     assert res["config"]["mode"] == "cfg4" and res["config"]["views_per_rank"] == 2
     assert res["scaling"] == "strong" and res["value"] > 0
+
+
+def test_plain_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE
+    unset) starts its two ranks itself as a child torchrun; the JSON line says
+    what ran (world size as torch.distributed saw it, backend, devices)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UCSA_BENCH_BACKEND="gloo", UCSA_BENCH_WATCHDOG="500")
+    out, err = tmp_path / "out.txt", tmp_path / "err.txt"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--pretrain-steps", "30", "--mode", "cfg4", "--views", "4"]
+    with open(out, "w") as fo, open(err, "w") as fe:
+        rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                              env=env, cwd=ROOT).wait(timeout=600)
+    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
+    res = json.loads(lines[0])
+    d = res["distributed"]
+    assert res["n_gpus"] == 2 and d["world_size"] == 2 and d["launcher"] == "self"
+    assert d["backend"].startswith("gloo") and len(d["devices"]) == 2

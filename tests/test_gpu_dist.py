@@ -186,3 +186,96 @@ def test_two_rank_train_joint_shards_frames_and_pixels(tmp_path, sharded):
         assert r0["results"][k]["test_nerf_mIoU"] == pytest.approx(
             r1["results"][k]["test_nerf_mIoU"], abs=1e-12)
     assert r0["saved_by"] == 0 and r1["saved_by"] is None
+
+
+# ---- continual stage with replay under two ranks ----------
+def _cl_worker(rank, world, port, root, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from ucsa_neural_rendering_amd import dist as udist
+    from ucsa_neural_rendering_amd.lightning import joint_train_lightning_net as jl
+    from scripts import cl_deeplab
+    torch.cuda.set_device(0)
+    udist.init_from_env("gloo")
+    try:
+        log = {"real": 0, "idle": 0, "per_step": [], "mixed": 0}
+        o_real = jl.JointTrainLightningNet._nerf_update
+        o_idle = jl.JointTrainLightningNet._nerf_update_idle
+        o_step = jl.JointTrainLightningNet.training_step_joint
+        o_end = jl.JointTrainLightningNet.on_predict_epoch_end
+        keep = {}
+
+        def real(self, *a, **k):
+            log["real"] += 1
+            return o_real(self, *a, **k)
+
+        def idle(self, *a, **k):
+            log["idle"] += 1
+            return o_idle(self, *a, **k)
+
+        def step(self, batch):
+            before = log["real"] + log["idle"]
+            old, new, _ = batch
+            if old is not None and (new is None or new["img"].shape[0] < 2):
+                log["mixed"] += 1
+            r = o_step(self, batch)
+            log["per_step"].append(log["real"] + log["idle"] - before)
+            return r
+
+        def grab(self):
+            keep[self._exp["general"]["name"]] = [
+                p.detach().cpu().clone() for p in self.nerf_model.parameters()]
+            return o_end(self)
+
+        jl.JointTrainLightningNet._nerf_update = real
+        jl.JointTrainLightningNet._nerf_update_idle = idle
+        jl.JointTrainLightningNet.training_step_joint = step
+        jl.JointTrainLightningNet.on_predict_epoch_end = grab
+        exp = {
+            "general": {"name": "x", "clean_up_folder_if_exists": True,
+                        "checkpoint_load": ""},
+            "model": {"pretrained": False, "pretrained_backbone": False,
+                      "num_classes": 40, "backbone": "resnet50"},
+            "optimizer": {"lr_seg": 1e-5, "lr_nerf": 1e-2, "name": "Adam"},
+            "trainer": {"load_from_checkpoint": True, "resume_from_checkpoint": False,
+                        "cudnn_benchmark": False},
+            "data_module": {"batch_size": 2, "output_size": (48, 64)},
+            "scenes": ["scene0000_00"],
+            "cl": {"active": False, "use_novel_viewpoints": False,
+                   "replay_buffer_size": 6},
+            "synthetic": {"n_views": 6, "H": 48, "W": 64},
+            "nerf": {"n_rays": 256, "num_steps": 16, "upsample_steps": 16,
+                     "sharded_optimizer": True},
+            "nerf_seed": 1,
+        }
+        env = {"results": os.path.join(root, "experiments"),
+               "scannet": os.path.join(root, "scans")}
+        res = cl_deeplab.main(["--exp_name", "cl", "--scenes", "2",
+                               "--nerf_train_epoch", "1", "--joint_train_epoch", "2"],
+                              exp=exp, env=env)
+        last = sorted(keep)[-1]
+        ret[rank] = dict(log=log, stages=len(res), params=keep[last])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_continual_stage_with_replay_keeps_collectives_aligned(tmp_path):
+    """Stage 1 of the continual loop mixes replayed old-scene frames into the
+    joint loader: a rank's batch then holds 0, 1 or 2 NEW frames, and each
+    NeRF update contains collectives.  Every rank must run the same number of
+    updates per step (idle ones with zero gradients), else the next
+    collective pairs with the wrong one (hang / size mismatch).  The run
+    finishes, both ranks made the same number of updates in every step, at
+    least one step had ranks holding different numbers of new frames, and
+    the replicas are bit-identical at the end."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cl_worker, args=(2, _free_port(), str(tmp_path), ret),
+             nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["stages"] == r1["stages"] == 2
+    assert r0["log"]["per_step"] == r1["log"]["per_step"]
+    assert r0["log"]["idle"] + r1["log"]["idle"] > 0, (r0["log"], r1["log"])
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)

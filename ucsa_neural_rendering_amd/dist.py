@@ -120,6 +120,25 @@ def broadcast_parameters_(module: torch.nn.Module, src: int = 0):
             torch.autograd.graph.increment_version(t)
 
 
+def broadcast_buffers_(module: torch.nn.Module, src: int = 0):
+    """Rank `src`'s buffers (DeepLab's BatchNorm running statistics) on every
+    rank.  Lightning DDP re-broadcasts buffers from rank 0 at every forward
+    (``broadcast_buffers=True``); here the ranks' statistics are allowed to
+    drift during a training epoch and are re-aligned before every
+    evaluation / predict pass, so that sharded metrics and the written
+    pseudo-labels all come from the model rank 0 saves."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return
+    gloo_cuda = dist.get_backend() == "gloo"
+    for t in module.buffers():
+        if gloo_cuda and t.is_cuda:
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src)
+            t.data.copy_(h)
+        else:
+            dist.broadcast(t.data, src=src)
+
+
 def average_grads_(params: Iterable[torch.nn.Parameter]):
     """DDP semantics: SUM all-reduce of the gradients, then / world."""
     params = [p for p in params if p.grad is not None]
@@ -182,6 +201,18 @@ def allreduce_max_(t: torch.Tensor) -> torch.Tensor:
     if is_dist() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
+
+
+def all_gather_ints(value: int, device) -> List[int]:
+    """Every rank's integer, in rank order (one 8-byte-per-rank all_gather and
+    a host read-back: used once per joint training step to agree on the
+    number of NeRF updates, see ``training_step_joint``)."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return [int(value)]
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [int(t.item()) for t in parts]
 
 
 def global_mean_scale(n_local: int, valid_local: torch.Tensor):

@@ -373,24 +373,64 @@ class JointTrainLightningNet(nn.Module):
             self.training_step_nerf(batch)
 
     def _nerf_update(self, optimizer_nerf, loss_color, loss_semantics,
-                     loss_depth):
+                     loss_depth, contributors=None):
         """reference :497-513.  Under torch.distributed every rank has drawn
         its own rays on its own frames (DDP semantics, reference
         scripts/train_joint.py:137-142): the gradients are averaged over the
         ranks -- inside ``ShardedHipAdam.step`` (reduce-scatter / all-gather),
-        or by one all-reduce here for the replicated ``HipAdam``."""
+        or by one all-reduce here for the replicated ``HipAdam``.
+
+        ``contributors`` (joint training, N > 1): the number of ranks that
+        hold a new-scene frame for this update.  The collectives divide the
+        summed gradient by the world size, so the loss is pre-scaled by
+        world / contributors: the update is the mean over the frames that
+        exist.  A rank WITHOUT a frame calls ``_nerf_update_idle`` instead and
+        enters the very same collectives with a zero gradient -- the number of
+        collectives per step must not depend on what a rank's sampler drew
+        (replayed old-scene frames, ``from_old_scene``)."""
         for nm, v in (("loss_nerf_rgb", loss_color), ("loss_depth", loss_depth),
                       ("loss_nerf_semantics", loss_semantics)):
             if v is not None:
                 self.log(f"{self._mode}/{nm}", v.detach())
         total = ulosses.nerf_total_loss(loss_color, loss_semantics, loss_depth)
+        self._nerf_backward_and_step(optimizer_nerf, total, contributors)
+
+    def _nerf_update_idle(self, optimizer_nerf, contributors):
+        """This rank has no new-scene frame for the update the others make: a
+        zero loss that depends on every NeRF parameter gives dense zero
+        gradients, and the step runs through the same scaler / optimizer /
+        collective sequence as on the contributing ranks."""
+        total = None
+        for p in self.nerf_model.parameters():
+            if p.requires_grad:
+                z = p.reshape(-1)[:1].sum() * 0.0
+                total = z if total is None else total + z
+        self._nerf_backward_and_step(optimizer_nerf, total, contributors,
+                                     dense_zero=True)
+
+    def _nerf_backward_and_step(self, optimizer_nerf, total, contributors,
+                                dense_zero=False):
+        w = udist.world()[1]
+        if contributors is not None and w > 1 and contributors != w:
+            total = total * (float(w) / float(contributors))
         optimizer_nerf.zero_grad()
         total = self.nerf_scaler.scale(total)
         self.manual_backward(total)
+        if dense_zero:
+            for p in self.nerf_model.parameters():
+                if p.requires_grad:
+                    p.grad = torch.zeros_like(p) if p.grad is None else p.grad.zero_()
         if not getattr(optimizer_nerf, "handles_collectives", False):
             udist.average_grads_(self.nerf_model.parameters())
         self.nerf_scaler.step(optimizer_nerf)
         self.nerf_scaler.update()
+
+    def _new_frame_counts(self, n_local):
+        """How many new-scene frames every rank holds in this step (one small
+        all_gather; [n_local] without torch.distributed)."""
+        if udist.world()[1] == 1:
+            return [int(n_local)]
+        return udist.all_gather_ints(int(n_local), self._reduce_device())
 
     def training_step_nerf(self, batch):
         """reference :473-513."""
@@ -409,7 +449,13 @@ class JointTrainLightningNet(nn.Module):
                 self.nerf_model.eval()
                 output_nerf = self.forward_nerf_test(batch_new)
                 self.nerf_model.train()
-        if not self.fix_nerf and batch_new is not None:
+        # NeRF updates: one per new-scene frame (reference :381-393).  Under
+        # torch.distributed the ranks' samplers mix replayed old-scene frames
+        # in, so a rank may hold 0..B new frames: every rank runs
+        # max-over-ranks updates, idle ones contribute zero gradients.
+        n_new = 0 if (self.fix_nerf or batch_new is None) else int(batch_new["img"].shape[0])
+        counts = [0] if self.fix_nerf else self._new_frame_counts(n_new)
+        if n_new > 0:
             self.seg_model.eval()
             if batch_new["img"].shape[0] > 1:  # BN trains only when B > 1
                 for m in self.seg_model.modules():
@@ -418,9 +464,13 @@ class JointTrainLightningNet(nn.Module):
             with torch.no_grad():
                 output_seg = self.forward_seg(batch_new)
             self.seg_model.train()
-            for bs in range(batch_new["img"].shape[0]):
+        for bs in range(max(counts)):
+            contributors = sum(1 for c in counts if c > bs)
+            if bs < n_new:
                 lc, ls, ld = self.forward_nerf_train(batch_new, output_seg, bs)
-                self._nerf_update(optimizer_nerf, lc, ls, ld)
+                self._nerf_update(optimizer_nerf, lc, ls, ld, contributors)
+            else:
+                self._nerf_update_idle(optimizer_nerf, contributors)
         with torch.no_grad():
             rgb_seg = label_seg = None
             if batch_new is not None:
@@ -459,6 +509,7 @@ class JointTrainLightningNet(nn.Module):
 
     # ---- validation (:541-646) ------------------------------------------------
     def on_validation_epoch_start(self):
+        udist.broadcast_buffers_(self.seg_model)   # rank 0's BN statistics
         self._mode = "val"
         self._meter["val_seg"].clear()
         self._meter["train_val_seg"].clear()
@@ -478,9 +529,9 @@ class JointTrainLightningNet(nn.Module):
         out = {}
         for mode in ("val", "train_val"):
             m = self._meter[f"{mode}_seg"]
+            self._reduce_meter(m)   # every rank enters, frames or not
             if m.conf_mat is None:
                 continue
-            self._reduce_meter(m)
             m_iou, total_acc, m_acc = m.measure()
             tag = self.prev_scene_name
             self.log(f"{mode}/seg_total_accuracy_{tag}", total_acc)
@@ -493,6 +544,7 @@ class JointTrainLightningNet(nn.Module):
 
     # ---- test (:648-693) --------------------------------------------------------
     def on_test_epoch_start(self):
+        udist.broadcast_buffers_(self.seg_model)   # rank 0's BN statistics
         self._mode = "test"
         self._meter["test_nerf"].clear()
         self._meter["test_25k"].clear()
@@ -513,19 +565,19 @@ class JointTrainLightningNet(nn.Module):
         out = {}
         for net_name in ["nerf", "25k"]:
             m = self._meter[f"test_{net_name}"]
+            self._reduce_meter(m)   # every rank enters, frames or not
             if m.conf_mat is not None:
-                self._reduce_meter(m)
                 m_iou, total_acc, m_acc = m.measure()
                 self.log(f"test/{net_name}_total_accuracy", total_acc)
                 self.log(f"test/{net_name}_mean_accuracy", m_acc)
                 self.log(f"test/{net_name}_mean_IoU", m_iou)
                 out[f"test_{net_name}_mIoU"] = m_iou
                 m.clear()
-        if self._psnr:
-            tot = torch.tensor([sum(self._psnr), float(len(self._psnr))],
-                               dtype=torch.float64)
-            if udist.world()[1] > 1:  # the ranks evaluated disjoint frames
-                tot = udist.allreduce_sum_tensor(tot.to(self._reduce_device()))
+        tot = torch.tensor([sum(self._psnr), float(len(self._psnr))],
+                           dtype=torch.float64)
+        if udist.world()[1] > 1:  # the ranks evaluated disjoint frames
+            tot = udist.allreduce_sum_tensor(tot.to(self._reduce_device()))
+        if float(tot[1]) > 0:
             out["test_nerf_PSNR"] = float(tot[0] / tot[1])
             self.log("test/nerf_PSNR", out["test_nerf_PSNR"])
         return out
@@ -540,8 +592,13 @@ class JointTrainLightningNet(nn.Module):
         own frames) instead of the reference's all_gather of label maps
         (:666-667)."""
         if udist.world()[1] > 1:
-            cm = torch.from_numpy(m.conf_mat).to(self._reduce_device())
-            m.conf_mat = udist.allreduce_confusion_(cm).cpu().numpy()
+            import numpy as np
+            local = (m.conf_mat if m.conf_mat is not None else
+                     np.zeros((m.number_classes, m.number_classes), dtype=np.int64))
+            cm = torch.from_numpy(np.ascontiguousarray(local)).to(self._reduce_device())
+            cm = udist.allreduce_confusion_(cm).cpu().numpy()
+            # a meter nobody fed stays empty (measure() is skipped for it)
+            m.conf_mat = cm if (m.conf_mat is not None or cm.any()) else None
 
     # ---- predict (:695-782) ---------------------------------------------------
     # Returns the tensors; with ``predict_to_disk`` (set by train_joint when the
@@ -552,6 +609,7 @@ class JointTrainLightningNet(nn.Module):
     predict_to_disk = False
 
     def on_predict_epoch_start(self):
+        udist.broadcast_buffers_(self.seg_model)   # rank 0's BN statistics
         self._mode = "predict"
         if self.predict_to_disk:
             for sub in ("", "novel_viewpoints"):

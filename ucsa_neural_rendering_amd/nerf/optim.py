@@ -149,8 +149,10 @@ class ShardedHipAdam(HipAdam):
       inside the Adam kernel (the unscale factor), not in a pass of its own.
     * ``comm_dtype`` (None | torch.float16 | torch.bfloat16): the gradient
       payload of the reduce-scatter is cast to it (halves the bytes on the
-      links; under GradScaler the gradients are already scaled into fp16's
-      range).  Moments, parameters and the all-gather stay fp32.
+      links).  fp16 payloads are range-normalised by the collective max|g|
+      first (``_reduce_scatter_low_precision``) so that neither a
+      GradScaler-scaled value nor a sum over the ranks can overflow after
+      the inf check.  Moments, parameters and the all-gather stay fp32.
     * under ``CollectiveGradScaler`` the found-inf flag is already the MAX
       over ranks when it arrives here; with a plain GradScaler it is
       MAX-reduced here (4 bytes) so that every rank skips the same step --
@@ -173,6 +175,39 @@ class ShardedHipAdam(HipAdam):
         self.comm_dtype = comm_dtype
         self.last_comm_bytes = 0
 
+    def _reduce_scatter_low_precision(self, g, per, world):
+        """SUM reduce-scatter of the fp32 gradient ``g`` with a 16-bit payload.
+
+        fp16 cannot hold what the fp32 gradient may: under the GradScaler the
+        values are scaled by up to 2^16 (one above 65504, or a sum over the
+        ranks that passes it, would turn into inf AFTER the scaler's inf check
+        ran on the fp32 values), and without a scaler small values flush to
+        zero.  So the payload is range-normalised first: the MAX over the
+        ranks of max|g| (one 4-byte all-reduce) is mapped to 2^14 / world --
+        no element and no partial sum can overflow, and the largest
+        gradients keep all of fp16's mantissa -- and the reduced slice is
+        scaled back in fp32.  A non-finite max (an overflow the scaler has
+        already flagged, on any rank) makes the factor 0: the payload is
+        finite zeros and the step is skipped by found_inf as before.  bf16
+        has fp32's range and is cast directly."""
+        if self.comm_dtype == torch.float16:
+            amax = torch.linalg.vector_norm(g, ord=float("inf")).reshape(1)
+            amax = udist.allreduce_max_(amax)
+            ok = torch.isfinite(amax) & (amax > 0)
+            amax = torch.where(ok, amax, torch.ones_like(amax))
+            # a power of two: the scaling itself is exact
+            k = torch.exp2(torch.floor(torch.log2((16384.0 / world) / amax)))
+            k = torch.where(ok, k, torch.zeros_like(k))
+            gh = torch.nan_to_num(g * k, nan=0.0, posinf=0.0, neginf=0.0).to(torch.float16)
+            inv = torch.where(ok, 1.0 / torch.where(ok, k, torch.ones_like(k)),
+                              torch.zeros_like(k))
+        else:
+            gh, inv = g.to(self.comm_dtype), None
+        oh = torch.empty(per, dtype=self.comm_dtype, device=g.device)
+        udist.reduce_scatter_sum_(oh, gh)
+        out = oh.float()
+        return out if inv is None else out * inv
+
     @torch.no_grad()
     def step(self, closure=None):
         rank, world = udist.world()
@@ -185,10 +220,15 @@ class ShardedHipAdam(HipAdam):
         grad_scale, found_inf, scaled = self._scaler_state()
         if scaled and not getattr(self, "_found_inf_is_collective", False):
             found_inf = udist.allreduce_max_(found_inf.clone())
+        # the flag describes ONE step (set by CollectiveGradScaler around it):
+        # a later step driven by a plain GradScaler must reduce again
+        self._found_inf_is_collective = False
         div = float(world) if self.average else 1.0
         devices = set()
-        small = []  # (group, p_view, g_view, state, key)
+        small = []  # (group, p_view, g_view, exp_avg, exp_avg_sq, step)
+        large = []  # (group, p, pf, g_shard, state, per, body)
         comm = 0
+        # phase 1: every gradient collective of the large parameters
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -217,25 +257,25 @@ class ShardedHipAdam(HipAdam):
                     st["tail_exp_avg"] = torch.zeros(n - body, device=p.device)
                     st["tail_exp_avg_sq"] = torch.zeros(n - body, device=p.device)
                 if self.comm_dtype is not None:
-                    gh = g[:body].to(self.comm_dtype)
-                    oh = torch.empty(per, dtype=self.comm_dtype, device=p.device)
-                    udist.reduce_scatter_sum_(oh, gh)
-                    g_shard = oh.float()
-                    comm += body * gh.element_size()
+                    g_shard = self._reduce_scatter_low_precision(g[:body], per, world)
+                    comm += body * torch.finfo(self.comm_dtype).bits // 8
                 else:
                     g_shard = torch.empty(per, device=p.device)
                     udist.reduce_scatter_sum_(g_shard, g[:body])
                     comm += body * 4
-                p_shard = pf[rank * per:(rank + 1) * per]
-                self._apply(p_shard, g_shard, st["exp_avg"], st["exp_avg_sq"],
-                            st["step"], group, grad_scale, found_inf, scaled,
-                            devices, extra_div=div)
-                udist.all_gather_into_(pf[:body], p_shard.clone())
-                comm += body * 4
+                large.append((group, p, pf, g_shard, st, per, body))
                 if n > body:
                     small.append((group, pf[body:], g[body:], st["tail_exp_avg"],
                                   st["tail_exp_avg_sq"], st["step"]))
-                torch.autograd.graph.increment_version(p)
+        # phase 2: Adam on this rank's slices, all-gather of the result
+        for group, p, pf, g_shard, st, per, body in large:
+            p_shard = pf[rank * per:(rank + 1) * per]
+            self._apply(p_shard, g_shard, st["exp_avg"], st["exp_avg_sq"],
+                        st["step"], group, grad_scale, found_inf, scaled,
+                        devices, extra_div=div)
+            udist.all_gather_into_(pf[:body], p_shard.clone())
+            comm += body * 4
+            torch.autograd.graph.increment_version(p)
         if small:
             flat = torch.cat([g for (_, _, g, _, _, _) in small])
             udist.allreduce_sum_([flat], small_bytes=0)
