@@ -422,10 +422,15 @@ def test_tile_order_kernel_equals_torch_ordering(ops, n, H, W, tile):
                                         (50, 256, 256, False), (3000, 8, 8, False),
                                         (700, 96, 96, True), (33, 16, 0, True)])
 def test_split_inference_composite_is_bit_identical_to_the_fused_kernel(ops, net, N, T, t, half):
-    """ucsa_composite_infer (k_weights_compact + k_shade_dense, what
-    ucsa_render_fwd uses) against ucsa_composite_fwd / _f16 (the fused kernel
-    the training path keeps) on the same staged inputs: same arithmetic in the
-    same order -> identical bits; rays that miss the box, rays without a
+    """ucsa_composite_infer (k_weights_compact + k_shade_dense / k_shade16,
+    what ucsa_render_fwd uses) against ucsa_composite_fwd / _f16 (the fused
+    kernel the training path keeps) on the same staged inputs.  f32-input
+    MFMA mode: same arithmetic in the same order -> identical bits.  f16
+    mode: same nets (same MFMA chain), but k_shade16 adds the per-ray sums as
+    per-lane partial sums + a row reduction instead of in sample order and
+    evaluates exp(l - max) as exp2(fma(l, log2e, -max log2e)): ordinary fp32
+    round-off apart (<= 1e-6 on outputs in [0, 1]), depth still bit-identical
+    (k_weights_compact is unchanged).  Rays that miss the box, rays without a
     sample above the mask and ragged last groups included."""
     import ctypes as C
     from ucsa_neural_rendering_amd._lib import check, lib
@@ -470,7 +475,11 @@ def test_split_inference_composite_is_bit_identical_to_the_fused_kernel(ops, net
     if N > 8:   # the no-survivor rays come out as exact zeros on both paths
         assert float(want[2][1::7].abs().sum()) == 0.0 and float(got[2][1::7].abs().sum()) == 0.0
     for a, b, name in zip(got, want, ("image", "depth", "semantics")):
-        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name
+        a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
+        if half and name != "depth":
+            assert maxabs(a, b) <= 1e-6, (name, maxabs(a, b))
+        else:
+            assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize("H,W,T,half", [(24, 40, 16, False), (17, 23, 8, False), (64, 64, 33, False),

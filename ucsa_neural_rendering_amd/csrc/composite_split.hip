@@ -53,7 +53,9 @@ struct WcArgs {
   float* image;        // rays without a survivor get zeros here
   float* semantics;
   uint32_t C;
-  float* sh;           // [N,16] SH basis of the ray direction (null: not wanted)
+  void* sh;            // per-ray SH basis of the direction in the form the
+                       // shading kernel's MFMA operand wants (null: not wanted)
+  uint32_t sh_mode;    // 1: [N][16] half; 2: [N][3 terms][16] bf16 (bf16x3 split)
 };
 
 #define WC_WAVES 4
@@ -156,7 +158,19 @@ __global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
       float sh[4];
       sh4_select(dd[0], dd[1], dd[2], lane >> 2, sh);
       const uint32_t q = lane & 3u;
-      a.sh[(size_t)r * 16 + lane] = q == 0 ? sh[0] : (q == 1 ? sh[1] : (q == 2 ? sh[2] : sh[3]));
+      const float v = q == 0 ? sh[0] : (q == 1 ? sh[1] : (q == 2 ? sh[2] : sh[3]));
+      if (a.sh_mode == 1) {
+        reinterpret_cast<_Float16*>(a.sh)[(size_t)r * 16 + lane] = (_Float16)v;
+      } else {  // the exact three-term bf16 split of mfma_mlp_x3.h, per value
+        uint16_t* o = reinterpret_cast<uint16_t*>(a.sh) + (size_t)r * 48 + lane;
+        const uint32_t p0 = bf16_pair(v, 0.0f);
+        const float r1 = v - pair_lo(p0);
+        const uint32_t p1 = bf16_pair(r1, 0.0f);
+        const float r2 = r1 - pair_lo(p1);
+        o[0] = (uint16_t)p0;
+        o[16] = (uint16_t)p1;
+        o[32] = (uint16_t)bf16_pair(r2, 0.0f);
+      }
     }
     if (kept == 0) {  // nothing survived the mask: all-zero outputs
       if (lane < 3) a.image[(size_t)r * 3 + lane] = 0.0f;
@@ -181,7 +195,7 @@ struct ShArgs {
   uint32_t rays_per_wave;
   float* image;
   float* semantics;
-  const float* sh;  // [N,16] from k_weights_compact (16-bit MFMA modes)
+  const void* sh;   // per-ray SH operands from k_weights_compact (16-bit MFMA modes)
 };
 
 template <int CBS>
@@ -196,27 +210,21 @@ struct Pre {  // one group's operands, requested one group ahead
   float ew[CBS];
   uint32_t eray[CBS];
   f32x4 hv[CBS];
-  float d[CBS][3];  // f32-input MFMA mode: the ray direction
-  f32x4 shv[CBS];   // 16-bit MFMA modes: this lane's four SH values of the ray
+  float d[CBS][3];  // the ray direction
 };
 
-// PREC: 0 = f32-input MFMA, 1 = f16 MFMA (tiny-cuda-nn's numerics), 2 = bf16x3
-// (fp32-grade on the bf16 MFMA pipe, mfma_mlp_x3.h)
-template <int NRB_SEM, int CBS, int PREC, int WAVES>
+// f32-input MFMA shading (bit-identical to the fused k_composite).  The 16-bit
+// MFMA modes have their own kernel, k_shade16 below.
+template <int NRB_SEM, int CBS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
-  constexpr bool HALF = PREC == 1;
   constexpr uint32_t G = 16u * CBS;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint32_t S = a.S, C = a.C;
   constexpr uint32_t CSTRIDE = 16 * NRB_SEM + 4;
 
-  constexpr uint32_t WC_FLOATS = PREC == 2   ? COLOR_H_FRAGS * 768
-                                 : PREC == 1 ? COLOR_H_FRAGS * 256
-                                             : 7168;
-  constexpr uint32_t WS_FLOATS = PREC == 2   ? SEM_H_FRAGS(NRB_SEM) * 768
-                                 : PREC == 1 ? SEM_H_FRAGS(NRB_SEM) * 256
-                                             : 1024 + NRB_SEM * 1024;
+  constexpr uint32_t WC_FLOATS = 7168;
+  constexpr uint32_t WS_FLOATS = 1024 + NRB_SEM * 1024;
   float* w_color = cs_smem;
   float* w_sem = w_color + WC_FLOATS;
   constexpr uint32_t per_wave_floats = 16 * CSTRIDE + 64;
@@ -273,15 +281,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
       const float* hp = ((row & ROW_FINE) ? a.h_f : a.h_c) +
                         (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
       p.hv[cb] = *reinterpret_cast<const f32x4*>(hp);
-      if constexpr (PREC == 0) {
-        const float* dd = a.rays_d + (size_t)en.ray[cb] * 3;
-        p.d[cb][0] = dd[0];
-        p.d[cb][1] = dd[1];
-        p.d[cb][2] = dd[2];
-      } else {
-        p.shv[cb] = *reinterpret_cast<const f32x4*>(
-            a.sh + (size_t)en.ray[cb] * 16 + 4 * g);
-      }
+      const float* dd = a.rays_d + (size_t)en.ray[cb] * 3;
+      p.d[cb][0] = dd[0];
+      p.d[cb][1] = dd[1];
+      p.d[cb][2] = dd[2];
     }
   };
 
@@ -297,89 +300,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
     }
     float rgb[CBS][3];
     f32x4 lg[CBS][NRB_SEM];
-    if constexpr (PREC == 2) {
-      // six bf16 partial products per fp32 product: 144 MFMAs (16 cycles
-      // each) per column block instead of 176 f32-input ones (32 cycles).
-      // Layer-major: a weight fragment (three terms, 3 ds_read_b128) is read
-      // once per group and used by all its column blocks.
-      uint32_t zoff = 0;
-      asm volatile("" : "+v"(zoff));  // keep the 72 fragments in LDS
-      const uint32_t wl = lane + zoff;
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      X3 b1[CBS];
-#pragma unroll
-      for (int cb = 0; cb < CBS; ++cb) {
-        split_pair(p.shv[cb][0], p.shv[cb][1], b1[cb], 0);
-        split_pair(p.shv[cb][2], p.shv[cb][3], b1[cb], 1);
-        split_pair(geo[cb][0], geo[cb][1], b1[cb], 2);
-        split_pair(geo[cb][2], geo[cb][3], b1[cb], 3);
-      }
-      f32x4 a1[CBS][4], a2[CBS][4];
-      X3 h0[CBS], h1[CBS];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const W3 w = frag_x3(w_color, rb, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) a1[cb][rb] = mfma_x3(w, b1[cb], z4);
-      }
-#pragma unroll
-      for (int cb = 0; cb < CBS; ++cb) {
-        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
-        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
-      }
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const W3 wa = frag_x3(w_color, 4 + 2 * rb, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = mfma_x3(wa, h0[cb], z4);
-        const W3 wb = frag_x3(w_color, 5 + 2 * rb, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = mfma_x3(wb, h1[cb], a2[cb][rb]);
-      }
-      // semantics L1 reads the h-row slots of b1: its fragments carry zeros
-      // in the SH slots' place (k-slots e >= 4 of the f16 layout <-> e < 4)
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const W3 w = frag_x3(w_sem, rb, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) {
-          X3 bs;
-#pragma unroll
-          for (int term = 0; term < 3; ++term)
-            bs.t[term] = u32x4{b1[cb].t[term][2], b1[cb].t[term][3], 0u, 0u};
-          a1[cb][rb] = mfma_x3(w, bs, z4);
-        }
-      }
-#pragma unroll
-      for (int cb = 0; cb < CBS; ++cb) {
-        h0[cb] = chain_relu_x3(a2[cb][0], a2[cb][1]);
-        h1[cb] = chain_relu_x3(a2[cb][2], a2[cb][3]);
-      }
-      {
-        const W3 wa = frag_x3(w_color, 12, wl), wb = frag_x3(w_color, 13, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) {
-          f32x4 o3 = mfma_x3(wa, h0[cb], z4);
-          o3 = mfma_x3(wb, h1[cb], o3);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
-        }
-      }
-#pragma unroll
-      for (int cb = 0; cb < CBS; ++cb) {
-        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
-        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
-      }
-#pragma unroll
-      for (int rb = 0; rb < NRB_SEM; ++rb) {
-        const W3 wa = frag_x3(w_sem, 4 + 2 * rb, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wa, h0[cb], z4);
-        const W3 wb = frag_x3(w_sem, 5 + 2 * rb, wl);
-#pragma unroll
-        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wb, h1[cb], lg[cb][rb]);
-      }
-    } else if constexpr (!HALF) {
+    {
       {  // colour net 32 -> 64 -> 64 -> 16 (composite.hip, same k order)
         f32x4 acc1[CBS][4];
 #pragma unroll
@@ -496,54 +417,6 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
           }
         }
       }
-    } else {
-      // fp16 weights / layer inputs, fp32 accumulate: 24 MFMAs per column block.
-      // The 24 A fragments (96 VGPRs) are loop-invariant, and the compiler
-      // would keep them in registers for the whole kernel -- 216 VGPRs, two
-      // waves per SIMD, or spills under a smaller budget.  Reading them from
-      // LDS per group costs 24 ds_read_b128 (shared by the group's column
-      // blocks) and lets four waves per SIMD hide this kernel's latency
-      // chains; `zoff` (an opaque zero, re-made per group) keeps the loads
-      // inside the loop.
-      uint32_t zoff = 0;
-      if (WAVES > 8) asm volatile("" : "+v"(zoff));
-      const uint32_t wl = lane + zoff;
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int cb = 0; cb < CBS; ++cb) {
-        half8 b1, bs;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          b1[r] = (_Float16)p.shv[cb][r];
-          b1[4 + r] = (_Float16)geo[cb][r];
-          bs[r] = (_Float16)geo[cb][r];
-          bs[4 + r] = (_Float16)0.f;
-        }
-        f32x4 a1[4], a2[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, wl), b1, z4);
-        half8 h0 = chain_relu_h(a1[0], a1[1]), h1 = chain_relu_h(a1[2], a1[3]);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, wl), h0, z4);
-          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, wl), h1, a2[rb]);
-        }
-        h0 = chain_relu_h(a2[0], a2[1]);
-        h1 = chain_relu_h(a2[2], a2[3]);
-        f32x4 o3 = mfma_h(frag_h(w_color, 12, wl), h0, z4);
-        o3 = mfma_h(frag_h(w_color, 13, wl), h1, o3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, wl), bs, z4);
-        h0 = chain_relu_h(a1[0], a1[1]);
-        h1 = chain_relu_h(a1[2], a1[3]);
-#pragma unroll
-        for (int rb = 0; rb < NRB_SEM; ++rb) {
-          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, wl), h0, z4);
-          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, wl), h1, lg[cb][rb]);
-        }
-      }
     }
 
     // softmax + contributions + per-ray sums in sample order.  Row of entry j
@@ -645,25 +518,475 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade_dense(ShArgs a) {
   if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
 }
 
+
+// ---------------------------------------------------------------------------
+// k_shade16: the colour + semantics nets on the 16-bit matrix pipe -- PREC 1:
+// f16 16x16x32 MFMA (tiny-cuda-nn's numerics), PREC 2: bf16x3 (six bf16 MFMAs
+// per fp32 product, fp32-grade, mfma_mlp_x3.h) -- and the per-ray sums of
+// w*rgb, w*p.  Same list walk and software pipeline as k_shade_dense.
+//
+// The kernel is bound by instruction issue: MFMA cycles and VALU cycles add up
+// on a SIMD, and on gfx950 only the plain fp32 add / mul / fma and the bitwise
+// ops issue at 2 cycles per wave; conversions, shifts, permutes, selects and
+// integer min/max take 4, v_exp / v_rcp 8, and packed fp32 (v_pk_*) costs
+// exactly two plain ones (tools/ubench/valu_rates.hip,
+// profiles/r03_valu_rates.txt).  So every instruction counts:
+//
+//  * per-ray sums in REGISTERS: lane (g, j) keeps partial sums of its own
+//    samples (entry j of every group) for its classes 16 rb + 4 g + r and, in
+//    row g = 0, for r, g, b; they are added over the 16 lanes of a row (four
+//    DPP row rotations per value) once per RAY.  The LDS tile of
+//    k_shade_dense costs 4 wide stores, 16 reads, 16 adds and two waits per
+//    16 samples.  The sums associate differently from the sample-ordered ones
+//    of the fused kernel (ordinary fp32 round-off, ~1e-7).
+//  * the SH operand arrives in MFMA operand form (k_weights_compact converts /
+//    splits it once per ray), 32-bit byte offsets off scalar bases where the
+//    sizes allow (OFF32), padded classes masked once by -inf logits, and the
+//    logits multiplied by log2(e) FIRST: exp2(l' - max') needs no further
+//    multiply, and fmaxf of a product is one v_max_f32 (of an MFMA result the
+//    compiler first quiets a possible signalling NaN: two more per max).
+//    No inline-asm VALU next to MFMAs: the hazard recogniser does not see it.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(
+                 0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float x) {
+  x = dpp_add<0x128>(x);  // row_ror:8
+  x = dpp_add<0x124>(x);  // row_ror:4
+  x = dpp_add<0x122>(x);  // row_ror:2
+  x = dpp_add<0x121>(x);  // row_ror:1
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ T ld_off32(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
+#define UCSA_LOG2E 1.4426950408889634f
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int CBS>
+struct Ent16 {
+  float w[CBS];
+  uint32_t row[CBS];
+  uint32_t ray[CBS];
+};
+template <int CBS, int PREC>
+struct Pre16 {
+  float ew[CBS];
+  uint32_t eray[CBS];
+  f32x4 hv[CBS];
+  u32x2 sh[CBS][PREC == 2 ? 3 : 1];  // this lane's 4 SH k-slots, operand form
+};
+
+// The sums of one ray: add the partial sums of the 16 lanes of every row, lane
+// j == 0 of row g stores classes 16 rb + 4 g + r (and row 0 r, g, b).  Once per
+// ray and out of line: the shading loop stays small.
+template <int NRB_SEM>
+struct Acc16 {  // by value: stays in VGPRs across the call
+  f32x4 s[NRB_SEM];
+  float c[3];
+};
+template <int NRB_SEM>
+__device__ __attribute__((noinline)) void shade16_flush(
+    Acc16<NRB_SEM> acc, uint32_t ray, uint32_t C, float* __restrict__ semantics,
+    float* __restrict__ image, uint32_t lane) {
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  f32x4 o[NRB_SEM];
+#pragma unroll
+  for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[rb][r] = row16_sum(acc.s[rb][r]);
+  float c3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) c3[c] = row16_sum(acc.c[c]);
+  if (j == 0) {
+    float* dst = semantics + (size_t)ray * C;
+#pragma unroll
+    for (int rb = 0; rb < NRB_SEM; ++rb) {
+      const uint32_t c0 = rb * 16 + 4 * g;
+      if ((C & 3u) == 0u) {  // rows are 16-byte aligned: whole quads
+        if (c0 < C) *reinterpret_cast<f32x4*>(dst + c0) = o[rb];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + r < C) dst[c0 + r] = o[rb][r];
+      }
+    }
+    if (g == 0) {
+      float* im = image + (size_t)ray * 3;
+      im[0] = c3[0];
+      im[1] = c3[1];
+      im[2] = c3[2];
+    }
+  }
+}
+
+template <int NRB_SEM, int CBS, int PREC, int WAVES, bool OFF32>
+__global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
+  static_assert(PREC == 1 || PREC == 2, "16-bit MFMA modes");
+  constexpr uint32_t G = 16u * CBS;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint32_t S = a.S, C = a.C;
+
+  constexpr uint32_t WC_FLOATS = PREC == 2 ? COLOR_H_FRAGS * 768 : COLOR_H_FRAGS * 256;
+  constexpr uint32_t WS_FLOATS =
+      PREC == 2 ? SEM_H_FRAGS(NRB_SEM) * 768 : SEM_H_FRAGS(NRB_SEM) * 256;
+  float* w_color = cs_smem;
+  float* w_sem = w_color + WC_FLOATS;
+  for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
+    w_color[i] = a.packed_color[i];
+  for (uint32_t i = threadIdx.x; i < WS_FLOATS; i += blockDim.x)
+    w_sem[i] = a.packed_sem[i];
+  __syncthreads();
+
+  const uint64_t gwave = (uint64_t)blockIdx.x * WAVES + wid;
+  const uint64_t r_begin64 = gwave * a.rays_per_wave;
+  if (r_begin64 >= a.N) return;
+  const uint32_t total =
+      (uint32_t)__builtin_amdgcn_readfirstlane((int)a.counts[gwave]);
+  if (total == 0) return;
+  // the wave's region of the survivor lists: scalar bases, 32-bit offsets
+  const size_t lbase = (size_t)r_begin64 * S;
+  const float* lw = a.list_w + lbase;
+  const uint32_t* lrow = a.list_row + lbase;
+  const uint32_t* lray = a.list_ray + lbase;
+  constexpr uint32_t SH_BYTES = PREC == 2 ? 96u : 32u;  // per ray
+
+  uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose partial sums sit in accS / accC
+  f32x4 accS[NRB_SEM];             // classes 16 rb + 4 g + r, entries j, j+16, ...
+  float accC[3];                   // r, g, b (row g == 0)
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < NRB_SEM; ++rb) accS[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accC[0] = accC[1] = accC[2] = 0.0f;
+  };
+  zero_acc();
+  auto flush_ray = [&](uint32_t ray) {  // also zeroes the accumulators
+    Acc16<NRB_SEM> v;
+#pragma unroll
+    for (int rb = 0; rb < NRB_SEM; ++rb) v.s[rb] = accS[rb];
+    v.c[0] = accC[0];
+    v.c[1] = accC[1];
+    v.c[2] = accC[2];
+    shade16_flush<NRB_SEM>(v, ray, C, a.semantics, a.image, lane);
+    zero_acc();
+  };
+
+  // stage 1: list entries (past `total`: the last real one at weight 0)
+  auto load_entries = [&](uint32_t gb, Ent16<CBS>& en) {
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      uint32_t e = gb + cb * 16 + j;
+      const bool live = e < total;
+      if (!live) e = total - 1;
+      const uint32_t off = e * 4u;
+      const float w = ld_off32<float>(lw, off);
+      en.w[cb] = live ? w : 0.0f;
+      en.row[cb] = ld_off32<uint32_t>(lrow, off);
+      en.ray[cb] = ld_off32<uint32_t>(lray, off);
+    }
+  };
+  // stage 2: h rows and SH operands of entries that have arrived
+  auto load_operands = [&](const Ent16<CBS>& en, Pre16<CBS, PREC>& p) {
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      p.ew[cb] = en.w[cb];
+      p.eray[cb] = en.ray[cb];
+      const uint32_t row = en.row[cb];
+      const bool fine = (row & ROW_FINE) != 0u;
+      const uint32_t r0 = row & ~ROW_FINE;
+      if constexpr (OFF32) {
+        const char* hb = reinterpret_cast<const char*>(fine ? a.h_f : a.h_c);
+        p.hv[cb] = *reinterpret_cast<const f32x4*>(hb + ((r0 << 6) | (g << 4)));
+        const uint32_t so = en.ray[cb] * SH_BYTES + 8u * g;
+#pragma unroll
+        for (int term = 0; term < (PREC == 2 ? 3 : 1); ++term)
+          p.sh[cb][term] = ld_off32<u32x2>(a.sh, so + 32u * term);
+      } else {
+        const float* hp = (fine ? a.h_f : a.h_c) + (size_t)r0 * 16 + 4 * g;
+        p.hv[cb] = *reinterpret_cast<const f32x4*>(hp);
+        const char* sp = reinterpret_cast<const char*>(a.sh) +
+                         (size_t)en.ray[cb] * SH_BYTES + 8u * g;
+#pragma unroll
+        for (int term = 0; term < (PREC == 2 ? 3 : 1); ++term)
+          p.sh[cb][term] = *reinterpret_cast<const u32x2*>(sp + 32 * term);
+      }
+    }
+  };
+
+  // classes of the last row block beyond C (per lane, loop-invariant)
+  bool pad[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pad[r] = (uint32_t)((NRB_SEM - 1) * 16 + 4 * g + r) >= C;
+  const int xor16 = (int)((lane ^ 16u) << 2), xor32 = (int)((lane ^ 32u) << 2);
+
+  auto shade = [&](const Pre16<CBS, PREC>& p) {
+    float geo[CBS][4];
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      geo[cb][0] = (g == 0) ? 1.0f : p.hv[cb][0];  // slot m == 0 -> the "ones" pad
+      geo[cb][1] = p.hv[cb][1];
+      geo[cb][2] = p.hv[cb][2];
+      geo[cb][3] = p.hv[cb][3];
+    }
+    f32x4 o3[CBS];
+    f32x4 lg[CBS][NRB_SEM];
+    // the weight fragments stay in LDS (`zoff`: an opaque zero re-made per
+    // group keeps the loads inside the loop instead of 96+ pinned VGPRs)
+    uint32_t zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const uint32_t wl = lane + zoff;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PREC == 2) {
+      // layer-major: a weight fragment (three terms, 3 ds_read_b128) is read
+      // once per group and used by all its column blocks
+      X3 b1[CBS];
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+          b1[cb].t[term][0] = p.sh[cb][term][0];
+          b1[cb].t[term][1] = p.sh[cb][term][1];
+        }
+        split_pair(geo[cb][0], geo[cb][1], b1[cb], 2);
+        split_pair(geo[cb][2], geo[cb][3], b1[cb], 3);
+      }
+      f32x4 a1[CBS][4], a2[CBS][4];
+      X3 h0[CBS], h1[CBS];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const W3 w = frag_x3(w_color, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a1[cb][rb] = mfma_x3(w, b1[cb], z4);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
+        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const W3 wa = frag_x3(w_color, 4 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = mfma_x3(wa, h0[cb], z4);
+        const W3 wb = frag_x3(w_color, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = mfma_x3(wb, h1[cb], a2[cb][rb]);
+      }
+      // semantics L1 reads the h-row slots of b1: its fragments carry zeros
+      // in the SH slots' place (k-slots e >= 4 of the f16 layout <-> e < 4)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const W3 w = frag_x3(w_sem, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          X3 bs;
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+            bs.t[term] = u32x4{b1[cb].t[term][2], b1[cb].t[term][3], 0u, 0u};
+          a1[cb][rb] = mfma_x3(w, bs, z4);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = chain_relu_x3(a2[cb][0], a2[cb][1]);
+        h1[cb] = chain_relu_x3(a2[cb][2], a2[cb][3]);
+      }
+      {
+        const W3 wa = frag_x3(w_color, 12, wl), wb = frag_x3(w_color, 13, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          o3[cb] = mfma_x3(wa, h0[cb], z4);
+          o3[cb] = mfma_x3(wb, h1[cb], o3[cb]);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
+        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb) {
+        const W3 wa = frag_x3(w_sem, 4 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wa, h0[cb], z4);
+        const W3 wb = frag_x3(w_sem, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wb, h1[cb], lg[cb][rb]);
+      }
+    } else {
+      // fp16 weights / layer inputs, fp32 accumulate: 24 MFMAs per column block
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        const uint32_t g01 = __builtin_bit_cast(uint32_t, cvt_pk_h(geo[cb][0], geo[cb][1]));
+        const uint32_t g23 = __builtin_bit_cast(uint32_t, cvt_pk_h(geo[cb][2], geo[cb][3]));
+        const half8 b1 = __builtin_bit_cast(half8, u32x4{p.sh[cb][0][0], p.sh[cb][0][1], g01, g23});
+        const half8 bs = __builtin_bit_cast(half8, u32x4{g01, g23, 0u, 0u});
+        f32x4 a1[4], a2[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, wl), b1, z4);
+        half8 h0 = chain_relu_h(a1[0], a1[1]), h1 = chain_relu_h(a1[2], a1[3]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, wl), h0, z4);
+          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, wl), h1, a2[rb]);
+        }
+        h0 = chain_relu_h(a2[0], a2[1]);
+        h1 = chain_relu_h(a2[2], a2[3]);
+        o3[cb] = mfma_h(frag_h(w_color, 12, wl), h0, z4);
+        o3[cb] = mfma_h(frag_h(w_color, 13, wl), h1, o3[cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, wl), bs, z4);
+        h0 = chain_relu_h(a1[0], a1[1]);
+        h1 = chain_relu_h(a1[2], a1[3]);
+#pragma unroll
+        for (int rb = 0; rb < NRB_SEM; ++rb) {
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, wl), h0, z4);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, wl), h1, lg[cb][rb]);
+        }
+      }
+    }
+
+    // sigmoid, softmax, weighted partial sums
+#pragma unroll
+    for (int cb = 0; cb < CBS; ++cb) {
+      float rgb[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        rgb[c] = fast_rcp(1.0f + exp2_hw(o3[cb][c] * -UCSA_LOG2E));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (pad[r]) lg[cb][NRB_SEM - 1][r] = -INFINITY;
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg[cb][rb][r] = lg[cb][rb][r] * UCSA_LOG2E;
+      float mx = lg[cb][0][0];
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (rb + r > 0) mx = fmaxf(mx, lg[cb][rb][r]);
+      mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_ds_bpermute(xor16, __float_as_int(mx))) + 0.0f);
+      mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_ds_bpermute(xor32, __float_as_int(mx))) + 0.0f);
+      float sum = 0.0f;
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ex = exp2_hw(lg[cb][rb][r] - mx);
+          lg[cb][rb][r] = ex;
+          sum += ex;
+        }
+      sum += __int_as_float(__builtin_amdgcn_ds_bpermute(xor16, __float_as_int(sum)));
+      sum += __int_as_float(__builtin_amdgcn_ds_bpermute(xor32, __float_as_int(sum)));
+      const float wgt = p.ew[cb];
+      const float ws = wgt * fast_rcp(sum);
+      // the list is sorted by ray: first == last means one ray for all 16
+      const uint32_t ray_a = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], 0);
+      const uint32_t ray_z = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb], 15);
+      if (ray_a == ray_z) {
+        if (ray_a != cur_ray) {
+          if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+          cur_ray = ray_a;
+        }
+#pragma unroll
+        for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            accS[rb][r] = __builtin_fmaf(lg[cb][rb][r], ws, accS[rb][r]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accC[c] = __builtin_fmaf(rgb[c], wgt, accC[c]);
+      } else {
+        uint32_t ray = ray_a;
+        for (;;) {
+          if (ray != cur_ray) {
+            if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+            cur_ray = ray;
+          }
+          const bool mine = p.eray[cb] == ray;
+          const float wsm = mine ? ws : 0.0f, wgm = mine ? wgt : 0.0f;
+#pragma unroll
+          for (int rb = 0; rb < NRB_SEM; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              accS[rb][r] = __builtin_fmaf(lg[cb][rb][r], wsm, accS[rb][r]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) accC[c] = __builtin_fmaf(rgb[c], wgm, accC[c]);
+          const unsigned long long later = __ballot(p.eray[cb] > ray) & 0xFFFFull;
+          if (later == 0ull) break;
+          ray = (uint32_t)__builtin_amdgcn_readlane((int)p.eray[cb],
+                                                    (int)__builtin_ctzll(later));
+        }
+      }
+    }
+  };
+
+  Ent16<CBS> e1, e2;
+  Pre16<CBS, PREC> p0, p1;
+  load_entries(0u, e1);
+  load_operands(e1, p0);
+  load_entries(G, e1);
+  for (uint32_t gb = 0; gb < total; gb += 2 * G) {
+    load_entries(gb + 2 * G, e2);
+    load_operands(e1, p1);
+    shade(p0);
+    if (gb + G >= total) break;
+    load_entries(gb + 3 * G, e1);
+    load_operands(e2, p0);
+    shade(p1);
+  }
+  if (cur_ray != 0xFFFFFFFFu) flush_ray(cur_ray);
+}
+
 static inline uint32_t cs_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
 
 extern "C" uint64_t ucsa_composite_infer_workspace_bytes(uint32_t N, uint32_t T,
                                                          uint32_t t) {
   const uint64_t S = (uint64_t)T + t;
   return (((uint64_t)N * S * 12 + 255) & ~255ull) + (((uint64_t)N * 4 + 255) & ~255ull) +
-         (uint64_t)N * 64;
+         (uint64_t)N * 96;  // per-ray SH operands: 32 B (f16) or 3 x 32 B (bf16x3)
 }
 
-template <int NRB, int CBS, int H, int WAVES>
+template <int NRB, int CBS, int WAVES>
 static int32_t launch_shade(const ShArgs& a, uint32_t blocks, size_t smem,
                             hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&k_shade_dense<NRB, CBS, H, WAVES>),
+      reinterpret_cast<const void*>(&k_shade_dense<NRB, CBS, WAVES>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return -(int32_t)e;
   UCSA_CLEAR_ERR();
-  hipLaunchKernelGGL((k_shade_dense<NRB, CBS, H, WAVES>), dim3(blocks),
+  hipLaunchKernelGGL((k_shade_dense<NRB, CBS, WAVES>), dim3(blocks),
                      dim3(64 * WAVES), smem, s, a);
+  return ucsa_launch_status();
+}
+
+template <int NRB, int CBS, int PREC, int WAVES>
+static int32_t launch_shade16(const ShArgs& a, uint32_t n_waves, bool off32,
+                              hipStream_t s) {
+  const size_t smem = (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(NRB)) *
+                      (PREC == 2 ? 768 : 256) * 4;
+  const uint32_t blocks = ucsa_div_up(n_waves, WAVES);
+  const void* fn = off32
+      ? reinterpret_cast<const void*>(&k_shade16<NRB, CBS, PREC, WAVES, true>)
+      : reinterpret_cast<const void*>(&k_shade16<NRB, CBS, PREC, WAVES, false>);
+  hipError_t e = hipFuncSetAttribute(
+      fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return -(int32_t)e;
+  UCSA_CLEAR_ERR();
+  if (off32)
+    hipLaunchKernelGGL((k_shade16<NRB, CBS, PREC, WAVES, true>), dim3(blocks),
+                       dim3(64 * WAVES), smem, s, a);
+  else
+    hipLaunchKernelGGL((k_shade16<NRB, CBS, PREC, WAVES, false>), dim3(blocks),
+                       dim3(64 * WAVES), smem, s, a);
   return ucsa_launch_status();
 }
 
@@ -697,33 +1020,23 @@ static int32_t composite_infer(int prec, const float* rays_d,
   UCSA_CHECK_ARG(ws, 18);
   if (N == 0) return 0;
   const uint32_t S = T + t;
-  const bool half = prec == 1;
   hipStream_t s = (hipStream_t)stream;
   char* wp = (char*)ws;
   float* list_w = (float*)wp;
   uint32_t* list_row = (uint32_t*)(wp + (size_t)N * S * 4);
   uint32_t* list_ray = (uint32_t*)(wp + (size_t)N * S * 8);
   uint32_t* counts = (uint32_t*)(wp + (((size_t)N * S * 12 + 255) & ~(size_t)255));
-  float* sh = prec == 0 ? nullptr
-                        : (float*)((char*)counts + (((size_t)N * 4 + 255) & ~(size_t)255));
+  void* sh = prec == 0 ? nullptr
+                       : (void*)((char*)counts + (((size_t)N * 4 + 255) & ~(size_t)255));
   const uint32_t nrb = cs_pad16(n_classes) / 16;
   const uint32_t cstride = 16 * nrb + 4;  // k_shade_dense's CSTRIDE
   const int variant = shade_variant();
-  // (waves per workgroup, column blocks per group); measured on the bench's
-  // 61 440-ray chunk, k_weights_compact (0.13 ms) included:
-  // fp16: 0 = (16, 1): 0.94 ms  <- default: 120 VGPRs, 4 waves per SIMD
-  //       1 = (8, 2): 1.17 (216 VGPRs: the compiler keeps the 24 weight
-  //           fragments in registers), 2 = (8, 4): 1.31, 3 = (12, 2): 2.30
-  //           (spills), 4 = (16, 2): 3.7 (spills)
-  // fp32: 0 = (16, 1): 2.49, 1 = (12, 2): 2.85, 2 = (8, 2): 2.63 -- all behind
-  //       the fused k_composite (2.33), which ucsa_render_fwd keeps for fp32
-  // bf16x3: 0 = (8, 2): 1.57 ms  <- default (a weight fragment, three terms,
-  //           read once for both column blocks), 1 = (16, 1): 1.60,
-  //           2 = (12, 2): 1.80, 3 = (12, 1): 1.74, 4 = (8, 4): 1.90
-  const uint32_t waves =
-      prec == 2 ? (variant == 1 ? 16u : ((variant == 2 || variant == 3) ? 12u : 8u))
-      : half    ? ((variant == 0 || variant == 4) ? 16u : (variant == 3 ? 12u : 8u))
-                : (variant == 0 ? 16u : (variant == 1 ? 12u : 8u));
+  // (waves per workgroup, column blocks per group) of the shading kernel;
+  // UCSA_SHADE_VARIANT picks another shape for experiments
+  // (tools/composite_split_bench.py), results do not depend on it.
+  //   fp32 (k_shade_dense): 0 = (16, 1), 1 = (12, 2), 2 = (8, 2) -- all behind
+  //     the fused k_composite, which ucsa_render_fwd keeps for fp32
+  //   f16 / bf16x3 (k_shade16): see launch table below
   // both kernels use the same ranges of whole rays per wave: enough waves to
   // fill the chip twice over
   const uint64_t total_waves = 256ull * 16 * 2;
@@ -735,7 +1048,7 @@ static int32_t composite_infer(int prec, const float* rays_d,
   {
     WcArgs a{rays_d, norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale,
              depth, list_w, list_row, list_ray, counts, rpw, image, semantics,
-             n_classes, sh};
+             n_classes, sh, (uint32_t)prec};
     const size_t smem = (size_t)WC_WAVES * 4 * S * 4;
     UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
     hipError_t e = hipFuncSetAttribute(
@@ -749,43 +1062,57 @@ static int32_t composite_infer(int prec, const float* rays_d,
     if (rc != 0) return rc;
   }
   // ---- B: dense shading of the survivor lists -------------------------------
-  const size_t w_floats =
-      prec == 2 ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 768
-      : half    ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
-                : 7168 + 1024 + (size_t)nrb * 1024;
-  const size_t per_wave = 16 * (size_t)cstride + 64;
-  const size_t smem = (w_floats + waves * per_wave) * 4;
-  const uint32_t blocks = ucsa_div_up(n_waves, waves);
   ShArgs b{rays_d, h_c, h_f, (const float*)packed_color, (const float*)packed_sem,
            list_w, list_row, list_ray, counts, N, S, n_classes, rpw, image,
            semantics, sh};
-#define SH_GO(NRB)                                                             \
-  do {                                                                         \
-    if (prec == 2) {                                                           \
-      if (variant == 0) return launch_shade<NRB, 2, 2, 8>(b, blocks, smem, s);  \
-      if (variant == 1) return launch_shade<NRB, 1, 2, 16>(b, blocks, smem, s); \
-      if (variant == 2) return launch_shade<NRB, 2, 2, 12>(b, blocks, smem, s); \
-      if (variant == 3) return launch_shade<NRB, 1, 2, 12>(b, blocks, smem, s); \
-      return launch_shade<NRB, 4, 2, 8>(b, blocks, smem, s);                   \
-    }                                                                          \
-    if (half) {                                                                \
-      if (variant == 0) return launch_shade<NRB, 1, 1, 16>(b, blocks, smem, s); \
-      if (variant == 1) return launch_shade<NRB, 2, 1, 8>(b, blocks, smem, s);  \
-      if (variant == 2) return launch_shade<NRB, 4, 1, 8>(b, blocks, smem, s);  \
-      if (variant == 3) return launch_shade<NRB, 2, 1, 12>(b, blocks, smem, s); \
-      return launch_shade<NRB, 2, 1, 16>(b, blocks, smem, s);                  \
-    }                                                                          \
-    if (variant == 0) return launch_shade<NRB, 1, 0, 16>(b, blocks, smem, s);  \
-    if (variant == 1) return launch_shade<NRB, 2, 0, 12>(b, blocks, smem, s);  \
-    return launch_shade<NRB, 2, 0, 8>(b, blocks, smem, s);                     \
+  if (prec == 0) {
+    const uint32_t waves = variant == 0 ? 16u : (variant == 1 ? 12u : 8u);
+    const size_t w_floats = 7168 + 1024 + (size_t)nrb * 1024;
+    const size_t per_wave = 16 * (size_t)cstride + 64;
+    const size_t smem = (w_floats + waves * per_wave) * 4;
+    const uint32_t blocks = ucsa_div_up(n_waves, waves);
+#define SH_GO(NRB)                                                         \
+  do {                                                                     \
+    if (variant == 0) return launch_shade<NRB, 1, 16>(b, blocks, smem, s); \
+    if (variant == 1) return launch_shade<NRB, 2, 12>(b, blocks, smem, s); \
+    return launch_shade<NRB, 2, 8>(b, blocks, smem, s);                    \
+  } while (0)
+    switch (nrb) {
+      case 1: SH_GO(1);
+      case 2: SH_GO(2);
+      case 3: SH_GO(3);
+      default: SH_GO(4);
+    }
+#undef SH_GO
+  }
+  // 32-bit byte offsets into h (64 B per sample) and the SH operands (<= 96 B
+  // per ray) when the launch is small enough -- it is for every chunk render()
+  // makes; the 64-bit form covers the rest of the C API's range
+  const uint64_t rows = (uint64_t)N * (T > t ? T : t);
+  const bool off32 = rows * 64 < (1ull << 32) && (uint64_t)N * 96 < (1ull << 32);
+  // measured on the bench's 61 440-ray chunk (ms, k_weights_compact included):
+  //   f16:    0 = (16 waves, 1 block)   1 = (8, 2)   2 = (8, 1)   3 = (12, 1)
+  //   bf16x3: 0 = (8, 2)   1 = (16, 1)   2 = (12, 1)   3 = (8, 1)
+#define SH_GO16(NRB)                                                                \
+  do {                                                                              \
+    if (prec == 2) {                                                                \
+      if (variant == 1) return launch_shade16<NRB, 1, 2, 16>(b, n_waves, off32, s); \
+      if (variant == 2) return launch_shade16<NRB, 1, 2, 12>(b, n_waves, off32, s); \
+      if (variant == 3) return launch_shade16<NRB, 1, 2, 8>(b, n_waves, off32, s);  \
+      return launch_shade16<NRB, 2, 2, 8>(b, n_waves, off32, s);                    \
+    }                                                                               \
+    if (variant == 1) return launch_shade16<NRB, 2, 1, 8>(b, n_waves, off32, s);    \
+    if (variant == 2) return launch_shade16<NRB, 1, 1, 8>(b, n_waves, off32, s);    \
+    if (variant == 3) return launch_shade16<NRB, 1, 1, 12>(b, n_waves, off32, s);   \
+    return launch_shade16<NRB, 1, 1, 16>(b, n_waves, off32, s);                     \
   } while (0)
   switch (nrb) {
-    case 1: SH_GO(1);
-    case 2: SH_GO(2);
-    case 3: SH_GO(3);
-    default: SH_GO(4);
+    case 1: SH_GO16(1);
+    case 2: SH_GO16(2);
+    case 3: SH_GO16(3);
+    default: SH_GO16(4);
   }
-#undef SH_GO
+#undef SH_GO16
 }
 
 extern "C" int32_t ucsa_composite_infer(

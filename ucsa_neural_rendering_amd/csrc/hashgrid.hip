@@ -11,6 +11,9 @@
 //    stores 512 contiguous bytes; the sigma-MLP kernel reads the same way.
 //  * One lane per sample; lanes of a wave are consecutive samples of one ray,
 //    which share cells on the coarse levels (the TA coalesces equal lines).
+#include <cstdlib>
+#include <cstring>
+
 #include "hashgrid_common.h"
 
 // the features are written once and read once by the next kernel: streamed
@@ -133,9 +136,19 @@ k_hashgrid_encode(GridDev g, uint32_t level0,
 // (64 B of z, 128 B of features per ray).  Arithmetic per sample is unchanged:
 // the features are bit-identical to k_hashgrid_encode's.
 #define TILE_S 16
+// Which level a workgroup works on: grid row y holds the `k` levels
+// lv[y * k .. y * k + k - 1], interleaved along x (workgroup x -> level
+// x % k).  k = 1 with the identity map is plain level-major order (the whole
+// chip on one table slice at a time); k = 2 pairing a coarse level with a
+// fine one puts a VALU-bound and a gather-bound workgroup on the same CU at
+// the same time.
+struct LevelMap {
+  uint8_t lv[UCSA_MAX_LEVELS];
+  uint32_t k;
+};
 template <typename TT = float2, typename FT = float2>
 __global__ void __launch_bounds__(256)
-k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
+k_hashgrid_encode_tiled(GridDev g, LevelMap lm,
                         const TT* __restrict__ table,
                         const float* __restrict__ rays_o,
                         const float* __restrict__ rays_d,
@@ -144,9 +157,10 @@ k_hashgrid_encode_tiled(GridDev g, uint32_t level0,
                         FT* __restrict__ feat) {
   __shared__ float z_s[64][TILE_S + 1];
   __shared__ FT f_s[64][TILE_S + 1];
-  const uint32_t level = level0 + blockIdx.y;
+  const uint32_t level = lm.lv[blockIdx.y * lm.k + blockIdx.x % lm.k];
+  const uint32_t bx = blockIdx.x / lm.k;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-  const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
+  const uint32_t sb = bx % s_blocks, tile = bx / s_blocks;
   const uint32_t tiles_x = (W + 7u) / 8u;
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
   const uint32_t s0 = sb * TILE_S;
@@ -252,6 +266,44 @@ extern "C" int32_t ucsa_hashgrid_encode_rays(
                              ucsa_aabb(aabb_host), T, M, feat, stream);
 }
 
+// Level order of the tiled kernel (see LevelMap).  Default: level-major,
+// FINEST level first -- one table slice at a time (it stays in each XCD's L2),
+// and the launch ends on the cheap coarse levels instead of draining the
+// slowest one: 0.80 vs 0.84 ms for the coarse pass of a 61 440-ray chunk,
+// fine pass unchanged.  Interleaving levels (k > 1) is slower in every
+// pairing tried (1.0 - 1.6 ms / 2.1 - 2.4 ms: two 4 MiB slices thrash the L2;
+// profiles/r03_encode_level_order.txt).  UCSA_ENC_ORDER (experiments only;
+// results do not depend on it): "k:l0,l1,..." = k levels per grid row in the
+// given order.
+static LevelMap level_map(uint32_t L) {
+  LevelMap lm;
+  lm.k = 1;
+  for (uint32_t i = 0; i < UCSA_MAX_LEVELS; ++i) lm.lv[i] = (uint8_t)(i < L ? L - 1 - i : 0);
+  const char* e = getenv("UCSA_ENC_ORDER");
+  if (e && *e) {
+    const uint32_t k = (uint32_t)strtoul(e, nullptr, 10);
+    const char* c = strchr(e, ':');
+    if (k >= 1 && L % k == 0 && c) {
+      uint32_t seen = 0, n = 0;
+      uint8_t lv[UCSA_MAX_LEVELS];
+      ++c;
+      while (*c && n < L) {
+        char* end;
+        const unsigned long v = strtoul(c, &end, 10);
+        if (end == c || v >= L || (seen >> v & 1u)) break;
+        lv[n++] = (uint8_t)v;
+        seen |= 1u << v;
+        c = (*end == ',') ? end + 1 : end;
+      }
+      if (n == L) {  // a full permutation: accept
+        lm.k = k;
+        for (uint32_t i = 0; i < L; ++i) lm.lv[i] = lv[i];
+      }
+    }
+  }
+  return lm;
+}
+
 // image_width > 0: rays are the pixels of full rows of an image that wide
 template <typename TT = float2, typename FT = float2>
 static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
@@ -277,11 +329,12 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
     const uint32_t rows = ucsa_div_up(N, image_width);
     const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
     const uint32_t s_blocks = ucsa_div_up(T, TILE_S);
+    const LevelMap lm = level_map(grid->n_levels);
     hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
-                       dim3(tiles * s_blocks, grid->n_levels - nc), dim3(256), 0,
-                       (hipStream_t)stream, gd, nc, (const TT*)table, rays_o,
-                       rays_d, z, bb, T, N, image_width, s_blocks,
-                       (FT*)feat);
+                       dim3(tiles * s_blocks * lm.k, grid->n_levels / lm.k),
+                       dim3(256), 0, (hipStream_t)stream, gd, lm,
+                       (const TT*)table, rays_o, rays_d, z, bb, T, N,
+                       image_width, s_blocks, (FT*)feat);
   }
   return ucsa_launch_status();
 }

@@ -27,6 +27,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // ReLU as ONE instruction (v_max_i32 on the bit pattern: a float is negative
 // iff its bit pattern is a negative integer; -0 -> +0).  fmaxf(x, 0) costs two
 // (the compiler first quiets a possible signalling NaN with v_max_f32 x, x).
+// Not inline asm: the operand usually comes straight out of an MFMA and goes
+// into the next one, and the compiler's hazard recogniser (which inserts the
+// s_nop an MFMA result needs before a VALU may read it) does not look inside
+// asm statements -- measured: wrong results.  v_max_f32 and v_max_i32 issue at
+// the same (half) rate on gfx950 anyway (tools/ubench/valu_rates.hip).
 __device__ __forceinline__ float relu1(float x) {
   const int b = __float_as_int(x);
   return __int_as_float(b > 0 ? b : 0);

@@ -18,19 +18,28 @@ __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// two floats -> two halves (round to nearest even) in one dword: ONE
+// v_cvt_pk_f16_f32 (gfx950) instead of two v_cvt_f16_f32 and a v_perm_b32 --
+// conversions issue at half the rate of plain fp32 arithmetic
+// (tools/ubench/valu_rates.hip)
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2_t cvt_pk_h(float a, float b) {
+  return __builtin_convertvector(f32x2_t{a, b}, half2_t);
+}
+
 // two accumulator blocks (ReLU) -> one 32-wide k-step operand.  Rounding is
 // monotonic and keeps the sign, so the ReLU runs AFTER the conversion, on the
 // packed halves (v_pk_max_i16 on the bit patterns: one instruction per pair).
 __device__ __forceinline__ half8 chain_relu_h(f32x4 lo, f32x4 hi) {
-  half8 v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    v[r] = (_Float16)lo[r];
-    v[4 + r] = (_Float16)hi[r];
-  }
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t w = {__builtin_bit_cast(uint32_t, cvt_pk_h(lo[0], lo[1])),
+                     __builtin_bit_cast(uint32_t, cvt_pk_h(lo[2], lo[3])),
+                     __builtin_bit_cast(uint32_t, cvt_pk_h(hi[0], hi[1])),
+                     __builtin_bit_cast(uint32_t, cvt_pk_h(hi[2], hi[3]))};
   const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   return __builtin_bit_cast(
-      half8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+      half8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w), z));
 }
 
 // A fragment f of a packed fp16 weight buffer (16 B per lane)
