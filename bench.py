@@ -53,6 +53,7 @@ F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak
 F16_MFMA_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA (SURVEY 8d's MLP roofline)
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 PMC_JSON = "profiles/r02_pmc_traffic.json"
+TRAIN_PMC_JSON = "profiles/r03_train_pmc.json"
 
 
 def parse():
@@ -161,6 +162,85 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
     return net.eval(), ds
 
 
+def masked_fraction(net, o, d, nrm, T, t, rt, ru):
+    """rho of a ray batch: fraction of the T + t samples per ray whose weight
+    passes the reference's mask w > 1e-4 (renderer_semantics.py:249-250) --
+    the samples the colour / semantics nets run on.  Staged ops, the
+    composite's own aux weights."""
+    from ucsa_neural_rendering_amd import ops
+    with torch.no_grad():
+        f = net._field()
+        aabb = net._aabb_list(net.training)
+        o, d, nrm = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous(), nrm.reshape(-1).contiguous()
+        N = o.shape[0]
+        near, far = ops.near_far_from_aabb(o, d, aabb)
+        zc = ops.sample_coarse(near, far, T, rt)
+        hc, sc = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zc, aabb),
+                                   f["packed_sigma"])
+        zf = ops.resample(zc, sc.view(N, T), ru)
+        hf, sf = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb),
+                                   f["packed_sigma"])
+        w = ops.composite_fwd(d, nrm, zc, sc.view(N, T), hc, zf, sf.view(N, t), hf,
+                              f["packed_color"], f["packed_sem"], N_CLASSES, 1.0, want_aux=True)[4]
+        return float((w > 1e-4).float().mean())
+
+
+def nerf_train_roofline(n_rays, S, rho, n_params, ms, pmc=None):
+    """fwd + bwd = 3 x the forward flop; bytes = the forward
+    gathers (L x 8 corners x F x 4 B = 1024 B per sample, fp32 table), the
+    same amount scattered into the gradient table by the backward, and Adam's
+    28 B per parameter (read p, g, m, v; write p, m, v)."""
+    flop = 3.0 * n_rays * S * (6144 + rho * 19584)
+    gather = n_rays * S * 1024.0
+    adam = 28.0 * n_params
+    byts = 2 * gather + adam
+    r = {
+        "what": "NeRF training step (fwd + bwd + Adam)",
+        "masked_fraction_rho": rho,
+        "mfma": {"algorithmic_flop": flop, "achieved_tflops": flop / ms / 1e9,
+                 "peak_fp32_mfma_tflops": F32_MFMA_PEAK_TF,
+                 "frac_of_fp32_mfma_peak": flop / ms / 1e9 / F32_MFMA_PEAK_TF,
+                 "frac_of_fp16_dense_peak": flop / ms / 1e9 / F16_MFMA_PEAK_TF},
+        "hbm": {"algorithmic_bytes": byts,
+                "of_which": {"forward_gathers": gather, "backward_scatter": gather,
+                             "adam_28B_per_param": adam},
+                "achieved_gbs": byts / ms / 1e6, "peak_gbs": HBM_PEAK_GBS,
+                "frac": byts / ms / 1e6 / HBM_PEAK_GBS},
+        "bound": "neither line is close: the step is a chain of ~25 launches "
+                 "(gather, MFMA, scatter, Adam phases in turn), each bound by its "
+                 "own resource (DESIGN 5)",
+    }
+    if pmc:
+        r["traffic"] = pmc
+    return r
+
+
+def conv_flops(model, x):
+    """Forward FLOP of the convolutions (2 x MACs) and linear layers of
+    `model` on input `x`, counted with forward hooks on the build's own
+    modules ('FLOPs from a counter on the build's own model')."""
+    total = [0]
+    hooks = []
+
+    def conv_hook(m, inp, out):
+        kh, kw = m.kernel_size
+        total[0] += 2 * out.numel() * (m.in_channels // m.groups) * kh * kw
+
+    def lin_hook(m, inp, out):
+        total[0] += 2 * out.numel() * m.in_features
+
+    for m in model.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            hooks.append(m.register_forward_hook(conv_hook))
+        elif isinstance(m, torch.nn.Linear):
+            hooks.append(m.register_forward_hook(lin_hook))
+    with torch.no_grad():
+        model(x)
+    for h in hooks:
+        h.remove()
+    return total[0]
+
+
 def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256,
                      train_precision="fp32"):
     """cfg3's NeRF half at the reference's native sizes: 4096 rays x (256+256)
@@ -205,10 +285,19 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256,
         one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    rho = masked_fraction(net, o, d, nrm, T, t, rt, ru)
+    n_params = sum(p.numel() for p in net.parameters())
+    pmc = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, TRAIN_PMC_JSON)))
+        pmc = pj.get(train_precision)
+    except (OSError, ValueError):
+        pass
     return {"workload": f"NeRF train step, {n_rays} rays x ({T}+{t}) samples, "
                         "fwd+bwd+Adam (reference native sizes; the 4096 random "
                         "pixels are handed over tile-ordered, ops.tile_order)",
-            "ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt}
+            "ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt,
+            "roofline": nerf_train_roofline(n_rays, T + t, rho, n_params, dt * 1e3, pmc)}
 
 
 def _nerf_optimizer(net, world, replicated=False, comm_dtype=None):
@@ -387,7 +476,22 @@ def seg_throughput(device, steps=5, B=8, find=False):
             one()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        out[mode] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt}
+        if "fwd_flop_per_image" not in out:
+            m.eval()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+                out["fwd_flop_per_image"] = conv_flops(m, x[:1])
+            m.train()
+        flop = 3.0 * B * out["fwd_flop_per_image"]
+        peak = F32_MFMA_PEAK_TF if mode == "fp32" else F16_MFMA_PEAK_TF
+        out[mode] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt,
+                     "roofline": {"bound": "mfma", "algorithmic_flop": flop,
+                                  "achieved": flop / dt / 1e12, "peak": peak,
+                                  "unit": "TFLOP/s", "frac": flop / dt / 1e12 / peak,
+                                  "note": "3 x the forward convolution flop of the "
+                                          "mirror (hook counter, conv_flops) x 8 images "
+                                          "/ step time; peak = " +
+                                          ("fp32-input MFMA (= fp32 vector) rate"
+                                           if mode == "fp32" else "bf16 dense MFMA")}}
         del m, opt
         torch.cuda.empty_cache()
     out["workload"] = ("DeepLabV3-ResNet-101 train step, batch 8 x 3x240x320, "
@@ -1286,6 +1390,52 @@ def main_cfg3(args, dev, dist, world, rank, backend):
         elapsed = float(tt.item())
     dt = elapsed / args.steps
     rays = world * B * (Hh * Ww + 4096)
+    # roofline of the whole joint step: algorithmic flop / bytes of its three
+    # parts over the step time.  rho is measured on 4096 rays of
+    # the first frame of the first batch.
+    roof = None
+    if rank == 0:
+        b0 = batches[0][1] if isinstance(batches[0], (tuple, list)) else batches[0]
+        nb = model.nerf_model
+        g = torch.Generator(device=dev).manual_seed(3)
+        sel = torch.randperm(Hh * Ww, device=dev, generator=g)[:4096]
+        S = 512
+        rho = masked_fraction(nb, b0["rays_o"][0][sel], b0["rays_d"][0][sel],
+                              b0["direction_norms"][0][sel], 256, 256, None,
+                              torch.rand(4096, 256, device=dev, generator=g))
+        per_sample = 6144 + rho * 19584
+        f_render = B * Hh * Ww * S * per_sample
+        f_train = B * 3.0 * 4096 * S * per_sample
+        seg = model.seg_model
+        seg.eval()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(args.seg_amp)):
+            f_seg_fwd = conv_flops(seg, torch.rand(1, 3, Hh, Ww, device=dev))
+        seg.train()
+        f_seg = 3.0 * B * f_seg_fwd
+        n_params = sum(p.numel() for p in nb.parameters())
+        by_render = B * Hh * Ww * (204 + S * 1024.0)
+        by_train = B * (2 * 4096 * S * 1024.0 + 28.0 * n_params)
+        n_seg = sum(p.numel() for p in seg.parameters())
+        by_seg = 28.0 * n_seg      # Adam only: activations are MIOpen's business
+        flop = f_render + f_train + f_seg
+        byts = by_render + by_train + by_seg
+        roof = {
+            "what": "one joint step per rank (ms_per_step)",
+            "masked_fraction_rho": rho,
+            "mfma": {"algorithmic_flop": flop,
+                     "of_which": {"renders_8x320x240x512": f_render,
+                                  "nerf_train_8x4096x512_fwd_bwd": f_train,
+                                  "deeplab_fwd_bwd_8_images": f_seg},
+                     "achieved_tflops": flop / dt / 1e12,
+                     "frac_of_fp32_mfma_peak": flop / dt / 1e12 / F32_MFMA_PEAK_TF,
+                     "frac_of_fp16_dense_peak": flop / dt / 1e12 / F16_MFMA_PEAK_TF},
+            "hbm": {"algorithmic_bytes": byts,
+                    "of_which": {"render_gathers_and_ray_io": by_render,
+                                 "nerf_train_gather_scatter_adam": by_train,
+                                 "deeplab_adam_28B_per_param": by_seg},
+                    "achieved_gbs": byts / dt / 1e9,
+                    "frac": byts / dt / 1e9 / HBM_PEAK_GBS},
+        }
     result = {
         "metric": "rays/sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
@@ -1301,6 +1451,7 @@ def main_cfg3(args, dev, dist, world, rank, backend):
                    "seg_images_per_s": world * B / dt,
                    "optimizer_nerf": type(model.optimizers()[1]).__name__},
         "losses": {k: v for k, v in model.logged.items()},
+        "roofline_step": roof,
     }
     _finish(dist, rank, result)
 
