@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=16384,
+    ap.add_argument("--cpu-rays", type=int, default=32768,
                     help="rays per pass of the CPU baseline (3 passes, median)")
     ap.add_argument("--pretrain-steps", type=int, default=200,
                     help="Adam steps on the synthetic scene before timing "
@@ -437,9 +437,18 @@ def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
 def seg_throughput(device, steps=5, B=8, find=False):
     """cfg3's segmentation half: DeepLabV3-ResNet-101 forward + backward +
     Adam on [8,3,240,320] uniform-random images / labels, with the
-    reference's CE-on-softmax loss through ucsa_seg_tail.  fp32 like the
-    reference (no autocast around seg), and bf16 channels_last as the MI355X
-    fast path.  Convolutions are MIOpen (library-shaped work)."""
+    reference's CE-on-softmax loss through ucsa_seg_tail.
+
+    * ``fp32``: the module's default path -- fp32 like the reference (no
+      autocast around seg), channels-last, every BatchNorm (+ add) (+ ReLU) one
+      fused HIP op (csrc/batchnorm.hip), 1x1 convolutions as one GEMM over the
+      batch; 3x3 / 7x7 convolutions are MIOpen.
+    * ``fp32_nchw_unfused``: the same modules on NCHW inputs, i.e.
+      F.batch_norm + add + relu kernels and MIOpen's per-image 1x1 GEMMs (what
+      rounds 1-2 measured as "fp32").
+    * ``bf16_channels_last``: bf16 autocast, fused BatchNorm in bf16.
+    * ``*_graph``: forward and backward replayed as HIP graphs
+      (torch.cuda.make_graphed_callables); the optimizer step stays eager."""
     from ucsa_neural_rendering_amd import losses as ul
     from ucsa_neural_rendering_amd.network import DeepLabV3
     out = {}
@@ -448,51 +457,68 @@ def seg_throughput(device, steps=5, B=8, find=False):
     before = torch.backends.cudnn.benchmark
     torch.backends.cudnn.benchmark = bool(find)
     out["miopen_find"] = bool(find)
-    for mode in ("fp32", "bf16_channels_last"):
+    for mode in ("fp32", "fp32_nchw_unfused", "bf16_channels_last", "fp32_graph",
+                 "bf16_graph"):
         torch.manual_seed(0)
+        amp = mode.startswith("bf16")
+        nchw = mode == "fp32_nchw_unfused"
         m = DeepLabV3({"pretrained": False, "pretrained_backbone": False,
                        "num_classes": N_CLASSES}).to(device).train()
         x = torch.rand(B, 3, 240, 320, device=device)
-        if mode != "fp32":
+        if not nchw:
             m = m.to(memory_format=torch.channels_last)
             x = x.contiguous(memory_format=torch.channels_last)
         y = torch.randint(-1, N_CLASSES, (B, 240, 320), device=device)
         opt = torch.optim.Adam(m.parameters(), lr=1e-5)
 
+        def net(inp):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                return m(inp)["out"]
+
+        fwd = net
+        try:
+            if mode.endswith("_graph"):
+                fwd = torch.cuda.make_graphed_callables(net, (x.clone().requires_grad_(False),))
+        except Exception as e:  # report, do not hide
+            out[mode] = {"failed": repr(e)[:300]}
+            del m, opt
+            torch.cuda.empty_cache()
+            continue
+
         def one():
-            with torch.autocast("cuda", dtype=torch.bfloat16,
-                                enabled=mode != "fp32"):
-                logits = m(x)["out"]
+            logits = fwd(x)
             loss = ul.seg_loss(logits.float().contiguous(), y)
             opt.zero_grad()
             loss.backward()
             opt.step()
+            return loss
 
         for _ in range(2):
             one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            one()
+            loss = one()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         if "fwd_flop_per_image" not in out:
             m.eval()
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 out["fwd_flop_per_image"] = conv_flops(m, x[:1])
             m.train()
         flop = 3.0 * B * out["fwd_flop_per_image"]
-        peak = F32_MFMA_PEAK_TF if mode == "fp32" else F16_MFMA_PEAK_TF
+        peak = F16_MFMA_PEAK_TF if amp else F32_MFMA_PEAK_TF
         out[mode] = {"ms_per_step": dt * 1e3, "images_per_s": B / dt,
+                     "loss": float(loss),
                      "roofline": {"bound": "mfma", "algorithmic_flop": flop,
                                   "achieved": flop / dt / 1e12, "peak": peak,
                                   "unit": "TFLOP/s", "frac": flop / dt / 1e12 / peak,
                                   "note": "3 x the forward convolution flop of the "
                                           "mirror (hook counter, conv_flops) x 8 images "
                                           "/ step time; peak = " +
-                                          ("fp32-input MFMA (= fp32 vector) rate"
-                                           if mode == "fp32" else "bf16 dense MFMA")}}
-        del m, opt
+                                          ("bf16 dense MFMA" if amp else
+                                           "fp32-input MFMA (= fp32 vector) rate")}}
+        del m, opt, fwd
         torch.cuda.empty_cache()
     out["workload"] = ("DeepLabV3-ResNet-101 train step, batch 8 x 3x240x320, "
                        "CE-on-softmax loss, Adam")
@@ -1256,6 +1282,11 @@ def main():
                                "MFMA (`nerf: {train_precision: fp16}`), sigma net and "
                                "grid fp32")
             result["train_f16_nets"] = tf
+            tx = train_throughput(net, scene_ds, dev, train_precision="bf16x3")
+            tx["workload"] += ("; forward of the colour / semantics stage on the split "
+                               "pair with bf16x3 nets (`nerf: {train_precision: bf16x3}`, "
+                               "fp32-grade), backward unchanged (f32-input MFMA)")
+            result["train_bf16x3_forward"] = tx
             _tick("training legs done")
             result["seg"] = seg_throughput(dev, find=args.seg_find)
             _tick("DeepLab leg done")

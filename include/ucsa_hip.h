@@ -358,6 +358,20 @@ int32_t ucsa_composite_infer_x3(const float* rays_d, const float* norms,
                                 float* depth, float* semantics,
                                 void* workspace, void* stream);
 
+/* Training forward of the same stage on the split pair with the bf16x3 nets:
+ * outputs of ucsa_composite_fwd plus its aux arrays src [N, T + t] (int32
+ * source index of every depth-sorted sample: < T coarse, else T + fine index)
+ * and w [N, T + t] (its weight) for ucsa_composite_bwd.  Reference:
+ * renderer_semantics.py:220-299 as called from forward_nerf_train
+ * (joint_train_lightning_net.py:167-223). */
+int32_t ucsa_composite_train_fwd_x3(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_x3,
+    const void* packed_sem_x3, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, int32_t* src, float* w, void* workspace, void* stream);
+
 /* ======================= fp16-MFMA inference option ======================== */
 /* tiny-cuda-nn evaluates the three MLPs with fp16 weights / layer inputs and
  * fp32 accumulation; the entry points below do the same (16x16x32 f16 MFMA)
@@ -558,6 +572,39 @@ int32_t ucsa_seg_tail(const float* logits, const int64_t* labels, uint32_t B,
                       uint32_t C, uint32_t P, float grad_scale, float* prob,
                       int64_t* argmax, float* loss, float* d_logits,
                       float* partial, void* stream);
+
+/* ============ fused BatchNorm2d (+ residual) (+ ReLU), channels-last ======
+ * The memory-bound passes between DeepLabV3's convolutions (row a14;
+ * reference nr4seg/network/deeplabv3.py:6-19 -> torchvision's bottlenecks:
+ * conv -> BatchNorm2d -> ReLU and conv -> BatchNorm2d -> (+ identity) -> ReLU;
+ * replaces torch.nn.functional.batch_norm + add + relu and their backward
+ * kernels).  Activations are NHWC, i.e. row-major [M = N*H*W][C], C % 4 == 0,
+ * 16-byte aligned; dtype 0 = fp32, 1 = bf16 (statistics, gamma / beta and all
+ * sums are fp32 / double either way).
+ *
+ * forward:  y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
+ *   training != 0: batch statistics (biased variance); running_mean /
+ *     running_var (may both be NULL) updated as torch.nn.BatchNorm2d does
+ *     (momentum, unbiased variance); save_mean / save_invstd [C] written for
+ *     the backward.
+ *   training == 0: the running statistics normalise; save_* untouched.
+ * backward: g = dy * (y > 0) when relu (y = the forward's output), else dy;
+ *   dresidual (may be NULL) = g; dbeta = sum g; dgamma = sum g * xhat;
+ *   dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M)   (training mode).
+ * workspace: ucsa_bn_workspace_bytes(M, C) bytes, caller-owned. */
+uint64_t ucsa_bn_workspace_bytes(uint32_t M, uint32_t C);
+int32_t ucsa_bn_act_fwd(const void* x, const void* residual, const float* gamma,
+                        const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps,
+                        uint32_t M, uint32_t C, int32_t relu, int32_t training,
+                        int32_t dtype, void* y, float* save_mean,
+                        float* save_invstd, void* workspace, void* stream);
+int32_t ucsa_bn_act_bwd(const void* dy, const void* x, const void* y,
+                        const float* gamma, const float* save_mean,
+                        const float* save_invstd, uint32_t M, uint32_t C,
+                        int32_t relu, int32_t dtype, void* dx, void* dresidual,
+                        float* dgamma, float* dbeta, void* workspace,
+                        void* stream);
 
 /* Confusion matrix, rows = truth, truth == -1 dropped (reference
  * nr4seg/utils/metrics.py:31-46); adds into cm [C,C] int64. */

@@ -1,0 +1,145 @@
+"""``FusedBatchNorm2d`` (ucsa_bn_act_fwd / ucsa_bn_act_bwd, csrc/batchnorm.hip)
+against ``torch.nn.BatchNorm2d`` + add + ReLU evaluated in fp64 on the CPU:
+outputs, every gradient (input, residual, gamma, beta), the running statistics
+and ``num_batches_tracked`` -- training and eval mode, fp32 and bf16, with and
+without the residual / the ReLU, channel counts from 4 to 2048, row counts that
+are not multiples of the workgroup tiling.  ``-m gpu``.
+
+Reference behaviour mirrored: torchvision's Bottleneck (conv -> BN -> ReLU,
+conv -> BN -> (+ identity) -> ReLU) inside the model of reference
+``nr4seg/network/deeplabv3.py:6-19``."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ucsa_neural_rendering_amd.network.fused_bn import FusedBatchNorm2d, _fusable
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x, res, bn64, relu):
+    y = bn64(x)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 30, 40), (2, 4, 3, 5), (3, 256, 17, 9),
+                                   (8, 2048, 6, 5), (1, 72, 1, 7), (4, 128, 60, 80)])
+@pytest.mark.parametrize("use_res,relu", [(False, True), (True, True), (False, False), (True, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_forward_backward_and_running_stats(shape, use_res, relu, dtype):
+    torch.manual_seed(sum(shape))
+    N, C, H, W = shape
+    dev = torch.device("cuda:0")
+    bn = FusedBatchNorm2d(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    ref = nn.BatchNorm2d(C).double().train()
+    ref.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.cpu()
+                         for k, v in bn.state_dict().items()})
+    x = (torch.randn(shape) * 1.7 + 0.3).to(dtype)
+    r = torch.randn(shape).to(dtype) if use_res else None
+    dy = torch.randn(shape).to(dtype)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rg = None if r is None else r.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    assert _fusable(xg)
+    y = bn(xg, residual=rg, relu=relu)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy.to(dev).contiguous(memory_format=torch.channels_last))
+    x64 = x.double().requires_grad_()
+    r64 = None if r is None else r.double().requires_grad_()
+    y64 = _reference(x64, r64, ref, relu)
+    y64.backward(dy.double())
+    # tolerances: fp32 -- round-off of ~N*H*W-term sums; bf16 -- the output /
+    # gradient rounding to 8 bits (2^-8 relative) dominates
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    scale = float(y64.abs().max())
+    assert float((y.detach().cpu().double() - y64.detach()).abs().max()) <= tol * max(1.0, scale)
+    gscale = float(x64.grad.abs().max())
+    assert float((xg.grad.cpu().double() - x64.grad).abs().max()) <= tol * max(1.0, gscale)
+    if use_res:
+        assert float((rg.grad.cpu().double() - r64.grad).abs().max()) <= tol * max(1.0, float(r64.grad.abs().max()))
+    M = N * H * W
+    wtol = (1e-4 if dtype == torch.float32 else 2e-2) * max(1.0, M ** 0.5)
+    assert float((bn.weight.grad.cpu().double() - ref.weight.grad).abs().max()) <= wtol
+    assert float((bn.bias.grad.cpu().double() - ref.bias.grad).abs().max()) <= wtol
+    # running statistics as nn.BatchNorm2d updates them (unbiased variance)
+    stol = 1e-5 if dtype == torch.float32 else 1e-5
+    assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) <= stol * 10
+    assert float((bn.running_var.cpu().double() - ref.running_var).abs().max()) <= stol * 30
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_mode_uses_the_running_statistics(dtype):
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    shape = (4, 96, 12, 20)
+    bn = FusedBatchNorm2d(96).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.5, 0.5)
+        bn.running_var.uniform_(0.3, 2.0)
+    before = {k: v.clone() for k, v in bn.state_dict().items()}
+    x = torch.randn(shape).to(dtype)
+    r = torch.randn(shape).to(dtype)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rg = r.to(dev).contiguous(memory_format=torch.channels_last)
+    y = bn(xg, residual=rg, relu=True)
+    y.sum().backward()
+    ref = nn.BatchNorm2d(96).double().eval()
+    ref.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu()
+                         for k, v in before.items()})
+    x64 = x.double().requires_grad_()
+    y64 = F.relu(ref(x64) + r.double())
+    y64.sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert float((y.detach().cpu().double() - y64.detach()).abs().max()) <= tol * max(1.0, float(y64.abs().max()))
+    assert float((xg.grad.cpu().double() - x64.grad).abs().max()) <= tol * max(1.0, float(x64.grad.abs().max()))
+    for k, v in bn.state_dict().items():          # eval mode touches no buffer
+        assert torch.equal(v, before[k]), k
+
+
+def test_fallback_path_equals_plain_modules_on_cpu_and_nchw():
+    torch.manual_seed(1)
+    bn = FusedBatchNorm2d(8).train()
+    ref = nn.BatchNorm2d(8).train()
+    ref.load_state_dict(bn.state_dict())
+    x, r = torch.randn(3, 8, 5, 6), torch.randn(3, 8, 5, 6)
+    assert not _fusable(x)
+    assert torch.equal(bn(x, residual=r, relu=True), F.relu(ref(x) + r))
+    assert torch.equal(bn.running_var, ref.running_var)
+    # a contiguous (NCHW) CUDA tensor also takes the fallback
+    assert not _fusable(x.cuda())
+
+
+def test_bottleneck_of_the_mirror_runs_the_fused_path_and_matches_nchw():
+    """One torchvision-style bottleneck of the DeepLab mirror: channels_last
+    (fused kernels) against NCHW (F.batch_norm + add + relu) on the same
+    weights and input, output and all gradients."""
+    from ucsa_neural_rendering_amd.network.deeplabv3 import Bottleneck, _conv1x1
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    ds = nn.Sequential(_conv1x1(64, 256), FusedBatchNorm2d(256))
+    a = Bottleneck(64, 64, downsample=ds).to(dev).train()
+    import copy
+    b = copy.deepcopy(a).to(memory_format=torch.channels_last)
+    x = torch.randn(4, 64, 30, 40, device=dev)
+    xa = x.clone().requires_grad_()
+    xb = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_()
+    ya, yb = a(xa), b(xb)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g.contiguous(memory_format=torch.channels_last))
+    assert float((ya - yb).abs().max()) <= 2e-4 * float(ya.abs().max())
+    assert float((xa.grad - xb.grad).abs().max()) <= 5e-4 * float(xa.grad.abs().max())
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((pa.grad - pb.grad).abs().max()) <= 1e-3 * max(1e-6, float(pa.grad.abs().max())), n
+    for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert float((ba.double() - bb.double()).abs().max()) <= 1e-4, n

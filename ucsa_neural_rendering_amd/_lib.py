@@ -116,6 +116,9 @@ SIGNATURES = {
                                        _p, _p, _p, _p]),
     "ucsa_composite_infer_x3": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32,
                                                          _f, _p, _p, _p, _p, _p]),
+    "ucsa_composite_train_fwd_x3": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32,
+                                                             _f, _p, _p, _p, _p, _p,
+                                                             _p, _p]),
     "ucsa_mlp_pack_f16_halves": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_f16": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_sigma_mlp_fwd_f16": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
@@ -165,6 +168,12 @@ SIGNATURES = {
     "ucsa_seg_tail": (C.c_int32, [_p, _p, _u32, _u32, _u32, _f, _p, _p, _p, _p,
                                   _p, _p]),
     "ucsa_confusion_matrix": (C.c_int32, [_p, _p, C.c_uint64, _u32, _p, _p]),
+    "ucsa_bn_workspace_bytes": (C.c_uint64, [_u32, _u32]),
+    "ucsa_bn_act_fwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _f, _f, _u32, _u32,
+                                    C.c_int32, C.c_int32, C.c_int32, _p, _p, _p,
+                                    _p, _p]),
+    "ucsa_bn_act_bwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _u32, _u32, C.c_int32,
+                                    C.c_int32, _p, _p, _p, _p, _p, _p]),
     # ---- occupancy-grid ray marching ----
     "ucsa_march_workspace_bytes": (C.c_uint64, [_u32]),
     "ucsa_march_rays_train": (C.c_int32, [_p, _p, _p, _f, _f, _f, _u32, _u32,

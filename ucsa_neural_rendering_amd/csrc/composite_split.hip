@@ -56,6 +56,8 @@ struct WcArgs {
   void* sh;            // per-ray SH basis of the direction in the form the
                        // shading kernel's MFMA operand wants (null: not wanted)
   uint32_t sh_mode;    // 1: [N][16] half; 2: [N][3 terms][16] bf16 (bf16x3 split)
+  int32_t* src_out;    // training forward: source index of sorted sample s (or null)
+  float* w_out;        // training forward: weight of sorted sample s (or null)
 };
 
 #define WC_WAVES 4
@@ -138,6 +140,10 @@ __global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
       const float w = alpha * (carry * excl);
       carry = carry * wave_bcast(incl, 63);
       const bool keep = (s < S) && (w > 1e-4f);
+      if (a.w_out && s < S) {  // what the backward needs (composite.hip phase A)
+        a.w_out[(size_t)r * S + s] = w;
+        a.src_out[(size_t)r * S + s] = (int32_t)srcs[s];
+      }
       if (keep) dsum += w * zi;
       const unsigned long long bal = __ballot(keep);
       if (keep) {
@@ -1007,8 +1013,10 @@ static int32_t composite_infer(int prec, const float* rays_d,
                                const void* packed_sem, uint32_t N, uint32_t T,
                                uint32_t t, uint32_t n_classes,
                                float density_scale, float* image, float* depth,
-                               float* semantics, void* ws, void* stream) {
+                               float* semantics, void* ws, void* stream,
+                               int32_t* src_out = nullptr, float* w_out = nullptr) {
   UCSA_CHECK_ARG(rays_d, 0);
+  UCSA_CHECK_ARG((src_out == nullptr) == (w_out == nullptr), 19);
   UCSA_CHECK_ARG(norms, 1);
   UCSA_CHECK_ARG(z_c && sigma_c && h_c, 2);
   UCSA_CHECK_ARG(t == 0 || (z_f && sigma_f && h_f), 5);
@@ -1048,7 +1056,7 @@ static int32_t composite_infer(int prec, const float* rays_d,
   {
     WcArgs a{rays_d, norms, z_c, sigma_c, z_f, sigma_f, N, T, t, density_scale,
              depth, list_w, list_row, list_ray, counts, rpw, image, semantics,
-             n_classes, sh, (uint32_t)prec};
+             n_classes, sh, (uint32_t)prec, src_out, w_out};
     const size_t smem = (size_t)WC_WAVES * 4 * S * 4;
     UCSA_CHECK_ARG(smem <= 160 * 1024, 12);
     hipError_t e = hipFuncSetAttribute(
@@ -1152,4 +1160,23 @@ extern "C" int32_t ucsa_composite_infer_x3(
                          packed_color_x3, packed_sem_x3, N, T, t, n_classes,
                          density_scale, image, depth, semantics, workspace,
                          stream);
+}
+
+// Training forward of the colour / semantics stage on the split pair with the
+// bf16x3 nets (fp32-grade): same outputs as ucsa_composite_fwd plus its aux
+// arrays -- src [N, T + t] (source index of every sorted sample: < T coarse,
+// else T + fine index) and w [N, T + t] (its weight, masked or not) -- which
+// ucsa_composite_bwd consumes.  Reference: renderer_semantics.py:220-299.
+extern "C" int32_t ucsa_composite_train_fwd_x3(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_x3,
+    const void* packed_sem_x3, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, int32_t* src, float* w, void* workspace, void* stream) {
+  UCSA_CHECK_ARG(src && w, 18);
+  return composite_infer(2, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                         packed_color_x3, packed_sem_x3, N, T, t, n_classes,
+                         density_scale, image, depth, semantics, workspace,
+                         stream, src, w);
 }

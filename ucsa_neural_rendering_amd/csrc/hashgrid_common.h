@@ -65,15 +65,20 @@ __device__ __forceinline__ float2 encode_level(const TT* __restrict__ tab,
   if (!hashed) {
     // dense level: idx(x0 + 1) = idx(x0) + 1, so the x-pair is one (possibly
     // unaligned) double-width access -- 4 instead of 8 per sample
+    // `% entries` only bites on the far faces of the box (a corner index of
+    // res - 1 + 1): the general unsigned modulo is a ~25-instruction sequence,
+    // four of them per sample were the bulk of a dense level's VALU work, so it
+    // sits behind a (practically never taken) branch.  Same indices.
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t lin = gx + (gy + (q & 1)) * res + (gz + (q >> 1)) * res * res;
-      const uint32_t i0 = lin % entries;
-      if (i0 + 1u < entries) {
+      uint32_t i0 = lin;
+      if (__builtin_expect(i0 >= entries, 0)) i0 = lin % entries;
+      if (__builtin_expect(i0 + 1u < entries, 1)) {
         tab_load_pair(tab, i0, v[2 * q], v[2 * q + 1]);
-      } else {  // the pair wraps around the end of the level's slab
-        v[2 * q] = tab_load(tab, i0);
-        v[2 * q + 1] = tab_load(tab, (lin + 1u) % entries);
+      } else {  // the pair wraps around the end of the level's slab:
+        v[2 * q] = tab_load(tab, i0);          // i0 == entries - 1, so
+        v[2 * q + 1] = tab_load(tab, 0u);      // (lin + 1) % entries == 0
       }
     }
   } else {

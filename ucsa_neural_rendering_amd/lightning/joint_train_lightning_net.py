@@ -83,7 +83,10 @@ class JointTrainLightningNet(nn.Module):
         self.seg_amp = str(exp["model"].get("amp", "")).lower() == "bf16"
         # `model: {channels_last: true}`: fp32, NHWC layout (1x1 convolutions as
         # one GEMM, MIOpen's NHWC kernels without layout transposes)
-        self.seg_channels_last = bool(exp["model"].get("channels_last", False))
+        # Default ON: the fused BatchNorm (+ add) (+ ReLU) kernels
+        # (network/fused_bn.py) work on channels-last activations; NCHW
+        # (`channels_last: false`) runs the same modules through F.batch_norm.
+        self.seg_channels_last = bool(exp["model"].get("channels_last", True))
         if self.seg_amp or self.seg_channels_last:
             self.seg_model = self.seg_model.to(memory_format=torch.channels_last)
         # NeRF-only steps replay the frozen segmentation forward as a HIP graph
@@ -459,7 +462,7 @@ class JointTrainLightningNet(nn.Module):
             self.seg_model.eval()
             if batch_new["img"].shape[0] > 1:  # BN trains only when B > 1
                 for m in self.seg_model.modules():
-                    if m.__class__.__name__.startswith("BatchNorm"):
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
                         m.train()
             with torch.no_grad():
                 output_seg = self.forward_seg(batch_new)

@@ -50,9 +50,19 @@ class _RenderFn(torch.autograd.Function):
             f = dict(f, packed_color=fh["packed_color"], packed_sem=fh["packed_sem"],
                      packed_color_t=fh["packed_color_t"],
                      packed_sem_t=fh["packed_sem_t"])
-        image, depth, sem, src, w = ops.composite_fwd(
-            d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, f["packed_color"],
-            f["packed_sem"], C, ds, want_aux=True, half=half)
+        if net.train_precision == "bf16x3":
+            # forward of the colour / semantics stage on the split pair with
+            # the bf16x3 nets (fp32-grade, the dense bf16 MFMA pipe): same
+            # values as the f32-input MFMA chain to ~1e-7; the backward
+            # recomputes the nets with the f32-input MFMA as before
+            image, depth, sem, src, w = ops.composite_train_fwd_x3(
+                d, nrm, z_c, s_c, h_c, z_f, s_f, h_f,
+                net._pack_x3("color", net.color_net),
+                net._pack_x3("sem", net.semantics_net), C, ds)
+        else:
+            image, depth, sem, src, w = ops.composite_fwd(
+                d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, f["packed_color"],
+                f["packed_sem"], C, ds, want_aux=True, half=half)
         ctx.half = half
         ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t = net, f, aabb, T, t
         ctx.saved = (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f,

@@ -7,10 +7,15 @@ names**, so reference checkpoints (keys ``_model.backbone.*``,
 ``_model.classifier.*``; rewrite at scripts/train_joint.py:116-128) load with
 ``strict=True``.
 
-Convolutions / batch-norm run through PyTorch-ROCm (MIOpen) -- dense,
-library-shaped work; the hand-written HIP part of the
-segmentation path is the fused tail (softmax / argmax / CE-on-softmax fwd+bwd,
-``ucsa_seg_tail``).  ``cfg_model["backbone"]`` ("resnet101" default,
+Convolutions run through PyTorch-ROCm (MIOpen / rocBLAS) -- dense,
+library-shaped work.  The hand-written HIP parts of the
+segmentation path are the memory-bound passes around them: every
+BatchNorm2d (+ residual add) (+ ReLU), forward and backward, is one fused
+channels-last op (``FusedBatchNorm2d`` -> ``ucsa_bn_act_fwd/bwd``,
+csrc/batchnorm.hip) instead of MIOpen's batch norm plus separate add / ReLU
+kernels, and the tail (softmax / argmax / CE-on-softmax fwd+bwd,
+``ucsa_seg_tail``).  On inputs the fused op does not take (CPU, NCHW) the same
+modules run ``F.batch_norm`` + add + relu.  ``cfg_model["backbone"]`` ("resnet101" default,
 "resnet50" for BASELINE cfg3's ResNet-50 wording) is an optional extra key.
 Pretrained weights cannot be downloaded here (no network): the flags are
 accepted and ignored with a warning unless ``cfg_model["weights_path"]`` points
@@ -24,6 +29,8 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .fused_bn import FusedBatchNorm2d
 
 __all__ = ["DeepLabV3"]
 
@@ -57,24 +64,24 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
         super().__init__()
         self.conv1 = _conv1x1(inplanes, planes)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         # torchvision "v1.5": the stride sits on the 3x3 convolution
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride,
                                padding=dilation, dilation=dilation, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.conv3 = _conv1x1(planes, planes * 4)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = FusedBatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
     def forward(self, x):
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
         if self.downsample is not None:
             identity = self.downsample(x)
-        return self.relu(out + identity)
+        # conv3 -> BN -> (+ identity) -> ReLU as one pass over the activation
+        return self.bn3(self.conv3(out), residual=identity, relu=True)
 
 
 class ResNetBackbone(nn.Module):
@@ -87,7 +94,7 @@ class ResNetBackbone(nn.Module):
         self.inplanes = 64
         self.dilation = 1
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = FusedBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         self.layer1 = self._make_layer(64, layers[0])
@@ -111,7 +118,7 @@ class ResNetBackbone(nn.Module):
         if stride != 1 or self.inplanes != planes * 4:
             downsample = nn.Sequential(
                 _conv1x1(self.inplanes, planes * 4, stride=stride),
-                nn.BatchNorm2d(planes * 4))
+                FusedBatchNorm2d(planes * 4))
         layers = [Bottleneck(self.inplanes, planes, stride, downsample,
                              previous_dilation)]
         self.inplanes = planes * 4
@@ -121,17 +128,29 @@ class ResNetBackbone(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return OrderedDict(out=x)
 
 
-class ASPPConv(nn.Sequential):
+class _ConvBNReLU(nn.Sequential):
+    """Sequential(conv, BatchNorm2d, ReLU[, ...]) (torchvision's module order
+    and state_dict keys) whose forward fuses the BatchNorm with the ReLU;
+    modules after index 2 (the projection's Dropout) run as usual."""
+
+    def forward(self, x):
+        x = self[1](self[0](x), relu=True)
+        for m in list(self)[3:]:
+            x = m(x)
+        return x
+
+
+class ASPPConv(_ConvBNReLU):
 
     def __init__(self, cin, cout, dilation):
         super().__init__(
             nn.Conv2d(cin, cout, 3, padding=dilation, dilation=dilation,
-                      bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+                      bias=False), FusedBatchNorm2d(cout), nn.ReLU())
 
 
 class ASPPPooling(nn.Sequential):
@@ -139,7 +158,7 @@ class ASPPPooling(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(nn.AdaptiveAvgPool2d(1),
                          nn.Conv2d(cin, cout, 1, bias=False),
-                         nn.BatchNorm2d(cout), nn.ReLU())
+                         FusedBatchNorm2d(cout), nn.ReLU())
 
     def forward(self, x):
         """torchvision's forward (pool -> 1x1 conv -> BN -> ReLU -> bilinear
@@ -171,14 +190,14 @@ class ASPP(nn.Module):
 
     def __init__(self, cin, rates, cout=256):
         super().__init__()
-        mods = [nn.Sequential(_conv1x1(cin, cout),
-                              nn.BatchNorm2d(cout), nn.ReLU())]
+        mods = [_ConvBNReLU(_conv1x1(cin, cout),
+                            FusedBatchNorm2d(cout), nn.ReLU())]
         mods += [ASPPConv(cin, cout, r) for r in rates]
         mods.append(ASPPPooling(cin, cout))
         self.convs = nn.ModuleList(mods)
-        self.project = nn.Sequential(
+        self.project = _ConvBNReLU(
             _conv1x1(len(self.convs) * cout, cout),
-            nn.BatchNorm2d(cout), nn.ReLU(), nn.Dropout(0.5))
+            FusedBatchNorm2d(cout), nn.ReLU(), nn.Dropout(0.5))
 
     def forward(self, x):
         return self.project(torch.cat([c(x) for c in self.convs], dim=1))
@@ -189,8 +208,13 @@ class DeepLabHead(nn.Sequential):
     def __init__(self, cin, num_classes):
         super().__init__(ASPP(cin, [12, 24, 36]),
                          nn.Conv2d(256, 256, 3, padding=1, bias=False),
-                         nn.BatchNorm2d(256), nn.ReLU(),
+                         FusedBatchNorm2d(256), nn.ReLU(),
                          _conv1x1(256, num_classes, bias=True))
+
+    def forward(self, x):
+        x = self[0](x)
+        x = self[2](self[1](x), relu=True)
+        return self[4](x)
 
 
 class _DeepLabV3Model(nn.Module):

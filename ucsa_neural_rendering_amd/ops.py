@@ -251,6 +251,33 @@ def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     return image, depth, sem
 
 
+def composite_train_fwd_x3(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                           packed_color_x3, packed_sem_x3, n_classes: int,
+                           density_scale: float = 1.0):
+    """Training forward of the colour / semantics stage on the split pair with
+    the bf16x3 nets -> (image, depth, sem, src, w) like
+    composite_fwd(want_aux=True)."""
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    norms = _f32(norms, "norms").view(-1)
+    N, T = z_c.shape
+    t = 0 if z_f is None else z_f.shape[1]
+    dev = z_c.device
+    image = torch.empty(N, 3, device=dev)
+    depth = torch.empty(N, device=dev)
+    sem = torch.empty(N, n_classes, device=dev)
+    src = torch.empty(N, T + t, dtype=torch.int32, device=dev)
+    w = torch.empty(N, T + t, device=dev)
+    ws = _scratch_named("composite_infer",
+                        int(lib().ucsa_composite_infer_workspace_bytes(N, T, t)),
+                        dev)
+    check(lib().ucsa_composite_train_fwd_x3(
+        _ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c), _ptr(z_f),
+        _ptr(sigma_f), _ptr(h_f), _ptr(packed_color_x3), _ptr(packed_sem_x3), N, T,
+        t, n_classes, float(density_scale), _ptr(image), _ptr(depth), _ptr(sem),
+        _ptr(src), _ptr(w), _ptr(ws), _stream()), "ucsa_composite_train_fwd_x3")
+    return image, depth, sem, src, w
+
+
 def composite_infer(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
                     packed_color, packed_sem, n_classes: int,
                     density_scale: float = 1.0, half: bool = False,
@@ -678,6 +705,61 @@ def seg_tail(logits, labels=None, grad_scale: float = 1.0,
                               _ptr(loss), _ptr(d_logits), _ptr(partial),
                               _stream()), "ucsa_seg_tail")
     return dict(prob=prob, argmax=arg, loss=loss, d_logits=d_logits)
+
+
+# ---------------------------------------------------------------------------
+# fused BatchNorm2d (+ residual) (+ ReLU) on channels-last activations
+# ---------------------------------------------------------------------------
+def _nhwc_rows(t: torch.Tensor, name: str):
+    """[N,C,H,W] channels_last tensor (fp32 / bf16) -> (M, C, dtype code)."""
+    if not t.is_cuda:
+        raise _lib.UcsaError(f"{name} must live on the GPU: no CPU fallback")
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise _lib.UcsaError(f"{name} must be a channels_last [N,C,H,W] tensor")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.UcsaError(f"{name}: fp32 or bf16, got {t.dtype}")
+    N, Cc, H, W = t.shape
+    return N * H * W, Cc, 0 if t.dtype == torch.float32 else 1
+
+
+def bn_act_fwd(x, residual, weight, bias, running_mean, running_var,
+               momentum: float, eps: float, relu: bool, training: bool):
+    """-> (y, save_mean, save_invstd); save_* are None in eval mode."""
+    M, Cc, dt = _nhwc_rows(x, "x")
+    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or
+                                 not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.UcsaError("residual must match x (shape, dtype, channels_last)")
+    y = torch.empty_like(x)   # preserves channels_last
+    save_mean = save_invstd = None
+    if training:
+        save_mean = torch.empty(Cc, device=x.device)
+        save_invstd = torch.empty(Cc, device=x.device)
+    ws = _scratch(int(lib().ucsa_bn_workspace_bytes(M, Cc)), x.device)
+    check(lib().ucsa_bn_act_fwd(
+        _ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
+        _ptr(running_var), float(momentum), float(eps), M, Cc, int(relu),
+        int(training), dt, _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws),
+        _stream()), "ucsa_bn_act_fwd")
+    return y, save_mean, save_invstd
+
+
+def bn_act_bwd(dy, x, y, weight, save_mean, save_invstd, relu: bool,
+               want_dres: bool, want_dwb: bool):
+    """-> (dx, dresidual | None, dweight | None, dbias | None)."""
+    M, Cc, dt = _nhwc_rows(x, "x")
+    if dy.dtype != x.dtype or dy.shape != x.shape:
+        raise _lib.UcsaError("dy must match x")
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dw = torch.empty(Cc, device=x.device) if want_dwb else None
+    db = torch.empty(Cc, device=x.device) if want_dwb else None
+    ws = _scratch(int(lib().ucsa_bn_workspace_bytes(M, Cc)), x.device)
+    check(lib().ucsa_bn_act_bwd(
+        _ptr(dy), _ptr(x), _ptr(y) if relu else None, _ptr(weight), _ptr(save_mean),
+        _ptr(save_invstd), M, Cc, int(relu), dt, _ptr(dx), _ptr(dres), _ptr(dw),
+        _ptr(db), _ptr(ws), _stream()), "ucsa_bn_act_bwd")
+    return dx, dres, dw, db
 
 
 def confusion_matrix(preds, truths, n_classes: int, cm=None):
