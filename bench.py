@@ -471,14 +471,20 @@ def seg_throughput(device, steps=5, B=8, find=False):
         y = torch.randint(-1, N_CLASSES, (B, 240, 320), device=device)
         opt = torch.optim.Adam(m.parameters(), lr=1e-5)
 
-        def net(inp):
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                return m(inp)["out"]
+        class _Net(torch.nn.Module):   # parameters visible to make_graphed_callables
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
 
+            def forward(self, inp):
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    return self.inner(inp)["out"]
+
+        net = _Net(m)
         fwd = net
         try:
             if mode.endswith("_graph"):
-                fwd = torch.cuda.make_graphed_callables(net, (x.clone().requires_grad_(False),))
+                fwd = torch.cuda.make_graphed_callables(net, (x.clone(),))
         except Exception as e:  # report, do not hide
             out[mode] = {"failed": repr(e)[:300]}
             del m, opt
@@ -1276,17 +1282,21 @@ def main():
                 result["march_option"] = {"error": repr(e), "failed": True}
         _tick("marcher option done")
         if extras and not args.no_train_bench:
-            result["train"] = train_throughput(net, scene_ds, dev)
+            # default training arithmetic (`nerf: {train_precision: bf16x3}`):
+            # forward of the colour / semantics stage on the split pair with
+            # the bf16x3 nets (fp32-grade), backward on the f32-input MFMA
+            result["train"] = train_throughput(net, scene_ds, dev, train_precision="bf16x3")
+            result["train"]["workload"] += (
+                "; colour / semantics forward on the split pair with bf16x3 nets "
+                "(fp32-grade), everything else fp32 (f32-input MFMA)")
+            tm = train_throughput(net, scene_ds, dev, train_precision="fp32")
+            tm["workload"] += "; forward on the fused f32-input-MFMA kernel (`nerf: {train_precision: fp32}`)"
+            result["train_f32_mfma_forward"] = tm
             tf = train_throughput(net, scene_ds, dev, train_precision="fp16")
             tf["workload"] += ("; colour / semantics nets forward + backward on f16 "
                                "MFMA (`nerf: {train_precision: fp16}`), sigma net and "
                                "grid fp32")
             result["train_f16_nets"] = tf
-            tx = train_throughput(net, scene_ds, dev, train_precision="bf16x3")
-            tx["workload"] += ("; forward of the colour / semantics stage on the split "
-                               "pair with bf16x3 nets (`nerf: {train_precision: bf16x3}`, "
-                               "fp32-grade), backward unchanged (f32-input MFMA)")
-            result["train_bf16x3_forward"] = tx
             _tick("training legs done")
             result["seg"] = seg_throughput(dev, find=args.seg_find)
             _tick("DeepLab leg done")

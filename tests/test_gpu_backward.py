@@ -266,6 +266,37 @@ def test_binned_grid_backward_rays_with_clustered_samples(ops):
     assert float((g_bin - g_dir).abs().sum()) <= 1e-5 * float(g_dir.abs().sum())
 
 
+def test_binned_grid_backward_with_a_dirty_oversized_workspace(ops):
+    """The bin workspace is cached per (device, stream) and only grows: a small
+    call after a large one gets an oversized buffer full of the large call's
+    records.  Nothing may be read that this call did not write (fresh
+    allocations are zero pages, which hides such a read when a test runs
+    alone): poison the cached buffer, then repeat the clustered-samples case."""
+    from ucsa_neural_rendering_amd import ops as uops
+    from ucsa_neural_rendering_amd._lib import make_grid
+    dev = torch.device("cuda:0")
+    grid = make_grid(4.0)
+    g = torch.Generator().manual_seed(5)
+    # a large call first (cfg3 size: 4096 rays x 256 samples)
+    N, T = 4096, 256
+    o = ((torch.rand(N, 3, generator=g) * 2 - 1) * 2.0).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(dev)
+    z = (torch.rand(N, T, generator=g) * 5 + 0.3).sort(-1).values.to(dev)
+    aabb = [-4.0, -4.0, -4.0, 4.0, 4.0, 4.0]
+    total = int(grid.total_entries)
+    gt = torch.zeros(total, 2, device=dev)
+    ops.hashgrid_bwd_rays(grid, o, d, z, aabb,
+                          torch.randn(grid.n_levels, N * T, 2, device=dev), gt, binned=True)
+    torch.cuda.synchronize()
+    for ws in uops._bwd_ws.values():
+        ws.fill_(0xFF)                     # NaN values, entry indices of 4 G
+    test_binned_grid_backward_rays_with_clustered_samples(ops)
+    for ws in uops._bwd_ws.values():
+        ws.fill_(0x7F)
+    for spread in ("box", "one_cell", "two_clusters"):
+        test_binned_grid_backward_equals_direct_atomics(ops, spread)
+
+
 def test_adam_kernel_on_misaligned_slices(ops):
     """ShardedHipAdam hands ucsa_adam_step[_scaled] SLICES of the parameter /
     moment tensors.  A slice that does not start on a 16-byte boundary must

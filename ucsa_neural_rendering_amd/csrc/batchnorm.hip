@@ -11,11 +11,12 @@
 // for their gradients: 20 / 32 bytes per element forward (without / with the
 // residual) and 32 / 44 backward in fp32.  Here:
 //
-//   forward   k_bn_stats      X            -> per-column partial sums (read 4 B)
-//             k_bn_finalize   partials     -> mean, invstd, running stats
+//   forward   k_bn_stats      X            -> per-column partial sums (read 4 B);
+//                                             the last workgroup of a column
+//                                             group: mean, invstd, running stats
 //             k_bn_apply      X, (R)       -> Y = relu(a X + b (+ R))  (8 / 12 B)
-//   backward  k_bn_bwd_stats  dY, Y, X     -> partial sum(g), sum(g xhat)
-//             k_bn_bwd_final  partials     -> dgamma, dbeta
+//   backward  k_bn_bwd_stats  dY, Y, X     -> partial sum(g), sum(g xhat); last
+//                                             workgroup: dgamma, dbeta
 //             k_bn_bwd_apply  dY, Y, X     -> dX (, dR = g)
 //   with g = dY * (Y > 0) when the ReLU is fused (Y is the layer's own output,
 //   which autograd keeps alive for the next convolution anyway).
@@ -66,7 +67,7 @@ struct Quad<__hip_bfloat16> {
 };
 
 // Launch geometry shared by the two reduction kernels: a workgroup covers TQ
-// channel quads (TQ = min(C/4, 64), a power of two) and 256/TQ rows per
+// channel quads (TQ = min(C/4, 16), a power of two) and 256/TQ rows per
 // iteration of a contiguous range of rows.
 struct BnGeom {
   uint32_t M, C;
@@ -82,22 +83,31 @@ static BnGeom bn_geom(uint32_t M, uint32_t C) {
   g.M = M;
   g.C = C;
   const uint32_t cq = C / 4;
+  // 16 channel quads (64 channels: 256 contiguous bytes of a row in fp32) per
+  // workgroup: wide layers get many column groups, and the workgroup has 16
+  // row lanes for the final reduction of a column group (at most 512
+  // partials, done by its last workgroup with four loads in flight per thread)
   uint32_t tq = 1;
-  while (tq < 64 && tq * 2 <= cq && cq % (tq * 2) == 0) tq *= 2;
+  while (tq < 16 && tq * 2 <= cq && cq % (tq * 2) == 0) tq *= 2;
   g.tq = tq;
   g.rows_per_it = BN_THREADS / tq;
   g.n_col_wg = cq / tq;
-  // ~2048 workgroups in flight, at least 8 iterations each where M allows
+  // ~2048 workgroups in all (8 per CU: the passes are latency-bound streams,
+  // they need many loads in flight), at most 512 per column group, at least 4
+  // iterations each
   uint32_t want = 2048 / g.n_col_wg;
   if (want < 1) want = 1;
+  if (want > 512) want = 512;
   uint32_t rows = (M + want - 1) / want;
-  const uint32_t min_rows = 8 * g.rows_per_it;
+  const uint32_t min_rows = 4 * g.rows_per_it;
   if (rows < min_rows) rows = min_rows;
   rows = (rows + g.rows_per_it - 1) / g.rows_per_it * g.rows_per_it;
   g.rows_per_wg = rows;
   g.n_row_wg = (M + rows - 1) / rows;
   return g;
 }
+
+extern "C" uint32_t ucsa_bn_counter_count(void) { return 1024u; }
 
 extern "C" uint64_t ucsa_bn_workspace_bytes(uint32_t M, uint32_t C) {
   if (M == 0 || C == 0 || C % 4) return 0;
@@ -126,20 +136,126 @@ __device__ __forceinline__ void wg_reduce2(bn_f32x4& a, bn_f32x4& b, uint32_t tq
   b = red[1][t % tq];
 }
 
+
+// The LAST workgroup of a column group to arrive (agent-scope counter) sums the
+// group's per-workgroup partials: thread (q, rr) adds partial rows rr, rr +
+// rows_per_it, ... of its channel quad in double, an LDS tree over rr finishes.
+// Returns true in the threads of row 0 of that workgroup, with the two sums of
+// their quad in s / ss; everybody else gets false.  Replaces a finalize launch
+// whose one-thread-per-channel loop over up to 2048 partials took 85 us.
+struct D4 {
+  double v[4];
+};
+__device__ __forceinline__ bool bn_last_wg_reduce(const BnGeom& g, float* partial,
+                                                  uint32_t* counters, D4& s, D4& ss) {
+  __shared__ uint32_t ticket;
+  __shared__ double red[2][BN_THREADS][4];
+  const uint32_t t = threadIdx.x;
+  __threadfence();   // this workgroup's partials are visible agent-wide
+  __syncthreads();
+  if (t == 0) ticket = atomicAdd(&counters[blockIdx.y], 1u);
+  __syncthreads();
+  if (ticket != g.n_row_wg - 1) return false;
+  __threadfence();   // acquire the other workgroups' partials
+  const uint32_t q = t % g.tq, rr = t / g.tq;
+  const uint32_t c = 4 * (blockIdx.y * g.tq + q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s.v[k] = ss.v[k] = 0.0;
+  // (the partials were written by other CUs: loads bypass this CU's L1)
+  uint32_t k = rr;
+  const uint32_t kstep = g.rows_per_it;
+  for (; k + 3 * kstep < g.n_row_wg; k += 4 * kstep) {  // eight loads in flight
+    bn_f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* p = partial + (size_t)(k + u * kstep) * 2 * g.C;
+      a[u] = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + c));
+      b[u] = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + g.C + c));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s.v[e] += (double)a[u][e];
+        ss.v[e] += (double)b[u][e];
+      }
+  }
+  for (; k < g.n_row_wg; k += kstep) {
+    const float* p = partial + (size_t)k * 2 * g.C;
+    const bn_f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + c));
+    const bn_f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + g.C + c));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s.v[e] += (double)a[e];
+      ss.v[e] += (double)b[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][t][e] = s.v[e];
+    red[1][t][e] = ss.v[e];
+  }
+  __syncthreads();
+  for (uint32_t st = g.rows_per_it / 2; st >= 1; st >>= 1) {
+    if (t < st * g.tq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[0][t][e] += red[0][t + st * g.tq][e];
+        red[1][t][e] += red[1][t + st * g.tq][e];
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) counters[blockIdx.y] = 0u;   // ready for the next call
+  if (t >= g.tq) return false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s.v[e] = red[0][t][e];
+    ss.v[e] = red[1][t][e];
+  }
+  return true;
+}
+
 // ---- forward ---------------------------------------------------------------
+struct BnFwdFin {   // what the finalizing workgroup needs
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
+  float* save_mean;
+  float* save_invstd;
+  float* coef;
+  uint32_t* counters;
+};
+
 template <typename T>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bn_stats(BnGeom g, const T* __restrict__ x, const float* __restrict__ shift,
-           float* __restrict__ partial) {
+           float* partial, BnFwdFin f) {
   const uint32_t t = threadIdx.x;
   const uint32_t q = blockIdx.y * g.tq + t % g.tq;  // channel quad
   const uint32_t c = 4 * q;
   const uint32_t r0 = blockIdx.x * g.rows_per_wg + t / g.tq;
   uint32_t r1 = (blockIdx.x + 1) * g.rows_per_wg;
   if (r1 > g.M) r1 = g.M;
-  const bn_f32x4 sh = *reinterpret_cast<const bn_f32x4*>(shift + c);
+  const bn_f32x4 sh = shift ? *reinterpret_cast<const bn_f32x4*>(shift + c)
+                            : bn_f32x4{0.f, 0.f, 0.f, 0.f};
   bn_f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
-  for (uint32_t r = r0; r < r1; r += g.rows_per_it) {
+  uint32_t r = r0;
+  const uint32_t step = g.rows_per_it;
+  for (; r + 3 * step < r1; r += 4 * step) {  // four row loads in flight
+    bn_f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = Quad<T>::load(x + (size_t)(r + k * step) * g.C + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bn_f32x4 d = v[k] - sh;
+      s += d;
+      ss += d * d;
+    }
+  }
+  for (; r < r1; r += step) {
     const bn_f32x4 v = Quad<T>::load(x + (size_t)r * g.C + c) - sh;
     s += v;
     ss += v * v;
@@ -150,44 +266,33 @@ k_bn_stats(BnGeom g, const T* __restrict__ x, const float* __restrict__ shift,
     *reinterpret_cast<bn_f32x4*>(p + c) = s;
     *reinterpret_cast<bn_f32x4*>(p + g.C + c) = ss;
   }
-}
-
-// one thread per channel: mean / invstd, running statistics as
-// torch.nn.BatchNorm2d updates them (biased variance normalises, the unbiased
-// one goes into running_var), coefficients a = gamma * invstd, b = beta - mean a
-__global__ void k_bn_finalize(uint32_t M, uint32_t C, uint32_t n_row_wg,
-                              const float* __restrict__ partial,
-                              const float* __restrict__ gamma,
-                              const float* __restrict__ beta,
-                              float* __restrict__ running_mean,
-                              float* __restrict__ running_var, float momentum,
-                              float eps, float* __restrict__ save_mean,
-                              float* __restrict__ save_invstd,
-                              float* __restrict__ coef) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (uint32_t k = 0; k < n_row_wg; ++k) {
-    s += (double)partial[(size_t)k * 2 * C + c];
-    ss += (double)partial[(size_t)k * 2 * C + C + c];
+  // mean / invstd, running statistics as torch.nn.BatchNorm2d updates them
+  // (the biased variance normalises, the unbiased one goes into running_var),
+  // coefficients a = gamma * invstd, b = beta - mean * a
+  D4 ds, dss;
+  if (!bn_last_wg_reduce(g, partial, f.counters, ds, dss)) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t ch = c + e;
+    const double shf = shift ? (double)shift[ch] : 0.0;
+    const double m1 = ds.v[e] / g.M;                 // E[x - shift]
+    double var = dss.v[e] / g.M - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    const double mean = m1 + shf;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float mf = (float)mean;
+    f.save_mean[ch] = mf;
+    f.save_invstd[ch] = invstd;
+    if (f.running_mean) {
+      const double unb = g.M > 1 ? var * ((double)g.M / (double)(g.M - 1)) : var;
+      f.running_mean[ch] = (float)((1.0 - f.momentum) * shf + f.momentum * mean);
+      f.running_var[ch] =
+          (float)((1.0 - f.momentum) * (double)f.running_var[ch] + f.momentum * unb);
+    }
+    const float a = (f.gamma ? f.gamma[ch] : 1.0f) * invstd;
+    f.coef[ch] = a;
+    f.coef[g.C + ch] = (f.beta ? f.beta[ch] : 0.0f) - mf * a;
   }
-  const double shift = running_mean ? (double)running_mean[c] : 0.0;
-  const double m1 = s / M;                 // E[x - shift]
-  double var = ss / M - m1 * m1;
-  if (var < 0.0) var = 0.0;
-  const double mean = m1 + shift;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float mf = (float)mean;
-  save_mean[c] = mf;
-  save_invstd[c] = invstd;
-  if (running_mean) {
-    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-    running_mean[c] = (float)((1.0 - momentum) * shift + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
-  }
-  const float a = (gamma ? gamma[c] : 1.0f) * invstd;
-  coef[c] = a;
-  coef[C + c] = (beta ? beta[c] : 0.0f) - mf * a;
 }
 
 // eval mode: coefficients from the running statistics
@@ -226,11 +331,19 @@ k_bn_apply(uint64_t n_quads, uint32_t cq, const T* __restrict__ x,
 }
 
 // ---- backward --------------------------------------------------------------
+struct BnBwdFin {
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  float* coef;
+  uint32_t* counters;
+};
+
 template <typename T, bool RELU>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bn_bwd_stats(BnGeom g, const T* __restrict__ dy, const T* __restrict__ y,
                const T* __restrict__ x, const float* __restrict__ mean,
-               const float* __restrict__ invstd, float* __restrict__ partial) {
+               const float* __restrict__ invstd, float* partial, BnBwdFin f) {
   const uint32_t t = threadIdx.x;
   const uint32_t q = blockIdx.y * g.tq + t % g.tq;
   const uint32_t c = 4 * q;
@@ -240,17 +353,33 @@ k_bn_bwd_stats(BnGeom g, const T* __restrict__ dy, const T* __restrict__ y,
   const bn_f32x4 mu = *reinterpret_cast<const bn_f32x4*>(mean + c);
   const bn_f32x4 is = *reinterpret_cast<const bn_f32x4*>(invstd + c);
   bn_f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
-  for (uint32_t r = r0; r < r1; r += g.rows_per_it) {
-    const size_t o = (size_t)r * g.C + c;
-    bn_f32x4 gv = Quad<T>::load(dy + o);
+  auto add_row = [&](bn_f32x4 gv, bn_f32x4 yv, bn_f32x4 xv) {
     if (RELU) {
-      const bn_f32x4 yv = Quad<T>::load(y + o);
 #pragma unroll
       for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.0f ? gv[k] : 0.0f;
     }
-    const bn_f32x4 xh = (Quad<T>::load(x + o) - mu) * is;
+    const bn_f32x4 xh = (xv - mu) * is;
     sg += gv;
     sgx += gv * xh;
+  };
+  uint32_t r = r0;
+  const uint32_t step = g.rows_per_it;
+  for (; r + step < r1; r += 2 * step) {  // two rows = up to six loads in flight
+    const size_t o0 = (size_t)r * g.C + c, o1 = (size_t)(r + step) * g.C + c;
+    const bn_f32x4 g0 = Quad<T>::load(dy + o0), g1 = Quad<T>::load(dy + o1);
+    bn_f32x4 y0 = g0, y1 = g1;
+    if (RELU) {
+      y0 = Quad<T>::load(y + o0);
+      y1 = Quad<T>::load(y + o1);
+    }
+    const bn_f32x4 x0 = Quad<T>::load(x + o0), x1 = Quad<T>::load(x + o1);
+    add_row(g0, y0, x0);
+    add_row(g1, y1, x1);
+  }
+  for (; r < r1; r += step) {
+    const size_t o = (size_t)r * g.C + c;
+    const bn_f32x4 gv = Quad<T>::load(dy + o);
+    add_row(gv, RELU ? Quad<T>::load(y + o) : gv, Quad<T>::load(x + o));
   }
   wg_reduce2(sg, sgx, g.tq, g.rows_per_it);
   if (t < g.tq) {
@@ -258,32 +387,21 @@ k_bn_bwd_stats(BnGeom g, const T* __restrict__ dy, const T* __restrict__ y,
     *reinterpret_cast<bn_f32x4*>(p + c) = sg;
     *reinterpret_cast<bn_f32x4*>(p + g.C + c) = sgx;
   }
-}
-
-// dbeta = sum g, dgamma = sum g xhat; coefficients of
-// dx = c1 (g - c2 - xhat c3) = c1 g - (c1 c3 invstd) x + (c1 c3 invstd mean - c1 c2)
-__global__ void k_bn_bwd_final(uint32_t M, uint32_t C, uint32_t n_row_wg,
-                               const float* __restrict__ partial,
-                               const float* __restrict__ gamma,
-                               const float* __restrict__ mean,
-                               const float* __restrict__ invstd,
-                               float* __restrict__ dgamma,
-                               float* __restrict__ dbeta,
-                               float* __restrict__ coef) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (uint32_t k = 0; k < n_row_wg; ++k) {
-    sg += (double)partial[(size_t)k * 2 * C + c];
-    sgx += (double)partial[(size_t)k * 2 * C + C + c];
+  // dbeta = sum g, dgamma = sum g xhat; coefficients of
+  // dx = c1 (g - c2 - xhat c3) = c1 g - (c1 c3 invstd) x + (c1 c3 invstd mean - c1 c2)
+  D4 dsg, dsgx;
+  if (!bn_last_wg_reduce(g, partial, f.counters, dsg, dsgx)) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t ch = c + e;
+    if (f.dbeta) f.dbeta[ch] = (float)dsg.v[e];
+    if (f.dgamma) f.dgamma[ch] = (float)dsgx.v[e];
+    const double c1 = (double)(f.gamma ? f.gamma[ch] : 1.0f) * (double)invstd[ch];
+    const double kx = c1 * (dsgx.v[e] / g.M) * (double)invstd[ch];
+    f.coef[ch] = (float)c1;                                            // * g
+    f.coef[g.C + ch] = (float)(-kx);                                   // * x
+    f.coef[2 * g.C + ch] = (float)(kx * (double)mean[ch] - c1 * (dsg.v[e] / g.M));
   }
-  if (dbeta) dbeta[c] = (float)sg;
-  if (dgamma) dgamma[c] = (float)sgx;
-  const double c1 = (double)(gamma ? gamma[c] : 1.0f) * (double)invstd[c];
-  const double kx = c1 * (sgx / M) * (double)invstd[c];
-  coef[c] = (float)c1;                                   // * g
-  coef[C + c] = (float)(-kx);                            // * x
-  coef[2 * C + c] = (float)(kx * (double)mean[c] - c1 * (sg / M));  // constant
 }
 
 template <typename T, bool RELU, bool DRES>
@@ -321,24 +439,18 @@ static int32_t bn_fwd(const void* x, const void* res, const float* gamma,
                       const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, uint32_t M, uint32_t C, int relu,
                       int training, void* y, float* save_mean, float* save_invstd,
-                      void* workspace, hipStream_t s) {
+                      void* workspace, uint32_t* counters, hipStream_t s) {
   const BnGeom g = bn_geom(M, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)g.n_row_wg * 2 * C;
   UCSA_CLEAR_ERR();
   if (training) {
-    // shift = running_mean when there is one, else zeros (coef[2C..3C) is free
-    // scratch of the right size until the backward uses it)
-    const float* shift = running_mean;
-    if (!shift) {
-      (void)hipMemsetAsync(coef + 2 * C, 0, C * sizeof(float), s);
-      shift = coef + 2 * C;
-    }
+    const BnFwdFin f{gamma, beta, running_mean, running_var, momentum, eps,
+                     save_mean, save_invstd, coef, counters};
+    // shift = running_mean (the best cheap guess of the mean) when there is one
     hipLaunchKernelGGL((k_bn_stats<T>), dim3(g.n_row_wg, g.n_col_wg),
-                       dim3(BN_THREADS), 0, s, g, (const T*)x, shift, partial);
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, M, C,
-                       g.n_row_wg, partial, gamma, beta, running_mean, running_var,
-                       momentum, eps, save_mean, save_invstd, coef);
+                       dim3(BN_THREADS), 0, s, g, (const T*)x,
+                       (const float*)running_mean, partial, f);
   } else {
     hipLaunchKernelGGL(k_bn_coef_eval, dim3((C + 255) / 256), dim3(256), 0, s, C,
                        gamma, beta, running_mean, running_var, eps, coef);
@@ -361,22 +473,20 @@ static int32_t bn_bwd(const void* dy, const void* x, const void* y,
                       const float* gamma, const float* save_mean,
                       const float* save_invstd, uint32_t M, uint32_t C, int relu,
                       void* dx, void* dres, float* dgamma, float* dbeta,
-                      void* workspace, hipStream_t s) {
+                      void* workspace, uint32_t* counters, hipStream_t s) {
   const BnGeom g = bn_geom(M, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)g.n_row_wg * 2 * C;
   UCSA_CLEAR_ERR();
+  const BnBwdFin f{gamma, dgamma, dbeta, coef, counters};
   if (relu)
     hipLaunchKernelGGL((k_bn_bwd_stats<T, true>), dim3(g.n_row_wg, g.n_col_wg),
                        dim3(BN_THREADS), 0, s, g, (const T*)dy, (const T*)y,
-                       (const T*)x, save_mean, save_invstd, partial);
+                       (const T*)x, save_mean, save_invstd, partial, f);
   else
     hipLaunchKernelGGL((k_bn_bwd_stats<T, false>), dim3(g.n_row_wg, g.n_col_wg),
                        dim3(BN_THREADS), 0, s, g, (const T*)dy, (const T*)y,
-                       (const T*)x, save_mean, save_invstd, partial);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, s, M, C,
-                     g.n_row_wg, partial, gamma, save_mean, save_invstd, dgamma,
-                     dbeta, coef);
+                       (const T*)x, save_mean, save_invstd, partial, f);
   const uint64_t nq = (uint64_t)M * (C / 4);
   const dim3 grid(bn_apply_blocks(nq));
 #define BN_BAPPLY(RELU, DRES)                                                      \
@@ -398,12 +508,13 @@ extern "C" int32_t ucsa_bn_act_fwd(const void* x, const void* residual,
                                    uint32_t C, int32_t relu, int32_t training,
                                    int32_t dtype, void* y, float* save_mean,
                                    float* save_invstd, void* workspace,
-                                   void* stream) {
+                                   uint32_t* counters, void* stream) {
+  UCSA_CHECK_ARG(!training || counters, 17);
   UCSA_CHECK_ARG(x && ((uintptr_t)x & 15u) == 0, 0);
   UCSA_CHECK_ARG(!residual || ((uintptr_t)residual & 15u) == 0, 1);
   UCSA_CHECK_ARG(training || (running_mean && running_var), 4);
   UCSA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), 5);
-  UCSA_CHECK_ARG(C >= 4 && C % 4 == 0 && (dtype == 0 || C % 8 == 0 || true), 9);
+  UCSA_CHECK_ARG(C >= 4 && C % 4 == 0 && C <= 4096, 9);
   UCSA_CHECK_ARG(dtype == 0 || dtype == 1, 12);
   UCSA_CHECK_ARG(y && ((uintptr_t)y & 15u) == 0, 13);
   UCSA_CHECK_ARG(!training || (save_mean && save_invstd), 14);
@@ -413,10 +524,10 @@ extern "C" int32_t ucsa_bn_act_fwd(const void* x, const void* residual,
   if (dtype == 0)
     return bn_fwd<float>(x, residual, gamma, beta, running_mean, running_var,
                          momentum, eps, M, C, relu, training, y, save_mean,
-                         save_invstd, workspace, (hipStream_t)stream);
+                         save_invstd, workspace, counters, (hipStream_t)stream);
   return bn_fwd<__hip_bfloat16>(x, residual, gamma, beta, running_mean,
                                 running_var, momentum, eps, M, C, relu, training,
-                                y, save_mean, save_invstd, workspace,
+                                y, save_mean, save_invstd, workspace, counters,
                                 (hipStream_t)stream);
 }
 
@@ -425,20 +536,22 @@ extern "C" int32_t ucsa_bn_act_bwd(const void* dy, const void* x, const void* y,
                                    const float* save_invstd, uint32_t M,
                                    uint32_t C, int32_t relu, int32_t dtype,
                                    void* dx, void* dresidual, float* dgamma,
-                                   float* dbeta, void* workspace, void* stream) {
+                                   float* dbeta, void* workspace,
+                                   uint32_t* counters, void* stream) {
+  UCSA_CHECK_ARG(counters, 15);
   UCSA_CHECK_ARG(dy && ((uintptr_t)dy & 15u) == 0, 0);
   UCSA_CHECK_ARG(x && ((uintptr_t)x & 15u) == 0, 1);
   UCSA_CHECK_ARG(!relu || (y && ((uintptr_t)y & 15u) == 0), 2);
   UCSA_CHECK_ARG(save_mean && save_invstd, 4);
-  UCSA_CHECK_ARG(C >= 4 && C % 4 == 0, 7);
+  UCSA_CHECK_ARG(C >= 4 && C % 4 == 0 && C <= 4096, 7);
   UCSA_CHECK_ARG(dtype == 0 || dtype == 1, 9);
   UCSA_CHECK_ARG(dx && ((uintptr_t)dx & 15u) == 0, 10);
   UCSA_CHECK_ARG(workspace, 14);
   if (M == 0) return 0;
   if (dtype == 0)
     return bn_bwd<float>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx,
-                         dresidual, dgamma, dbeta, workspace, (hipStream_t)stream);
+                         dresidual, dgamma, dbeta, workspace, counters, (hipStream_t)stream);
   return bn_bwd<__hip_bfloat16>(dy, x, y, gamma, save_mean, save_invstd, M, C,
                                 relu, dx, dresidual, dgamma, dbeta, workspace,
-                                (hipStream_t)stream);
+                                counters, (hipStream_t)stream);
 }

@@ -649,11 +649,10 @@ k_composite(CmpArgs a) {
         alpha = 1.0f - expf(-delta * a.density_scale * sgm[s]);
       }
       const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
-      const float incl = wave_incl_scan_mul(fac, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 1.0f;
+      const float incl = wave_incl_scan_mul_dpp(fac);
+      const float excl = wave_shift_up1(incl, 1.0f);
       const float w = alpha * (carry * excl);
-      carry = carry * wave_bcast(incl, 63);
+      carry = carry * wave_last(incl);
       const bool keep = (s < S) && (w > 1e-4f);
       if (keep) dsum += w * zi;
       if (s < S) {

@@ -684,11 +684,10 @@ k_weights_bwd(const float* __restrict__ z_c, const float* __restrict__ z_f,
     const bool ok = k < S;
     const uint32_t i = ok ? S - 1 - k : 0;
     const float q = ok ? G[(size_t)r * S + i] * weights[(size_t)r * S + i] : 0.0f;
-    const float incl = wave_incl_scan_add(q, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0.0f;
+    const float incl = wave_incl_scan_add_dpp(q);
+    const float excl = wave_shift_up1(incl, 0.0f);
     if (ok) suf[i] = carry + excl;
-    carry = carry + wave_bcast(incl, 63);
+    carry = carry + wave_last(incl);
   }
   cb_sync();
   float tcarry = 1.0f;
@@ -702,11 +701,10 @@ k_weights_bwd(const float* __restrict__ z_c, const float* __restrict__ z_f,
       alpha = 1.0f - ex;
     }
     const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
-    const float incl = wave_incl_scan_mul(fac, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0f;
+    const float incl = wave_incl_scan_mul_dpp(fac);
+    const float excl = wave_shift_up1(incl, 1.0f);
     const float Ti = tcarry * excl;
-    tcarry = tcarry * wave_bcast(incl, 63);
+    tcarry = tcarry * wave_last(incl);
     if (s < S) {
       const float Gi = G[(size_t)r * S + s];
       const float dalpha = Gi * Ti - suf[s] / fac;

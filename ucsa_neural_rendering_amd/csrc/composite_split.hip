@@ -134,11 +134,10 @@ __global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
         alpha = 1.0f - expf(-delta * a.density_scale * sgm[s]);
       }
       const float fac = (s < S) ? (1.0f - alpha + 1e-15f) : 1.0f;
-      const float incl = wave_incl_scan_mul(fac, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 1.0f;
+      const float incl = wave_incl_scan_mul_dpp(fac);
+      const float excl = wave_shift_up1(incl, 1.0f);
       const float w = alpha * (carry * excl);
-      carry = carry * wave_bcast(incl, 63);
+      carry = carry * wave_last(incl);
       const bool keep = (s < S) && (w > 1e-4f);
       if (a.w_out && s < S) {  // what the backward needs (composite.hip phase A)
         a.w_out[(size_t)r * S + s] = w;
@@ -636,6 +635,7 @@ template <int NRB_SEM, int CBS, int PREC, int WAVES, bool OFF32>
 __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
   static_assert(PREC == 1 || PREC == 2, "16-bit MFMA modes");
   constexpr uint32_t G = 16u * CBS;
+  const X3Sel sel = x3_selectors();  // bf16x3 split constants, once per kernel
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t g = lane >> 4, j = lane & 15u;
@@ -731,7 +731,6 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
   bool pad[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) pad[r] = (uint32_t)((NRB_SEM - 1) * 16 + 4 * g + r) >= C;
-  const int xor16 = (int)((lane ^ 16u) << 2), xor32 = (int)((lane ^ 32u) << 2);
 
   auto shade = [&](const Pre16<CBS, PREC>& p) {
     float geo[CBS][4];
@@ -761,8 +760,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
           b1[cb].t[term][0] = p.sh[cb][term][0];
           b1[cb].t[term][1] = p.sh[cb][term][1];
         }
-        split_pair(geo[cb][0], geo[cb][1], b1[cb], 2);
-        split_pair(geo[cb][2], geo[cb][3], b1[cb], 3);
+        split_pair(geo[cb][0], geo[cb][1], b1[cb], 2, sel);
+        split_pair(geo[cb][2], geo[cb][3], b1[cb], 3, sel);
       }
       f32x4 a1[CBS][4], a2[CBS][4];
       X3 h0[CBS], h1[CBS];
@@ -774,8 +773,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
       }
 #pragma unroll
       for (int cb = 0; cb < CBS; ++cb) {
-        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
-        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
+        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1], sel);
+        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3], sel);
       }
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
@@ -802,8 +801,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
       }
 #pragma unroll
       for (int cb = 0; cb < CBS; ++cb) {
-        h0[cb] = chain_relu_x3(a2[cb][0], a2[cb][1]);
-        h1[cb] = chain_relu_x3(a2[cb][2], a2[cb][3]);
+        h0[cb] = chain_relu_x3(a2[cb][0], a2[cb][1], sel);
+        h1[cb] = chain_relu_x3(a2[cb][2], a2[cb][3], sel);
       }
       {
         const W3 wa = frag_x3(w_color, 12, wl), wb = frag_x3(w_color, 13, wl);
@@ -815,8 +814,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
       }
 #pragma unroll
       for (int cb = 0; cb < CBS; ++cb) {
-        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1]);
-        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3]);
+        h0[cb] = chain_relu_x3(a1[cb][0], a1[cb][1], sel);
+        h1[cb] = chain_relu_x3(a1[cb][2], a1[cb][3], sel);
       }
 #pragma unroll
       for (int rb = 0; rb < NRB_SEM; ++rb) {
@@ -880,8 +879,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (rb + r > 0) mx = fmaxf(mx, lg[cb][rb][r]);
-      mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_ds_bpermute(xor16, __float_as_int(mx))) + 0.0f);
-      mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_ds_bpermute(xor32, __float_as_int(mx))) + 0.0f);
+      mx = rows4_max(mx);
       float sum = 0.0f;
 #pragma unroll
       for (int rb = 0; rb < NRB_SEM; ++rb)
@@ -891,8 +889,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
           lg[cb][rb][r] = ex;
           sum += ex;
         }
-      sum += __int_as_float(__builtin_amdgcn_ds_bpermute(xor16, __float_as_int(sum)));
-      sum += __int_as_float(__builtin_amdgcn_ds_bpermute(xor32, __float_as_int(sum)));
+      sum = rows4_sum(sum);
       const float wgt = p.ew[cb];
       const float ws = wgt * fast_rcp(sum);
       // the list is sorted by ray: first == last means one ray for all 16
@@ -1098,16 +1095,19 @@ static int32_t composite_infer(int prec, const float* rays_d,
   // makes; the 64-bit form covers the rest of the C API's range
   const uint64_t rows = (uint64_t)N * (T > t ? T : t);
   const bool off32 = rows * 64 < (1ull << 32) && (uint64_t)N * 96 < (1ull << 32);
-  // measured on the bench's 61 440-ray chunk (ms, k_weights_compact included):
-  //   f16:    0 = (16 waves, 1 block)   1 = (8, 2)   2 = (8, 1)   3 = (12, 1)
-  //   bf16x3: 0 = (8, 2)   1 = (16, 1)   2 = (12, 1)   3 = (8, 1)
+  // measured on the bench's 61 440-ray chunk (ms, k_weights_compact's 0.14
+  // included; round 3, tools/x3_bench.py):
+  //   f16:    0 = (16 waves, 1 block) 0.55 <- default   1 = (8, 2) 0.61
+  //           2 = (8, 1) 0.55   3 = (12, 1) 0.57
+  //   bf16x3: 0 = (8 waves, 1 block) 1.43 <- default   1 = (16, 1) 1.50
+  //           2 = (12, 1) 1.60   3 = (8, 2) 1.63
 #define SH_GO16(NRB)                                                                \
   do {                                                                              \
     if (prec == 2) {                                                                \
       if (variant == 1) return launch_shade16<NRB, 1, 2, 16>(b, n_waves, off32, s); \
       if (variant == 2) return launch_shade16<NRB, 1, 2, 12>(b, n_waves, off32, s); \
-      if (variant == 3) return launch_shade16<NRB, 1, 2, 8>(b, n_waves, off32, s);  \
-      return launch_shade16<NRB, 2, 2, 8>(b, n_waves, off32, s);                    \
+      if (variant == 3) return launch_shade16<NRB, 2, 2, 8>(b, n_waves, off32, s);  \
+      return launch_shade16<NRB, 1, 2, 8>(b, n_waves, off32, s);                    \
     }                                                                               \
     if (variant == 1) return launch_shade16<NRB, 2, 1, 8>(b, n_waves, off32, s);    \
     if (variant == 2) return launch_shade16<NRB, 1, 1, 8>(b, n_waves, off32, s);    \

@@ -46,25 +46,58 @@ __device__ __forceinline__ float pair_hi(uint32_t u) {
   return __uint_as_float(u & 0xFFFF0000u);
 }
 
+// The residuals a - lo(p), b - hi(p) of a bf16 pair p as ONE instruction each:
+// v_dot2_f32_bf16  D = A.lo * B.lo + A.hi * B.hi + C  with B = (-1, 0) resp.
+// (0, -1) and C = the fp32 value.  Both products are exact (x * -1, x * 0) and
+// the sum is the exactly representable difference, so the result equals the
+// shift / mask + subtract form bit for bit (tools/ubench/dot2_check.hip: 0
+// mismatches over 2^21 pairs) at 2 instead of 4 instructions per pair
+// (8.5 vs 11.3 issue cycles, profiles/r03_valu_rates.txt).  The two selector
+// constants live in registers (made opaque once per kernel) so that they cannot
+// be folded into an inline operand of unknown half placement.
+struct X3Sel {
+  uint32_t lo, hi;   // (-1, 0) and (0, -1) as bf16 pairs
+};
+__device__ __forceinline__ X3Sel x3_selectors() {
+  X3Sel s{0x0000BF80u, 0xBF800000u};
+  asm volatile("" : "+v"(s.lo), "+v"(s.hi));
+  return s;
+}
+__device__ __forceinline__ float resid_lo(uint32_t p, float a, const X3Sel& s) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p),
+                                         __builtin_bit_cast(bf16x2, s.lo), a, false);
+}
+__device__ __forceinline__ float resid_hi(uint32_t p, float b, const X3Sel& s) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p),
+                                         __builtin_bit_cast(bf16x2, s.hi), b, false);
+}
+
 // exact three-term split of two values into dword `d` of each term
-__device__ __forceinline__ void split_pair(float a, float b, X3& x, int d) {
+__device__ __forceinline__ void split_pair(float a, float b, X3& x, int d,
+                                           const X3Sel& sel) {
   const uint32_t p0 = bf16_pair(a, b);
-  const float ra = a - pair_lo(p0), rb = b - pair_hi(p0);
+  const float ra = resid_lo(p0, a, sel), rb = resid_hi(p0, b, sel);
   const uint32_t p1 = bf16_pair(ra, rb);
-  const float sa = ra - pair_lo(p1), sb = rb - pair_hi(p1);
+  const float sa = resid_lo(p1, ra, sel), sb = resid_hi(p1, rb, sel);
   x.t[0][d] = p0;
   x.t[1][d] = p1;
   x.t[2][d] = bf16_pair(sa, sb);
 }
+__device__ __forceinline__ void split_pair(float a, float b, X3& x, int d) {
+  split_pair(a, b, x, d, x3_selectors());
+}
 
 // two accumulator blocks (ReLU) -> one 32-wide k-step operand
-__device__ __forceinline__ X3 chain_relu_x3(f32x4 lo, f32x4 hi) {
+__device__ __forceinline__ X3 chain_relu_x3(f32x4 lo, f32x4 hi, const X3Sel& sel) {
   X3 x;
-  split_pair(relu1(lo[0]), relu1(lo[1]), x, 0);
-  split_pair(relu1(lo[2]), relu1(lo[3]), x, 1);
-  split_pair(relu1(hi[0]), relu1(hi[1]), x, 2);
-  split_pair(relu1(hi[2]), relu1(hi[3]), x, 3);
+  split_pair(relu1(lo[0]), relu1(lo[1]), x, 0, sel);
+  split_pair(relu1(lo[2]), relu1(lo[3]), x, 1, sel);
+  split_pair(relu1(hi[0]), relu1(hi[1]), x, 2, sel);
+  split_pair(relu1(hi[2]), relu1(hi[3]), x, 3, sel);
   return x;
+}
+__device__ __forceinline__ X3 chain_relu_x3(f32x4 lo, f32x4 hi) {
+  return chain_relu_x3(lo, hi, x3_selectors());
 }
 
 struct W3 {  // one A fragment, three terms

@@ -44,13 +44,12 @@ k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
       if (i + 1 < T) bins[i] = zi + 0.5f * delta;
     }
     const float fac = (i < T) ? (1.0f - alpha + 1e-15f) : 1.0f;
-    const float incl = wave_incl_scan_mul(fac, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0f;
+    const float incl = wave_incl_scan_mul_dpp(fac);
+    const float excl = wave_shift_up1(incl, 1.0f);
     const float w = alpha * (carry * excl);
     if (i < T) cdf[i] = w;
     if (i >= 1 && i + 1 < T) wsum += w + 1e-5f;
-    carry = carry * wave_bcast(incl, 63);
+    carry = carry * wave_last(incl);
   }
   wsum = wave_sum(wsum);
   __builtin_amdgcn_wave_barrier();
@@ -61,10 +60,10 @@ k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
     const uint32_t k = base + lane;  // output index
     float p = 0.0f;
     if (k >= 1 && k + 1 < T) p = (cdf[k] + 1e-5f) / wsum;
-    const float incl = wave_incl_scan_add(p, lane);
+    const float incl = wave_incl_scan_add_dpp(p);
     __builtin_amdgcn_wave_barrier();
     if (k + 1 < T) cdf[k] = run + incl;
-    run = run + wave_bcast(incl, 63);
+    run = run + wave_last(incl);
   }
   __builtin_amdgcn_wave_barrier();
 

@@ -75,7 +75,10 @@ class JointTrainLightningNet(nn.Module):
         # `nerf: {train_precision: fp16}`: colour / semantics nets of the
         # training pass on f16 MFMA too; the GradScaler's scale (reference :46)
         # already protects the fp16 gradient operands, so no extra one
-        self.nerf_model.train_precision = str(nerf_cfg.get("train_precision", "fp32"))
+        # Default "bf16x3": the training forward's colour / semantics stage on
+        # the split pair with the bf16x3 nets (fp32-grade, 1e-7 from the
+        # f32-input MFMA chain that "fp32" selects); the backward is the same.
+        self.nerf_model.train_precision = str(nerf_cfg.get("train_precision", "bf16x3"))
         self.nerf_model.f16_bwd_scale = float(nerf_cfg.get("f16_bwd_scale", 1.0))
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
