@@ -469,7 +469,7 @@ def seg_throughput(device, steps=5, B=8, find=False):
             m = m.to(memory_format=torch.channels_last)
             x = x.contiguous(memory_format=torch.channels_last)
         y = torch.randint(-1, N_CLASSES, (B, 240, 320), device=device)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=not nchw)
 
         class _Net(torch.nn.Module):   # parameters visible to make_graphed_callables
             def __init__(self, inner):

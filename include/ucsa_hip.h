@@ -592,25 +592,20 @@ int32_t ucsa_seg_tail(const float* logits, const int64_t* labels, uint32_t B,
  *   dresidual (may be NULL) = g; dbeta = sum g; dgamma = sum g * xhat;
  *   dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M)   (training mode).
  * workspace: ucsa_bn_workspace_bytes(M, C) bytes of caller-owned scratch.
- * counters: ucsa_bn_counter_count() uint32, caller-owned and PERSISTENT: zero
- *   before the first call, left zero by every call (arrival counters of the
- *   "last workgroup finalizes" reduction); calls sharing them must be ordered
- *   on one stream.  C <= 4096. */
+ * C <= 4096. */
 uint64_t ucsa_bn_workspace_bytes(uint32_t M, uint32_t C);
-uint32_t ucsa_bn_counter_count(void);
 int32_t ucsa_bn_act_fwd(const void* x, const void* residual, const float* gamma,
                         const float* beta, float* running_mean,
                         float* running_var, float momentum, float eps,
                         uint32_t M, uint32_t C, int32_t relu, int32_t training,
                         int32_t dtype, void* y, float* save_mean,
-                        float* save_invstd, void* workspace, uint32_t* counters,
-                        void* stream);
+                        float* save_invstd, void* workspace, void* stream);
 int32_t ucsa_bn_act_bwd(const void* dy, const void* x, const void* y,
                         const float* gamma, const float* save_mean,
                         const float* save_invstd, uint32_t M, uint32_t C,
                         int32_t relu, int32_t dtype, void* dx, void* dresidual,
                         float* dgamma, float* dbeta, void* workspace,
-                        uint32_t* counters, void* stream);
+                        void* stream);
 
 /* Confusion matrix, rows = truth, truth == -1 dropped (reference
  * nr4seg/utils/metrics.py:31-46); adds into cm [C,C] int64. */

@@ -14,7 +14,7 @@ m = DeepLabV3({"pretrained": False, "pretrained_backbone": False, "num_classes":
 cl = mode.endswith("cl")
 if cl:
     m = m.to(memory_format=torch.channels_last)
-opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=cl)
 x = torch.rand(B, 3, 240, 320, device=dev)
 if cl:
     x = x.contiguous(memory_format=torch.channels_last)

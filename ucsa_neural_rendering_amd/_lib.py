@@ -169,12 +169,11 @@ SIGNATURES = {
                                   _p, _p]),
     "ucsa_confusion_matrix": (C.c_int32, [_p, _p, C.c_uint64, _u32, _p, _p]),
     "ucsa_bn_workspace_bytes": (C.c_uint64, [_u32, _u32]),
-    "ucsa_bn_counter_count": (C.c_uint32, []),
     "ucsa_bn_act_fwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _f, _f, _u32, _u32,
                                     C.c_int32, C.c_int32, C.c_int32, _p, _p, _p,
-                                    _p, _p, _p]),
+                                    _p, _p]),
     "ucsa_bn_act_bwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _u32, _u32, C.c_int32,
-                                    C.c_int32, _p, _p, _p, _p, _p, _p, _p]),
+                                    C.c_int32, _p, _p, _p, _p, _p, _p]),
     # ---- occupancy-grid ray marching ----
     "ucsa_march_workspace_bytes": (C.c_uint64, [_u32]),
     "ucsa_march_rays_train": (C.c_int32, [_p, _p, _p, _f, _f, _f, _u32, _u32,

@@ -11,12 +11,12 @@
 // for their gradients: 20 / 32 bytes per element forward (without / with the
 // residual) and 32 / 44 backward in fp32.  Here:
 //
-//   forward   k_bn_stats      X            -> per-column partial sums (read 4 B);
-//                                             the last workgroup of a column
-//                                             group: mean, invstd, running stats
+//   forward   k_bn_stats      X            -> per-column partial sums (read 4 B)
+//             k_bn_finalize   partials     -> mean, invstd, running stats (one
+//                                             workgroup per 64 channels)
 //             k_bn_apply      X, (R)       -> Y = relu(a X + b (+ R))  (8 / 12 B)
-//   backward  k_bn_bwd_stats  dY, Y, X     -> partial sum(g), sum(g xhat); last
-//                                             workgroup: dgamma, dbeta
+//   backward  k_bn_bwd_stats  dY, Y, X     -> partial sum(g), sum(g xhat)
+//             k_bn_bwd_final  partials     -> dgamma, dbeta
 //             k_bn_bwd_apply  dY, Y, X     -> dX (, dR = g)
 //   with g = dY * (Y > 0) when the ReLU is fused (Y is the layer's own output,
 //   which autograd keeps alive for the next convolution anyway).
@@ -93,11 +93,11 @@ static BnGeom bn_geom(uint32_t M, uint32_t C) {
   g.rows_per_it = BN_THREADS / tq;
   g.n_col_wg = cq / tq;
   // ~2048 workgroups in all (8 per CU: the passes are latency-bound streams,
-  // they need many loads in flight), at most 512 per column group, at least 4
-  // iterations each
+  // they need many loads in flight), at most 128 per column group (the finalize
+  // launch sums them with 16 row lanes), at least 4 iterations each
   uint32_t want = 2048 / g.n_col_wg;
   if (want < 1) want = 1;
-  if (want > 512) want = 512;
+  if (want > 128) want = 128;
   uint32_t rows = (M + want - 1) / want;
   const uint32_t min_rows = 4 * g.rows_per_it;
   if (rows < min_rows) rows = min_rows;
@@ -106,8 +106,6 @@ static BnGeom bn_geom(uint32_t M, uint32_t C) {
   g.n_row_wg = (M + rows - 1) / rows;
   return g;
 }
-
-extern "C" uint32_t ucsa_bn_counter_count(void) { return 1024u; }
 
 extern "C" uint64_t ucsa_bn_workspace_bytes(uint32_t M, uint32_t C) {
   if (M == 0 || C == 0 || C % 4) return 0;
@@ -137,31 +135,28 @@ __device__ __forceinline__ void wg_reduce2(bn_f32x4& a, bn_f32x4& b, uint32_t tq
 }
 
 
-// The LAST workgroup of a column group to arrive (agent-scope counter) sums the
-// group's per-workgroup partials: thread (q, rr) adds partial rows rr, rr +
-// rows_per_it, ... of its channel quad in double, an LDS tree over rr finishes.
-// Returns true in the threads of row 0 of that workgroup, with the two sums of
-// their quad in s / ss; everybody else gets false.  Replaces a finalize launch
-// whose one-thread-per-channel loop over up to 2048 partials took 85 us.
+// Sum of a column group's per-workgroup partials, by ONE workgroup of the
+// finalize launch (blockIdx.x = column group): thread (q, rr) adds partial rows
+// rr, rr + rows_per_it, ... of its channel quad in double with eight loads in
+// flight, an LDS tree over rr finishes.  Returns true in the threads of row 0,
+// with the two sums of their quad in s / ss.
+// (Tried first: no second launch, the LAST stats workgroup to arrive -- agent-
+// scope ticket -- reduces.  Every workgroup then needs a release fence, and
+// __threadfence() costs ~3.5 us per workgroup on this chip, x4 at four
+// workgroups per CU (MI355X_MICROARCH.md, inter-workgroup visibility): the
+// stats kernels took 45 - 130 us instead of ~8.  A dependent launch boundary
+// is 1.5 - 1.9 us.)
 struct D4 {
   double v[4];
 };
-__device__ __forceinline__ bool bn_last_wg_reduce(const BnGeom& g, float* partial,
-                                                  uint32_t* counters, D4& s, D4& ss) {
-  __shared__ uint32_t ticket;
+__device__ __forceinline__ bool bn_group_reduce(const BnGeom& g, const float* partial,
+                                                D4& s, D4& ss) {
   __shared__ double red[2][BN_THREADS][4];
   const uint32_t t = threadIdx.x;
-  __threadfence();   // this workgroup's partials are visible agent-wide
-  __syncthreads();
-  if (t == 0) ticket = atomicAdd(&counters[blockIdx.y], 1u);
-  __syncthreads();
-  if (ticket != g.n_row_wg - 1) return false;
-  __threadfence();   // acquire the other workgroups' partials
   const uint32_t q = t % g.tq, rr = t / g.tq;
-  const uint32_t c = 4 * (blockIdx.y * g.tq + q);
+  const uint32_t c = 4 * (blockIdx.x * g.tq + q);
 #pragma unroll
   for (int k = 0; k < 4; ++k) s.v[k] = ss.v[k] = 0.0;
-  // (the partials were written by other CUs: loads bypass this CU's L1)
   uint32_t k = rr;
   const uint32_t kstep = g.rows_per_it;
   for (; k + 3 * kstep < g.n_row_wg; k += 4 * kstep) {  // eight loads in flight
@@ -169,8 +164,8 @@ __device__ __forceinline__ bool bn_last_wg_reduce(const BnGeom& g, float* partia
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float* p = partial + (size_t)(k + u * kstep) * 2 * g.C;
-      a[u] = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + c));
-      b[u] = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + g.C + c));
+      a[u] = *reinterpret_cast<const bn_f32x4*>(p + c);
+      b[u] = *reinterpret_cast<const bn_f32x4*>(p + g.C + c);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -182,8 +177,8 @@ __device__ __forceinline__ bool bn_last_wg_reduce(const BnGeom& g, float* partia
   }
   for (; k < g.n_row_wg; k += kstep) {
     const float* p = partial + (size_t)k * 2 * g.C;
-    const bn_f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + c));
-    const bn_f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const bn_f32x4*>(p + g.C + c));
+    const bn_f32x4 a = *reinterpret_cast<const bn_f32x4*>(p + c);
+    const bn_f32x4 b = *reinterpret_cast<const bn_f32x4*>(p + g.C + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s.v[e] += (double)a[e];
@@ -206,7 +201,6 @@ __device__ __forceinline__ bool bn_last_wg_reduce(const BnGeom& g, float* partia
     }
     __syncthreads();
   }
-  if (t == 0) counters[blockIdx.y] = 0u;   // ready for the next call
   if (t >= g.tq) return false;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -226,13 +220,12 @@ struct BnFwdFin {   // what the finalizing workgroup needs
   float* save_mean;
   float* save_invstd;
   float* coef;
-  uint32_t* counters;
 };
 
 template <typename T>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bn_stats(BnGeom g, const T* __restrict__ x, const float* __restrict__ shift,
-           float* partial, BnFwdFin f) {
+           float* __restrict__ partial) {
   const uint32_t t = threadIdx.x;
   const uint32_t q = blockIdx.y * g.tq + t % g.tq;  // channel quad
   const uint32_t c = 4 * q;
@@ -266,11 +259,18 @@ k_bn_stats(BnGeom g, const T* __restrict__ x, const float* __restrict__ shift,
     *reinterpret_cast<bn_f32x4*>(p + c) = s;
     *reinterpret_cast<bn_f32x4*>(p + g.C + c) = ss;
   }
-  // mean / invstd, running statistics as torch.nn.BatchNorm2d updates them
-  // (the biased variance normalises, the unbiased one goes into running_var),
-  // coefficients a = gamma * invstd, b = beta - mean * a
+}
+
+// mean / invstd, running statistics as torch.nn.BatchNorm2d updates them (the
+// biased variance normalises, the unbiased one goes into running_var),
+// coefficients a = gamma * invstd, b = beta - mean * a.  One workgroup per
+// column group.
+__global__ void __launch_bounds__(BN_THREADS)
+k_bn_finalize(BnGeom g, const float* __restrict__ partial,
+              const float* __restrict__ shift, BnFwdFin f) {
   D4 ds, dss;
-  if (!bn_last_wg_reduce(g, partial, f.counters, ds, dss)) return;
+  if (!bn_group_reduce(g, partial, ds, dss)) return;
+  const uint32_t c = 4 * (blockIdx.x * g.tq + threadIdx.x);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const uint32_t ch = c + e;
@@ -336,14 +336,13 @@ struct BnBwdFin {
   float* dgamma;
   float* dbeta;
   float* coef;
-  uint32_t* counters;
 };
 
 template <typename T, bool RELU>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bn_bwd_stats(BnGeom g, const T* __restrict__ dy, const T* __restrict__ y,
                const T* __restrict__ x, const float* __restrict__ mean,
-               const float* __restrict__ invstd, float* partial, BnBwdFin f) {
+               const float* __restrict__ invstd, float* __restrict__ partial) {
   const uint32_t t = threadIdx.x;
   const uint32_t q = blockIdx.y * g.tq + t % g.tq;
   const uint32_t c = 4 * q;
@@ -387,10 +386,17 @@ k_bn_bwd_stats(BnGeom g, const T* __restrict__ dy, const T* __restrict__ y,
     *reinterpret_cast<bn_f32x4*>(p + c) = sg;
     *reinterpret_cast<bn_f32x4*>(p + g.C + c) = sgx;
   }
-  // dbeta = sum g, dgamma = sum g xhat; coefficients of
-  // dx = c1 (g - c2 - xhat c3) = c1 g - (c1 c3 invstd) x + (c1 c3 invstd mean - c1 c2)
+}
+
+// dbeta = sum g, dgamma = sum g xhat; coefficients of
+// dx = c1 (g - c2 - xhat c3) = c1 g - (c1 c3 invstd) x + (c1 c3 invstd mean - c1 c2)
+__global__ void __launch_bounds__(BN_THREADS)
+k_bn_bwd_final(BnGeom g, const float* __restrict__ partial,
+               const float* __restrict__ mean, const float* __restrict__ invstd,
+               BnBwdFin f) {
   D4 dsg, dsgx;
-  if (!bn_last_wg_reduce(g, partial, f.counters, dsg, dsgx)) return;
+  if (!bn_group_reduce(g, partial, dsg, dsgx)) return;
+  const uint32_t c = 4 * (blockIdx.x * g.tq + threadIdx.x);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const uint32_t ch = c + e;
@@ -439,18 +445,20 @@ static int32_t bn_fwd(const void* x, const void* res, const float* gamma,
                       const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, uint32_t M, uint32_t C, int relu,
                       int training, void* y, float* save_mean, float* save_invstd,
-                      void* workspace, uint32_t* counters, hipStream_t s) {
+                      void* workspace, hipStream_t s) {
   const BnGeom g = bn_geom(M, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)g.n_row_wg * 2 * C;
   UCSA_CLEAR_ERR();
   if (training) {
     const BnFwdFin f{gamma, beta, running_mean, running_var, momentum, eps,
-                     save_mean, save_invstd, coef, counters};
+                     save_mean, save_invstd, coef};
     // shift = running_mean (the best cheap guess of the mean) when there is one
     hipLaunchKernelGGL((k_bn_stats<T>), dim3(g.n_row_wg, g.n_col_wg),
                        dim3(BN_THREADS), 0, s, g, (const T*)x,
-                       (const float*)running_mean, partial, f);
+                       (const float*)running_mean, partial);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(g.n_col_wg), dim3(BN_THREADS), 0, s, g,
+                       (const float*)partial, (const float*)running_mean, f);
   } else {
     hipLaunchKernelGGL(k_bn_coef_eval, dim3((C + 255) / 256), dim3(256), 0, s, C,
                        gamma, beta, running_mean, running_var, eps, coef);
@@ -473,20 +481,22 @@ static int32_t bn_bwd(const void* dy, const void* x, const void* y,
                       const float* gamma, const float* save_mean,
                       const float* save_invstd, uint32_t M, uint32_t C, int relu,
                       void* dx, void* dres, float* dgamma, float* dbeta,
-                      void* workspace, uint32_t* counters, hipStream_t s) {
+                      void* workspace, hipStream_t s) {
   const BnGeom g = bn_geom(M, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)g.n_row_wg * 2 * C;
   UCSA_CLEAR_ERR();
-  const BnBwdFin f{gamma, dgamma, dbeta, coef, counters};
+  const BnBwdFin f{gamma, dgamma, dbeta, coef};
   if (relu)
     hipLaunchKernelGGL((k_bn_bwd_stats<T, true>), dim3(g.n_row_wg, g.n_col_wg),
                        dim3(BN_THREADS), 0, s, g, (const T*)dy, (const T*)y,
-                       (const T*)x, save_mean, save_invstd, partial, f);
+                       (const T*)x, save_mean, save_invstd, partial);
   else
     hipLaunchKernelGGL((k_bn_bwd_stats<T, false>), dim3(g.n_row_wg, g.n_col_wg),
                        dim3(BN_THREADS), 0, s, g, (const T*)dy, (const T*)y,
-                       (const T*)x, save_mean, save_invstd, partial, f);
+                       (const T*)x, save_mean, save_invstd, partial);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(g.n_col_wg), dim3(BN_THREADS), 0, s, g,
+                     (const float*)partial, save_mean, save_invstd, f);
   const uint64_t nq = (uint64_t)M * (C / 4);
   const dim3 grid(bn_apply_blocks(nq));
 #define BN_BAPPLY(RELU, DRES)                                                      \
@@ -508,8 +518,7 @@ extern "C" int32_t ucsa_bn_act_fwd(const void* x, const void* residual,
                                    uint32_t C, int32_t relu, int32_t training,
                                    int32_t dtype, void* y, float* save_mean,
                                    float* save_invstd, void* workspace,
-                                   uint32_t* counters, void* stream) {
-  UCSA_CHECK_ARG(!training || counters, 17);
+                                   void* stream) {
   UCSA_CHECK_ARG(x && ((uintptr_t)x & 15u) == 0, 0);
   UCSA_CHECK_ARG(!residual || ((uintptr_t)residual & 15u) == 0, 1);
   UCSA_CHECK_ARG(training || (running_mean && running_var), 4);
@@ -524,10 +533,10 @@ extern "C" int32_t ucsa_bn_act_fwd(const void* x, const void* residual,
   if (dtype == 0)
     return bn_fwd<float>(x, residual, gamma, beta, running_mean, running_var,
                          momentum, eps, M, C, relu, training, y, save_mean,
-                         save_invstd, workspace, counters, (hipStream_t)stream);
+                         save_invstd, workspace, (hipStream_t)stream);
   return bn_fwd<__hip_bfloat16>(x, residual, gamma, beta, running_mean,
                                 running_var, momentum, eps, M, C, relu, training,
-                                y, save_mean, save_invstd, workspace, counters,
+                                y, save_mean, save_invstd, workspace,
                                 (hipStream_t)stream);
 }
 
@@ -536,9 +545,7 @@ extern "C" int32_t ucsa_bn_act_bwd(const void* dy, const void* x, const void* y,
                                    const float* save_invstd, uint32_t M,
                                    uint32_t C, int32_t relu, int32_t dtype,
                                    void* dx, void* dresidual, float* dgamma,
-                                   float* dbeta, void* workspace,
-                                   uint32_t* counters, void* stream) {
-  UCSA_CHECK_ARG(counters, 15);
+                                   float* dbeta, void* workspace, void* stream) {
   UCSA_CHECK_ARG(dy && ((uintptr_t)dy & 15u) == 0, 0);
   UCSA_CHECK_ARG(x && ((uintptr_t)x & 15u) == 0, 1);
   UCSA_CHECK_ARG(!relu || (y && ((uintptr_t)y & 15u) == 0), 2);
@@ -550,8 +557,8 @@ extern "C" int32_t ucsa_bn_act_bwd(const void* dy, const void* x, const void* y,
   if (M == 0) return 0;
   if (dtype == 0)
     return bn_bwd<float>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx,
-                         dresidual, dgamma, dbeta, workspace, counters, (hipStream_t)stream);
+                         dresidual, dgamma, dbeta, workspace, (hipStream_t)stream);
   return bn_bwd<__hip_bfloat16>(dy, x, y, gamma, save_mean, save_invstd, M, C,
                                 relu, dx, dresidual, dgamma, dbeta, workspace,
-                                counters, (hipStream_t)stream);
+                                (hipStream_t)stream);
 }

@@ -229,6 +229,11 @@ class _DeepLabV3Model(nn.Module):
         size = x.shape[-2:]
         feats = self.backbone(x)
         out = self.classifier(feats["out"])
+        # the logits leave in the reference's NCHW layout: re-striding the small
+        # pre-upsample map (1/64 of the output) is free, transposing the
+        # upsampled [B,C,H,W] afterwards (what `.contiguous()` on a
+        # channels-last result does, forward and backward) is 2 x 98 MB
+        out = out.contiguous()
         out = F.interpolate(out, size=size, mode="bilinear",
                             align_corners=False)
         return OrderedDict(out=out)

@@ -722,20 +722,6 @@ def _nhwc_rows(t: torch.Tensor, name: str):
     return N * H * W, Cc, 0 if t.dtype == torch.float32 else 1
 
 
-_bn_counters = {}
-
-
-def _bn_sync_counters(device) -> torch.Tensor:
-    """Persistent, zero-initialised arrival counters of the BatchNorm
-    reductions (one buffer per device; every call leaves them zero)."""
-    buf = _bn_counters.get(device)
-    if buf is None:
-        buf = torch.zeros(int(lib().ucsa_bn_counter_count()), dtype=torch.int32,
-                          device=device)
-        _bn_counters[device] = buf
-    return buf
-
-
 def bn_act_fwd(x, residual, weight, bias, running_mean, running_var,
                momentum: float, eps: float, relu: bool, training: bool):
     """-> (y, save_mean, save_invstd); save_* are None in eval mode."""
@@ -753,7 +739,7 @@ def bn_act_fwd(x, residual, weight, bias, running_mean, running_var,
         _ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
         _ptr(running_var), float(momentum), float(eps), M, Cc, int(relu),
         int(training), dt, _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws),
-        _ptr(_bn_sync_counters(x.device)), _stream()), "ucsa_bn_act_fwd")
+        _stream()), "ucsa_bn_act_fwd")
     return y, save_mean, save_invstd
 
 
@@ -772,8 +758,7 @@ def bn_act_bwd(dy, x, y, weight, save_mean, save_invstd, relu: bool,
     check(lib().ucsa_bn_act_bwd(
         _ptr(dy), _ptr(x), _ptr(y) if relu else None, _ptr(weight), _ptr(save_mean),
         _ptr(save_invstd), M, Cc, int(relu), dt, _ptr(dx), _ptr(dres), _ptr(dw),
-        _ptr(db), _ptr(ws), _ptr(_bn_sync_counters(x.device)), _stream()),
-          "ucsa_bn_act_bwd")
+        _ptr(db), _ptr(ws), _stream()), "ucsa_bn_act_bwd")
     return dx, dres, dw, db
 
 
