@@ -247,7 +247,12 @@ def test_binned_grid_backward_rays_with_clustered_samples(ops):
     centres = torch.rand(N, 3, generator=g) * 3.0 + 0.3
     width = 10.0 ** (-(torch.rand(N, 3, generator=g) * 2 + 1.7))
     z = (centres[:, :, None] + width[:, :, None] * torch.rand(N, 3, 43, generator=g)).reshape(N, -1)
-    z = torch.cat([z, z[:, :T - z.shape[1]]], 1).sort(-1).values       # duplicates too
+    # 3 x 43 = 129 depths: keep T of them (round 2 had `z[:, :T - 129]` here,
+    # which appended 128 more columns -- z was [N, 257] against a d_feat of
+    # N * 128 rows, and the kernels read past the end of d_feat; found in
+    # round 3 when the suite's allocation order changed)
+    z = z[:, :T].sort(-1).values
+    z[:, 1::16] = z[:, 0::16]                                          # duplicates too
     z[::7] = z[0]                                                      # identical rays
     o[::7], d[::7] = o[0], d[0]
     aabb = [-4.0, -4.0, -4.0, 4.0, 4.0, 4.0]

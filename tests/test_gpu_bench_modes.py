@@ -94,3 +94,32 @@ def test_plain_bench_gpus_2_launches_its_own_ranks(tmp_path):
     d = res["distributed"]
     assert res["n_gpus"] == 2 and d["world_size"] == 2 and d["launcher"] == "self"
     assert d["backend"].startswith("gloo") and len(d["devices"]) == 2
+
+
+def test_cfg3_mode_two_joint_steps_one_process(tmp_path):
+    """`bench.py --mode cfg3`: BASELINE cfg3's joint step (8 frames of 320x240:
+    8 full no-grad renders at 256+256 samples + 8 NeRF training steps of 4096
+    rays + DeepLabV3 forward/backward/Adam on the 8 augmented renders) through
+    the LightningModule mirror, two timed steps; the line carries the
+    roofline of the whole step (flop and bytes of its three parts)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out, err = tmp_path / "out.txt", tmp_path / "err.txt"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "cfg3", "--steps", "2",
+           "--warmup", "1", "--no-seg-find"]
+    with open(out, "w") as fo, open(err, "w") as fe:
+        rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                              env=env, cwd=ROOT).wait(timeout=900)
+    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
+    res = json.loads(lines[0])
+    assert res["config"]["mode"] == "cfg3" and res["n_gpus"] == 1
+    assert res["config"]["nerf_rays_per_step_per_rank"] == 8 * (320 * 240 + 4096)
+    assert res["value"] > 0 and res["ms_per_step"] < 2000
+    rs = res["roofline_step"]
+    parts = rs["mfma"]["of_which"]
+    assert abs(sum(parts.values()) - rs["mfma"]["algorithmic_flop"]) <= 1e-6 * rs["mfma"]["algorithmic_flop"]
+    assert 0.0 < rs["mfma"]["frac_of_fp32_mfma_peak"] < 1.0 and 0.0 < rs["hbm"]["frac"] < 1.0
+    assert 0.3 < rs["masked_fraction_rho"] <= 1.0
+    for k in ("train/loss_nerf_rgb", "train/loss_seg"):
+        assert k in res["losses"] and res["losses"][k] == res["losses"][k]      # finite

@@ -145,6 +145,11 @@ k_hashgrid_encode(GridDev g, uint32_t level0,
 struct LevelMap {
   uint8_t lv[UCSA_MAX_LEVELS];
   uint32_t k;
+  // hashed levels below this index take the plain 8-load gather instead of
+  // the x-pair form (6 accesses + 24 selects per sample): on the coarse
+  // hashed levels the lanes of a wave share their cells, the gathers hit the
+  // L1 and the level is bound by VALU issue, not by the TA
+  uint32_t simple_below;
 };
 template <typename TT = float2, typename FT = float2>
 __global__ void __launch_bounds__(256)
@@ -205,8 +210,9 @@ k_hashgrid_encode_tiled(GridDev g, LevelMap lm,
                   y01 = to_unit(py, g.bound, two_b, inv),
                   z01 = to_unit(pz, g.bound, two_b, inv);
       to_feat(f_s[lane][ss],
-              hashed ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
-                     : encode_level(tab, x01, y01, z01, scale, res, entries, 0u));
+              (hashed && level >= lm.simple_below)
+                  ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
+                  : encode_level(tab, x01, y01, z01, scale, res, entries, hashed));
     }
   }
   __syncthreads();
@@ -278,6 +284,8 @@ extern "C" int32_t ucsa_hashgrid_encode_rays(
 static LevelMap level_map(uint32_t L) {
   LevelMap lm;
   lm.k = 1;
+  const char* sb = getenv("UCSA_ENC_SIMPLE");
+  lm.simple_below = sb ? (uint32_t)strtoul(sb, nullptr, 10) : 0u;
   for (uint32_t i = 0; i < UCSA_MAX_LEVELS; ++i) lm.lv[i] = (uint8_t)(i < L ? L - 1 - i : 0);
   const char* e = getenv("UCSA_ENC_ORDER");
   if (e && *e) {

@@ -523,6 +523,12 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
     rec_scale > 0 (binned only): 8-byte bin records, values as half2 x
     rec_scale (the f16 training mode)."""
     N, T = z.shape
+    if tuple(d_feat.shape) != (grid.n_levels, N * T, 2) or not d_feat.is_contiguous():
+        raise _lib.UcsaError(
+            f"d_feat must be a contiguous [{grid.n_levels}, {N * T}, 2] tensor "
+            f"(levels, N*T samples of z {tuple(z.shape)}, 2), got {tuple(d_feat.shape)}")
+    if tuple(rays_o.shape) != (N, 3) or tuple(rays_d.shape) != (N, 3):
+        raise _lib.UcsaError("rays_o / rays_d must be [N, 3] with N = z.shape[0]")
     ws = None
     if binned:
         need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(N, T, grid.n_levels))
@@ -548,6 +554,10 @@ def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
     """Backward of hashgrid_encode_points: adds into grad_table."""
     x = _f32(x, "x").view(-1, 3)
     M = x.shape[0]
+    if tuple(d_feat.shape) != (grid.n_levels, M, 2) or not d_feat.is_contiguous():
+        raise _lib.UcsaError(
+            f"d_feat must be a contiguous [{grid.n_levels}, {M}, 2] tensor, got "
+            f"{tuple(d_feat.shape)}")
     ws = None
     if binned:
         need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(M, 1, grid.n_levels))
