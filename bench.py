@@ -1297,6 +1297,19 @@ def main():
                                "MFMA (`nerf: {train_precision: fp16}`), sigma net and "
                                "grid fp32")
             result["train_f16_nets"] = tf
+            tt = train_throughput(net, scene_ds, dev, train_precision="tcnn")
+            tt["workload"] += ("; tiny-cuda-nn's numerics end to end (`nerf: {train_precision: "
+                               "tcnn}`): fp16 table copy and features, all three nets on f16 "
+                               "MFMA, half2 bin records; fp32 master parameters")
+            result["train_tcnn_numerics"] = tt
+            result["value_tcnn_numerics"] = {
+                "render_rays_per_s": result.get("value_fp16_nets_fp16_table"),
+                "train_rays_per_s": tt["rays_per_s"],
+                "note": "the reference's own arithmetic (tiny-cuda-nn: fp16 table, fp16 "
+                        "nets, fp32 accumulate) next to the fp32-grade headline `value`; "
+                        "parity of both modes against the oracle with those roundings "
+                        "emulated: tests/test_gpu_configs.py (render), "
+                        "tests/test_gpu_backward.py::test_tcnn_numerics_* (training)"}
             _tick("training legs done")
             result["seg"] = seg_throughput(dev, find=args.seg_find)
             _tick("DeepLab leg done")

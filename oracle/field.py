@@ -332,7 +332,13 @@ class OracleField:
     # reference density(): :130-144
     def density(self, x: torch.Tensor):
         x01 = (x + self.bound) / (2 * self.bound)
-        enc = hashgrid_encode(self.grid, x01, self.grid_params)
+        if getattr(self, "fp16_table", False):
+            # tiny-cuda-nn stores the table and the features in fp16 (fp32
+            # interpolation in between); the casts pass gradients straight
+            # through to the fp32 master parameters
+            enc = _q16(hashgrid_encode(self.grid, x01, _q16(self.grid_params)))
+        else:
+            enc = hashgrid_encode(self.grid, x01, self.grid_params)
         h = mlp_forward(self.sigma_spec, enc, self.sigma_params,
                         self._emu("sigma"))
         sigma = trunc_exp(h[:, 0])

@@ -374,6 +374,51 @@ def test_f16_training_forward_and_gradients_match_fp16_emulating_oracle(N, T, t)
         assert e <= 2e-2 and c >= 0.999, name
 
 
+@pytest.mark.parametrize("N,T,t", [(48, 16, 16), (40, 96, 96)])
+def test_tcnn_numerics_training_matches_the_fully_fp16_emulating_oracle(N, T, t):
+    """nerf.train_precision = tcnn: tiny-cuda-nn's numerics end to end (the
+    reference's own arithmetic, network_tcnn_semantics.py:36-58) -- fp16 hash
+    table and features, all three nets with fp16 weights / layer inputs and
+    fp32 accumulation, half2 grid-gradient records -- against the oracle with
+    every one of those roundings emulated (``emulate_fp16=True`` +
+    ``fp16_table``; casts pass gradients straight through).  Forward <= 3e-3;
+    gradients of a linear functional <= 3e-2 relative L2, cosine >= 0.999 (the
+    kernels also round each layer's incoming gradient to fp16 under a loss
+    scale, and the sigma net's backward keeps its hidden layer in fp32)."""
+    import copy
+    fld = lively_oracle_field().requires_grad_(True)
+    f16 = copy.copy(fld)
+    f16.emulate_fp16 = True
+    f16.fp16_table = True
+    net = hip_network_from_oracle(fld).train()
+    net.train_precision = "tcnn"
+    o, d, norms = make_rays(N, 900 + N)
+    g = torch.Generator().manual_seed(900 + N)
+    t_rand, u = torch.rand(N, T, generator=g), torch.rand(N, t, generator=g)
+    ci, cd, cs = (torch.rand(1, N, 3, generator=g), torch.rand(1, N, generator=g),
+                  torch.rand(1, N, 40, generator=g))
+    ref = oren.run(f16, o[None], d[None], norms[None], AABB4, num_steps=T,
+                   upsample_steps=t, t_rand=t_rand, u=u)
+    ((ref["image"] * ci).sum() + (ref["depth"] * cd).sum() + (ref["semantics"] * cs).sum()).backward()
+    res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(), perturb=True,
+                     num_steps=T, upsample_steps=t, rng_t=t_rand.cuda(), rng_u=u.cuda())
+    print(f"tcnn-train forward: image {maxabs(res['image'], ref['image']):.2e} "
+          f"sem {maxabs(res['semantics'], ref['semantics']):.2e}")
+    assert maxabs(res["image"], ref["image"]) <= 3e-3
+    assert maxabs(res["semantics"], ref["semantics"]) <= 3e-3
+    ((res["image"] * ci.cuda()).sum() + (res["depth"] * cd.cuda()).sum()
+     + (res["semantics"] * cs.cuda()).sum()).backward()
+    cos = lambda a, b: float(torch.nn.functional.cosine_similarity(
+        a.detach().double().reshape(1, -1).cpu(), b.detach().double().reshape(1, -1)))
+    for name, got, want in (("color", net.color_net.params.grad, fld.color_params.grad),
+                            ("sem", net.semantics_net.params.grad, fld.sem_params.grad),
+                            ("sigma", net.sigma_net.params.grad, fld.sigma_params.grad),
+                            ("grid", net.encoder.params.grad, fld.grid_params.grad)):
+        e, c = rel_l2(got, want), cos(got, want)
+        print(f"tcnn-train {name}: rel L2 {e:.3e} cos {c:.6f}")
+        assert e <= 3e-2 and c >= 0.999, name
+
+
 def test_f16_training_reduces_the_loss_like_fp32():
     """30 Adam steps on a fixed target through the f16 training nets: the loss
     falls, and ends within 10 % of the fp32 run's."""

@@ -102,7 +102,7 @@ k_hashgrid_encode_coarse(GridDev g, uint32_t n_coarse,
 // Fine levels [level0, n_levels): level-major (see file header).
 template <bool FROM_RAYS, typename TT = float2, typename FT = float2>
 __global__ void __launch_bounds__(256)
-k_hashgrid_encode(GridDev g, uint32_t level0,
+k_hashgrid_encode(GridDev g, uint32_t level0, uint32_t simple_below,
                   const TT* __restrict__ table,
                   const float* __restrict__ rays_o,
                   const float* __restrict__ rays_d,
@@ -114,12 +114,12 @@ k_hashgrid_encode(GridDev g, uint32_t level0,
   float x01, y01, z01;
   sample_x01<FROM_RAYS>(g, rays_o, rays_d, zs, bb, T, m, x01, y01, z01);
   float2 f;
-  if (g.hashed[level])
+  if (g.hashed[level] && level >= simple_below)
     f = encode_level_hashed(table + g.offset[level], x01, y01, z01,
                             g.scale[level], g.entries[level]);
   else
     f = encode_level(table + g.offset[level], x01, y01, z01, g.scale[level],
-                     g.res[level], g.entries[level], 0u);
+                     g.res[level], g.entries[level], g.hashed[level]);
   feat_store(feat + (uint64_t)level * M + m, f);
 }
 
@@ -234,6 +234,20 @@ static uint32_t coarse_levels(const ucsa_grid* grid) {
   return n;
 }
 
+// Hashed levels below this index take the plain 8-load gather
+// (encode_level) instead of the x-pair form (encode_level_hashed: 6 accesses
+// but 24 selects per sample).  Measured in round 3 on the tiled kernel with
+// the fp32 table (tools/encode_order_sweep.py, 61 440-ray chunk): the plain
+// gather is FASTER on every level -- coarse pass 0.80 -> 0.64 ms, fine pass
+// 1.41 -> 1.23 ms -- the x-pair trick of rounds 1-2 (then a gain on the
+// ray-ordered kernel) costs more VALU issue than the accesses it saves now
+// that the lanes of a tile share their cache lines.  `env` overrides the
+// default for experiments; results do not depend on it.
+static uint32_t simple_gather_below(const char* env, uint32_t dflt) {
+  const char* v = getenv(env);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
 template <bool FROM_RAYS, typename TT = float2, typename FT = float2>
 static int32_t launch_encode(const ucsa_grid* grid, const void* table,
                              const float* a, const float* b, const float* z,
@@ -251,8 +265,9 @@ static int32_t launch_encode(const ucsa_grid* grid, const void* table,
   if (nc < grid->n_levels)
     hipLaunchKernelGGL((k_hashgrid_encode<FROM_RAYS, TT, FT>),
                        dim3(ucsa_div_up(M, 256), grid->n_levels - nc), blk, 0,
-                       (hipStream_t)stream, gd, nc, (const TT*)table, a, b,
-                       z, bb, T, M, (FT*)feat);
+                       (hipStream_t)stream, gd, nc,
+                       simple_gather_below("UCSA_ENC_SIMPLE_RAYS", 0u),
+                       (const TT*)table, a, b, z, bb, T, M, (FT*)feat);
   return ucsa_launch_status();
 }
 
@@ -284,8 +299,7 @@ extern "C" int32_t ucsa_hashgrid_encode_rays(
 static LevelMap level_map(uint32_t L) {
   LevelMap lm;
   lm.k = 1;
-  const char* sb = getenv("UCSA_ENC_SIMPLE");
-  lm.simple_below = sb ? (uint32_t)strtoul(sb, nullptr, 10) : 0u;
+  lm.simple_below = 0u;   // set per table type by the caller
   for (uint32_t i = 0; i < UCSA_MAX_LEVELS; ++i) lm.lv[i] = (uint8_t)(i < L ? L - 1 - i : 0);
   const char* e = getenv("UCSA_ENC_ORDER");
   if (e && *e) {
@@ -337,7 +351,12 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
     const uint32_t rows = ucsa_div_up(N, image_width);
     const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
     const uint32_t s_blocks = ucsa_div_up(T, TILE_S);
-    const LevelMap lm = level_map(grid->n_levels);
+    LevelMap lm = level_map(grid->n_levels);
+    // fp32 table: plain gather on every level (measured faster, see
+    // simple_gather_below); half2 table: its group-of-four form stays
+    lm.simple_below = sizeof(TT) == 8
+                          ? simple_gather_below("UCSA_ENC_SIMPLE", UCSA_MAX_LEVELS)
+                          : simple_gather_below("UCSA_ENC_SIMPLE_H", 0u);
     hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
                        dim3(tiles * s_blocks * lm.k, grid->n_levels / lm.k),
                        dim3(256), 0, (hipStream_t)stream, gd, lm,

@@ -31,25 +31,43 @@ class _RenderFn(torch.autograd.Function):
         ds = float(net.density_scale)
         near, far = ops.near_far_from_aabb(o, d, aabb, min_near)
         z_c = ops.sample_coarse(near, far, T, rng_t)
-        feat_c = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z_c, aabb)
-        h_c, s_c = ops.sigma_mlp_fwd(feat_c, f["packed_sigma"])
+        # train_precision="tcnn": tiny-cuda-nn's numerics end to end -- the
+        # hash table read from its fp16 copy, fp16 features, all three nets on
+        # f16 MFMA (fp16 weights / layer inputs, fp32 accumulate), half2 bin
+        # records; the fp32 parameters are the optimizer's master copy, as in
+        # tcnn (network_tcnn_semantics.py:36-58 of the reference)
+        tcnn = net.train_precision == "tcnn"
+        if tcnn:
+            fh = net._field_f16(transposed=True)
+            table, sig_fwd, sig_pack = net._table_half(), ops.sigma_mlp_fwd_f16, fh["packed_sigma"]
+        else:
+            table, sig_fwd, sig_pack = f["table"], ops.sigma_mlp_fwd, f["packed_sigma"]
+        feat_c = ops.hashgrid_encode_rays(f["grid"], table, o, d, z_c, aabb)
+        h_c, s_c = sig_fwd(feat_c, sig_pack)
         s_c = s_c.view(N, T)
         if t > 0:
             z_f = ops.resample(z_c, s_c, rng_u, ds)
-            feat_f = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z_f,
-                                              aabb)
-            h_f, s_f = ops.sigma_mlp_fwd(feat_f, f["packed_sigma"])
+            feat_f = ops.hashgrid_encode_rays(f["grid"], table, o, d, z_f, aabb)
+            h_f, s_f = sig_fwd(feat_f, sig_pack)
             s_f = s_f.view(N, t)
         else:
             z_f = feat_f = h_f = s_f = None
         # train_precision="fp16": the colour / semantics nets (forward and
         # backward) on f16 MFMA; the sigma net and the hash grid stay fp32
-        half = net.train_precision == "fp16"
+        half = net.train_precision in ("fp16", "tcnn")
         if half:
             fh = net._field_f16(transposed=True)
             f = dict(f, packed_color=fh["packed_color"], packed_sem=fh["packed_sem"],
                      packed_color_t=fh["packed_color_t"],
                      packed_sem_t=fh["packed_sem_t"])
+        if tcnn:
+            # the sigma net's backward runs the fp32 kernel on the forward's
+            # fp16-rounded operands (rounded weights, rounded features; fp32
+            # accumulation like the f16 MFMA) -- its hidden layer is not
+            # re-rounded to fp16 there (tcnn does), the one place this mode is
+            # "fp16 operands, fp32 arithmetic" rather than tcnn's exact kernel
+            ps, pst = net._pack_rounded_sigma()
+            f = dict(f, packed_sigma=ps, packed_sigma_t=pst)
         if net.train_precision == "bf16x3":
             # forward of the colour / semantics stage on the split pair with
             # the bf16x3 nets (fp32-grade, the dense bf16 MFMA pipe): same
@@ -64,6 +82,7 @@ class _RenderFn(torch.autograd.Function):
                 d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, f["packed_color"],
                 f["packed_sem"], C, ds, want_aux=True, half=half)
         ctx.half = half
+        ctx.tcnn = tcnn
         ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t = net, f, aabb, T, t
         ctx.saved = (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f,
                      src, w)
@@ -87,12 +106,15 @@ class _RenderFn(torch.autograd.Function):
         ops.reduce_partials(ps, g_sem, False)
         g_sigma = torch.empty_like(net.sigma_net.params)
         g_grid = torch.zeros_like(net.encoder.params)
+        if ctx.tcnn:   # fp16 features -> the fp32 kernel's operand type
+            feat_c = feat_c.float()
+            feat_f = None if feat_f is None else feat_f.float()
         d_feat, part = ops.sigma_mlp_bwd(feat_c, d_h_c, f["packed_sigma"],
                                          f["packed_sigma_t"])
         ops.reduce_partials(part, g_sigma, False)
         # f16 training mode: 8-byte bin records (half2 values under the same
         # loss scale as the nets' gradient operands)
-        rs = float(net.f16_bwd_scale) if (ctx.half and net.f16_grid_records) else 0.0
+        rs = float(net.f16_bwd_scale) if (ctx.half and (net.f16_grid_records or ctx.tcnn)) else 0.0
         ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid,
                               rec_scale=rs)
         if t > 0:
@@ -240,6 +262,20 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
                                         out=out)
             self._packed[name + "_th"] = (key, packed)
         return self._packed[name + "_th"][1]
+
+    def _pack_rounded_sigma(self):
+        """fp32 packs (forward and transposed) of the sigma net's weights
+        ROUNDED to fp16: what the f16 forward multiplied with, for the fp32
+        backward kernel of train_precision="tcnn"."""
+        p = self.sigma_net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get("sigma_r16")
+        if hit is None or hit[0] != key or hit[1][0].device != p.device:
+            r = p.detach().half().float()
+            self._packed["sigma_r16"] = (key, (
+                ops.mlp_pack(self.sigma_net.kind, r, self.num_semantic_classes),
+                ops.mlp_pack_t(self.sigma_net.kind, r, self.num_semantic_classes)))
+        return self._packed["sigma_r16"][1]
 
     def _pack_x3(self, name: str, net: FullyFusedMLP):
         p = net.params
