@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak
 F16_MFMA_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA (SURVEY 8d's MLP roofline)
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
-PMC_JSON = "profiles/r02_pmc_traffic.json"
+PMC_JSON = "profiles/r03_pmc_traffic.json"
 TRAIN_PMC_JSON = "profiles/r03_train_pmc.json"
 
 
@@ -277,14 +277,22 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256,
         loss.backward()
         opt.step()
 
+    import gc
     for _ in range(3):
         one()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # three timed blocks of `steps` steps, the median reported: a collection
+    # of the previous legs' deep-copied fields (hipFree synchronises) landing
+    # inside one block once doubled a leg's figure
+    gc.collect()
+    blocks = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / steps)
+    dt = sorted(blocks)[1]
     rho = masked_fraction(net, o, d, nrm, T, t, rt, ru)
     n_params = sum(p.numel() for p in net.parameters())
     pmc = None
@@ -297,6 +305,7 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256,
                         "fwd+bwd+Adam (reference native sizes; the 4096 random "
                         "pixels are handed over tile-ordered, ops.tile_order)",
             "ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt,
+            "ms_per_step_blocks": [b * 1e3 for b in blocks],
             "roofline": nerf_train_roofline(n_rays, T + t, rho, n_params, dt * 1e3, pmc)}
 
 
@@ -616,7 +625,7 @@ def composite_roofline(mode, mlp_tf, sig_tf, launch_ms):
                     "SURVEY 8d's 2.5 PF line"}
     if mode == "bf16x3":
         return {
-            "kernel": "k_weights_compact + k_shade_dense<bf16x3> (colour + "
+            "kernel": "k_weights_compact + k_shade16<bf16x3> (colour + "
                       "semantics MLPs, six bf16 MFMA passes per fp32 product)",
             "bound": "mfma", "achieved": mlp_tf, "peak": F16_MFMA_PEAK_TF,
             "unit": "TFLOP/s", "frac": mlp_tf / F16_MFMA_PEAK_TF,
@@ -628,11 +637,11 @@ def composite_roofline(mode, mlp_tf, sig_tf, launch_ms):
                     "launch time against the 2.5 PF 16-bit dense line "
                     "(SURVEY 8d); issued_* counts the six bf16 passes and the "
                     "padding (144 MFMAs per 16 samples).  Measured (PMC, "
-                    "profiles/r02_shade_x3_pmc.txt): kernel time = MFMA-busy "
+                    "profiles/r03_shade16_pmc.txt): kernel time = MFMA-busy "
                     "cycles + VALU issue cycles, the two do not overlap on a "
                     "SIMD shared by several waves"}
     return {
-        "kernel": "k_weights_compact + k_shade_dense<f16> (colour+semantics "
+        "kernel": "k_weights_compact + k_shade16<f16> (colour+semantics "
                   "MLPs on 16x16x32 f16 MFMA, fp32 accumulate)",
         "bound": "mfma", "achieved": mlp_tf, "peak": F16_MFMA_PEAK_TF,
         "unit": "TFLOP/s", "frac": mlp_tf / F16_MFMA_PEAK_TF,
@@ -1138,8 +1147,8 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, PMC_JSON)))
             if int(pmc.get("pretrain_steps", -1)) == int(args.pretrain_steps):
-                cmp_kernel = {"fp32": "k_composite", "bf16x3": "k_shade_dense_x3",
-                              "fp16": "k_shade_dense_f16"}[args.nerf_precision]
+                cmp_kernel = {"fp32": "k_composite", "bf16x3": "k_shade16_x3",
+                              "fp16": "k_shade16_f16"}[args.nerf_precision]
                 for key, kn in (("roofline_composite", cmp_kernel),
                                 ("roofline_encode", "k_hashgrid_encode_tiled")):
                     if kn not in pmc or "fetch_bytes" not in pmc[kn]:
@@ -1149,6 +1158,10 @@ def main():
                             result[key]["pmc_source"] = PMC_JSON
                         continue
                     tr = pmc[kn]["fetch_bytes"] + pmc[kn]["write_bytes"]
+                    if kn.startswith("k_shade16") and "k_weights_compact" in pmc:
+                        # the stage is two launches: weights / compaction, nets
+                        tr += (pmc["k_weights_compact"]["fetch_bytes"] +
+                               pmc["k_weights_compact"]["write_bytes"])
                     r = result[key]
                     r["traffic"] = tr
                     r["traffic_source"] = PMC_JSON
@@ -1169,11 +1182,12 @@ def main():
                         "frac": l2b / (e["launch_ms"] * 1e-3) / 1e9 / L2_PEAK_GBS,
                         "bytes_per_launch": l2b,
                         "source": "TCC request counter x 128-B lines (" + PMC_JSON + ")"}
-                if "k_shade_dense_f16" in pmc and "mfma_busy_frac" in pmc["k_shade_dense_f16"]:
-                    result["pmc_k_shade_dense_f16"] = {
-                        "mfma_pipe_busy_frac": pmc["k_shade_dense_f16"]["mfma_busy_frac"],
+                if "k_shade16_f16" in pmc and "mfma_busy_frac" in pmc["k_shade16_f16"]:
+                    result["pmc_k_shade16_f16"] = {
+                        "mfma_pipe_busy_frac": pmc["k_shade16_f16"]["mfma_busy_frac"],
+                        "valu_issue_frac": pmc["k_shade16_f16"].get("valu_issue_frac"),
                         "valu_wave_instructions_per_launch":
-                            pmc["k_shade_dense_f16"].get("valu_wave_instructions"),
+                            pmc["k_shade16_f16"].get("valu_wave_instructions"),
                         "source": PMC_JSON}
         except OSError as e:
             raise SystemExit(f"bench.py: {PMC_JSON} (the committed PMC passes the "

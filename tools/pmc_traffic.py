@@ -60,8 +60,9 @@ def main(d, tag):
     }
     for key, prefix in (("k_composite", "void k_composite<3, 2, false, false>"),
                         ("k_hashgrid_encode_tiled", "void k_hashgrid_encode_tiled<HIP_vector_t"),
-                        ("k_shade_dense_f16", "void k_shade_dense<3, 1, 1, 16>"),
-                        ("k_shade_dense_x3", "void k_shade_dense<3, 2, 2, 8>")):
+                        ("k_weights_compact", "k_weights_compact"),
+                        ("k_shade16_f16", "void k_shade16<3, 1, 1,"),
+                        ("k_shade16_x3", "void k_shade16<3, 1, 2,")):
         f, w, s = pick(fetch, prefix), pick(wr, prefix), pick(sq, prefix)
         if not (f and w):
             continue

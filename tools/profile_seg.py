@@ -9,6 +9,7 @@ dev = torch.device("cuda", 0)
 mode = os.environ.get("MODE", "fp32_nchw")
 B = int(os.environ.get("B", "8"))
 torch.manual_seed(0)
+torch.backends.cudnn.benchmark = os.environ.get("FIND", "0") == "1"
 m = DeepLabV3({"pretrained": False, "pretrained_backbone": False, "num_classes": 40,
                "backbone": os.environ.get("BACKBONE", "resnet101")}).to(dev).train()
 cl = mode.endswith("cl")
@@ -36,4 +37,4 @@ n = int(os.environ.get("STEPS", "10"))
 for _ in range(n):
     step()
 torch.cuda.synchronize()
-print(f"{mode} B={B}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms/step")
+print(f"{mode} B={B} find={torch.backends.cudnn.benchmark}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms/step", flush=True)

@@ -11,3 +11,7 @@ ROOT_DIR = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 
 if "ENV_WORKSTATION_NAME" not in os.environ:  # reference nr4seg/__init__.py:5-6
     os.environ["ENV_WORKSTATION_NAME"] = "env"
+
+from ._miopen_db import use_shipped_db as _use_shipped_db  # noqa: E402
+
+MIOPEN_DB_PATH = _use_shipped_db()

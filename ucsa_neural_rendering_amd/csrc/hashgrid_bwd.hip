@@ -14,6 +14,8 @@
 // Both use float atomics somewhere (global or LDS), so the table gradient is
 // order-dependent at fp32 round-off (run-to-run ~1e-7 relative); the MLP
 // gradients are reduced in a fixed order and are bit-reproducible.
+#include <cstdlib>
+#include <mutex>
 #include "ucsa_common.h"
 #include "wave_ops.h"
 
@@ -545,6 +547,38 @@ extern "C" uint64_t ucsa_hashgrid_bwd_workspace_bytes(uint32_t N, uint32_t T,
          (uint64_t)n_levels * BIN_COUNT * bg.cap * sizeof(float4);
 }
 
+// The coarse levels (LDS hash accumulators, k_hashgrid_bwd) and the fine levels
+// (bin records through HBM, k_grid_bwd_bin / _accum) write disjoint slices of
+// grad_table and wait on different resources, so the coarse kernel runs on a
+// side stream forked from / joined to the caller's stream by events
+// (capturable; UCSA_BWD_OVERLAP=0 keeps everything on the caller's stream).
+struct BwdSide {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static BwdSide* bwd_side() {
+  static std::mutex mu;
+  static BwdSide per_dev[16];
+  static int enabled = -1;
+  std::lock_guard<std::mutex> lk(mu);
+  if (enabled < 0) {
+    const char* e = getenv("UCSA_BWD_OVERLAP");
+    enabled = !(e && e[0] == '0');
+  }
+  if (!enabled) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  BwdSide& b = per_dev[dev];
+  if (!b.side) {
+    b.ok = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&b.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&b.join, hipEventDisableTiming) == hipSuccess;
+    if (!b.side) b.side = (hipStream_t)-1;  // do not retry
+  }
+  return b.ok ? &b : nullptr;
+}
+
 // z == nullptr: rays_o holds M = N explicit points (T = 1), aabb unused.
 static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    const float* rays_d, const float* z,
@@ -564,6 +598,25 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
     while (n_lo < grid->n_levels && (!grid->level[n_lo].hashed ||
                                      grid->level[n_lo].scale < 160.0f)) ++n_lo;
   }
+  // both halves present: fork the coarse half onto the side stream
+  BwdSide* side = (workspace && n_lo > 0 && n_lo < grid->n_levels) ? bwd_side() : nullptr;
+  hipStream_t coarse_stream = (hipStream_t)stream;
+  if (side) {
+    if (hipEventRecord(side->fork, (hipStream_t)stream) == hipSuccess &&
+        hipStreamWaitEvent(side->side, side->fork, 0) == hipSuccess)
+      coarse_stream = side->side;
+    else
+      side = nullptr;
+  }
+  auto join = [&](int32_t rc) -> int32_t {
+    if (side) {
+      const hipError_t e1 = hipEventRecord(side->join, side->side);
+      const hipError_t e2 = hipStreamWaitEvent((hipStream_t)stream, side->join, 0);
+      if (rc == 0 && e1 != hipSuccess) rc = -(int32_t)e1;
+      if (rc == 0 && e2 != hipSuccess) rc = -(int32_t)e2;
+    }
+    return rc;
+  };
   if (workspace && n_lo < grid->n_levels) {
     const BinGeom bg = bin_geometry(grid, M);
     const GridDev gd = ucsa_grid_dev(grid);
@@ -599,7 +652,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                          1.0f);
     }
     const int32_t rc = ucsa_launch_status();
-    if (rc) return rc;
+    if (rc) return join(rc);
   }
   if (n_lo == 0) return 0;
   // (no workspace: direct-atomics path)
@@ -621,14 +674,14 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
   if (n_run > 0)
     hipLaunchKernelGGL(k_hashgrid_bwd<true>,
                        dim3(ucsa_div_up(M, 256 * tiles), n_run),
-                       dim3(256), 0, (hipStream_t)stream, gd, rays_o, rays_d, z,
+                       dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
                        bb, T, M, 0u, tiles, (const float2*)d_feat, grad_table);
   if (n_run < n_lo)
     hipLaunchKernelGGL(k_hashgrid_bwd<false>,
                        dim3(ucsa_div_up(M, 256), n_lo - n_run),
-                       dim3(256), 0, (hipStream_t)stream, gd, rays_o, rays_d, z,
+                       dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
                        bb, T, M, n_run, 1u, (const float2*)d_feat, grad_table);
-  return ucsa_launch_status();
+  return join(ucsa_launch_status());
 }
 
 extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
