@@ -54,6 +54,7 @@ F16_MFMA_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA (SURVEY 8d's MLP roofline)
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 PMC_JSON = "profiles/r03_pmc_traffic.json"
 TRAIN_PMC_JSON = "profiles/r03_train_pmc.json"
+SEG_PMC_JSON = "profiles/r03_seg_pmc.json"
 
 
 def parse():
@@ -533,6 +534,21 @@ def seg_throughput(device, steps=5, B=8, find=False):
                                           "/ step time; peak = " +
                                           ("bf16 dense MFMA" if amp else
                                            "fp32-input MFMA (= fp32 vector) rate")}}
+        # HBM traffic / MFMA-busy per step from the committed PMC passes
+        # (tools/seg_pmc.sh; rocprofv3 cannot run inside this process)
+        key = {"fp32": "fp32_cl", "bf16_channels_last": "bf16_cl"}.get(mode)
+        if key:
+            try:
+                pj = json.load(open(os.path.join(ROOT, SEG_PMC_JSON))).get(key)
+            except (OSError, ValueError):
+                pj = None
+            if pj:
+                r = out[mode]["roofline"]
+                r["traffic"] = pj["hbm_bytes_per_step"]
+                r["traffic_source"] = SEG_PMC_JSON
+                r["hbm_utilisation"] = pj["hbm_bytes_per_step"] / dt / 1e9 / HBM_PEAK_GBS
+                r["mfma_pipe_busy_frac"] = pj["mfma_busy_frac"]
+                r["valu_issue_frac"] = pj["valu_issue_frac"]
         del m, opt, fwd
         torch.cuda.empty_cache()
     out["workload"] = ("DeepLabV3-ResNet-101 train step, batch 8 x 3x240x320, "

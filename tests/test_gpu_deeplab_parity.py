@@ -294,3 +294,29 @@ def test_deeplab_matches_torchvision_when_present(backbone):
     assert float((want.double() - ref["eval_logits"]).abs().max()) <= 3 * fl + 1e-6
     assert float((got.cpu().double() - ref["eval_logits"]).abs().max()) <= 3 * fl + 1e-6
     assert fl <= 5e-3 * scale
+
+
+def test_tuned_gemm_table_is_looked_up_not_tuned():
+    """Constructing the model switches TunableOp to look-up-only mode on the
+    shipped table (network/_gemm_tuning.py); a 1x1 convolution of a shape in
+    the table and one outside it both give the plain GEMM's result."""
+    import os
+    if any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
+        pytest.skip("TunableOp is under the user's control")
+    from ucsa_neural_rendering_amd.network import DeepLabV3
+    from ucsa_neural_rendering_amd.network import _gemm_tuning
+    DeepLabV3({"pretrained": False, "pretrained_backbone": False, "num_classes": 5,
+               "backbone": "resnet50"})
+    tun = torch.cuda.tunable
+    assert tun.is_enabled() and not tun.tuning_is_enabled()
+    assert tun.get_filename() == _gemm_tuning.TABLE
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for rows in (9600, 1000):   # 8 x 30 x 40 pixels (in the table) / not in it
+        x = torch.randn(rows, 1024, device="cuda", generator=g)
+        w = torch.randn(256, 1024, device="cuda", generator=g)
+        y = F.linear(x, w)
+        ref = (x.double() @ w.double().t())
+        assert float((y.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    n_before = len(tun.get_results())
+    F.linear(torch.randn(777, 96, device="cuda"), torch.randn(48, 96, device="cuda"))
+    assert len(tun.get_results()) == n_before   # an unknown shape is not tuned

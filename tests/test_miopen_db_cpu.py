@@ -42,3 +42,24 @@ def test_db_holds_the_deeplab_configurations():
             for direction in "FBW":
                 assert any(f"-30-40-8-{dil}-1x1-{dil}-0-NHWC-NHWC-NHWC-{dt}-{direction}" in k
                            for k in keys), (dil, dt, direction)
+
+
+def test_gemm_table_ships_and_names_the_1x1_convolution_shapes():
+    path = os.path.join(ROOT, "ucsa_neural_rendering_amd", "gemm_tuning", "tunableop_gfx950.csv")
+    rows = [ln.strip().split(",") for ln in open(path) if ln.strip()]
+    assert any(r[0] == "Validator" and r[1] == "GCN_ARCH_NAME" and r[2].startswith("gfx950")
+               for r in rows)
+    keys = {(r[0], r[1]) for r in rows if r[0] != "Validator"}
+    # layer3's bottleneck 1x1 convolutions at 8 x 30 x 40 pixels: forward (TN),
+    # dX (NN) and dW (NT), fp32 and bf16
+    for dt in ("float", "BFloat16"):
+        assert (f"GemmTunableOp_{dt}_TN", "tn_256_9600_1024_ld_1024_1024_256") in keys
+        assert (f"GemmTunableOp_{dt}_NN", "nn_1024_9600_256_ld_1024_256_1024") in keys
+        assert (f"GemmTunableOp_{dt}_NT", "nt_1024_256_9600_ld_1024_256_1024") in keys
+
+
+def test_gemm_table_is_left_alone_when_the_user_controls_tunableop(monkeypatch):
+    from ucsa_neural_rendering_amd.network import _gemm_tuning
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_ENABLED", "0")
+    monkeypatch.setattr(_gemm_tuning, "_done", False)
+    assert _gemm_tuning.ensure() is None

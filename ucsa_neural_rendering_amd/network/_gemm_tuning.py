@@ -1,0 +1,40 @@
+"""rocBLAS / hipBLASLt solution choices for DeepLab's 1x1 convolutions.
+
+In channels-last every 1x1 convolution (forward, dX, dW) is one GEMM over all
+pixels of the batch; which library kernel runs it is the library's heuristic,
+and for these tall-skinny shapes ([9600 or 38400] x [64..2048]) the heuristic
+is up to 2x off the best solution (e.g. 9600 x 512 -> 256, fp32: 54 us default,
+25 us tuned).  ``gemm_tuning/tunableop_gfx950.csv`` is PyTorch TunableOp's
+result file for those shapes, tuned on an MI355X (tools/gemm_tune.sh) at the
+benchmark's batch of 8 images of 240x320, fp32 and bf16.  ``ensure()`` switches
+TunableOp on in look-up-only mode (tuning disabled: nothing is timed or written at run time):
+shapes that are not in the table run the default solution.  R-101 fp32 step:
+41.5 -> 39.5 ms.
+
+Left alone when the user controls TunableOp through ``PYTORCH_TUNABLEOP_*``.
+The file carries validator lines (PyTorch / ROCm / hipBLASLt / rocBLAS versions,
+gfx arch): on another stack TunableOp ignores the entries.
+"""
+import os
+
+TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(__file__))),
+                     "gemm_tuning", "tunableop_gfx950.csv")
+_done = False
+
+
+def ensure():
+    """Idempotent; returns the table path when it was installed."""
+    global _done
+    if _done:
+        return TABLE
+    if any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
+        return None
+    import torch
+    if not (torch.cuda.is_available() and os.path.isfile(TABLE)):
+        return None
+    tun = torch.cuda.tunable
+    tun.set_filename(TABLE, insert_device_ordinal=False)
+    tun.tuning_enable(False)
+    tun.enable(True)
+    _done = True
+    return TABLE

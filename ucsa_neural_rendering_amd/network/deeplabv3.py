@@ -248,6 +248,8 @@ class DeepLabV3(nn.Module):
 
     def __init__(self, cfg_model):
         super().__init__()
+        from ._gemm_tuning import ensure as _tuned_gemms
+        _tuned_gemms()   # look-up-only TunableOp table for the 1x1 convolutions
         name = cfg_model.get("backbone", "resnet101")
         self._model = _DeepLabV3Model(ResNetBackbone(_LAYERS[name]),
                                       DeepLabHead(2048, cfg_model["num_classes"]))
