@@ -55,6 +55,7 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregat
 PMC_JSON = "profiles/r03_pmc_traffic.json"
 TRAIN_PMC_JSON = "profiles/r03_train_pmc.json"
 SEG_PMC_JSON = "profiles/r03_seg_pmc.json"
+ENC_BINDING_JSON = "profiles/r03_encoder_binding.json"
 
 
 def parse():
@@ -1189,15 +1190,25 @@ def main():
                     if "valu_issue_frac" in pmc[kn]:
                         r["valu_issue_frac"] = pmc[kn]["valu_issue_frac"]
                 e = result["roofline_encode"]
-                if "l2_request_bytes" in pmc["k_hashgrid_encode_tiled"]:
-                    l2b = pmc["k_hashgrid_encode_tiled"]["l2_request_bytes"]
-                    e["binding_resource"] = {
-                        "resource": "L2 -> L1 (TCP) path of divergent gathers",
-                        "achieved_gbs": l2b / (e["launch_ms"] * 1e-3) / 1e9,
-                        "peak_gbs": L2_PEAK_GBS,
-                        "frac": l2b / (e["launch_ms"] * 1e-3) / 1e9 / L2_PEAK_GBS,
-                        "bytes_per_launch": l2b,
-                        "source": "TCC request counter x 128-B lines (" + PMC_JSON + ")"}
+                # what binds the encoder: the per-CU L1's (TCP) line look-up
+                # rate, from the PMC passes of the kernel alone
+                eb = json.load(open(os.path.join(ROOT, ENC_BINDING_JSON)))
+                acc = 0.5 * (eb["coarse"]["tcp_accesses_per_clock_per_cu"] +
+                             eb["fine"]["tcp_accesses_per_clock_per_cu"])
+                e["binding_resource"] = {
+                    "resource": "TCP (per-CU vector L1) line look-ups of divergent gathers, "
+                                "1 per clock and CU",
+                    "achieved": acc, "peak": 1.0, "unit": "line accesses / clock / CU",
+                    "frac": acc,
+                    "fine_pass": {k: eb["fine"][k] for k in (
+                        "tcp_accesses_per_clock_per_cu", "l1_hit_rate", "l2_latency_cycles",
+                        "misses_in_flight_per_tcp", "tcp_pending_stall_frac",
+                        "valu_issue_frac", "l2_request_frac_of_34500")},
+                    "coarse_pass": {k: eb["coarse"][k] for k in (
+                        "tcp_accesses_per_clock_per_cu", "l1_hit_rate", "l2_latency_cycles",
+                        "misses_in_flight_per_tcp", "tcp_pending_stall_frac",
+                        "valu_issue_frac", "l2_request_frac_of_34500")},
+                    "source": ENC_BINDING_JSON + " (tools/encode_pmc.sh)"}
                 if "k_shade16_f16" in pmc and "mfma_busy_frac" in pmc["k_shade16_f16"]:
                     result["pmc_k_shade16_f16"] = {
                         "mfma_pipe_busy_frac": pmc["k_shade16_f16"]["mfma_busy_frac"],
@@ -1442,7 +1453,11 @@ def main_cfg3(args, dev, dist, world, rank, backend):
     }
     tmp = tempfile.mkdtemp()
     torch.manual_seed(123)
-    torch.backends.cudnn.benchmark = not args.no_seg_find   # default: as scripts/train_joint.py sets it
+    # default: as scripts/train_joint.py sets it (a look-up in the shipped MIOpen
+    # databases; the exhaustive search only without them or with --seg-find)
+    from ucsa_neural_rendering_amd._miopen_db import default_cudnn_benchmark
+    torch.backends.cudnn.benchmark = (True if args.seg_find else
+                                      False if args.no_seg_find else default_cudnn_benchmark())
     model = JointTrainLightningNet(exp, {"results": tmp, "scannet": tmp})
     dm = JointTrainDataModule(exp)
     dm.setup()

@@ -57,12 +57,14 @@ def train(exp, env, exp_cfg_path, env_cfg_path, args):
         shutil.copy(env_cfg_path, model_path)
     exp["general"]["name"] = model_path
 
-    # MIOpen's exhaustive solver search for the (static-shape) DeepLab
-    # convolutions: measured 49.4 -> 44.4 ms per R-101 fp32 train step on
-    # 8 x 240x320 (tools/seg_bench.py); `trainer: {cudnn_benchmark: false}`
-    # keeps PyTorch's default (immediate mode)
+    # The reference sets cudnn.benchmark (MIOpen's exhaustive solver search for
+    # the static-shape DeepLab convolutions).  Here the search result ships with
+    # the package (ucsa_neural_rendering_amd/miopen_db), so the default is a
+    # look-up; `trainer: {cudnn_benchmark: true|false}` decides otherwise.
+    from ucsa_neural_rendering_amd._miopen_db import default_cudnn_benchmark
     bench_before = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = bool(exp["trainer"].get("cudnn_benchmark", True))
+    want = exp["trainer"].get("cudnn_benchmark")
+    torch.backends.cudnn.benchmark = default_cudnn_benchmark() if want is None else bool(want)
     try:
         return _train(exp, env, args, rank, local_rank, world, model_path)
     finally:  # a process-wide flag: hand it back as found

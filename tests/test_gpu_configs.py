@@ -101,7 +101,20 @@ def _weight_noise(aux):
         dz = dz + torch.gather(dz_cat, 1, aux["order"])
     delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
     dz_next = torch.cat([dz[:, 1:], torch.zeros_like(dz[:, :1])], -1)
-    return w * (dz + dz_next) / delta.clamp_min(1e-12)
+    r = ((dz + dz_next) / delta.clamp_min(1e-12)).double()      # d(delta)/delta per sample
+    # ... and the transmittance in front of the sample: T_s = prod_{j<s} (1 -
+    # alpha_j) with 1 - alpha_j = exp(-x_j), x_j = sigma_j delta_j, so
+    # dT/T = sum_{j<s} x_j * d(delta_j)/delta_j -- the interval noise of every
+    # sample in front, AMPLIFIED by its optical depth.  The samples near the
+    # mask threshold mostly sit behind a surface (T ~ 1e-4 / alpha), i.e.
+    # behind a few samples with x of 5-20: this term is the larger one there
+    # (observed: a weight 0.7 % off between the two implementations).
+    w64 = w.double()
+    T_front = (1.0 - (torch.cumsum(w64, -1) - w64)).clamp_min(1e-12)
+    alpha = (w64 / T_front).clamp(0.0, 1.0 - 1e-12)
+    x = -torch.log1p(-alpha)
+    up = torch.cumsum(x * r, -1) - x * r
+    return (w64 * (r + up)).to(w.dtype)
 
 
 def _check(res, ref, sel=None, tag=""):
@@ -125,7 +138,9 @@ def _check(res, ref, sel=None, tag=""):
     # a weight "at the threshold": within what fp32 round-off can move it (at
     # least 1e-7, at most 2 % of the threshold)
     dw = _weight_noise(ref["aux"])
-    tol = dw.clamp(1e-7, 2e-6)
+    # x3: the model's constants (2 ulp per depth, 4 x 2^-23 on the cdf) are
+    # estimates of a round-off that depends on the summation order
+    tol = (3.0 * dw).clamp(1e-7, 2e-6)
     at_mask = ((w - 1e-4).abs() <= tol).any(-1)                 # per ray
     # the same weight noise carried into the depth sum, relative to the depth
     z_all = ref["aux"]["z"]

@@ -317,6 +317,16 @@ def test_tuned_gemm_table_is_looked_up_not_tuned():
         y = F.linear(x, w)
         ref = (x.double() @ w.double().t())
         assert float((y.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # under autocast the launch-bound step skips TunableOp's per-call host work
+    m = DeepLabV3({"pretrained": False, "pretrained_backbone": False, "num_classes": 5,
+                   "backbone": "resnet50"}).cuda().eval()
+    img = torch.rand(1, 3, 64, 64, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        m(img)
+    assert not tun.is_enabled()
+    with torch.no_grad():
+        m(img)
+    assert tun.is_enabled() and not tun.tuning_is_enabled()
     n_before = len(tun.get_results())
     F.linear(torch.randn(777, 96, device="cuda"), torch.randn(48, 96, device="cuda"))
     assert len(tun.get_results()) == n_before   # an unknown shape is not tuned

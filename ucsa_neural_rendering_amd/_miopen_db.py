@@ -35,3 +35,24 @@ def use_shipped_db():
         path = copy
     os.environ["MIOPEN_USER_DB_PATH"] = path
     return path
+
+
+def default_cudnn_benchmark():
+    """What ``torch.backends.cudnn.benchmark`` should be when the experiment
+    does not say: the reference sets it (scripts/train_joint.py) so that MIOpen
+    searches its solvers exhaustively -- which MIOpen does AGAIN in every new
+    process (the naive direct kernels included: ~18 s for a DeepLab step's
+    configurations) even when the result is already in its databases.  With
+    the shipped databases in use the search has been done: False (PyTorch then
+    asks MIOpen for the recorded best solver, tuned parameters included, and
+    only searches -- once, non-exhaustively -- for configurations the
+    databases do not hold).  Without them: True, the reference's setting."""
+    cur = os.environ.get("MIOPEN_USER_DB_PATH", "")
+    shipped = {os.path.basename(f) for f in os.listdir(_PKG_DB)} if os.path.isdir(_PKG_DB) else set()
+    try:
+        have = set(os.listdir(cur)) if cur else set()
+    except OSError:
+        have = set()
+    in_use = bool(shipped) and shipped <= have and (
+        os.path.realpath(cur) == _PKG_DB or "ucsa_neural_rendering_amd_miopen_db_" in cur)
+    return not in_use

@@ -6,10 +6,13 @@ and for these tall-skinny shapes ([9600 or 38400] x [64..2048]) the heuristic
 is up to 2x off the best solution (e.g. 9600 x 512 -> 256, fp32: 54 us default,
 25 us tuned).  ``gemm_tuning/tunableop_gfx950.csv`` is PyTorch TunableOp's
 result file for those shapes, tuned on an MI355X (tools/gemm_tune.sh) at the
-benchmark's batch of 8 images of 240x320, fp32 and bf16.  ``ensure()`` switches
+benchmark's batch of 8 images of 240x320, fp32.  ``ensure()`` switches
 TunableOp on in look-up-only mode (tuning disabled: nothing is timed or written at run time):
 shapes that are not in the table run the default solution.  R-101 fp32 step:
-41.5 -> 39.5 ms.
+41.5 -> 39.5 ms.  TunableOp costs host time per GEMM call (it builds and hashes a
+signature string): the launch-bound bf16-autocast step got 2-4 ms SLOWER with
+it (24.9 -> 27-29 ms), so ``use()`` -- called by ``DeepLabV3.forward`` --
+switches it off while autocast is on.
 
 Left alone when the user controls TunableOp through ``PYTORCH_TUNABLEOP_*``.
 The file carries validator lines (PyTorch / ROCm / hipBLASLt / rocBLAS versions,
@@ -24,7 +27,7 @@ _done = False
 
 def ensure():
     """Idempotent; returns the table path when it was installed."""
-    global _done
+    global _done, _state
     if _done:
         return TABLE
     if any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
@@ -36,5 +39,20 @@ def ensure():
     tun.set_filename(TABLE, insert_device_ordinal=False)
     tun.tuning_enable(False)
     tun.enable(True)
-    _done = True
+    _done, _state = True, True
     return TABLE
+
+
+_state = None
+
+
+def use(flag):
+    """Route GEMMs through the table (fp32) or straight to the library
+    (autocast: launch-bound, see above).  No-op when ``ensure()`` did not
+    install the table."""
+    global _state
+    if not _done or flag == _state:
+        return
+    import torch
+    torch.cuda.tunable.enable(bool(flag))
+    _state = bool(flag)

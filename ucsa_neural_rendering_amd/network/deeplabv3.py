@@ -265,4 +265,6 @@ class DeepLabV3(nn.Module):
                 "access and no cfg_model['weights_path']: random initialisation")
 
     def forward(self, data):
+        from . import _gemm_tuning
+        _gemm_tuning.use(not torch.is_autocast_enabled())
         return self._model(data)
