@@ -63,3 +63,13 @@ def test_gemm_table_is_left_alone_when_the_user_controls_tunableop(monkeypatch):
     monkeypatch.setenv("PYTORCH_TUNABLEOP_ENABLED", "0")
     monkeypatch.setattr(_gemm_tuning, "_done", False)
     assert _gemm_tuning.ensure() is None
+
+
+def test_cudnn_benchmark_default_is_a_lookup_only_with_the_shipped_db():
+    code = ("from ucsa_neural_rendering_amd._miopen_db import default_cudnn_benchmark as d; "
+            "import ucsa_neural_rendering_amd; print(d())")
+    env = {k: v for k, v in os.environ.items() if k != "MIOPEN_USER_DB_PATH"}
+    r = _run(code, env)
+    assert r.returncode == 0 and r.stdout.strip() == "False", r.stdout + r.stderr
+    r = _run(code, dict(env, MIOPEN_USER_DB_PATH="/tmp/not_ours"))
+    assert r.returncode == 0 and r.stdout.strip() == "True", r.stdout + r.stderr
