@@ -223,9 +223,9 @@ int32_t ucsa_render_fwd(const ucsa_grid* grid_host, const float* table,
 
 /* The same computation for INFERENCE as two dense kernels (no `src` /
  * `weights` outputs): k_weights_compact (one wave per ray: merge, weights,
- * mask, depth, survivors compacted into a global list) and k_shade_dense
- * (colour + semantics nets over the survivor list with a software-pipelined
- * operand fetch, per-ray sums in sample order).  Bit-identical outputs to
+ * mask, depth, survivors compacted into a global list) and k_shade_dense /
+ * k_shade16 (colour + semantics nets over the survivor list with a
+ * software-pipelined operand fetch, per-ray sums in sample order).  Bit-identical outputs to
  * ucsa_composite_fwd; what ucsa_render_fwd uses.  `workspace`:
  * ucsa_composite_infer_workspace_bytes(N, T, t) bytes, caller-owned. */
 uint64_t ucsa_composite_infer_workspace_bytes(uint32_t N, uint32_t T, uint32_t t);

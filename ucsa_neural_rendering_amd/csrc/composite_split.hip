@@ -14,15 +14,18 @@
 //      w > 1e-4, depth, ballot+popcount compaction of the survivors into the
 //      ray's own region of a global list (w, row, ray) -- every access
 //      coalesced; also the 16 SH values of the ray's direction, once per ray.
-//  k_shade_dense      each wave owns a range of rays whose survivors form one
-//      virtual list; it walks that list G entries at a time, REQUESTS the next
-//      group's entries / h rows / SH values before shading the current one
-//      (software pipeline), runs the colour + semantics nets -- PREC 0: f32
-//      16x16x4 MFMA (vector-ALU work on gfx950), 1: f16 16x16x32 MFMA, 2:
-//      bf16x3 (six bf16 16x16x32 MFMAs per product, fp32-grade,
-//      mfma_mlp_x3.h) -- and sums w*rgb, w*p per ray in sample order through a
-//      16-row LDS tile.  The kernel is bound by instruction issue (MFMA cycles
-//      + VALU cycles): every VALU instruction in the loop counts.
+//  k_shade_dense / k_shade16   each wave owns a range of rays whose survivors
+//      form one virtual list; it walks that list 16 entries at a time, REQUESTS
+//      the next group's entries / h rows / SH values before shading the current
+//      one (software pipeline) and runs the colour + semantics nets:
+//      k_shade_dense (precision "fp32"): f32 16x16x4 MFMA (vector-ALU work on
+//      gfx950), per-ray sums in sample order through a 16-row LDS tile;
+//      k_shade16 (round 3; "fp16": f16 16x16x32 MFMA; "bf16x3", the default:
+//      six bf16 16x16x32 MFMAs per product, fp32-grade, mfma_mlp_x3.h): per-ray
+//      sums in REGISTERS, the SH operand per ray from k_weights_compact in
+//      operand form, 32-bit offsets -- see the comment above k_shade16.
+//      Both are bound by instruction issue (MFMA cycles + VALU cycles add up,
+//      DESIGN 5): every VALU instruction in the loop counts.
 //
 // The list costs 8 B per survivor each way (<= 0.1 ms per 61 440-ray chunk at
 // HBM rates).  The arithmetic -- k order of every contraction, expf vs
