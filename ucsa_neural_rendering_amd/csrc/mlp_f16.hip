@@ -297,6 +297,7 @@ k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
   for (int rb = 0; rb < 4; ++rb) w1[rb] = frag_x3(packed, rb, lane);
 #pragma unroll
   for (int s = 0; s < 2; ++s) w2[s] = frag_x3(packed, 4 + s, lane);
+  const X3Sel sel = x3_selectors();   // the two dot2 selector constants, once
   const uint64_t span = 16 * SIGX_UNROLL;
   for (uint64_t base = wave * span; base < M; base += nwaves * span) {
     float2 raw[SIGX_UNROLL][4];
@@ -312,12 +313,12 @@ k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
       const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
       X3 xin;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) split_pair(raw[sb][q].x, raw[sb][q].y, xin, q);
+      for (int q = 0; q < 4; ++q) split_pair(raw[sb][q].x, raw[sb][q].y, xin, q, sel);
       f32x4 a1[4];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_x3(w1[rb], xin, z4);
-      f32x4 out = mfma_x3(w2[0], chain_relu_x3(a1[0], a1[1]), z4);
-      out = mfma_x3(w2[1], chain_relu_x3(a1[2], a1[3]), out);
+      f32x4 out = mfma_x3(w2[0], chain_relu_x3(a1[0], a1[1], sel), z4);
+      out = mfma_x3(w2[1], chain_relu_x3(a1[2], a1[3], sel), out);
       const uint64_t m = base + sb * 16 + j;
       if (m < M) {
         *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out;
