@@ -81,7 +81,7 @@ def ensure_synthetic_scenes(exp, env, scenes):
                    int(syn.get("H", 240)), int(syn.get("W", 320)),
                    device="cuda" if torch.cuda.is_available() else "cpu",
                    scene_name=s)
-    if world > 1:
+    if udist.active():
         torch.distributed.barrier()
 
 

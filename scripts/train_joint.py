@@ -73,7 +73,7 @@ def train(exp, env, exp_cfg_path, env_cfg_path, args):
 
 def _train(exp, env, args, rank, local_rank, world, model_path):
     model = JointTrainLightningNet(exp, env)
-    if world > 1:
+    if udist.active():
         # identical initial parameters on every rank (same seed above), then
         # rank-specific random streams: each rank draws its own pixels,
         # stratified-sampling noise and augmentations (DDP semantics; the
@@ -85,7 +85,7 @@ def _train(exp, env, args, rank, local_rank, world, model_path):
     exp["seed"] = args.seed          # shared shuffling seed of the samplers
     datamodule = JointTrainDataModule(exp, env)
     datamodule.setup()
-    if world > 1:
+    if udist.active():
         torch.distributed.barrier()  # files written by rank 0 during setup
     # ScanNet-layout root: the predict pass writes the PNGs the next stage's
     # replay reads (reference :695-782)

@@ -1,0 +1,289 @@
+"""Full-size render parity: the stated tolerance, and a CAUSAL explanation for
+every ray above it (test infrastructure; used by tests/test_gpu_configs.py,
+tested on the CPU by tests/test_parity_check_cpu.py).
+
+Stated tolerance (fp32): image / semantics 1e-4 abs, depth 2e-4 rel -- for at
+least 99.5 % of the rays; every ray within 2e-3 / 5e-3; median <= 5e-6.
+
+Why not 100 % at thousands of rays: the reference has two STEP functions in
+this path, and a ray that sits on one is decided by fp32 round-off:
+
+1. the mask ``weights > 1e-4`` (reference renderer_semantics.py:249-250): a
+   sample at the threshold is shaded on one side and dropped on the other;
+2. ``sample_pdf``'s ``denom < 1e-5 -> 1`` (:40-41): an empty bin's pdf is
+   1e-5 / (sum(w) + (T-2) 1e-5), within 1e-8 of that threshold on an opaque
+   ray, so a fine sample landing in one is placed by either branch.
+
+Round 3 excused a loose ray when it HAD such a sample (true for 23 % of all
+rays before looking at the result).  Now the explanation is causal: for every
+loose ray the ORACLE is re-evaluated on that ray with the candidate decisions
+taken the other way -- each subset of the (<= 3) samples whose weight is
+within the fp32 noise of 1e-4 toggled in the mask, each subset of the (<= 2)
+fine samples whose cdf interval is within 1e-6 of 1e-5 placed by the other
+branch (which moves the sample, so density, sort, weights and masks are
+recomputed) -- and the result under test must MATCH ONE ALTERNATIVE in all
+three outputs at once: image and semantics within ``ALT_ABS``, depth within
+``ALT_REL``.  There is no blanket escape: a loose ray that matches no
+alternative fails the test, wherever it sits.
+"""
+from __future__ import annotations
+
+import itertools
+
+import torch
+
+from oracle import renderer as oren
+from oracle.rays import near_far_from_aabb
+
+TOL_ABS, TOL_DEPTH_REL = 1e-4, 2e-4          # the stated tolerance
+CAP_ABS, CAP_DEPTH_REL = 2e-3, 5e-3          # no ray beyond
+ALT_ABS, ALT_REL = 2e-5, 5e-5                # match to an alternative
+MAX_MASK_CAND, MAX_DENOM_CAND = 3, 2
+DENOM_WINDOW = 1e-6
+
+
+def fine_sample_cdf(aux):
+    """``inverse_cdf`` recomputed from the oracle's own bins / weights / u:
+    per fine sample the cdf interval ``denom = c1 - c0`` and the bin width."""
+    w = aux["w_coarse"][:, 1:-1] + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = aux["u"].contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = torch.clamp(hi - 1, min=0)
+    hi = torch.clamp(hi, max=cdf.shape[-1] - 1)
+    denom = torch.gather(cdf, 1, hi) - torch.gather(cdf, 1, lo)
+    bins = aux["z_mid_coarse"]
+    width = torch.gather(bins, 1, hi) - torch.gather(bins, 1, lo)
+    return denom, width
+
+
+def weight_noise(aux):
+    """Per sorted sample: how far fp32 round-off can move its weight.
+
+    ``alpha_s ~ sigma_s * (z[s+1] - z[s])``, so ``dw/w ~ (dz_s + dz_s+1) /
+    delta_s``.  A coarse depth carries ~2 ulp(z).  A FINE depth is ``b0 + (u -
+    c0) / denom * (b1 - b0)``: the cdf is an fp32 running sum of ~T terms
+    (round-off of a few 2^-23, different between a sequential and a parallel
+    scan), so the depth moves by ``4 * 2^-23 / denom * (b1 - b0)``.  Plus the
+    transmittance in front of the sample: ``dT/T = sum_{j<s} x_j d(delta_j) /
+    delta_j`` with ``x_j = sigma_j delta_j`` -- the interval noise of every
+    sample in front, amplified by its optical depth.  Returned: the
+    un-clamped estimate of |dw| per sorted sample."""
+    z, w = aux["z"], aux["weights"]
+    ulp = torch.exp2(torch.floor(torch.log2(z.abs().clamp_min(1e-30))) - 23)
+    dz = 2 * ulp
+    if "w_coarse" in aux:
+        denom, width = fine_sample_cdf(aux)
+        denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+        dz_fine = 4 * 2.0 ** -23 / denom * width.abs()
+        T = aux["w_coarse"].shape[1]
+        dz_cat = torch.cat([torch.zeros(z.shape[0], T), dz_fine], -1)
+        dz = dz + torch.gather(dz_cat, 1, aux["order"])
+    delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
+    dz_next = torch.cat([dz[:, 1:], torch.zeros_like(dz[:, :1])], -1)
+    r = ((dz + dz_next) / delta.clamp_min(1e-12)).double()
+    w64 = w.double()
+    T_front = (1.0 - (torch.cumsum(w64, -1) - w64)).clamp_min(1e-12)
+    alpha = (w64 / T_front).clamp(0.0, 1.0 - 1e-12)
+    x = -torch.log1p(-alpha)
+    up = torch.cumsum(x * r, -1) - x * r
+    return (w64 * (r + up)).to(w.dtype)
+
+
+def mask_window(aux):
+    """Per sorted sample: the half-width around 1e-4 inside which round-off
+    decides the mask -- 6 x the modelled noise (its constants are estimates of
+    an order-dependent round-off), at least 1e-7, at most 3 % of the threshold."""
+    return (6.0 * weight_noise(aux)).clamp(1e-7, 3e-6)
+
+
+def _inverse_cdf_flipped(bins, weights, u, flip):
+    """oracle.renderer.inverse_cdf with the ``denom < 1e-5`` decision of the
+    fine samples in ``flip`` [N,t] taken the other way."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = torch.clamp(hi - 1, min=0)
+    hi = torch.clamp(hi, max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b0, b1 = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+    denom = c1 - c0
+    small = (denom < 1e-5) ^ flip
+    denom = torch.where(small, torch.ones_like(denom), denom)
+    return b0 + (u - c0) / denom * (b1 - b0)
+
+
+class RayOracle:
+    """The oracle's ``run`` on ONE ray, split at the two step functions so that
+    either can be decided by hand (follows oracle/renderer.run line by line)."""
+
+    def __init__(self, fld, o, d, nrm, aabb, T, t, u_row, t_rand_row=None,
+                 density_scale=1.0, min_near=0.2):
+        self.fld, self.aabb, self.T, self.t = fld, aabb, T, t
+        self.o, self.d, self.nrm = o.view(1, 3), d.view(1, 3), nrm.view(1)
+        self.ds = density_scale
+        nears, fars = near_far_from_aabb(self.o, self.d, aabb, min_near)
+        self.zc = oren.coarse_z(nears.unsqueeze(-1), fars.unsqueeze(-1), T,
+                                None if t_rand_row is None else t_rand_row.view(1, T))
+        self.xyz_c = oren.positions(self.o, self.d, self.zc, aabb)
+        den = fld.density(self.xyz_c.reshape(-1, 3))
+        self.sig_c = den["sigma"].view(1, T)
+        self.geo_c = den["geo_feat"].view(1, T, -1)
+        self.u = None if u_row is None else u_row.view(1, t)
+        if t > 0:
+            deltas, w = oren.alpha_weights(self.zc, self.sig_c, self.ds)
+            self.z_mid = self.zc[:, :-1] + 0.5 * deltas[:, :-1]
+            self.w_c = w
+
+    def sorted_samples(self, denom_flip=None):
+        """(z, sigma, geo, xyz) of the merged, sorted samples; ``denom_flip``:
+        indices of fine samples placed by the other branch of the denom step."""
+        if self.t == 0:
+            return self.zc, self.sig_c, self.geo_c, self.xyz_c, None
+        flip = torch.zeros(1, self.t, dtype=torch.bool)
+        for j in (denom_flip or ()):
+            flip[0, j] = True
+        new_z = _inverse_cdf_flipped(self.z_mid, self.w_c[:, 1:-1], self.u, flip)
+        new_xyz = oren.positions(self.o, self.d, new_z, self.aabb)
+        den2 = self.fld.density(new_xyz.reshape(-1, 3))
+        z = torch.cat([self.zc, new_z], 1)
+        z, order = torch.sort(z, dim=1)
+        xyz = torch.gather(torch.cat([self.xyz_c, new_xyz], 1), 1,
+                           order.unsqueeze(-1).expand(-1, -1, 3))
+        sigma = torch.gather(torch.cat([self.sig_c, den2["sigma"].view(1, self.t)], 1), 1, order)
+        geo_all = torch.cat([self.geo_c, den2["geo_feat"].view(1, self.t, -1)], 1)
+        geo = torch.gather(geo_all, 1, order.unsqueeze(-1).expand_as(geo_all))
+        return z, sigma, geo, xyz, order
+
+    def shade_all(self, z, sigma, geo, xyz):
+        """weights and the nets' outputs on EVERY sample (no mask)."""
+        _, weights = oren.alpha_weights(z, sigma, self.ds)
+        S = z.shape[1]
+        dirs = self.d.view(1, 1, 3).expand(1, S, 3).reshape(-1, 3)
+        every = torch.ones(S, dtype=torch.bool)
+        fg = geo.reshape(S, -1)
+        rgbs = self.fld.color(xyz.reshape(-1, 3), dirs, mask=every, geo_feat=fg).view(S, 3)
+        probs = self.fld.semantics(xyz.reshape(-1, 3), dirs, mask=every, geo_feat=fg).view(S, -1)
+        return weights[0], rgbs, probs
+
+    def composite(self, z, weights, rgbs, probs, mask):
+        w = torch.where(mask, weights, torch.zeros_like(weights))
+        return {"depth": (w * z[0]).sum() / self.nrm[0],
+                "image": (w[:, None] * rgbs).sum(0),
+                "semantics": (w[:, None] * probs).sum(0)}
+
+
+def _errors(got, ref):
+    return (float((got["image"].double() - ref["image"].double()).abs().max()),
+            float((got["semantics"].double() - ref["semantics"].double()).abs().max()),
+            float((got["depth"].double() - ref["depth"].double()).abs() /
+                  ref["depth"].double().abs().clamp_min(1e-3)))
+
+
+def explain_ray(ro: RayOracle, got, window_fn=None):
+    """Best alternative for one ray: (score, description, errors).  score <= 1
+    means ``got`` matches that alternative within ALT_ABS / ALT_REL in all
+    three outputs.  Alternatives: subsets of the denom-step fine samples
+    flipped x subsets of the at-threshold samples toggled."""
+    with torch.no_grad():
+        denom_cand = []
+        if ro.t > 0:
+            aux1 = {"w_coarse": ro.w_c, "z_mid_coarse": ro.z_mid, "u": ro.u}
+            denom, _ = fine_sample_cdf(aux1)
+            near = (denom[0] - 1e-5).abs()
+            idx = torch.nonzero(near <= DENOM_WINDOW).flatten()
+            idx = idx[torch.argsort(near[idx])][:MAX_DENOM_CAND]
+            denom_cand = idx.tolist()
+        best = (float("inf"), None, None)
+        n_alt = 0
+        for kd in range(len(denom_cand) + 1):
+            for dflip in itertools.combinations(denom_cand, kd):
+                z, sigma, geo, xyz, order = ro.sorted_samples(dflip)
+                weights, rgbs, probs = ro.shade_all(z, sigma, geo, xyz)
+                aux = {"z": z, "weights": weights[None]}
+                if ro.t > 0:     # the window needs the merged order of THIS alternative
+                    aux.update(w_coarse=ro.w_c, z_mid_coarse=ro.z_mid, u=ro.u, order=order)
+                win = (window_fn or mask_window)(aux)[0]
+                dist = (weights - 1e-4).abs()
+                cand = torch.nonzero(dist <= win).flatten()
+                cand = cand[torch.argsort((dist / win)[cand])][:MAX_MASK_CAND].tolist()
+                base = weights > 1e-4
+                for km in range(len(cand) + 1):
+                    for tog in itertools.combinations(cand, km):
+                        mask = base.clone()
+                        for s in tog:
+                            mask[s] = ~mask[s]
+                        alt = ro.composite(z, weights, rgbs, probs, mask)
+                        ei, es, ed = _errors(got, alt)
+                        score = max(ei / ALT_ABS, es / ALT_ABS, ed / ALT_REL)
+                        n_alt += 1
+                        if score < best[0]:
+                            best = (score, {"denom_flipped": list(dflip), "mask_toggled": list(tog),
+                                            "toggled_weights": [float(weights[s]) for s in tog]},
+                                    (ei, es, ed))
+        return best + (n_alt,)
+
+
+def flagged_a_priori(aux):
+    """Per ray, BEFORE looking at any result: does it have a candidate at all
+    (a weight inside the mask window, or a fine sample on the denom step)?"""
+    w = aux["weights"]
+    at_mask = ((w - 1e-4).abs() <= mask_window(aux)).any(-1)
+    if "w_coarse" in aux:
+        denom, _ = fine_sample_cdf(aux)
+        at_denom = ((denom - 1e-5).abs() <= DENOM_WINDOW).any(-1)
+    else:
+        at_denom = torch.zeros_like(at_mask)
+    return at_mask, at_denom
+
+
+def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
+                 max_loose_frac=5e-3):
+    """``res``: the outputs under test ([1, N(, C)] tensors, any device);
+    ``ref``: ``oracle.renderer.run(..., return_aux=True)`` on ``rays`` = (o, d,
+    nrm) [1, n, .] CPU tensors (the rows ``sel`` of what ``res`` rendered)."""
+    o, d, nrm = rays[0].reshape(-1, 3), rays[1].reshape(-1, 3), rays[2].reshape(-1)
+    aux = ref["aux"]
+    pick = (lambda x: x[0].cpu()) if sel is None else (lambda x: x[0][sel.to(x.device)].cpu())
+    got = {k: pick(res[k]) for k in ("image", "semantics", "depth")}
+    e_img = (got["image"].double() - ref["image"][0].double()).abs().max(-1)[0]
+    e_sem = (got["semantics"].double() - ref["semantics"][0].double()).abs().max(-1)[0]
+    rel = ((got["depth"].double() - ref["depth"][0].double()).abs() /
+           ref["depth"][0].double().abs().clamp_min(1e-3))
+    n = rel.numel()
+    for name, e, tol, cap in (("image", e_img, TOL_ABS, CAP_ABS), ("semantics", e_sem, TOL_ABS, CAP_ABS),
+                              ("depth(rel)", rel, TOL_DEPTH_REL, CAP_DEPTH_REL)):
+        print(f"{tag} {name}: median {float(e.median()):.2e} p99.5 {float(e.quantile(0.995)):.2e} "
+              f"max {float(e.max()):.2e}; {int((e > tol).sum())} of {n} rays above {tol:g}")
+        assert float(e.max()) <= cap, (tag, name, float(e.max()))
+        assert float(e.median()) <= 5e-6, (tag, name, float(e.median()))
+    loose = (e_img > TOL_ABS) | (e_sem > TOL_ABS) | (rel > TOL_DEPTH_REL)
+    at_mask, at_denom = flagged_a_priori(aux)
+    frac = float((at_mask | at_denom).float().mean())
+    print(f"{tag} a-priori candidates: {int(at_mask.sum())} rays with a weight in the mask window, "
+          f"{int(at_denom.sum())} with a fine sample on the denom step = {100 * frac:.1f} % of {n} "
+          "(informational: having a candidate excuses nothing)")
+    # every loose ray must match one alternative of ITS OWN candidates
+    unexplained = []
+    for i in torch.nonzero(loose).flatten().tolist():
+        ro = RayOracle(fld, o[i], d[i], nrm[i], aabb, T, t,
+                       None if t == 0 else aux["u"][i],
+                       None if t_rand is None else t_rand[i])
+        g1 = {k: got[k][i] for k in got}
+        score, what, errs, n_alt = explain_ray(ro, g1)
+        line = (f"{tag} ray {i}: err img {float(e_img[i]):.2e} sem {float(e_sem[i]):.2e} depth "
+                f"{float(rel[i]):.2e}; best of {n_alt} alternatives {what} -> "
+                f"img {errs[0]:.2e} sem {errs[1]:.2e} depth {errs[2]:.2e}")
+        print(line)
+        if not (score <= 1.0 and (what["denom_flipped"] or what["mask_toggled"])):
+            unexplained.append(line)
+    assert not unexplained, ("rays above the tolerance that NO alternative decision of the "
+                             "reference's two step functions reproduces within "
+                             f"{ALT_ABS:g} / {ALT_REL:g}:\n" + "\n".join(unexplained[:10]))
+    assert int(loose.sum()) <= max(4, int(max_loose_frac * n)), int(loose.sum())
+    return {"loose": int(loose.sum()), "flagged_frac": frac}

@@ -19,7 +19,28 @@ def test_package_points_miopen_at_the_shipped_db():
              "print(os.environ['MIOPEN_USER_DB_PATH']); print(u.MIOPEN_DB_PATH)", env)
     assert r.returncode == 0, r.stderr
     a, b = r.stdout.split()
-    assert a == b == os.path.join(ROOT, "ucsa_neural_rendering_amd", "miopen_db")
+    # a per-user COPY (MIOpen appends to what it is pointed at: never the
+    # package's tracked files), holding exactly the shipped files
+    pkg = os.path.join(ROOT, "ucsa_neural_rendering_amd", "miopen_db")
+    assert a == b and os.path.realpath(a) != os.path.realpath(pkg)
+    assert "ucsa_neural_rendering_amd_miopen_db_" in os.path.basename(a)
+    for f in os.listdir(pkg):
+        assert open(os.path.join(a, f), "rb").read() == open(os.path.join(pkg, f), "rb").read()
+
+
+def test_copy_is_atomic_under_concurrent_imports(tmp_path):
+    """Eight processes importing the package at once into an empty cache: all
+    end on the same complete directory, no half-copied state is visible."""
+    env = {k: v for k, v in os.environ.items() if k != "MIOPEN_USER_DB_PATH"}
+    env["XDG_CACHE_HOME"] = str(tmp_path)
+    code = ("import os, ucsa_neural_rendering_amd as u; d = u.MIOPEN_DB_PATH; "
+            "print(d, sorted((f, os.path.getsize(os.path.join(d, f))) for f in os.listdir(d)))")
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, text=True) for _ in range(8)]
+    outs = {p.communicate(timeout=300)[0] for p in procs}
+    assert all(p.returncode == 0 for p in procs) and len(outs) == 1, outs
+    assert str(tmp_path) in next(iter(outs))
+    assert [d for d in os.listdir(tmp_path) if d.startswith(".ucsa_miopen_")] == []
 
 
 def test_a_user_setting_wins():
@@ -65,11 +86,22 @@ def test_gemm_table_is_left_alone_when_the_user_controls_tunableop(monkeypatch):
     assert _gemm_tuning.ensure() is None
 
 
-def test_cudnn_benchmark_default_is_a_lookup_only_with_the_shipped_db():
-    code = ("from ucsa_neural_rendering_amd._miopen_db import default_cudnn_benchmark as d; "
-            "import ucsa_neural_rendering_amd; print(d())")
+def test_cudnn_benchmark_default_needs_a_matching_device():
+    """Without a GPU (or on a device / MIOpen build the shipped names were not
+    tuned for) the reference's cudnn.benchmark = True stays; the lookup-only
+    mode on a matching MI355X is asserted by tests/test_gpu_deeplab_parity.py."""
+    code = ("from ucsa_neural_rendering_amd._miopen_db import default_cudnn_benchmark as d, "
+            "shipped_db_matches as m; import ucsa_neural_rendering_amd; print(d(), m()['matched'])")
     env = {k: v for k, v in os.environ.items() if k != "MIOPEN_USER_DB_PATH"}
     r = _run(code, env)
-    assert r.returncode == 0 and r.stdout.strip() == "False", r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.split() == ["True", "False"], r.stdout + r.stderr
     r = _run(code, dict(env, MIOPEN_USER_DB_PATH="/tmp/not_ours"))
-    assert r.returncode == 0 and r.stdout.strip() == "True", r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.split()[0] == "True", r.stdout + r.stderr
+
+
+def test_db_name_parse():
+    from ucsa_neural_rendering_amd import _miopen_db as m
+    for f in m.shipped_files():
+        g = m._NAME.match(f)
+        assert g and g.group(1) == "gfx950" and int(g.group(2), 16) == 256
+        assert g.groups()[2:5] == ("3", "5", "0")

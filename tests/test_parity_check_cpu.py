@@ -1,0 +1,138 @@
+"""Test of the test: tests/parity_check.check_render (the causal rule of the
+full-size GPU parity tests) on the CPU, with the oracle standing in for the
+result under test.
+
+* the oracle's own output passes (nothing is loose);
+* an error of 3e-4 injected into 5 rays that sit on NO step fails;
+* the same error injected into rays that DO have a candidate (a weight inside
+  the mask window) fails as well -- having a candidate excuses nothing;
+* a result in which a genuine threshold sample was decided the other way
+  (its mask bit flipped: depth moves by > 2e-4 rel) passes, and is reported as
+  explained by exactly that toggle;
+* the same for a fine sample on sample_pdf's denom step placed by the other
+  branch."""
+import copy
+
+import pytest
+import torch
+
+from oracle import renderer as oren
+from tests import parity_check as pc
+from tests.util import AABB4, lively_oracle_field, make_rays
+
+N, T, t = 1024, 48, 48
+
+
+@pytest.fixture(scope="module")
+def case():
+    fld = lively_oracle_field()
+    o, d, n = make_rays(N, 5)
+    u = torch.rand(N, t, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = oren.run(fld, o[None], d[None], n[None], AABB4, num_steps=T, upsample_steps=t,
+                       u=u, return_aux=True)
+    return fld, (o[None], d[None], n[None]), u, ref
+
+
+def _res(ref):
+    return {k: ref[k].clone() for k in ("image", "semantics", "depth")}
+
+
+def test_the_oracle_itself_passes(case):
+    fld, rays, u, ref = case
+    out = pc.check_render(_res(ref), ref, fld, rays, AABB4, T, t, tag="self")
+    assert out["loose"] == 0
+
+
+def test_an_injected_error_off_any_step_fails(case):
+    fld, rays, u, ref = case
+    am, ad = pc.flagged_a_priori(ref["aux"])
+    clean = torch.nonzero(~(am | ad)).flatten()[:5]
+    res = _res(ref)
+    res["image"][0, clean, 1] += 3e-4
+    with pytest.raises(AssertionError, match="NO alternative"):
+        pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-clean")
+
+
+def test_an_injected_error_on_a_flagged_ray_fails_too(case):
+    fld, rays, u, ref = case
+    am, _ = pc.flagged_a_priori(ref["aux"])
+    flagged = torch.nonzero(am).flatten()[:5]
+    assert len(flagged) == 5
+    for key in ("semantics", "depth"):
+        res = _res(ref)
+        if key == "depth":
+            res["depth"][0, flagged] *= 1.0 + 6e-4
+        else:
+            res["semantics"][0, flagged, 3] += 3e-4
+        with pytest.raises(AssertionError, match="NO alternative"):
+            pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-flagged-" + key)
+
+
+def _toggle_case(case):
+    """A ray + sample whose weight is inside the mask window and whose toggle
+    moves the depth by more than the tolerance."""
+    fld, rays, u, ref = case
+    aux = ref["aux"]
+    w, z = aux["weights"], aux["z"]
+    near = (w - 1e-4).abs() <= pc.mask_window(aux)
+    eff = w * z / rays[2][0].reshape(-1, 1) / ref["depth"][0][:, None].abs().clamp_min(1e-3)
+    eff = torch.where(near, eff, torch.zeros_like(eff))
+    i = int(eff.max(-1)[0].argmax())
+    s = int(eff[i].argmax())
+    assert float(eff[i, s]) > 2.5e-4, "fixture has no consequential threshold sample"
+    return i, s
+
+
+def test_a_genuine_threshold_flip_passes_and_is_named(case, capsys):
+    fld, rays, u, ref = case
+    i, s = _toggle_case(case)
+    ro = pc.RayOracle(fld, rays[0][0, i], rays[1][0, i], rays[2][0, i], AABB4, T, t, u[i])
+    with torch.no_grad():
+        z, sigma, geo, xyz, _ = ro.sorted_samples()
+        w, rgbs, probs = ro.shade_all(z, sigma, geo, xyz)
+        mask = w > 1e-4
+        mask[s] = ~mask[s]
+        alt = ro.composite(z, w, rgbs, probs, mask)
+    res = _res(ref)
+    for k in res:
+        res[k][0, i] = alt[k]
+    out = pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="flip")
+    assert out["loose"] == 1
+    assert f"'mask_toggled': [{s}]" in capsys.readouterr().out
+    # ... and the same ray with an extra 1e-4 on top of the flip does not
+    res["image"][0, i, 0] += 1e-4
+    with pytest.raises(AssertionError, match="NO alternative"):
+        pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="flip+error")
+
+
+def test_a_denom_step_sample_placed_by_the_other_branch_passes(case):
+    """Fabricated: no fine sample of this small fixture sits within 1e-6 of the
+    step (its emptiest bins have a cdf interval of 9e-5), so the window is
+    widened for the test: the machinery -- move the sample, re-evaluate the
+    density, re-sort, re-mask -- is what is exercised."""
+    fld, rays, u, ref = case
+    denom, _ = pc.fine_sample_cdf(ref["aux"])
+    old = pc.DENOM_WINDOW
+    try:
+        pc.DENOM_WINDOW = 1e-4
+        cand = torch.nonzero((denom - 1e-5).abs() <= pc.DENOM_WINDOW)
+        if len(cand) == 0:
+            pytest.skip("no fine sample near the denom step in this fixture")
+        done = 0
+        order = torch.argsort((denom - 1e-5).abs()[cand[:, 0], cand[:, 1]])
+        for i, j in cand[order].tolist()[:6]:
+            ro = pc.RayOracle(fld, rays[0][0, i], rays[1][0, i], rays[2][0, i], AABB4, T, t, u[i])
+            with torch.no_grad():
+                z, sigma, geo, xyz, _ = ro.sorted_samples((j,))
+                w, rgbs, probs = ro.shade_all(z, sigma, geo, xyz)
+                alt = ro.composite(z, w, rgbs, probs, w > 1e-4)
+            res = _res(ref)
+            for k in res:
+                res[k][0, i] = alt[k]
+            out = pc.check_render(res, ref, fld, rays, AABB4, T, t, tag=f"denom[{i},{j}]")
+            done += out["loose"]
+        assert done > 0, "no fabricated move was large enough to be loose"
+        assert done > 0
+    finally:
+        pc.DENOM_WINDOW = old

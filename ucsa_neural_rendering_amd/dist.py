@@ -47,20 +47,43 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def forced() -> bool:
+    """``UCSA_FORCE_DIST=1``: run the distributed code path even with ONE
+    rank -- ``init_from_env`` / ``bench.py`` create a world-size-1 process
+    group (``nccl`` = RCCL on a GPU) and every collective below is issued
+    instead of short-circuited.  A 1-GPU box can execute the RCCL branches
+    (reduce_scatter_tensor / all_gather_into_tensor on device tensors,
+    ``device_id=`` init, all_gather_object) this way; results equal the
+    non-distributed run bit for bit (tests/test_gpu_dist.py)."""
+    return os.environ.get("UCSA_FORCE_DIST", "") not in ("", "0")
+
+
+def active() -> bool:
+    """Collectives are issued: a process group exists and it has more than
+    one rank, or ``forced()``."""
+    return is_dist() and (dist.get_world_size() > 1 or forced())
+
+
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)."""
     w = int(os.environ.get("WORLD_SIZE", "1"))
     r = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    if w > 1 and not is_dist():
+    if (w > 1 or forced()) and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if w == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(lr)
             kw["device_id"] = torch.device("cuda", lr)
-        dist.init_process_group(backend, **kw)
+        dist.init_process_group(backend, rank=r, world_size=w, **kw)
     return r, lr, w
 
 
@@ -79,7 +102,7 @@ def allreduce_sum_(tensors: Sequence[torch.Tensor], small_bytes: int = 1 << 20):
     """In-place SUM all-reduce.  Tensors below `small_bytes` are coalesced into
     one flat buffer (one collective for the three MLP gradients); large ones
     (the hash grid) go on their own, un-copied."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not active():
         return
     small = [t for t in tensors if t.numel() * t.element_size() < small_bytes]
     large = [t for t in tensors if t.numel() * t.element_size() >= small_bytes]
@@ -106,7 +129,7 @@ def broadcast_parameters_(module: torch.nn.Module, src: int = 0):
     construction).  Needed whenever the replicas were produced by a
     non-deterministic computation -- e.g. a pre-training whose hash-grid
     gradient uses float atomics -- before they are trained data-parallel."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not active():
         return
     gloo_cuda = dist.get_backend() == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):
@@ -127,7 +150,7 @@ def broadcast_buffers_(module: torch.nn.Module, src: int = 0):
     drift during a training epoch and are re-aligned before every
     evaluation / predict pass, so that sharded metrics and the written
     pseudo-labels all come from the model rank 0 saves."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not active():
         return
     gloo_cuda = dist.get_backend() == "gloo"
     for t in module.buffers():
@@ -143,7 +166,7 @@ def average_grads_(params: Iterable[torch.nn.Parameter]):
     """DDP semantics: SUM all-reduce of the gradients, then / world."""
     params = [p for p in params if p.grad is not None]
     _, w = world()
-    if w == 1:
+    if not active():
         return
     allreduce_sum_([p.grad for p in params])
     for p in params:
@@ -176,7 +199,7 @@ def all_gather_into_(out: torch.Tensor, inp: torch.Tensor):
 
 
 def allreduce_sum_tensor(t: torch.Tensor) -> torch.Tensor:
-    if is_dist() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -198,7 +221,7 @@ class RankShardSampler(torch.utils.data.Sampler):
 
 
 def allreduce_max_(t: torch.Tensor) -> torch.Tensor:
-    if is_dist() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
@@ -207,7 +230,7 @@ def all_gather_ints(value: int, device) -> List[int]:
     """Every rank's integer, in rank order (one 8-byte-per-rank all_gather and
     a host read-back: used once per joint training step to agree on the
     number of NeRF updates, see ``training_step_joint``)."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not active():
         return [int(value)]
     mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
     parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
@@ -227,7 +250,7 @@ def global_mean_scale(n_local: int, valid_local: torch.Tensor):
                                      device=valid_local.device),
                      valid_local.detach().to(torch.float64).reshape(())])
     tot = v.clone()
-    if is_dist() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     sc = (v / tot.clamp_min(1.0)).to(torch.float32)
     return sc[0], sc[1]
@@ -236,7 +259,7 @@ def global_mean_scale(n_local: int, valid_local: torch.Tensor):
 def global_count(local_count: torch.Tensor) -> torch.Tensor:
     """Sum of a (scalar) count over ranks; float64 to stay exact."""
     c = local_count.detach().to(torch.float64).clone()
-    if is_dist() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return c
 
@@ -245,7 +268,7 @@ def gather_rows(local: torch.Tensor, sizes: Sequence[int], dst: int = 0):
     """Gather per-rank row blocks (ragged along dim 0) on `dst`; returns the
     concatenation there, None elsewhere."""
     rank, w = world()
-    if w == 1:
+    if not active():
         return local
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype,
@@ -259,6 +282,6 @@ def gather_rows(local: torch.Tensor, sizes: Sequence[int], dst: int = 0):
 
 
 def allreduce_confusion_(cm: torch.Tensor) -> torch.Tensor:
-    if is_dist() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(cm, op=dist.ReduceOp.SUM)
     return cm

@@ -92,7 +92,7 @@ class JointTrainDataModule:
         ``set_epoch``; what Lightning DDP does in the reference), evaluation
         and predict loaders a strided shard without duplicates."""
         rank, world = udist.world()
-        if world > 1:
+        if udist.active():
             if shuffle:
                 sampler = torch.utils.data.distributed.DistributedSampler(
                     ds, num_replicas=world, rank=rank, shuffle=True,

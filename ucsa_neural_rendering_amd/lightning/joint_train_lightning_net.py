@@ -434,7 +434,7 @@ class JointTrainLightningNet(nn.Module):
     def _new_frame_counts(self, n_local):
         """How many new-scene frames every rank holds in this step (one small
         all_gather; [n_local] without torch.distributed)."""
-        if udist.world()[1] == 1:
+        if not udist.active():
             return [int(n_local)]
         return udist.all_gather_ints(int(n_local), self._reduce_device())
 
@@ -581,7 +581,7 @@ class JointTrainLightningNet(nn.Module):
                 m.clear()
         tot = torch.tensor([sum(self._psnr), float(len(self._psnr))],
                            dtype=torch.float64)
-        if udist.world()[1] > 1:  # the ranks evaluated disjoint frames
+        if udist.active():  # the ranks evaluated disjoint frames
             tot = udist.allreduce_sum_tensor(tot.to(self._reduce_device()))
         if float(tot[1]) > 0:
             out["test_nerf_PSNR"] = float(tot[0] / tot[1])
@@ -597,7 +597,7 @@ class JointTrainLightningNet(nn.Module):
         """Sum the 40x40 confusion matrix over the ranks (each evaluated its
         own frames) instead of the reference's all_gather of label maps
         (:666-667)."""
-        if udist.world()[1] > 1:
+        if udist.active():
             import numpy as np
             local = (m.conf_mat if m.conf_mat is not None else
                      np.zeros((m.number_classes, m.number_classes), dtype=np.int64))
@@ -676,7 +676,7 @@ class JointTrainLightningNet(nn.Module):
         else:
             raise ValueError(name)
         lr_nerf = self._exp["optimizer"]["lr_nerf"]
-        sharded = self.sharded_optimizer and udist.world()[1] > 1
+        sharded = self.sharded_optimizer and udist.active()
         ctor = ShardedHipAdam if sharded else HipAdam
         extra = {"comm_dtype": self.grad_comm_dtype} if sharded else {}
         optimizer_nerf = ctor(

@@ -35,7 +35,7 @@ class CollectiveGradScaler(torch.amp.GradScaler):
     def _unscale_grads_(self, optimizer, inv_scale, found_inf, allow_fp16):
         out = super()._unscale_grads_(optimizer, inv_scale, found_inf,
                                       allow_fp16)
-        if udist.world()[1] > 1:
+        if udist.active():
             for t in out.values():
                 udist.allreduce_max_(t)
             optimizer._found_inf_is_collective = True
@@ -211,7 +211,7 @@ class ShardedHipAdam(HipAdam):
     @torch.no_grad()
     def step(self, closure=None):
         rank, world = udist.world()
-        if world == 1:
+        if not udist.active():      # one process, no (forced) group: plain HipAdam
             return super().step(closure)
         loss = None
         if closure is not None:

@@ -46,6 +46,35 @@ def ensure():
 _state = None
 
 
+def table_matches():
+    """{"matched": bool, "why": str}: do the table's validator lines (PyTorch,
+    HIP, hipBLASLt, rocBLAS versions, gfx arch) equal the running stack's?
+    TunableOp silently ignores every entry of a file whose validators differ;
+    this says so out loud (bench.py's ``tuning_tables_matched``).  Needs a GPU."""
+    import torch
+    if not torch.cuda.is_available():
+        return {"matched": False, "why": "no GPU"}
+    if not os.path.isfile(TABLE):
+        return {"matched": False, "why": "no shipped table"}
+    want = {}
+    with open(TABLE) as fh:
+        for ln in fh:
+            r = ln.strip().split(",")
+            if r and r[0] == "Validator" and len(r) >= 3:
+                want[r[1]] = ",".join(r[2:])
+    try:
+        have = {k: str(v) for k, v in torch.cuda.tunable.get_validators()}
+    except Exception as e:  # noqa: BLE001
+        return {"matched": False, "why": f"get_validators failed: {e!r}"}
+    bad = [f"{k}: table {want[k]} / running {have.get(k)}" for k in want if have.get(k) != want[k]]
+    if bad:
+        return {"matched": False, "why": "; ".join(bad)}
+    if not _done:
+        return {"matched": False, "why": "validators equal, table not installed "
+                                         "(PYTORCH_TUNABLEOP_* set, or no DeepLabV3 built yet)"}
+    return {"matched": True, "why": "validators equal, look-up only"}
+
+
 def use(flag):
     """Route GEMMs through the table (fp32) or straight to the library
     (autocast: launch-bound, see above).  No-op when ``ensure()`` did not
