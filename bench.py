@@ -79,9 +79,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=16, help="cfg5: training frames per scene")
     ap.add_argument("--mode", choices=["render", "train", "cfg3", "cfg4", "cfg5"],
                     default="render")
-    ap.add_argument("--backbone", default="resnet50",
-                    help="cfg3: DeepLab backbone (BASELINE cfg3 says ResNet-50; "
-                         "the reference's model is resnet101)")
+    ap.add_argument("--backbone", default=None,
+                    help="DeepLab backbone.  cfg3 default resnet50 (BASELINE cfg3 says "
+                         "ResNet-50; the reference's model is resnet101); cfg5 default: "
+                         "what cfg/exp/multi_step/cl_base.yml says (resnet101)")
     ap.add_argument("--seg-amp", default="", help="cfg3: '' (fp32, the reference) or bf16")
     ap.add_argument("--nerf-precision", default="bf16x3",
                     choices=["fp32", "bf16x3", "fp16"],
@@ -149,11 +150,11 @@ def cpu_baseline(net, pose, intr, n_rays, threads):
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start
     the N ranks as a CHILD `python -m torch.distributed.run` and relay its
-    stdout / exit code.  This process never touches the GPU (no torch.cuda
-    call that initialises HIP happens before this point;
-    ``torch.cuda.device_count()`` does not) -- a process that has initialised
-    the GPU must not exec or be replaced, so the ranks are children and the
-    parent only waits.  The reference's DDP site: scripts/train_joint.py:137-142
+    stdout / exit code.  The ranks are CHILD processes and the parent only
+    waits: a process that has initialised the GPU must never exec or be
+    replaced, and ``torch.cuda.device_count()`` may initialise HIP here (on
+    ROCm without amdsmi it falls back to hipGetDeviceCount) -- harmless,
+    because nothing is exec'ed from this process.  The reference's DDP site: scripts/train_joint.py:137-142
     (Lightning spawns the ranks there)."""
     import socket
     import subprocess
@@ -334,6 +335,7 @@ def main():
 
     from ucsa_neural_rendering_amd import ops
     if args.mode == "cfg3":
+        args.backbone = args.backbone or "resnet50"
         from tools.bench_legs.cfg3 import main_cfg3
         return main_cfg3(args, dev, dist, world, rank, backend)
     if args.mode == "cfg5":

@@ -132,7 +132,7 @@ def hashgrid_encode(spec: GridSpec, x01: torch.Tensor,
         cell = torch.floor(pos)
         frac = pos - cell
         cell = cell.to(torch.int64)
-        acc = torch.zeros(x01.shape[0], spec.n_features, dtype=torch.float32)
+        ws, idxs = [], []
         for c in range(8):
             w = torch.ones(x01.shape[0], dtype=torch.float32)
             g = []
@@ -143,8 +143,15 @@ def hashgrid_encode(spec: GridSpec, x01: torch.Tensor,
                 else:
                     w = w * (1.0 - frac[:, d])
                     g.append(cell[:, d])
-            idx = grid_index(spec, level, g[0], g[1], g[2]) + level.offset
-            acc = acc + w.unsqueeze(-1) * table[idx]
+            ws.append(w)
+            idxs.append(grid_index(spec, level, g[0], g[1], g[2]) + level.offset)
+        # ONE gather per level (autograd then builds one dense table gradient
+        # per level instead of one per corner); the corners are still summed
+        # in the order c = 0..7, so the values are unchanged bit for bit
+        vals = table[torch.stack(idxs, dim=1)]                 # [M, 8, F]
+        acc = torch.zeros(x01.shape[0], spec.n_features, dtype=torch.float32)
+        for c in range(8):
+            acc = acc + ws[c].unsqueeze(-1) * vals[:, c]
         outs.append(acc)
     return torch.cat(outs, dim=-1)
 

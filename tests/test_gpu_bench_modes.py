@@ -39,9 +39,23 @@ def _run2(extra, tmp_path, timeout=600):
         except subprocess.TimeoutExpired:
             proc.kill()
             raise AssertionError("bench.py timed out:\n" + err.read_text()[-3000:])
-    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    return _parse(rc, out, err)
+
+
+def _parse(rc, out, err):
+    """The LAST stdout line is the compact record (<= 4 KB, what the driver
+    parses); everything else a run measured is in the detail file it names."""
+    text = out.read_text()
+    lines = [l for l in text.splitlines() if l.startswith("{")]
     assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
-    return json.loads(lines[0])
+    assert text.strip().splitlines()[-1] == lines[0] and len(lines[0].encode()) <= 4096
+    res = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "dtype", "config", "distributed", "detail"):
+        assert k in res, k
+    res["_full"] = json.load(open(os.path.join(ROOT, res["detail"])))
+    assert res["_full"]["value"] == pytest.approx(res["value"], rel=1e-5)
+    return res
 
 
 def test_default_render_line_at_two_ranks_carries_train_dp(tmp_path):
@@ -49,7 +63,7 @@ def test_default_render_line_at_two_ranks_carries_train_dp(tmp_path):
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["metric"] == "rays/sec"
     assert res["value"] > 0 and res["roofline"]["bound"] == "hbm"
     assert "cpu_baseline" not in res            # single-GPU legs run at N = 1 only
-    dp = res["train_dp"]
+    dp = res["_full"]["train_dp"]
     assert dp["collective_ranks"] == 2 and dp["replicas_identical"] is True
     assert dp["optimizer"].startswith("ShardedHipAdam")
     assert dp["allreduce_ms"] > 0 and dp["reduce_scatter_allgather_ms"] > 0
@@ -60,10 +74,11 @@ def test_default_render_line_at_two_ranks_carries_train_dp(tmp_path):
 def test_train_mode_two_ranks(extra, tmp_path):
     res = _run2(["--mode", "train", "--steps", "3", "--warmup", "1",
                  "--pretrain-steps", "30"] + extra, tmp_path)
-    dp = res["train_dp"]
+    dp = res["_full"]["train_dp"]
     assert res["config"]["mode"] == "train" and res["n_gpus"] == 2
     assert dp["replicas_identical"] is True and dp["collective_ranks"] == 2
-    assert dp["final_loss"] == dp["final_loss"] and res["value"] == dp["rays_per_s"]
+    assert dp["final_loss"] == dp["final_loss"]
+    assert res["value"] == pytest.approx(dp["rays_per_s"], rel=1e-5)   # 6 significant digits
     want = "HipAdam" if "--replicated-adam" in extra else "ShardedHipAdam"
     assert dp["optimizer"].startswith(want)
 
@@ -71,7 +86,7 @@ def test_train_mode_two_ranks(extra, tmp_path):
 def test_cfg4_mode_two_ranks_with_gather(tmp_path):
     res = _run2(["--mode", "cfg4", "--views", "4", "--warmup", "1", "--gather",
                  "--pretrain-steps", "30"], tmp_path)
-    assert res["config"]["mode"] == "cfg4" and res["config"]["views_per_rank"] == 2
+    assert res["config"]["mode"] == "cfg4" and res["_full"]["config"]["views_per_rank"] == 2
     assert res["scaling"] == "strong" and res["value"] > 0
 
 
@@ -88,9 +103,7 @@ def test_plain_bench_gpus_2_launches_its_own_ranks(tmp_path):
     with open(out, "w") as fo, open(err, "w") as fe:
         rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
                               env=env, cwd=ROOT).wait(timeout=600)
-    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
-    assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
-    res = json.loads(lines[0])
+    res = _parse(rc, out, err)
     d = res["distributed"]
     assert res["n_gpus"] == 2 and d["world_size"] == 2 and d["launcher"] == "self"
     assert d["backend"].startswith("gloo") and len(d["devices"]) == 2
@@ -110,16 +123,77 @@ def test_cfg3_mode_two_joint_steps_one_process(tmp_path):
     with open(out, "w") as fo, open(err, "w") as fe:
         rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
                               env=env, cwd=ROOT).wait(timeout=900)
-    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
-    assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
-    res = json.loads(lines[0])
+    res = _parse(rc, out, err)
+    full = res["_full"]
     assert res["config"]["mode"] == "cfg3" and res["n_gpus"] == 1
-    assert res["config"]["nerf_rays_per_step_per_rank"] == 8 * (320 * 240 + 4096)
+    assert full["config"]["nerf_rays_per_step_per_rank"] == 8 * (320 * 240 + 4096)
     assert res["value"] > 0 and res["ms_per_step"] < 2000
-    rs = res["roofline_step"]
+    rs = full["roofline_step"]
     parts = rs["mfma"]["of_which"]
     assert abs(sum(parts.values()) - rs["mfma"]["algorithmic_flop"]) <= 1e-6 * rs["mfma"]["algorithmic_flop"]
     assert 0.0 < rs["mfma"]["frac_of_fp32_mfma_peak"] < 1.0 and 0.0 < rs["hbm"]["frac"] < 1.0
     assert 0.3 < rs["masked_fraction_rho"] <= 1.0
     for k in ("train/loss_nerf_rgb", "train/loss_seg"):
-        assert k in res["losses"] and res["losses"][k] == res["losses"][k]      # finite
+        assert k in full["losses"] and full["losses"][k] == full["losses"][k]      # finite
+
+
+def test_the_default_command_prints_the_compact_record(tmp_path):
+    """`python bench.py` (short: 3 steps, 30 pre-training steps): ONE stdout
+    line, <= 4 KB, with the roofline and cpu_baseline objects the driver
+    records; the side legs are in the detail file."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out, err = tmp_path / "out.txt", tmp_path / "err.txt"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+           "--pretrain-steps", "30", "--cpu-rays", "2048"]
+    with open(out, "w") as fo, open(err, "w") as fe:
+        rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                              env=env, cwd=ROOT).wait(timeout=900)
+    res = _parse(rc, out, err)
+    r, c = res["roofline"], res["cpu_baseline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "k_hashgrid_encode_tiled"
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / r["launch_ms"] / 1e6,
+                                          rel=1e-4)
+    assert set(r["binding_resource"]) == {"resource", "frac"}
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert res["speedup_vs_cpu"] == pytest.approx(res["value"] / c["value"], rel=1e-4)
+    assert set(res["tuning_tables_matched"]) >= {"miopen", "tunableop"}
+    assert res["config"]["workload"].startswith("cfg2") and res["dtype"] == "f32"
+    assert "train" in res["_full"] and "stage_ms_per_chunk" in res["_full"]
+
+
+def test_cfg5_mode_three_stages_at_true_sizes(tmp_path):
+    """`bench.py --mode cfg5` -- the continual loop AT ITS WORKLOAD's sizes
+    (240x320 frames, 4096 rays x (256+256), batch and replay buffer of
+    cfg/exp/multi_step/cl_base.yml, the predict pass writing the PNGs the
+    next stage replays), cut to three stages, 8 training frames per scene,
+    one NeRF-only and one joint epoch, ResNet-50, to fit the suite's budget.
+    tools/bench_legs/cfg5.py; the 10-stage run is profiles/r04_cfg5.json."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out, err = tmp_path / "out.txt", tmp_path / "err.txt"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "cfg5", "--scenes", "3",
+           "--frames", "8", "--nerf-epochs", "1", "--joint-epochs", "1",
+           "--backbone", "resnet50", "--no-seg-find"]
+    with open(out, "w") as fo, open(err, "w") as fe:
+        rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                              env=env, cwd=ROOT).wait(timeout=1200)
+    res = _parse(rc, out, err)
+    full = res["_full"]
+    assert res["config"]["mode"] == "cfg5" and res["value"] > 0
+    st = full["stages"]
+    assert [s["stage"] for s in st] == ["stage_0", "stage_1", "stage_2"]
+    assert [s["scenes"] for s in st] == [1, 2, 3]
+    # stage i's joint loader: 8 new frames + 8 replayed frames of each earlier
+    # scene (100 // i >= 8), batch 2 -> 4 (i + 1) joint steps; the NeRF-only
+    # loader is one frame per step (reference joint_train_data_module.py): 8
+    assert [s["joint_steps"] for s in st] == [4, 8, 12]
+    assert [s["nerf_steps"] for s in st] == [8, 8, 8]
+    # NeRF rays trained: 4096 per NEW-scene frame per step (replayed frames
+    # are not re-trained): 8 frames per epoch, 2 epochs per stage
+    assert all(s["rays_trained"] == 2 * 8 * 4096 for s in st)
+    assert all(s["rays_rendered"] >= 8 * 240 * 320 for s in st)     # full native renders
+    q = full["quality"]["final_stage"]
+    assert 0.0 <= q["test_nerf_mIoU"] <= 1.0 and q["test_nerf_PSNR"] == q["test_nerf_PSNR"]
+    assert full["throughput"]["joint_steps_per_s"] > 0

@@ -119,6 +119,32 @@ def test_fallback_path_equals_plain_modules_on_cpu_and_nchw():
     assert not _fusable(x.cuda())
 
 
+def test_half_precision_module_takes_the_fallback_and_raw_op_refuses(monkeypatch):
+    """``model.bfloat16()`` gives 2-byte BN parameters; the kernels
+    read float* -- the module must not take the fused path with them (it
+    would read out of bounds), and the raw op must refuse them loudly."""
+    from ucsa_neural_rendering_amd import _lib, ops
+    torch.manual_seed(2)
+    x = torch.randn(2, 16, 6, 5, device="cuda").to(torch.bfloat16) \
+        .contiguous(memory_format=torch.channels_last)
+    bn = FusedBatchNorm2d(16).cuda().bfloat16().train()
+    assert _fusable(x) and bn.weight.dtype == torch.bfloat16
+    calls = []
+    real = ops.bn_act_fwd
+    monkeypatch.setattr(ops, "bn_act_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    ref = nn.BatchNorm2d(16).cuda().bfloat16().train()
+    ref.load_state_dict(bn.state_dict())
+    y = bn(x, relu=True)
+    assert not calls                              # F.batch_norm path
+    assert torch.equal(y, F.relu(ref(x)))
+    with pytest.raises(_lib.UcsaError, match="fp32"):
+        real(x, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1, 1e-5, True, True)
+    # fp32 parameters under the same bf16 input (what autocast produces): fused
+    bn32 = FusedBatchNorm2d(16).cuda().train()
+    bn32(x, relu=True)
+    assert calls
+
+
 def test_bottleneck_of_the_mirror_runs_the_fused_path_and_matches_nchw():
     """One torchvision-style bottleneck of the DeepLab mirror: channels_last
     (fused kernels) against NCHW (F.batch_norm + add + relu) on the same

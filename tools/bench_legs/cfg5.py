@@ -1,0 +1,164 @@
+"""`bench.py --mode cfg5`: BASELINE cfg5 -- the continual loop of
+``run_scripts/multi_step.sh`` / ``scripts/cl_deeplab.py`` (reference
+scripts/cl_deeplab.py:11-22,53-91) AT ITS WORKLOAD: ten synthetic rooms (seeds
+0-9) of 240x320 frames written in the reference's ScanNet layout, stage i =
+NeRF-only epochs on scene i, then joint NeRF + DeepLab epochs on scene i plus
+the replay of the i earlier scenes (``cl.replay_buffer_size`` 100,
+cfg/exp/multi_step/cl_base.yml), test passes, the predict pass that writes the
+pseudo-label PNGs the later stages replay, checkpoint chaining.  4096 rays x
+(256+256) samples per NeRF step, batch size and backbone from the YAML.
+
+Timed: the whole ``cl_deeplab.main`` call (every stage: data-module setup,
+PNG reads, training, test / predict passes, checkpoint writes) -- the scene
+export (data generation) runs before the clock.  Reported: `value` = NeRF rays
+(trained + rendered) per second over the loop, joint steps/s, per-stage wall
+time and metrics, and the FINAL stage's mIoU / PSNR (what BASELINE.json asks:
+"throughput + final mIoU").  The number of epochs is a flag: the reference
+runs 10 + 10 per stage, hours of wall clock; the default here is small and is
+stated in the output."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+from .common import *  # noqa: F401,F403
+from .common import _tick, finish, max_over_ranks
+
+
+def main_cfg5(args, dev, dist, world, rank, backend):
+    from scripts import cl_deeplab
+    from ucsa_neural_rendering_amd import dist as udist
+    from ucsa_neural_rendering_amd.lightning import joint_train_lightning_net as jl
+    from ucsa_neural_rendering_amd.nerf import renderer_semantics as rs
+    from ucsa_neural_rendering_amd.utils import load_yaml
+
+    exp = load_yaml(os.path.join(ROOT, "cfg/exp/multi_step/cl_base.yml"))
+    n_views = int(round(args.frames / 0.8))           # 80 % train / 20 % val split
+    exp["synthetic"].update(n_views=n_views, H=240, W=320)
+    if args.backbone:
+        exp["model"]["backbone"] = args.backbone
+    if args.seg_amp:
+        exp["model"]["amp"] = args.seg_amp
+    exp["nerf"]["precision"] = args.nerf_precision
+    exp["trainer"]["cudnn_benchmark"] = (True if args.seg_find else
+                                         False if args.no_seg_find else None)
+    if exp["trainer"]["cudnn_benchmark"] is None:
+        del exp["trainer"]["cudnn_benchmark"]
+    root = tempfile.mkdtemp(prefix="ucsa_cfg5_")
+    env = {"results": os.path.join(root, "experiments"), "scannet": os.path.join(root, "scans")}
+    scenes = cl_deeplab.SCENE_ORDER[:args.scenes]
+    t0 = time.perf_counter()
+    cl_deeplab.ensure_synthetic_scenes(exp, env, scenes)     # rank 0 writes, the rest wait
+    export_s = time.perf_counter() - t0
+    _tick(f"cfg5: {len(scenes)} synthetic rooms exported ({export_s:.1f} s, not timed)")
+
+    # counters: rays through render() with / without grad, training steps
+    count = {"rays_trained": 0, "rays_rendered": 0, "nerf_steps": 0, "joint_steps": 0,
+             "seg_images": 0}
+    orig_render = rs.SemanticNeRFRenderer.render
+
+    def render_spy(self, rays_o, *a, **k):
+        n = rays_o.shape[0] * rays_o.shape[1] if rays_o.dim() == 3 else rays_o.shape[0]
+        count["rays_trained" if torch.is_grad_enabled() and self.training else
+              "rays_rendered"] += int(n)
+        return orig_render(self, rays_o, *a, **k)
+
+    orig_step = jl.JointTrainLightningNet.training_step
+
+    def step_spy(self, batch, batch_idx):
+        count["joint_steps" if self.joint_train else "nerf_steps"] += 1
+        return orig_step(self, batch, batch_idx)
+
+    stage_marks = []
+    orig_train = cl_deeplab.train
+
+    def train_spy(cfg, env_, a, b, cargs):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        before = dict(count)
+        r = orig_train(cfg, env_, a, b, cargs)
+        torch.cuda.synchronize()
+        stage_marks.append({"stage": cfg["general"]["name"].split("/")[-1],
+                            "scenes": len(cfg["scenes"]),
+                            "seconds": time.perf_counter() - t1,
+                            **{k: count[k] - before[k] for k in count}})
+        return r
+
+    rs.SemanticNeRFRenderer.render = render_spy
+    jl.JointTrainLightningNet.training_step = step_spy
+    cl_deeplab.train = train_spy
+    argv = ["--exp_name", "cfg5", "--scenes", str(len(scenes)),
+            "--nerf_train_epoch", str(args.nerf_epochs),
+            "--joint_train_epoch", str(args.joint_epochs), "--seed", "123"]
+    try:
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        results = cl_deeplab.main(argv, exp=exp, env=env)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        rs.SemanticNeRFRenderer.render = orig_render
+        jl.JointTrainLightningNet.training_step = orig_step
+        cl_deeplab.train = orig_train
+    elapsed = max_over_ranks(elapsed, dist, dev, backend)
+    # whole-job counts: every rank ran its shard of every loader
+    tot = torch.tensor([count["rays_trained"], count["rays_rendered"], count["nerf_steps"],
+                        count["joint_steps"]], dtype=torch.float64,
+                       device=dev if backend == "nccl" else "cpu")
+    if dist:
+        dist.all_reduce(tot)
+    rays_trained, rays_rendered, nerf_steps, joint_steps = [float(x) for x in tot]
+    stages = []
+    for mark, res in zip(stage_marks, results):
+        row = dict(mark)
+        for phase in ("test_after_nerf", "test_after_joint"):
+            for k, v in (res.get(phase) or {}).items():
+                row[f"{phase}.{k}"] = v
+        stages.append(row)
+    last = results[-1]["test_after_joint"]
+    final = {k: last.get(k) for k in ("test_nerf_mIoU", "test_seg_mIoU", "test_nerf_PSNR")}
+    result = {
+        "metric": "rays/sec", "value": (rays_trained + rays_rendered) / elapsed,
+        "unit": "rays/s", "n_gpus": world, "steps": int(joint_steps + nerf_steps),
+        "warmup": 0, "ms_per_step": elapsed / max(1.0, joint_steps + nerf_steps) * 1e3 * world,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"cfg5: continual loop over {len(scenes)} synthetic rooms (seeds 0-"
+                        f"{len(scenes) - 1}), 240x320 frames, {args.frames} training frames per "
+                        f"scene, 4096 rays x (256+256) per NeRF step, batch "
+                        f"{exp['data_module']['batch_size']}, replay buffer "
+                        f"{exp['cl']['replay_buffer_size']}, DeepLabV3-{exp['model']['backbone']}, "
+                        f"{args.nerf_epochs} NeRF-only + {args.joint_epochs} joint epochs per stage "
+                        "(reference: 10 + 10)",
+            "mode": "cfg5", "timed_region": "scripts/cl_deeplab.main: all stages incl. data-module "
+                                            "setup, PNG I/O, test / predict passes, checkpoints; "
+                                            "scene export excluded",
+            "rays_per_step_per_gpu": 4096,
+            "nerf_epochs": args.nerf_epochs, "joint_epochs": args.joint_epochs,
+            "frames_per_scene": args.frames, "seg_precision": args.seg_amp or "fp32",
+            "nerf_render_nets": args.nerf_precision,
+        },
+        "quality": {"final_stage": final,
+                    "note": "test pass after the last stage's joint epochs (reference "
+                            "train_joint.py: trainer_joint.test on the NeRF train loader)"},
+        "throughput": {"total_s": elapsed, "joint_steps": joint_steps, "nerf_only_steps": nerf_steps,
+                       "joint_steps_per_s": joint_steps / elapsed,
+                       "rays_trained": rays_trained, "rays_rendered": rays_rendered,
+                       "rays_trained_per_s": rays_trained / elapsed,
+                       "export_s_not_timed": export_s},
+        "stages": stages,
+    }
+    import shutil
+    if rank == 0:
+        shutil.rmtree(root, ignore_errors=True)
+    finish(dist, rank, result)

@@ -135,6 +135,11 @@ def seg_throughput(device, steps=5, B=8, find=False):
                 pj = json.load(open(os.path.join(ROOT, SEG_PMC_JSON))).get(key)
             except (OSError, ValueError):
                 pj = None
+            if not pj:
+                out[mode]["roofline"]["traffic"] = None
+                out[mode]["roofline"]["traffic_source"] = (
+                    None, f"{SEG_PMC_JSON} absent: rocprofv3 --pmc of the DeepLab step "
+                          "aborts on this pool (profiles/README.md)")
             if pj:
                 r = out[mode]["roofline"]
                 r["traffic"] = pj["hbm_bytes_per_step"]

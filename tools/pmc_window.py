@@ -23,17 +23,22 @@ def main(path):
     tail = float(os.environ.get("TAIL_FRAC", "0.1"))
     cut = ids[int(len(ids) * (1.0 - tail))]
     marker = os.environ.get("MARKER", "k_nerf_loss_grad")
+    # whole steps only: the window runs from just AFTER the first marker at or
+    # beyond the tail cut to the LAST marker (inclusive) -- a partial first
+    # step would otherwise inflate the per-step figures
+    mark_ids = sorted({r[0] for r in rows if marker in r[1] and r[0] >= cut})
+    if len(mark_ids) >= 2:
+        lo, hi = mark_ids[0], mark_ids[-1]
+        steps = len(mark_ids) - 1
+    else:                       # fewer than two markers: the raw tail, one "step"
+        lo, hi, steps = cut - 1, ids[-1], max(1, len(mark_ids))
     tot = defaultdict(float)
     per_kernel = defaultdict(lambda: defaultdict(float))
-    marks = set()
     for did, name, cn, v in rows:
-        if did < cut:
+        if did <= lo or did > hi:
             continue
         tot[cn] += v
         per_kernel[name.split("(")[0][:60]][cn] += v
-        if marker in name:
-            marks.add(did)
-    steps = max(1, len(marks))
     out = {"db": os.path.basename(path), "tail_frac": tail, "marker": marker,
            "steps_in_window": steps,
            "per_step": {k: v / steps for k, v in tot.items()},

@@ -552,14 +552,23 @@ extern "C" uint64_t ucsa_hashgrid_bwd_workspace_bytes(uint32_t N, uint32_t T,
 // grad_table and wait on different resources, so the coarse kernel runs on a
 // side stream forked from / joined to the caller's stream by events
 // (capturable; UCSA_BWD_OVERLAP=0 keeps everything on the caller's stream).
+// One (side stream, fork event, join event) triple per CALLER STREAM: two
+// caller streams (or two devices) never share events, so their fork / join
+// pairs cannot mis-order each other.  The device is the caller stream's
+// (hipStreamGetDevice; the null stream falls back to the current device), not
+// whatever device happens to be current.  Two HOST THREADS launching on the
+// SAME caller stream concurrently are not supported (a stream is an ordered
+// queue: the caller serialises its own stream).
 struct BwdSide {
+  hipStream_t caller = nullptr;
+  int dev = -1;
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
+  bool ok = false, used = false;
 };
-static BwdSide* bwd_side() {
+static BwdSide* bwd_side(hipStream_t caller) {
   static std::mutex mu;
-  static BwdSide per_dev[16];
+  static BwdSide slots[64];
   static int enabled = -1;
   std::lock_guard<std::mutex> lk(mu);
   if (enabled < 0) {
@@ -567,15 +576,27 @@ static BwdSide* bwd_side() {
     enabled = !(e && e[0] == '0');
   }
   if (!enabled) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  BwdSide& b = per_dev[dev];
-  if (!b.side) {
-    b.ok = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&b.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&b.join, hipEventDisableTiming) == hipSuccess;
-    if (!b.side) b.side = (hipStream_t)-1;  // do not retry
+  int dev = -1;
+  hipDevice_t sdev;
+  if (caller && hipStreamGetDevice(caller, &sdev) == hipSuccess) dev = (int)sdev;
+  else if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  BwdSide* free_slot = nullptr;
+  for (BwdSide& b : slots) {
+    if (b.used && b.caller == caller && b.dev == dev) return b.ok ? &b : nullptr;
+    if (!b.used && !free_slot) free_slot = &b;
   }
+  if (!free_slot) return nullptr;   // > 64 caller streams: no overlap, still correct
+  BwdSide& b = *free_slot;
+  b.used = true;
+  b.caller = caller;
+  b.dev = dev;
+  int cur = -1;
+  const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
+  if (sw && hipSetDevice(dev) != hipSuccess) return nullptr;
+  b.ok = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&b.fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&b.join, hipEventDisableTiming) == hipSuccess;
+  if (sw) (void)hipSetDevice(cur);
   return b.ok ? &b : nullptr;
 }
 
@@ -599,7 +620,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                      grid->level[n_lo].scale < 160.0f)) ++n_lo;
   }
   // both halves present: fork the coarse half onto the side stream
-  BwdSide* side = (workspace && n_lo > 0 && n_lo < grid->n_levels) ? bwd_side() : nullptr;
+  BwdSide* side = (workspace && n_lo > 0 && n_lo < grid->n_levels) ? bwd_side((hipStream_t)stream) : nullptr;
   hipStream_t coarse_stream = (hipStream_t)stream;
   if (side) {
     if (hipEventRecord(side->fork, (hipStream_t)stream) == hipSuccess &&

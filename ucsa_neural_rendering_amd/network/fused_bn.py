@@ -6,8 +6,10 @@ reference ``nr4seg/network/deeplabv3.py:6-19`` -> torchvision's bottlenecks).
 ``FusedBatchNorm2d`` IS an ``nn.BatchNorm2d`` (same parameters, buffers and
 state_dict keys -- reference checkpoints load unchanged); its ``forward`` takes
 two optional extras, ``residual`` and ``relu``.  The fused kernels run when the
-input is a channels_last CUDA tensor in fp32 or bf16; any other input (CPU,
-NCHW, 1x1 maps whose strides are ambiguous) goes through
+input is a channels_last CUDA tensor in fp32 or bf16 AND the parameters /
+running statistics are contiguous fp32 on the same device (autocast keeps
+them so; ``model.bfloat16()`` does not) AND C <= 4096; any other case (CPU,
+NCHW, 1x1 maps whose strides are ambiguous, a half-precision module) goes through
 ``F.batch_norm`` + add + relu, the reference's own sequence, so the module is
 usable everywhere and the two paths can be compared against each other
 (tests/test_gpu_fused_bn.py).
@@ -81,9 +83,17 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None, relu: bool = False):
         training = self.training or (self.running_mean is None)
-        if _fusable(x) and (residual is None or
-                            (residual.shape == x.shape and residual.dtype == x.dtype
-                             and residual.is_contiguous(memory_format=torch.channels_last))):
+        C = x.shape[1] if x.dim() == 4 else 0
+        # the kernels read the per-channel operands as float*: a module cast
+        # with .half() / .bfloat16() (2-byte parameters), parameters on another
+        # device, or C beyond the kernels' tables take the F.batch_norm path
+        vecs_ok = C <= ops.BN_MAX_CHANNELS and all(
+            ops.bn_vec_ok(v, C, x.device)
+            for v in (self.weight, self.bias, self.running_mean, self.running_var))
+        if vecs_ok and _fusable(x) and (
+                residual is None or
+                (residual.shape == x.shape and residual.dtype == x.dtype
+                 and residual.is_contiguous(memory_format=torch.channels_last))):
             momentum = self.momentum
             if self.training and self.track_running_stats and self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)

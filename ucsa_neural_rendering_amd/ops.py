@@ -732,10 +732,38 @@ def _nhwc_rows(t: torch.Tensor, name: str):
     return N * H * W, Cc, 0 if t.dtype == torch.float32 else 1
 
 
+BN_MAX_CHANNELS = 4096   # csrc/batchnorm.hip: per-workgroup column tables
+
+
+def _bn_vec(t, name: str, Cc: int, device):
+    """A per-channel operand of the BatchNorm kernels, which read ``float*`` of
+    length C: fp32, contiguous, on x's device -- or None.  (A ``model.half()``
+    / ``.bfloat16()`` module has 2-byte parameters: handing those over would be
+    an out-of-bounds read and silently wrong statistics.)"""
+    if t is None:
+        return None
+    if (t.dtype != torch.float32 or t.device != device or not t.is_contiguous()
+            or t.numel() != Cc):
+        raise _lib.UcsaError(
+            f"bn_act: {name} must be a contiguous fp32 [{Cc}] tensor on {device}, got "
+            f"{t.dtype} {tuple(t.shape)} on {t.device}")
+    return t
+
+
+def bn_vec_ok(t, Cc: int, device) -> bool:
+    return t is None or (t.dtype == torch.float32 and t.device == device
+                         and t.is_contiguous() and t.numel() == Cc)
+
+
 def bn_act_fwd(x, residual, weight, bias, running_mean, running_var,
                momentum: float, eps: float, relu: bool, training: bool):
     """-> (y, save_mean, save_invstd); save_* are None in eval mode."""
     M, Cc, dt = _nhwc_rows(x, "x")
+    if Cc > BN_MAX_CHANNELS:
+        raise _lib.UcsaError(f"bn_act: C = {Cc} > {BN_MAX_CHANNELS}")
+    for name, v in (("weight", weight), ("bias", bias), ("running_mean", running_mean),
+                    ("running_var", running_var)):
+        _bn_vec(v, name, Cc, x.device)
     if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or
                                  not residual.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.UcsaError("residual must match x (shape, dtype, channels_last)")
@@ -759,6 +787,11 @@ def bn_act_bwd(dy, x, y, weight, save_mean, save_invstd, relu: bool,
     M, Cc, dt = _nhwc_rows(x, "x")
     if dy.dtype != x.dtype or dy.shape != x.shape:
         raise _lib.UcsaError("dy must match x")
+    for name, v in (("weight", weight), ("save_mean", save_mean), ("save_invstd", save_invstd)):
+        _bn_vec(v, name, Cc, x.device)
+    if relu and (y is None or y.dtype != x.dtype or y.shape != x.shape or
+                 not y.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.UcsaError("bn_act_bwd: y must match x (relu mask)")
     dy = dy.contiguous(memory_format=torch.channels_last)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
