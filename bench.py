@@ -55,6 +55,8 @@ from tools.bench_legs.common import (ENC_BINDING_JSON, F16_MFMA_PEAK_TF,  # noqa
                                      T_FINE, W, _tick, build_field, effective_cores,
                                      forced_dist, max_over_ranks)
 from tools.bench_legs.cfg4 import cfg4_job  # noqa: E402,F401  (tests/test_gpu_configs.py)
+from tools.bench_legs.render_modes import stage_times  # noqa: E402,F401  (tools/*.py)
+from tools.bench_legs.train import train_throughput  # noqa: E402,F401  (tools/*.py)
 
 
 def parse():

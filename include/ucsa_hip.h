@@ -546,9 +546,9 @@ uint32_t ucsa_loss_partial_floats(uint32_t n);
  * weighting of :44-45,:503-507, and (when d_* != NULL) the gradient of
  * grad_scale * total wrt the rendered outputs.
  *   rgb,gt_rgb [N,3]; sem [N,C] composited probabilities; depth, gt_depth [N];
- *   labels [N] int64 (-1 ignored).  stats[6] (device) = {loss_color,
+ *   labels [N] int64 (-1 ignored).  stats[8] (device) = {loss_color,
  *   loss_semantics (NaN = the reference's None), loss_depth, n_invalid_sem,
- *   n_valid_depth, total}. */
+ *   n_valid_depth, total, loss_semantics with None as 0, 0}. */
 int32_t ucsa_nerf_loss(const float* rgb, const float* sem, const float* depth,
                        const float* gt_rgb, const int64_t* labels,
                        const float* gt_depth, uint32_t N, uint32_t C,
@@ -556,6 +556,21 @@ int32_t ucsa_nerf_loss(const float* rgb, const float* sem, const float* depth,
                        float grad_scale, float* stats, float* d_rgb,
                        float* d_sem, float* d_depth, float* partial,
                        void* stream);
+
+/* Backward of the loss node of reference joint_train_lightning_net.py:497-513
+ * (`total.backward()` / `scaler.scale(total).backward()`) in one launch, in
+ * place on the gradients ucsa_nerf_loss wrote with the same w_sem / w_depth:
+ *   d_rgb *= g_total + g_color,  d_sem *= g_total + g_sem / w_sem,
+ *   d_depth *= g_total + g_depth / w_depth
+ * where g_* are DEVICE scalars (the cotangents autograd hands back: of the
+ * total, and of the single terms when a caller combined them itself); NULL = 0.
+ * Replaces the ~10 elementwise launches torch's autograd spends on
+ * `lc + 0.04 ls + 0.1 ld` and its backward. */
+int32_t ucsa_nerf_loss_apply(float* d_rgb, float* d_sem, float* d_depth,
+                             uint32_t N, uint32_t C, const float* g_total,
+                             const float* g_color, const float* g_sem,
+                             const float* g_depth, float w_sem, float w_depth,
+                             void* stream);
 
 /* reference joint_train_lightning_net.py:246-251: rows summing to 0 become
  * uniform, normalise, argmax.  normalised may be NULL. */

@@ -233,8 +233,15 @@ def mlp_split(spec: MLPSpec, params: torch.Tensor):
 
 
 def _q16(t: torch.Tensor) -> torch.Tensor:
-    """Round to fp16 and back (emulates an fp16 MFMA operand)."""
-    return t.half().float()
+    """Round to fp16 and back (emulates an fp16 MFMA operand).  Straight
+    through for autograd: the gradient passes in fp32, unrounded.  (A plain
+    ``t.half().float()`` would cast the GRADIENT to fp16 as well, WITHOUT a
+    loss scale: at the tcnn-style initial state that flushed 70 % of the
+    hash-grid gradient and all but 74 of the sigma net's 3072 entries to zero
+    -- found by tests/scripts/tcnn_init_grad.py in round 4.)"""
+    if not t.requires_grad:
+        return t.half().float()
+    return t + (t.half().float() - t).detach()
 
 
 def mlp_forward(spec: MLPSpec, x: torch.Tensor, params: torch.Tensor,

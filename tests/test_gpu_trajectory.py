@@ -4,17 +4,29 @@ style, seed 123), same frames, same ray indices, same stratified-sampling
 (``rng_t``) and inverse-CDF (``rng_u``) tensors at every step, the reference's
 loss weights and Adam settings (reference
 ``nr4seg/lightning/joint_train_lightning_net.py:473-513`` training_step_nerf,
-``:897-919`` optimizer) -- for 150 steps of 512 rays x (32+32) samples on the
-synthetic room; then four HELD-OUT 64x48 views are rendered by each with ITS
-OWN trained parameters and compared with the analytic ground truth:
+``:897-919`` optimizer) -- for 200 steps of 2048 rays x (16+16) samples on the
+synthetic room.  At 14 checkpoints (every 10 steps from step 70) all 12 views
+(8 trained on, 4 held out) are rendered by each side with ITS OWN parameters
+and compared with the analytic ground truth; the MEANS over the checkpoints
+must agree:
 
     |PSNR_hip - PSNR_oracle| <= 0.5 dB,  |mIoU_hip - mIoU_oracle| <= 0.5 pt
 
-for ``train_precision`` fp32, bf16x3 (against the fp32 oracle) and tcnn
-(against the oracle emulating tiny-cuda-nn's fp16 roundings: fp16 table and
-features, fp16 weights / layer inputs).  Per-step gradient parity is
-tests/test_gpu_backward.py / test_gpu_configs.py; this is the trajectory.
-``-m gpu``."""
+on the training views (what the reference's final test pass renders; held-out
+views: +-1.5 dB, see ``_compare``), for ``train_precision`` fp32, bf16x3
+(against the fp32 oracle) and tcnn (against the oracle emulating tiny-cuda-nn's
+fp16 roundings: fp16 table and features, fp16 weights / layer inputs).
+
+Why means over checkpoints, and 2048 rays: with the reference's Adam (lr 1e-2,
+eps 1e-15) the loss of a small-batch run oscillates by tens of per cent from
+step to step, and two fp32 runs decorrelate -- measured at 512 rays x (32+32):
+HIP vs HIP (float atomics in the grid backward) +-0.5 dB on a single parameter
+state after 150 steps, +-0.9 dB on held-out views.  At 2048 rays the same
+comparison gives 0.007 / 0.065 dB, and single checkpoints of HIP and oracle
+still differ by up to 2 dB / 3 pt late in the run while their means agree to
+0.1-0.3 dB / 0.1-0.25 pt (round-4 measurements).  Per-step gradient
+parity is tests/test_gpu_backward.py / test_gpu_configs.py; this is the
+trajectory.  ``-m gpu``."""
 import copy
 
 import numpy as np
@@ -29,7 +41,10 @@ from tests.util import AABB4, hip_network_from_oracle
 
 pytestmark = pytest.mark.gpu
 
-STEPS, N, T, t, C = 150, 512, 32, 32, 40
+STEPS, N, T, t, C = 200, 2048, 16, 16, 40
+# quality = mean over the parameter states after these steps (0-based); by
+# step 70 the loss has fallen from 0.545 to ~0.009
+CHECKPOINTS = (69, 79, 89, 99, 109, 119, 129, 139, 149, 159, 169, 179, 189, 199)
 H, W, VIEWS, HELD = 48, 64, 12, 4   # frames 0..7 train, frames 8..11 held out
 LR, WD = 1e-2, 1e-6
 
@@ -53,7 +68,7 @@ def scene():
                   inds=torch.randint(0, H * W, (N,), generator=g),
                   rt=torch.rand(N, T, generator=g), ru=torch.rand(N, t, generator=g))
              for _ in range(STEPS)]
-    u_eval = torch.rand(HELD * H * W, t, generator=g)
+    u_eval = torch.rand(VIEWS * H * W, t, generator=g)
     return frames, draws, u_eval
 
 
@@ -63,18 +78,34 @@ def _batch(frames, dr):
             f["label"][i][None], f["depth"][i][None])
 
 
-def _held(frames, key):
-    return torch.cat([frames[i][key] for i in range(VIEWS - HELD, VIEWS)], 0)
+def _all(frames, key):
+    return torch.cat([f[key] for f in frames], 0)
 
 
 def _quality(img, sem, frames):
-    """PSNR (mean over the held-out views of the per-view PSNR, as the
-    module's test loop does) and mIoU (one confusion matrix over all of them)."""
-    img, gt = img.cpu().view(HELD, H * W, 3), _held(frames, "rgb").view(HELD, H * W, 3)
-    psnr = float((-10 * torch.log10(((img - gt) ** 2).mean((1, 2)))).mean())
+    """Per view set -- "train" = every pixel of the 8 training frames (what the
+    reference's final test pass renders: scripts/train_joint.py tests on the
+    NeRF TRAIN loader after the joint phase), "held" = the 4 held-out frames
+    (its test_after_nerf split) -- PSNR as the mean over the views of the
+    per-view PSNR (the module's test loop) and mIoU from one
+    confusion matrix."""
+    img, gt = img.cpu().view(VIEWS, H * W, 3), _all(frames, "rgb").view(VIEWS, H * W, 3)
+    per_view = -10 * torch.log10(((img - gt) ** 2).mean((1, 2)))
     _, lab = olosses.semantic_postproc(sem.cpu())
-    miou = ometrics.measure(ometrics.confusion(lab.numpy(), _held(frames, "label").numpy(), C))[0]
-    return psnr, 100.0 * miou
+    lab, gt_lab = lab.view(VIEWS, -1).numpy(), _all(frames, "label").view(VIEWS, -1).numpy()
+    k = VIEWS - HELD
+    miou = lambda a, b: 100.0 * ometrics.measure(ometrics.confusion(a, b, C))[0]
+    return {"train": (float(per_view[:k].mean()), miou(lab[:k], gt_lab[:k])),
+            "held": (float(per_view[k:].mean()), miou(lab[k:], gt_lab[k:]))}
+
+
+def _mean_quality(quals):
+    """Mean over the checkpoints (module docstring)."""
+    out = {k: (float(np.mean([q[k][0] for q in quals])), float(np.mean([q[k][1] for q in quals])))
+           for k in ("train", "held")}
+    out["per_checkpoint_train_psnr"] = [round(q["train"][0], 2) for q in quals]
+    out["per_checkpoint_train_miou"] = [round(q["train"][1], 1) for q in quals]
+    return out
 
 
 def _train_oracle(frames, draws, u_eval, emulate_tcnn):
@@ -84,7 +115,16 @@ def _train_oracle(frames, draws, u_eval, emulate_tcnn):
         fld.fp16_table = True
     fld.requires_grad_(True)
     st = [dict(m=torch.zeros_like(p), v=torch.zeros_like(p)) for p in fld.parameters()]
-    losses = []
+    losses, quals = [], []
+
+    def evaluate():
+        with torch.no_grad():
+            out = oren.render(fld, _all(frames, "o")[None], _all(frames, "d")[None],
+                              _all(frames, "nrm")[None], AABB4, staged=True,
+                              max_ray_batch=6144, num_steps=T, upsample_steps=t,
+                              u=u_eval[None])
+        quals.append(_quality(out["image"][0], out["semantics"][0], frames))
+
     for k, dr in enumerate(draws):
         o, d, nrm, rgb, lab, dep = _batch(frames, dr)
         out = oren.run(fld, o, d, nrm, AABB4, num_steps=T, upsample_steps=t,
@@ -101,11 +141,9 @@ def _train_oracle(frames, draws, u_eval, emulate_tcnn):
                 pn, s["m"], s["v"] = olosses.adam_step(
                     p, p.grad, s["m"], s["v"], k + 1, LR, weight_decay=0.0 if i == 0 else WD)
                 p.copy_(pn)
-    fld.requires_grad_(False)
-    with torch.no_grad():
-        out = oren.run(fld, _held(frames, "o")[None], _held(frames, "d")[None],
-                       _held(frames, "nrm")[None], AABB4, num_steps=T, upsample_steps=t, u=u_eval)
-    return _quality(out["image"][0], out["semantics"][0], frames) + (losses,)
+        if k in CHECKPOINTS:
+            evaluate()
+    return _mean_quality(quals), losses, {}
 
 
 def _train_hip(frames, draws, u_eval, precision):
@@ -121,8 +159,21 @@ def _train_hip(frames, draws, u_eval, precision):
     # the reference steps the NeRF optimizer through a GradScaler (:46, :509-513);
     # the tcnn arithmetic (fp16 gradients between layers) needs its scale
     scaler = torch.amp.GradScaler("cuda", enabled=True)
-    losses = []
-    for dr in draws:
+    losses, quals = [], []
+    ev_rays = [_all(frames, k)[None].cuda() for k in ("o", "d", "nrm")]
+    infer = {"fp32": "fp32", "bf16x3": "bf16x3", "tcnn": "fp16"}[precision]
+
+    def evaluate():
+        # inference arithmetic of the same family as the training one
+        net.eval()
+        net.precision, net.fp16_table = infer, precision == "tcnn"
+        with torch.no_grad():
+            out = net.render(*ev_rays, staged=True, num_steps=T, upsample_steps=t,
+                             rng_u=u_eval.cuda())
+        net.train()
+        quals.append(_quality(out["image"][0], out["semantics"][0], frames))
+
+    for k, dr in enumerate(draws):
         o, d, nrm, rgb, lab, dep = [x.cuda() for x in _batch(frames, dr)]
         out = net.render(o, d, nrm, perturb=True, num_steps=T, upsample_steps=t,
                          rng_t=dr["rt"].cuda(), rng_u=dr["ru"].cuda())
@@ -134,49 +185,94 @@ def _train_hip(frames, draws, u_eval, precision):
         scaler.step(opt)
         scaler.update()
         losses.append(loss.detach())
-    net.eval()
-    # inference arithmetic of the same family as the training one
-    net.precision = {"fp32": "fp32", "bf16x3": "bf16x3", "tcnn": "fp16"}[precision]
-    net.fp16_table = precision == "tcnn"
-    with torch.no_grad():
-        out = net.render(_held(frames, "o")[None].cuda(), _held(frames, "d")[None].cuda(),
-                         _held(frames, "nrm")[None].cuda(), staged=True, num_steps=T,
-                         upsample_steps=t, rng_u=u_eval.cuda())
-    return _quality(out["image"][0], out["semantics"][0], frames) + \
-        ([float(x) for x in torch.stack(losses).cpu()],)
+        if k in CHECKPOINTS:
+            evaluate()
+    skipped = sum(int(v) for v in opt._skipped.values()) if opt._skipped else 0
+    info = {"skipped_steps": skipped, "final_scale": float(scaler.get_scale())}
+    return _mean_quality(quals), [float(x) for x in torch.stack(losses).cpu()], info
+
+
+def _oracle_worker(args):
+    frames, draws, u_eval, emulate_tcnn, threads = args
+    torch.set_num_threads(threads)
+    return _train_oracle(frames, draws, u_eval, emulate_tcnn)
 
 
 @pytest.fixture(scope="module")
-def oracle_fp32(scene):
-    return _train_oracle(*scene, emulate_tcnn=False)
+def oracles(scene):
+    """Both oracle trajectories (fp32, fp16-emulating), each in its own CPU
+    worker process with half of the cores, started before the HIP runs: the
+    suite's wall clock sees max(.) of them instead of their sum."""
+    import multiprocessing as mp
+    from tests.conftest import _effective_cores
+    threads = max(1, _effective_cores() // 2)
+    ctx = mp.get_context("spawn")      # this process has initialised the GPU: no fork
+    pool = ctx.Pool(2)
+    jobs = {k: pool.apply_async(_oracle_worker, ((*scene, k == "tcnn", threads),))
+            for k in ("fp32", "tcnn")}
+    pool.close()
+    yield jobs
+    pool.terminate()
 
 
 @pytest.fixture(scope="module")
-def oracle_tcnn(scene):
-    return _train_oracle(*scene, emulate_tcnn=True)
+def oracle_fp32(oracles):
+    return oracles["fp32"].get(timeout=1500)
+
+
+@pytest.fixture(scope="module")
+def oracle_tcnn(oracles):
+    return oracles["tcnn"].get(timeout=1500)
+
+
+HELD_OUT_DB = 1.5
 
 
 def _compare(tag, hip, ora):
-    (ph, mh, lh), (po, mo, lo) = hip, ora
+    """+-0.5 dB / +-0.5 pt on the training views (the reference's final test
+    set).  Held-out views are reported and held to +-1.5 dB only: with the
+    reference's Adam (eps 1e-15) a grid entry whose gradient is round-off
+    noise still moves by a full lr step in the noise's direction, so runs that
+    agree on the training loss to 2 % differ more where only such entries
+    decide -- in cells no training ray constrained (observed here: <= 0.3 dB)."""
+    (qh, lh, ih), (qo, lo, _) = hip, ora
     lh, lo = np.array(lh), np.array(lo)
-    print(f"{tag}: held-out PSNR hip {ph:.3f} dB / oracle {po:.3f} dB (d {ph - po:+.3f}); "
-          f"mIoU hip {mh:.2f} / oracle {mo:.2f} pt (d {mh - mo:+.2f}); "
-          f"loss step 1 {lh[0]:.5f} / {lo[0]:.5f}, mean of last 10 {lh[-10:].mean():.5f} / "
-          f"{lo[-10:].mean():.5f}; max |loss difference| first 20 steps "
-          f"{np.abs(lh[:20] - lo[:20]).max():.2e}")
+    for k in ("train", "held"):
+        (ph, mh), (po, mo) = qh[k], qo[k]
+        print(f"{tag} [{k} views]: PSNR hip {ph:.3f} dB / oracle {po:.3f} dB (d {ph - po:+.3f}); "
+              f"mIoU hip {mh:.2f} / oracle {mo:.2f} pt (d {mh - mo:+.2f})")
+    print(f"{tag} train-view PSNR per checkpoint hip {qh['per_checkpoint_train_psnr']} / oracle "
+          f"{qo['per_checkpoint_train_psnr']}")
+    print(f"{tag} train-view mIoU per checkpoint hip {qh['per_checkpoint_train_miou']} / oracle "
+          f"{qo['per_checkpoint_train_miou']}")
+    print(f"{tag}: loss step 1 {lh[0]:.5f} / {lo[0]:.5f}, mean of last 20 {lh[-20:].mean():.5f} / "
+          f"{lo[-20:].mean():.5f}; max |loss difference| first 20 steps "
+          f"{np.abs(lh[:20] - lo[:20]).max():.2e}; {ih}")
+    print(f"{tag} loss every 10 steps hip   : " + " ".join(f"{x:.4f}" for x in lh[::10]))
+    print(f"{tag} loss every 10 steps oracle: " + " ".join(f"{x:.4f}" for x in lo[::10]))
     assert lo[-10:].mean() < 0.6 * lo[0] and lh[-10:].mean() < 0.6 * lh[0]   # both learned
-    assert po > 14.0                                      # the run means something
-    assert abs(ph - po) <= 0.5, (tag, ph, po)
-    assert abs(mh - mo) <= 0.5, (tag, mh, mo)
+    assert qo["train"][0] > 14.0                          # the run means something
+    assert abs(qh["train"][0] - qo["train"][0]) <= 0.5, (tag, qh, qo)
+    assert abs(qh["train"][1] - qo["train"][1]) <= 0.5, (tag, qh, qo)
+    assert abs(qh["held"][0] - qo["held"][0]) <= HELD_OUT_DB, (tag, qh, qo)
     return lh, lo
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_trajectory_quality_matches_the_fp32_oracle(scene, oracle_fp32, precision):
-    lh, lo = _compare(precision, _train_hip(*scene, precision), oracle_fp32)
+def test_trajectory_quality_matches_the_fp32_oracle(scene, oracles, precision):
+    hip = _train_hip(*scene, precision)
+    oracle_fp32 = oracles["fp32"].get(timeout=1500)
+    if precision == "fp32":
+        # run-to-run spread of the HIP path itself (float atomics in the grid
+        # backward: a different round-off every run), for the record
+        again = _train_hip(*scene, precision)[0]
+        print("fp32 HIP run 2 vs run 1: train-view PSNR %+.3f dB, held-out %+.3f dB"
+              % (again["train"][0] - hip[0]["train"][0], again["held"][0] - hip[0]["held"][0]))
+    lh, lo = _compare(precision, hip, oracle_fp32)
     # before round-off has had time to grow the two runs are the same run
     assert np.abs(lh[:5] - lo[:5]).max() <= 2e-5 * max(1.0, lo[0])
 
 
-def test_trajectory_quality_tcnn_numerics_matches_the_fp16_emulating_oracle(scene, oracle_tcnn):
-    _compare("tcnn", _train_hip(*scene, "tcnn"), oracle_tcnn)
+def test_trajectory_quality_tcnn_numerics_matches_the_fp16_emulating_oracle(scene, oracles):
+    hip = _train_hip(*scene, "tcnn")
+    _compare("tcnn", hip, oracles["tcnn"].get(timeout=1500))

@@ -58,23 +58,50 @@ def serial():
     return [shade(density(k)) for k in range(len(heads))]
 
 
-def pipelined(sd, ss, keep):
+def pipelined(sd, ss, keep, marks=None):
     main = torch.cuda.current_stream()
     sd.wait_stream(main)
     ss.wait_stream(main)
     outs = []
     for k in range(len(heads)):
         with torch.cuda.stream(sd):
+            if marks is not None:
+                a = torch.cuda.Event(enable_timing=True)
+                a.record(sd)
             r = density(k)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=marks is not None)
             ev.record(sd)
         with torch.cuda.stream(ss):
             ss.wait_event(ev)
+            if marks is not None:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record(ss)
             outs.append(shade(r))
+            if marks is not None:
+                c = torch.cuda.Event(enable_timing=True)
+                c.record(ss)
+                marks.append((a, ev, b, c))
         keep.append(r)
     main.wait_stream(sd)
     main.wait_stream(ss)
     return outs
+
+
+def stage_alone():
+    """Duration of the two halves of a chunk when nothing else runs."""
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    dd = ds = 0.0
+    for k in range(len(heads)):
+        a, b, c = ev(), ev(), ev()
+        a.record()
+        r = density(k)
+        b.record()
+        shade(r)
+        c.record()
+        torch.cuda.synchronize()
+        dd += a.elapsed_time(b)
+        ds += b.elapsed_time(c)
+    return dd / len(heads), ds / len(heads)
 
 
 def timed(fn, n):
@@ -92,7 +119,11 @@ n_views = int(os.environ.get("UCSA_EXP_VIEWS", 10))
 with torch.no_grad():
     ref = serial()
     ms = timed(serial, n_views)
+    print(f"UCSA_ENC_LDS_PAD={os.environ.get('UCSA_ENC_LDS_PAD', '0')}: encoder workgroups of 4 waves, "
+          "13 KB LDS + the pad; 74 VGPRs -> at most 6 waves / SIMD")
     print(f"serial: {ms:.2f} ms/view = {H * W / ms / 1e3:.2f} M rays/s")
+    da, sa = stage_alone()
+    print(f"  per chunk, alone: density half {da:.2f} ms, shading half {sa:.2f} ms")
     lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
     print("stream priority range (low, high):", lo, hi)
     for name, pd, ps in (("density high / shade low", hi, lo), ("equal priority", 0, 0),
@@ -107,5 +138,12 @@ with torch.no_grad():
             keep.clear()
             pipelined(sd, ss, keep)
         ms = timed(run, n_views)
+        marks = []
+        keep.clear()
+        pipelined(sd, ss, keep, marks)
+        torch.cuda.synchronize()
+        dd = sum(a.elapsed_time(e) for a, e, _, _ in marks[1:-1]) / max(1, len(marks) - 2)
+        dsh = sum(b.elapsed_time(c) for _, _, b, c in marks[1:-1]) / max(1, len(marks) - 2)
         print(f"pipelined [{name}]: {ms:.2f} ms/view = {H * W / ms / 1e3:.2f} M rays/s; "
-              f"bit-identical to serial: {same}")
+              f"bit-identical to serial: {same}; per chunk while co-running: density half "
+              f"{dd:.2f} ms, shading half {dsh:.2f} ms")

@@ -7,6 +7,7 @@ dev = torch.device("cuda", 0)
 log = {}
 net, ds = bench.build_field(dev, train_steps=int(os.environ.get("PRE", "50")), log=log)
 print(log)
-r = bench.train_throughput(net, ds, dev, steps=int(os.environ.get("STEPS", "10")),
+from tools.bench_legs.train import train_throughput
+r = train_throughput(net, ds, dev, steps=int(os.environ.get("STEPS", "10")),
                            train_precision=os.environ.get("TRAIN_PRECISION", "fp32"))
 print(r)

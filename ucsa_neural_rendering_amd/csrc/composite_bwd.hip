@@ -22,6 +22,7 @@
 // not fit -- and end no faster than the fp32 kernel (1.43 vs 1.48 ms); 4 waves
 // (1 per SIMD, no spills) it is.
 #define CB_WAVES_H 4
+#define CB_WAVES_SPLIT 8  // per-net kernels (NET = 1, 2): two waves per SIMD
 #define CB_CAP 80  // 15 pending + one 64-sample chunk
 #define ROW_FINE 0x80000000u
 
@@ -151,19 +152,28 @@ __device__ __forceinline__ f32x4 gate4(f32x4 pre, f32x4 v) {
 // inputs, accumulated in fp32 registers for the whole kernel) -- as f32-input
 // MFMAs the 176 weight-gradient k-steps per 16 samples were four fifths of
 // this variant's matrix work and ran on the vector ALU.
-template <int NRB, bool MARCH, bool HALF>
-__global__ void __launch_bounds__(64 * (HALF ? CB_WAVES_H : CB_WAVES))
+//
+// NET: 0 = both nets in one kernel (the dW accumulators of both, 176 fp32x4
+// registers, pin it to ONE wave per SIMD); 1 = the colour net only, 2 = the
+// semantics net only -- launched as a pair (colour first: it stores its part
+// of d(geo_feat), the semantics kernel adds its own) each holds only its own
+// dW accumulators (112 / 64 registers) and weights (52 / 32 KB of LDS), so
+// CB_WAVES_SPLIT = 8 waves per workgroup = TWO waves per SIMD fit, and the LDS
+// round trips / global loads of one wave hide behind the MFMAs of the other.
+template <int NRB, bool MARCH, bool HALF, int NET = 0>
+__global__ void __launch_bounds__(64 * (NET ? CB_WAVES_SPLIT : (HALF ? CB_WAVES_H : CB_WAVES)))
 k_shade_bwd(ShadeBwdArgs a) {
-  constexpr uint32_t NW = HALF ? CB_WAVES_H : CB_WAVES;
+  constexpr uint32_t NW = NET ? CB_WAVES_SPLIT : (HALF ? CB_WAVES_H : CB_WAVES);
+  constexpr bool DO_C = NET != 2, DO_S = NET != 1;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint32_t T = a.T, t = a.t, S = a.T + a.t, C = a.C;
   constexpr int NS = (NRB + 1) / 2;  // half8 k-steps covering the class logits
 
-  constexpr uint32_t WC = HALF ? COLOR_H_FRAGS * 256 : 7168;
-  constexpr uint32_t WS = HALF ? SEM_H_FRAGS(NRB) * 256 : 1024 + NRB * 1024;
-  constexpr uint32_t WTC = HALF ? 14 * 256 : 6144;
-  constexpr uint32_t WTS = HALF ? (4 * NS + 2) * 256 : (16 * NRB + 16) * 64;
+  constexpr uint32_t WC = !DO_C ? 0 : HALF ? COLOR_H_FRAGS * 256 : 7168;
+  constexpr uint32_t WS = !DO_S ? 0 : HALF ? SEM_H_FRAGS(NRB) * 256 : 1024 + NRB * 1024;
+  constexpr uint32_t WTC = !DO_C ? 0 : HALF ? 14 * 256 : 6144;
+  constexpr uint32_t WTS = !DO_S ? 0 : HALF ? (4 * NS + 2) * 256 : (16 * NRB + 16) * 64;
   float* w_color = cb_smem;
   float* w_sem = w_color + WC;
   float* wt_color = w_sem + WS;
@@ -188,11 +198,15 @@ k_shade_bwd(ShadeBwdArgs a) {
 
   const uint64_t gwave = (uint64_t)blockIdx.x * NW + wid;
   f32x4 dwc1[4][2], dwc2[4][4], dwc3[1][4], dws1[4][1], dws2[NRB][4];
-  dw_zero(dwc1);
-  dw_zero(dwc2);
-  dw_zero(dwc3);
-  dw_zero(dws1);
-  dw_zero(dws2);
+  if constexpr (DO_C) {
+    dw_zero(dwc1);
+    dw_zero(dwc2);
+    dw_zero(dwc3);
+  }
+  if constexpr (DO_S) {
+    dw_zero(dws1);
+    dw_zero(dws2);
+  }
 
   uint32_t cnt = 0;
 
@@ -222,23 +236,27 @@ k_shade_bwd(ShadeBwdArgs a) {
     b.fine = (row & ROW_FINE) != 0;
     b.hoff = (size_t)(row & ~ROW_FINE) * 16 + 4 * g;
     b.geo = *reinterpret_cast<const f32x4*>((b.fine ? a.h_f : a.h_c) + b.hoff);
-    const float* dptr = a.rays_d + (size_t)b.ray * 3;
-    b.dir[0] = dptr[0];
-    b.dir[1] = dptr[1];
-    b.dir[2] = dptr[2];
-    const float* di = a.d_image + (size_t)b.ray * 3;
-    b.di[0] = di[0];
-    b.di[1] = di[1];
-    b.di[2] = di[2];
-    b.dd = a.d_depth[b.ray];
-    b.nrm = a.norms[b.ray];
+    if constexpr (DO_C) {
+      const float* dptr = a.rays_d + (size_t)b.ray * 3;
+      b.dir[0] = dptr[0];
+      b.dir[1] = dptr[1];
+      b.dir[2] = dptr[2];
+      const float* di = a.d_image + (size_t)b.ray * 3;
+      b.di[0] = di[0];
+      b.di[1] = di[1];
+      b.di[2] = di[2];
+      b.dd = a.d_depth[b.ray];
+      b.nrm = a.norms[b.ray];
+    }
+    if constexpr (DO_S) {
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+      for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t cls = rb * 16 + 4 * g + r;
-        b.dsem[rb * 4 + r] = cls < C ? a.d_sem[(size_t)b.ray * C + cls] : 0.0f;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t cls = rb * 16 + 4 * g + r;
+          b.dsem[rb * 4 + r] = cls < C ? a.d_sem[(size_t)b.ray * C + cls] : 0.0f;
+        }
+    }
   };
 
   // ---- one block of up to 16 surviving samples ---------------------------
@@ -249,260 +267,280 @@ k_shade_bwd(ShadeBwdArgs a) {
     const size_t hoff = b.hoff;
     f32x4 geo = b.geo;
     if (g == 0) geo[0] = 1.0f;
-    f32x4 sh;
-    sh4_select_b(b.dir[0], b.dir[1], b.dir[2], g, sh);
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dslot[1] = {z4}, dslot_s[1] = {z4};
 
-    // ------------------------- forward (recompute) ------------------------
-    f32x4 a1c[4], a2c[4], o3[1], a1s[4], lg[NRB];
-    if constexpr (HALF) {
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      half8 b1, bs;
+    // =========================== colour net ===============================
+    if constexpr (DO_C) {
+      f32x4 sh;
+      sh4_select_b(b.dir[0], b.dir[1], b.dir[2], g, sh);
+      // forward (recompute)
+      f32x4 a1c[4], a2c[4], o3[1];
+      f32x4 geo_c = geo;
+      if constexpr (HALF) {
+        half8 b1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        b1[r] = (_Float16)sh[r];
-        b1[4 + r] = (_Float16)geo[r];
-        bs[r] = (_Float16)geo[r];
-        bs[4 + r] = (_Float16)0.f;
+        for (int r = 0; r < 4; ++r) {
+          b1[r] = (_Float16)sh[r];
+          b1[4 + r] = (_Float16)geo[r];
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1c[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
+        half8 h0 = chain_relu_h(a1c[0], a1c[1]), h1 = chain_relu_h(a1c[2], a1c[3]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          a2c[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
+          a2c[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2c[rb]);
+        }
+        h0 = chain_relu_h(a2c[0], a2c[1]);
+        h1 = chain_relu_h(a2c[2], a2c[3]);
+        o3[0] = mfma_h(frag_h(w_color, 12, lane), h0, z4);
+        o3[0] = mfma_h(frag_h(w_color, 13, lane), h1, o3[0]);
+        // the layer inputs the forward actually used (fp16-rounded): dW sees them
+        sh = q4(sh);
+        geo_c = q4(geo);
+      } else {
+        float xin[8] = {sh[0], sh[1], sh[2], sh[3], geo[0], geo[1], geo[2], geo[3]};
+        mfma_layer<8, 4>(xin, [&](int rb, int ks) { return w_color[(rb * 8 + ks) * 64 + lane]; }, a1c);
+        float hid[16];
+        chain_relu(a1c, hid);
+        mfma_layer<16, 4>(hid, [&](int rb, int ks) { return w_color[(COLOR_L1_FRAGS + rb * 16 + ks) * 64 + lane]; }, a2c);
+        chain_relu(a2c, hid);
+        mfma_layer<16, 1>(hid, [&](int, int ks) { return w_color[(COLOR_L1_FRAGS + COLOR_L2_FRAGS + ks) * 64 + lane]; }, o3);
       }
+      // upstream gradients
+      const float* di = b.di;
+      f32x4 dy3 = z4;
+      if (g == 0) {
+        float dwsum = b.dd * zz / b.nrm;
+        // image = sum_s w*rgb  ->  d_rgb = w*d_image, d_w += d_image . rgb
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) a1c[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
-      half8 h0 = chain_relu_h(a1c[0], a1c[1]), h1 = chain_relu_h(a1c[2], a1c[3]);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        a2c[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
-        a2c[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2c[rb]);
+        for (int c = 0; c < 3; ++c) {
+          const float rgb = fast_sigmoid(o3[0][c]);  // as the forward
+          dwsum += di[c] * rgb;
+          dy3[c] = gs * (wgt * di[c] * rgb * (1.0f - rgb));
+        }
+        if (live) a.G[MARCH ? (size_t)smp : (size_t)ray * S + smp] = dwsum;
       }
-      h0 = chain_relu_h(a2c[0], a2c[1]);
-      h1 = chain_relu_h(a2c[2], a2c[3]);
-      o3[0] = mfma_h(frag_h(w_color, 12, lane), h0, z4);
-      o3[0] = mfma_h(frag_h(w_color, 13, lane), h1, o3[0]);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) a1s[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
-      h0 = chain_relu_h(a1s[0], a1s[1]);
-      h1 = chain_relu_h(a1s[2], a1s[3]);
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) {
-        lg[rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
-        lg[rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[rb]);
-      }
-      // the layer inputs the forward actually used (fp16-rounded): dW sees them
-      sh = q4(sh);
-      geo = q4(geo);
-    } else {
-      float xin[8] = {sh[0], sh[1], sh[2], sh[3], geo[0], geo[1], geo[2], geo[3]};
-      mfma_layer<8, 4>(xin, [&](int rb, int ks) { return w_color[(rb * 8 + ks) * 64 + lane]; }, a1c);
-      float hid[16];
-      chain_relu(a1c, hid);
-      mfma_layer<16, 4>(hid, [&](int rb, int ks) { return w_color[(COLOR_L1_FRAGS + rb * 16 + ks) * 64 + lane]; }, a2c);
-      chain_relu(a2c, hid);
-      mfma_layer<16, 1>(hid, [&](int, int ks) { return w_color[(COLOR_L1_FRAGS + COLOR_L2_FRAGS + ks) * 64 + lane]; }, o3);
-      float xs[4] = {geo[0], geo[1], geo[2], geo[3]};
-      mfma_layer<4, 4>(xs, [&](int rb, int ks) { return w_sem[(rb * 4 + ks) * 64 + lane]; }, a1s);
-      chain_relu(a1s, hid);
-      mfma_layer<16, NRB>(hid, [&](int rb, int ks) { return w_sem[(SEM_L1_FRAGS + rb * 16 + ks) * 64 + lane]; }, lg);
-    }
-    // softmax
-    float mx = -INFINITY;
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fast_max(mx, lg[rb][r]);
-    mx = fast_max(mx, __shfl_xor(mx, 16, 64));
-    mx = fast_max(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.0f;
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
-        const float ex = ok ? __expf(lg[rb][r] - mx) : 0.0f;  // as the forward (composite.hip fast_exp)
-        lg[rb][r] = ex;
-        sum += ex;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv_sum = fast_rcp(sum);  // as the forward
-
-    // ------------------------- upstream gradients -------------------------
-    const float* di = b.di;
-    f32x4 dy3 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (g == 0) {
-      float dwsum = b.dd * zz / b.nrm;
-      // image = sum_s w*rgb  ->  d_rgb = w*d_image, d_w += d_image . rgb
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float rgb = fast_sigmoid(o3[0][c]);  // as the forward
-        dwsum += di[c] * rgb;
-        dy3[c] = gs * (wgt * di[c] * rgb * (1.0f - rgb));
-      }
-      if (live) a.G[MARCH ? (size_t)smp : (size_t)ray * S + smp] = dwsum;
-    }
-    // semantics = sum_s w_detached * p ; p = softmax(logits)
-    float dot = 0.0f;
-    f32x4 dlg[NRB];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t cls = rb * 16 + 4 * g + r;
-        const float p = lg[rb][r] * inv_sum;
-        const float dp = cls < C ? wgt * b.dsem[rb * 4 + r] : 0.0f;
-        lg[rb][r] = p;
-        dlg[rb][r] = dp;
-        dot += p * dp;
-      }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dlg[rb][r] = gs * (lg[rb][r] * (dlg[rb][r] - dot));
-
-    // ------------------------- colour net backward ------------------------
-    // L3: dW3 += dy3 (x) relu(a2c);  d_hid2 = W3^T dy3
-    tile_store(dy_tile, g, j, 0, dy3);
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-      tile_store(x_tile, g, j, rb, HALF ? relu_q4(a2c[rb]) : relu4(a2c[rb]));
-    cb_sync();
-    if constexpr (HALF) dw_accumulate_h<1, 4>(dy_tile, x_tile, lane, dwc3);
-    else dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
-    cb_sync();
-    f32x4 dh2[4];
-    if constexpr (HALF) {
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      const half8 bd = chain_h(dy3, z4);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) dh2[rb] = mfma_h(frag_h(wt_color, rb, lane), bd, z4);
-    } else {
-      float b[4] = {dy3[0], dy3[1], dy3[2], dy3[3]};
-      mfma_layer<4, 4>(b, [&](int rb, int ks) { return wt_color[(rb * 4 + ks) * 64 + lane]; }, dh2);
-    }
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) dh2[rb] = gate4(a2c[rb], dh2[rb]);
-    // L2: dW2 += d_hid2 (x) relu(a1c);  d_hid1 = W2^T d_hid2
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      tile_store(dy_tile, g, j, rb, dh2[rb]);
-      tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1c[rb]) : relu4(a1c[rb]));
-    }
-    cb_sync();
-    if constexpr (HALF) dw_accumulate_h<4, 4>(dy_tile, x_tile, lane, dwc2);
-    else dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
-    cb_sync();
-    f32x4 dh1[4];
-    if constexpr (HALF) {
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      const half8 d0 = chain_h(dh2[0], dh2[1]), d1 = chain_h(dh2[2], dh2[3]);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        dh1[rb] = mfma_h(frag_h(wt_color, 4 + 2 * rb, lane), d0, z4);
-        dh1[rb] = mfma_h(frag_h(wt_color, 5 + 2 * rb, lane), d1, dh1[rb]);
-      }
-    } else {
-      float b[16];
+      // L3: dW3 += dy3 (x) relu(a2c);  d_hid2 = W3^T dy3
+      tile_store(dy_tile, g, j, 0, dy3);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
+        tile_store(x_tile, g, j, rb, HALF ? relu_q4(a2c[rb]) : relu4(a2c[rb]));
+      cb_sync();
+      if constexpr (HALF) dw_accumulate_h<1, 4>(dy_tile, x_tile, lane, dwc3);
+      else dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
+      cb_sync();
+      f32x4 dh2[4];
+      if constexpr (HALF) {
+        const half8 bd = chain_h(dy3, z4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dh2[rb][r];
-      mfma_layer<16, 4>(b, [&](int rb, int ks) { return wt_color[(16 + rb * 16 + ks) * 64 + lane]; }, dh1);
-    }
+        for (int rb = 0; rb < 4; ++rb) dh2[rb] = mfma_h(frag_h(wt_color, rb, lane), bd, z4);
+      } else {
+        float bb[4] = {dy3[0], dy3[1], dy3[2], dy3[3]};
+        mfma_layer<4, 4>(bb, [&](int rb, int ks) { return wt_color[(rb * 4 + ks) * 64 + lane]; }, dh2);
+      }
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) dh1[rb] = gate4(a1c[rb], dh1[rb]);
-    // L1: dW1 += d_hid1 (x) [SH16 | geo15 | 1];  d_slot = W1^T(slot rows) d_hid1
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) tile_store(dy_tile, g, j, rb, dh1[rb]);
-    tile_store(x_tile, g, j, 0, sh);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t m = 4 * g + r;
-      x_tile[j * TILE_LD + (m == 0 ? 31u : 15u + m)] = geo[r];
-    }
-    cb_sync();
-    if constexpr (HALF) dw_accumulate_h<4, 2>(dy_tile, x_tile, lane, dwc1);
-    else dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
-    cb_sync();
-    f32x4 dslot[1];
-    if constexpr (HALF) {
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      dslot[0] = mfma_h(frag_h(wt_color, 12, lane), chain_h(dh1[0], dh1[1]), z4);
-      dslot[0] = mfma_h(frag_h(wt_color, 13, lane), chain_h(dh1[2], dh1[3]), dslot[0]);
-    } else {
-      float b[16];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dh1[rb][r];
-      mfma_layer<16, 1>(b, [&](int, int ks) { return wt_color[(80 + ks) * 64 + lane]; }, dslot);
-    }
-
-    // ------------------------- semantics net backward ---------------------
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) tile_store(dy_tile, g, j, rb, dlg[rb]);
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-      tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1s[rb]) : relu4(a1s[rb]));
-    cb_sync();
-    if constexpr (HALF) dw_accumulate_h<NRB, 4>(dy_tile, x_tile, lane, dws2);
-    else dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
-    cb_sync();
-    f32x4 dhs[4];
-    if constexpr (HALF) {
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      half8 ld[NS];
-#pragma unroll
-      for (int sx = 0; sx < NS; ++sx)
-        ld[sx] = chain_h(dlg[2 * sx], (2 * sx + 1 < NRB) ? dlg[(2 * sx + 1 < NRB) ? 2 * sx + 1 : 0] : z4);
+      for (int rb = 0; rb < 4; ++rb) dh2[rb] = gate4(a2c[rb], dh2[rb]);
+      // L2: dW2 += d_hid2 (x) relu(a1c);  d_hid1 = W2^T d_hid2
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
-        dhs[rb] = z4;
-#pragma unroll
-        for (int sx = 0; sx < NS; ++sx)
-          dhs[rb] = mfma_h(frag_h(wt_sem, NS * rb + sx, lane), ld[sx], dhs[rb]);
+        tile_store(dy_tile, g, j, rb, dh2[rb]);
+        tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1c[rb]) : relu4(a1c[rb]));
       }
-    } else {
-      float b[4 * NRB];
+      cb_sync();
+      if constexpr (HALF) dw_accumulate_h<4, 4>(dy_tile, x_tile, lane, dwc2);
+      else dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
+      cb_sync();
+      f32x4 dh1[4];
+      if constexpr (HALF) {
+        const half8 d0 = chain_h(dh2[0], dh2[1]), d1 = chain_h(dh2[2], dh2[3]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          dh1[rb] = mfma_h(frag_h(wt_color, 4 + 2 * rb, lane), d0, z4);
+          dh1[rb] = mfma_h(frag_h(wt_color, 5 + 2 * rb, lane), d1, dh1[rb]);
+        }
+      } else {
+        float bb[16];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bb[rb * 4 + r] = dh2[rb][r];
+        mfma_layer<16, 4>(bb, [&](int rb, int ks) { return wt_color[(16 + rb * 16 + ks) * 64 + lane]; }, dh1);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) dh1[rb] = gate4(a1c[rb], dh1[rb]);
+      // L1: dW1 += d_hid1 (x) [SH16 | geo15 | 1];  d_slot = W1^T(slot rows) d_hid1
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) tile_store(dy_tile, g, j, rb, dh1[rb]);
+      tile_store(x_tile, g, j, 0, sh);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t m = 4 * g + r;
+        x_tile[j * TILE_LD + (m == 0 ? 31u : 15u + m)] = geo_c[r];
+      }
+      cb_sync();
+      if constexpr (HALF) dw_accumulate_h<4, 2>(dy_tile, x_tile, lane, dwc1);
+      else dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
+      cb_sync();
+      if constexpr (HALF) {
+        dslot[0] = mfma_h(frag_h(wt_color, 12, lane), chain_h(dh1[0], dh1[1]), z4);
+        dslot[0] = mfma_h(frag_h(wt_color, 13, lane), chain_h(dh1[2], dh1[3]), dslot[0]);
+      } else {
+        float bb[16];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bb[rb * 4 + r] = dh1[rb][r];
+        mfma_layer<16, 1>(bb, [&](int, int ks) { return wt_color[(80 + ks) * 64 + lane]; }, dslot);
+      }
+    }
+
+    // ========================== semantics net =============================
+    if constexpr (DO_S) {
+      f32x4 a1s[4], lg[NRB];
+      f32x4 geo_s = geo;
+      if constexpr (HALF) {
+        half8 bs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bs[r] = (_Float16)geo[r];
+          bs[4 + r] = (_Float16)0.f;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1s[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
+        const half8 h0 = chain_relu_h(a1s[0], a1s[1]), h1 = chain_relu_h(a1s[2], a1s[3]);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+          lg[rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
+          lg[rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[rb]);
+        }
+        geo_s = q4(geo);
+      } else {
+        float xs[4] = {geo[0], geo[1], geo[2], geo[3]};
+        mfma_layer<4, 4>(xs, [&](int rb, int ks) { return w_sem[(rb * 4 + ks) * 64 + lane]; }, a1s);
+        float hid[16];
+        chain_relu(a1s, hid);
+        mfma_layer<16, NRB>(hid, [&](int rb, int ks) { return w_sem[(SEM_L1_FRAGS + rb * 16 + ks) * 64 + lane]; }, lg);
+      }
+      // softmax
+      float mx = -INFINITY;
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dlg[rb][r];
-      mfma_layer<4 * NRB, 4>(b, [&](int rb, int ks) { return wt_sem[(rb * 4 * NRB + ks) * 64 + lane]; }, dhs);
-    }
+        for (int r = 0; r < 4; ++r)
+          if ((uint32_t)(rb * 16 + 4 * g + r) < C) mx = fast_max(mx, lg[rb][r]);
+      mx = fast_max(mx, __shfl_xor(mx, 16, 64));
+      mx = fast_max(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.0f;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      dhs[rb] = gate4(a1s[rb], dhs[rb]);
-      tile_store(dy_tile, g, j, rb, dhs[rb]);
-    }
+      for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t m = 4 * g + r;
-      x_tile[j * TILE_LD + (m == 0 ? 15u : m - 1u)] = geo[r];
-    }
-    cb_sync();
-    if constexpr (HALF) dw_accumulate_h<4, 1>(dy_tile, x_tile, lane, dws1);
-    else dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
-    cb_sync();
-    f32x4 dslot_s[1];
-    if constexpr (HALF) {
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS, lane), chain_h(dhs[0], dhs[1]), z4);
-      dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS + 1, lane), chain_h(dhs[2], dhs[3]), dslot_s[0]);
-    } else {
-      float b[16];
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (uint32_t)(rb * 16 + 4 * g + r) < C;
+          const float ex = ok ? __expf(lg[rb][r] - mx) : 0.0f;  // as the forward (composite.hip fast_exp)
+          lg[rb][r] = ex;
+          sum += ex;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv_sum = fast_rcp(sum);  // as the forward
+      // semantics = sum_s w_detached * p ; p = softmax(logits)
+      float dot = 0.0f;
+      f32x4 dlg[NRB];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t cls = rb * 16 + 4 * g + r;
+          const float p = lg[rb][r] * inv_sum;
+          const float dp = cls < C ? wgt * b.dsem[rb * 4 + r] : 0.0f;
+          lg[rb][r] = p;
+          dlg[rb][r] = dp;
+          dot += p * dp;
+        }
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dlg[rb][r] = gs * (lg[rb][r] * (dlg[rb][r] - dot));
+      // L2: dW2 += dlogits (x) relu(a1s);  d_hid = W2^T dlogits
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) tile_store(dy_tile, g, j, rb, dlg[rb]);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
+        tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1s[rb]) : relu4(a1s[rb]));
+      cb_sync();
+      if constexpr (HALF) dw_accumulate_h<NRB, 4>(dy_tile, x_tile, lane, dws2);
+      else dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
+      cb_sync();
+      f32x4 dhs[4];
+      if constexpr (HALF) {
+        half8 ld[NS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[rb * 4 + r] = dhs[rb][r];
-      mfma_layer<16, 1>(b, [&](int, int ks) { return wt_sem[(16 * NRB + ks) * 64 + lane]; }, dslot_s);
+        for (int sx = 0; sx < NS; ++sx)
+          ld[sx] = chain_h(dlg[2 * sx], (2 * sx + 1 < NRB) ? dlg[(2 * sx + 1 < NRB) ? 2 * sx + 1 : 0] : z4);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          dhs[rb] = z4;
+#pragma unroll
+          for (int sx = 0; sx < NS; ++sx)
+            dhs[rb] = mfma_h(frag_h(wt_sem, NS * rb + sx, lane), ld[sx], dhs[rb]);
+        }
+      } else {
+        float bb[4 * NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bb[rb * 4 + r] = dlg[rb][r];
+        mfma_layer<4 * NRB, 4>(bb, [&](int rb, int ks) { return wt_sem[(rb * 4 * NRB + ks) * 64 + lane]; }, dhs);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        dhs[rb] = gate4(a1s[rb], dhs[rb]);
+        tile_store(dy_tile, g, j, rb, dhs[rb]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t m = 4 * g + r;
+        x_tile[j * TILE_LD + (m == 0 ? 15u : m - 1u)] = geo_s[r];
+      }
+      cb_sync();
+      if constexpr (HALF) dw_accumulate_h<4, 1>(dy_tile, x_tile, lane, dws1);
+      else dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
+      cb_sync();
+      if constexpr (HALF) {
+        dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS, lane), chain_h(dhs[0], dhs[1]), z4);
+        dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS + 1, lane), chain_h(dhs[2], dhs[3]), dslot_s[0]);
+      } else {
+        float bb[16];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bb[rb * 4 + r] = dhs[rb][r];
+        mfma_layer<16, 1>(bb, [&](int, int ks) { return wt_sem[(16 * NRB + ks) * 64 + lane]; }, dslot_s);
+      }
     }
+
     if (live) {
+      f32x4* dst = reinterpret_cast<f32x4*>((fine ? a.d_h_f : a.d_h_c) + hoff);
       f32x4 out;
-      out[0] = (g == 0) ? 0.0f : inv_gs * (dslot[0][0] + dslot_s[0][0]);  // slot 0: k_weights_bwd
-      out[1] = inv_gs * (dslot[0][1] + dslot_s[0][1]);
-      out[2] = inv_gs * (dslot[0][2] + dslot_s[0][2]);
-      out[3] = inv_gs * (dslot[0][3] + dslot_s[0][3]);
-      *reinterpret_cast<f32x4*>((fine ? a.d_h_f : a.d_h_c) + hoff) = out;
+      if constexpr (NET == 2) {
+        // the colour kernel (launched first on the same stream) stored its
+        // part; slot 0 stays what it is (k_weights_bwd writes it afterwards)
+        const f32x4 prev = *dst;
+        out[0] = (g == 0) ? prev[0] : prev[0] + inv_gs * dslot_s[0][0];
+        out[1] = prev[1] + inv_gs * dslot_s[0][1];
+        out[2] = prev[2] + inv_gs * dslot_s[0][2];
+        out[3] = prev[3] + inv_gs * dslot_s[0][3];
+      } else {
+        out[0] = (g == 0) ? 0.0f : inv_gs * (dslot[0][0] + dslot_s[0][0]);  // slot 0: k_weights_bwd
+        out[1] = inv_gs * (dslot[0][1] + dslot_s[0][1]);
+        out[2] = inv_gs * (dslot[0][2] + dslot_s[0][2]);
+        out[3] = inv_gs * (dslot[0][3] + dslot_s[0][3]);
+      }
+      *dst = out;
     }
   };
 
@@ -557,7 +595,7 @@ k_shade_bwd(ShadeBwdArgs a) {
           const size_t m = (size_t)offset + (in ? s : sbase);
           const float w = in ? a.weights[m] : 0.0f;
           const bool keep = in && w > a.w_min;
-          if (in && !keep) a.G[m] = 0.0f;
+          if (DO_C && in && !keep) a.G[m] = 0.0f;
           const unsigned long long bal = __ballot(keep);
           if (keep) {
             const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -579,7 +617,7 @@ k_shade_bwd(ShadeBwdArgs a) {
         if (s < S) {
           w = a.weights[(size_t)r * S + s];
           keep = w > 1e-4f;
-          if (!keep) a.G[(size_t)r * S + s] = 0.0f;
+          if (DO_C && !keep) a.G[(size_t)r * S + s] = 0.0f;
         }
         const unsigned long long bal = __ballot(keep);
         if (keep) {
@@ -604,20 +642,26 @@ k_shade_bwd(ShadeBwdArgs a) {
     }
   }
   // per-wave partial gradients, tcnn layout
-  if constexpr (HALF) {
-    dw_scale(dwc1, inv_gs);
-    dw_scale(dwc2, inv_gs);
-    dw_scale(dwc3, inv_gs);
-    dw_scale(dws1, inv_gs);
-    dw_scale(dws2, inv_gs);
+  if constexpr (DO_C) {
+    if constexpr (HALF) {
+      dw_scale(dwc1, inv_gs);
+      dw_scale(dwc2, inv_gs);
+      dw_scale(dwc3, inv_gs);
+    }
+    float* pc = a.partial_color + (size_t)gwave * 7168;
+    dw_store<4, 2>(pc, 32, lane, dwc1);
+    dw_store<4, 4>(pc + 2048, 64, lane, dwc2);
+    dw_store<1, 4>(pc + 6144, 64, lane, dwc3);
   }
-  float* pc = a.partial_color + (size_t)gwave * 7168;
-  dw_store<4, 2>(pc, 32, lane, dwc1);
-  dw_store<4, 4>(pc + 2048, 64, lane, dwc2);
-  dw_store<1, 4>(pc + 6144, 64, lane, dwc3);
-  float* ps = a.partial_sem + (size_t)gwave * (1024 + NRB * 1024);
-  dw_store<4, 1>(ps, 16, lane, dws1);
-  dw_store<NRB, 4>(ps + 1024, 64, lane, dws2);
+  if constexpr (DO_S) {
+    if constexpr (HALF) {
+      dw_scale(dws1, inv_gs);
+      dw_scale(dws2, inv_gs);
+    }
+    float* ps = a.partial_sem + (size_t)gwave * (1024 + NRB * 1024);
+    dw_store<4, 1>(ps, 16, lane, dws1);
+    dw_store<NRB, 4>(ps + 1024, 64, lane, dws2);
+  }
 }
 
 static inline uint32_t cb_pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
@@ -637,17 +681,30 @@ static void shade_bwd_geometry(uint32_t N, uint32_t& rpw, uint32_t& blocks,
   blocks = ucsa_div_up(n_waves, waves);
 }
 
+// fp32 kernel as a per-net pair (NET = 1 then 2, two waves per SIMD each):
+// UCSA_SHADE_BWD_SPLIT=0 keeps the single kernel (one wave per SIMD).
+static bool shade_bwd_split() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UCSA_SHADE_BWD_SPLIT");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
 // number of per-wave partial slots the caller must provide
 extern "C" uint32_t ucsa_composite_bwd_parts(uint32_t N) {
   uint32_t rpw, blocks;
-  shade_bwd_geometry(N ? N : 1, rpw, blocks);
-  return blocks * CB_WAVES;
+  const uint32_t waves = shade_bwd_split() ? CB_WAVES_SPLIT : CB_WAVES;
+  shade_bwd_geometry(N ? N : 1, rpw, blocks, waves);
+  return blocks * waves;
 }
 
 extern "C" uint32_t ucsa_composite_bwd_parts_f16(uint32_t N) {
   uint32_t rpw, blocks;
-  shade_bwd_geometry(N ? N : 1, rpw, blocks, CB_WAVES_H);
-  return blocks * CB_WAVES_H;
+  const uint32_t waves = shade_bwd_split() ? CB_WAVES_SPLIT : CB_WAVES_H;
+  shade_bwd_geometry(N ? N : 1, rpw, blocks, waves);
+  return blocks * waves;
 }
 
 // ---------------------------------------------------------------------------
@@ -745,7 +802,8 @@ static int32_t composite_bwd_impl(
   hipStream_t s = (hipStream_t)stream;
   const uint32_t nrb = cb_pad16(n_classes) / 16;
   uint32_t rpw, blocks;
-  const uint32_t waves = half ? CB_WAVES_H : CB_WAVES;
+  const bool split = shade_bwd_split();
+  const uint32_t waves = split ? CB_WAVES_SPLIT : half ? CB_WAVES_H : CB_WAVES;
   shade_bwd_geometry(N, rpw, blocks, waves);
   // d_h rows of samples outside the mask get no geo gradient
   hipError_t e = hipMemsetAsync(d_h_c, 0, (size_t)N * T * 16 * sizeof(float), s);
@@ -760,8 +818,40 @@ static int32_t composite_bwd_impl(
                  partial_color, partial_sem, rpw, nullptr, nullptr, 0u, 0.0f,
                  half ? f16_scale : 1.0f};
   const size_t w_floats = shade_bwd_weight_floats(half, nrb);
-  const size_t smem = (w_floats +
-                       (size_t)waves * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
+  const size_t per_wave_b = (size_t)waves * (5 * CB_CAP + 2 * 16 * TILE_LD) * 4;
+  const size_t smem = w_floats * 4 + per_wave_b;
+  if (split) {
+    const size_t ns = (nrb + 1) / 2;
+    const size_t smem_c = (half ? (size_t)(COLOR_H_FRAGS + 14) * 256 : 7168 + 6144) * 4 + per_wave_b;
+    const size_t smem_s = (half ? (size_t)(SEM_H_FRAGS(nrb) + 4 * ns + 2) * 256
+                                : 1024 + (size_t)nrb * 1024 + (16 * (size_t)nrb + 16) * 64) * 4 +
+                          per_wave_b;
+#define LAUNCH_NET(NRB, H, NET, SM)                                           \
+  do {                                                                        \
+    hipError_t e2 = hipFuncSetAttribute(                                      \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, false, H, NET>),      \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SM));               \
+    if (e2 != hipSuccess) return -(int32_t)e2;                                \
+    UCSA_CLEAR_ERR();                                                         \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, false, H, NET>), dim3(blocks),       \
+                       dim3(64 * waves), (SM), s, a);                         \
+    int32_t rc2 = ucsa_launch_status();                                       \
+    if (rc2) return rc2;                                                      \
+  } while (0)
+#define LAUNCH_PAIR(NRB)                                                      \
+  do {                                                                        \
+    if (half) { LAUNCH_NET(NRB, true, 1, smem_c); LAUNCH_NET(NRB, true, 2, smem_s); } \
+    else { LAUNCH_NET(NRB, false, 1, smem_c); LAUNCH_NET(NRB, false, 2, smem_s); }    \
+  } while (0)
+    switch (nrb) {
+      case 1: LAUNCH_PAIR(1); break;
+      case 2: LAUNCH_PAIR(2); break;
+      case 3: LAUNCH_PAIR(3); break;
+      default: LAUNCH_PAIR(4); break;
+    }
+#undef LAUNCH_PAIR
+#undef LAUNCH_NET
+  } else {
 #define LAUNCH(NRB, H)                                                        \
   do {                                                                        \
     hipError_t e2 = hipFuncSetAttribute(                                      \
@@ -788,6 +878,7 @@ static int32_t composite_bwd_impl(
     }
   }
 #undef LAUNCH
+  }
   int32_t rc = ucsa_launch_status();
   if (rc) return rc;
   const size_t smem2 = (size_t)WB_WAVES * 3 * (T + t) * sizeof(float);

@@ -357,9 +357,16 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
     lm.simple_below = sizeof(TT) == 8
                           ? simple_gather_below("UCSA_ENC_SIMPLE", UCSA_MAX_LEVELS)
                           : simple_gather_below("UCSA_ENC_SIMPLE_H", 0u);
+    // UCSA_ENC_LDS_PAD (experiments only, tools/coresident_exp.py): extra
+    // dynamic LDS per workgroup = fewer encoder workgroups per CU, i.e. free
+    // registers / wave slots for a co-resident kernel.  Results do not change.
+    static const uint32_t lds_pad = []() {
+      const char* v = getenv("UCSA_ENC_LDS_PAD");
+      return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 0u;
+    }();
     hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
                        dim3(tiles * s_blocks * lm.k, grid->n_levels / lm.k),
-                       dim3(256), 0, (hipStream_t)stream, gd, lm,
+                       dim3(256), lds_pad, (hipStream_t)stream, gd, lm,
                        (const TT*)table, rays_o, rays_d, z, bb, T, N,
                        image_width, s_blocks, (FT*)feat);
   }

@@ -616,8 +616,14 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
   uint32_t n_lo = grid->n_levels;
   if (workspace) {
     n_lo = 0;
+    // UCSA_BWD_BIN_SCALE (tuning only; the result does not depend on it):
+    // hashed levels with scale >= this go through the bins
+    static const float bin_scale = []() {
+      const char* v = getenv("UCSA_BWD_BIN_SCALE");
+      return v && *v ? (float)atof(v) : 160.0f;
+    }();
     while (n_lo < grid->n_levels && (!grid->level[n_lo].hashed ||
-                                     grid->level[n_lo].scale < 160.0f)) ++n_lo;
+                                     grid->level[n_lo].scale < bin_scale)) ++n_lo;
   }
   // both halves present: fork the coarse half onto the side stream
   BwdSide* side = (workspace && n_lo > 0 && n_lo < grid->n_levels) ? bwd_side((hipStream_t)stream) : nullptr;

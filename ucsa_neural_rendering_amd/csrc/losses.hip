@@ -88,6 +88,57 @@ __global__ void k_nerf_loss_final(const float* __restrict__ partial,
   if (sem_ok) total += ls * w_sem;
   total += ld * w_depth;  // NaN when no pixel has depth, like the reference
   stats[5] = total;
+  stats[6] = ls;  // the semantics term with "None" as a zero (no read-back)
+  stats[7] = 0.f;
+}
+
+// Backward of the loss node in ONE launch: the gradients ucsa_nerf_loss wrote
+// (of w-weighted terms, i.e. of `total`) times the cotangents autograd hands
+// back -- of the total (g_total) and, when a caller used the terms one by one,
+// of the single terms (g_color / g_sem / g_depth; a term's own gradient is the
+// stored one / its weight).  Device scalars, NULL = 0: no host read-back.
+__global__ void __launch_bounds__(256)
+k_nerf_loss_apply(float* __restrict__ d_rgb, float* __restrict__ d_sem,
+                  float* __restrict__ d_depth, uint32_t N, uint32_t C,
+                  const float* __restrict__ g_total,
+                  const float* __restrict__ g_color,
+                  const float* __restrict__ g_sem,
+                  const float* __restrict__ g_depth, float inv_w_sem,
+                  float inv_w_depth) {
+  const float gt = g_total ? g_total[0] : 0.f;
+  const float kc = gt + (g_color ? g_color[0] : 0.f);
+  const float ks = gt + (g_sem ? g_sem[0] * inv_w_sem : 0.f);
+  const float kd = gt + (g_depth ? g_depth[0] * inv_w_depth : 0.f);
+  const uint64_t n_rgb = (uint64_t)N * 3, n_sem = (uint64_t)N * C;
+  const uint64_t total = n_rgb + n_sem + N;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i < n_rgb) d_rgb[i] *= kc;
+    else if (i < n_rgb + n_sem) d_sem[i - n_rgb] *= ks;
+    else d_depth[i - n_rgb - n_sem] *= kd;
+  }
+}
+
+extern "C" int32_t ucsa_nerf_loss_apply(float* d_rgb, float* d_sem,
+                                        float* d_depth, uint32_t N, uint32_t C,
+                                        const float* g_total,
+                                        const float* g_color,
+                                        const float* g_sem, const float* g_depth,
+                                        float w_sem, float w_depth,
+                                        void* stream) {
+  UCSA_CHECK_ARG(d_rgb && d_sem && d_depth, 0);
+  UCSA_CHECK_ARG(N > 0 && C >= 1, 3);
+  UCSA_CHECK_ARG(g_total || g_color || g_sem || g_depth, 5);
+  UCSA_CHECK_ARG((!g_sem || w_sem != 0.f) && (!g_depth || w_depth != 0.f), 9);
+  const uint64_t total = (uint64_t)N * (4 + C);
+  uint32_t blocks = (uint32_t)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_nerf_loss_apply, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, d_rgb, d_sem, d_depth, N, C, g_total,
+                     g_color, g_sem, g_depth, g_sem ? 1.0f / w_sem : 0.f,
+                     g_depth ? 1.0f / w_depth : 0.f);
+  return ucsa_launch_status();
 }
 
 __global__ void __launch_bounds__(256)

@@ -655,7 +655,7 @@ def adam_count_skipped(found_inf: torch.Tensor, skipped: torch.Tensor):
 def nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom: float,
               w_sem: float = 0.04, w_depth: float = 0.1,
               grad_scale: float = 1.0, want_grad: bool = True):
-    """-> stats[6] (device), (d_rgb, d_sem, d_depth) | None."""
+    """-> stats[8] (device), (d_rgb, d_sem, d_depth) | None."""
     rgb = _f32(rgb, "rgb").view(-1, 3)
     N = rgb.shape[0]
     sem = _f32(sem, "sem").view(N, -1)
@@ -665,7 +665,7 @@ def nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom: float,
     gt_depth = _f32(gt_depth, "gt_depth").view(N)
     labels = labels.reshape(N).to(torch.int64).contiguous()
     dev = rgb.device
-    stats = torch.empty(6, device=dev)
+    stats = torch.empty(8, device=dev)
     partial = torch.empty(int(lib().ucsa_loss_partial_floats(N)), device=dev)
     grads = None
     if want_grad:
@@ -679,6 +679,30 @@ def nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom: float,
         _ptr(grads[2]) if grads else None, _ptr(partial), _stream()),
         "ucsa_nerf_loss")
     return stats, grads
+
+
+def nerf_loss_apply(grads, g_total, g_color, g_sem, g_depth, w_sem: float,
+                    w_depth: float):
+    """In place on ``grads`` = (d_rgb [N,3], d_sem [N,C], d_depth [N]) of
+    ``nerf_loss``: times the loss node's cotangents (0-d / 1-element device
+    tensors or None), one launch (ucsa_nerf_loss_apply)."""
+    d_rgb, d_sem, d_depth = grads
+    N, Cn = d_sem.shape
+
+    def sc(t):
+        if t is None:
+            return None
+        t = t.detach().reshape(-1)
+        if not t.is_cuda or t.dtype != torch.float32 or t.numel() != 1:
+            t = t.to(d_rgb.device, torch.float32).reshape(1)
+        return t.contiguous()
+
+    gt, gc, gs, gd = sc(g_total), sc(g_color), sc(g_sem), sc(g_depth)
+    check(lib().ucsa_nerf_loss_apply(_ptr(d_rgb), _ptr(d_sem), _ptr(d_depth), N, Cn,
+                                     _ptr(gt), _ptr(gc), _ptr(gs), _ptr(gd),
+                                     float(w_sem), float(w_depth), _stream()),
+          "ucsa_nerf_loss_apply")
+    return grads
 
 
 def semantic_postproc(sem, want_normalised: bool = True):
