@@ -335,6 +335,27 @@ int32_t ucsa_mlp_pack_x3(int32_t kind, const float* params, void* packed_x3,
 int32_t ucsa_sigma_mlp_fwd_x3(const float* feat, const void* packed_sigma_x3,
                               uint32_t M, uint32_t n_levels, float* h,
                               float* sigma, void* stream);
+/* A whole batch of rays (e.g. one view) in `chunk`-ray pieces, what the
+ * reference's staged `render` loop does (renderer_semantics.py:321-342), as ONE
+ * call: software-pipelined over two internal streams (density half of chunk
+ * k+1 || shading half of chunk k; events fork from / join to `stream`), two
+ * workspaces of ucsa_render_workspace_bytes(min(N, chunk), T, t, L) bytes each
+ * (ws1 NULL = serial loop).  mode: 0 = ucsa_render_fwd, 1 = _f16, 2 = _x3,
+ * 3 = _f16_h16 (their table / packed-weight formats).  Arrays are for all N
+ * rays; image_width as in ucsa_render_fwd (needs chunk % (8 * image_width) == 0
+ * and N % image_width == 0, else the ray-ordered gather is used -- same
+ * results).  Bit-identical to calling ucsa_render_fwd* per chunk. */
+int32_t ucsa_render_view(uint32_t mode, const ucsa_grid* grid, const void* table,
+                         const void* packed_sigma, const void* packed_color,
+                         const void* packed_sem, const float* rays_o,
+                         const float* rays_d, const float* norms,
+                         const float* aabb_host, float min_near,
+                         const float* t_rand, const float* u, uint32_t N,
+                         uint32_t T, uint32_t t, uint32_t n_classes,
+                         float density_scale, uint32_t image_width,
+                         uint32_t chunk, float* image, float* depth,
+                         float* semantics, void* ws0, void* ws1, void* stream);
+
 /* run() as one enqueue (cf. ucsa_render_fwd; same workspace) */
 int32_t ucsa_render_fwd_x3(const ucsa_grid* grid, const float* table,
                            const void* packed_sigma_x3,

@@ -110,6 +110,8 @@ SIGNATURES = {
     "ucsa_mlp_pack_x3_bytes": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_x3": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_sigma_mlp_fwd_x3": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
+    "ucsa_render_view": (C.c_int32, [_u32, C.POINTER(Grid)] + [_p] * 7 + [C.POINTER(_f), _f, _p, _p,
+                                     _u32, _u32, _u32, _u32, _f, _u32, _u32] + [_p] * 6),
     "ucsa_render_fwd_x3": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                        _p, _p, C.POINTER(_f), _f, _p, _p,
                                        _u32, _u32, _u32, _u32, _f, _u32, _p,

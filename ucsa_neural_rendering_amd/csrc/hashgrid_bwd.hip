@@ -620,7 +620,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
     // hashed levels with scale >= this go through the bins
     static const float bin_scale = []() {
       const char* v = getenv("UCSA_BWD_BIN_SCALE");
-      return v && *v ? (float)atof(v) : 160.0f;
+      return v && *v ? (float)atof(v) : 100.0f;  // measured: 160 -> 4.81, 100 -> 4.76, 60 -> 5.04 ms per step
     }();
     while (n_lo < grid->n_levels && (!grid->level[n_lo].hashed ||
                                      grid->level[n_lo].scale < bin_scale)) ++n_lo;

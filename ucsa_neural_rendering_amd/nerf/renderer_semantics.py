@@ -58,6 +58,9 @@ class SemanticNeRFRenderer(nn.Module):
         # measured on MI355X: no gain (every kernel already fills the chip),
         # so one stream by default
         self.hip_streams = 1
+        # no-grad renders of >= 2 chunks as one software-pipelined call
+        # (ucsa_render_view: density half of chunk k+1 || shading half of chunk k)
+        self.hip_pipeline = True
         # inference (no-grad render) arithmetic of the three MLPs:
         #   "fp32"   f32-input MFMA, bit for bit a k-ordered fmaf chain (the
         #            same kernels arithmetic as the training forward);
@@ -487,6 +490,18 @@ class SemanticNeRFRenderer(nn.Module):
         else:
             image_width = 0
         n_chunks = (N + chunk - 1) // chunk
+        if self.hip_pipeline and n_chunks >= 2 and int(self.hip_streams) <= 1:
+            # ONE call for the whole batch: density half of chunk k+1 next to
+            # the shading half of chunk k (ucsa_render_view; bit-identical)
+            mode = {"fp32": "fp32", "bf16x3": "bf16x3"}.get(
+                self.precision, "fp16_h16" if self.fp16_table else "fp16")
+            ws = self._workspace(
+                ops.render_workspace_bytes(min(N, chunk), T, t, f["grid"].n_levels), dev, 2)
+            ops.render_view(mode, f["grid"], f["table"], f["packed_sigma"],
+                            f["packed_color"], f["packed_sem"], o, d, nrm, aabb, min_near,
+                            rng_t, rng_u, T, t, C, float(self.density_scale), image, depth,
+                            sem, chunk, ws[0], ws[1], image_width)
+            return image, depth, sem
         n_str = max(1, min(int(self.hip_streams), n_chunks))
         ws = self._workspace(
             ops.render_workspace_bytes(min(N, chunk), T, t, f["grid"].n_levels),

@@ -468,6 +468,25 @@ def render_fwd_x3(grid: Grid, table, packed_sigma_x3, packed_color_x3,
         _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_x3")
 
 
+RENDER_MODES = {"fp32": 0, "fp16": 1, "bf16x3": 2, "fp16_h16": 3}
+
+
+def render_view(mode: str, grid: Grid, table, packed_sigma, packed_color, packed_sem,
+                rays_o, rays_d, norms, aabb, min_near: float, t_rand, u, T: int,
+                t: int, n_classes: int, density_scale: float, image, depth,
+                semantics, chunk: int, ws0: torch.Tensor, ws1, image_width: int = 0):
+    """All N rays in `chunk`-ray pieces as ONE call (ucsa_render_view): the
+    density half of chunk k+1 overlaps the shading half of chunk k on two
+    internal streams; ``ws1`` None = the serial loop.  Same bits either way."""
+    N = rays_o.shape[0]
+    check(lib().ucsa_render_view(
+        RENDER_MODES[mode], C.byref(grid), _ptr(table), _ptr(packed_sigma),
+        _ptr(packed_color), _ptr(packed_sem), _ptr(rays_o), _ptr(rays_d), _ptr(norms),
+        fvec(aabb), float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
+        float(density_scale), int(image_width), int(chunk), _ptr(image), _ptr(depth),
+        _ptr(semantics), _ptr(ws0), _ptr(ws1), _stream()), "ucsa_render_view")
+
+
 # ============================ training (backward) ===========================
 def mlp_pack_t(kind: int, params: torch.Tensor, n_classes: int = 0,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
