@@ -10,8 +10,9 @@ from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
 pose = _slerp_loop_poses(4, seed=999)[1:2].to(dev)
 o, d, n = ops.get_rays(pose, (0.89 * W, 0.89 * W, W / 2, H / 2), H, W)
 u = torch.rand(H * W, 96, device=dev)
-for chunk in (32768, 65536, 102400, 131072, 204800, 307200):
-    net.hip_ray_chunk = chunk
+net.precision = os.environ.get("PREC", "bf16x3")
+for pipe, chunk in [(p, c) for p in (True, False) for c in (15360, 20480, 30720, 40960, 51200, 65536, 102400, 153600, 307200)]:
+    net.hip_ray_chunk, net.hip_pipeline = chunk, pipe
     with torch.no_grad():
         for _ in range(3):
             net.render(o, d, n, num_steps=96, upsample_steps=96, rng_u=u, image_width=W)
@@ -19,4 +20,4 @@ for chunk in (32768, 65536, 102400, 131072, 204800, 307200):
         for _ in range(10):
             net.render(o, d, n, num_steps=96, upsample_steps=96, rng_u=u, image_width=W)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-    print(f"chunk {chunk}: {dt*1e3:.2f} ms/view, {H*W/dt/1e6:.2f} M rays/s")
+    print(f"pipeline {pipe} chunk {chunk}: {dt*1e3:.2f} ms/view, {H*W/dt/1e6:.2f} M rays/s")

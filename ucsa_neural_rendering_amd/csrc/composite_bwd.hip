@@ -1005,7 +1005,12 @@ extern "C" int32_t ucsa_march_train_bwd(
   hipStream_t s = (hipStream_t)stream;
   const uint32_t nrb = cb_pad16(n_classes) / 16;
   uint32_t rpw, blocks;
-  shade_bwd_geometry(N, rpw, blocks);
+  // same geometry (and so the same number of partial slots,
+  // ucsa_composite_bwd_parts) as the live path: the per-net pair at two waves
+  // per SIMD, or the single kernel under UCSA_SHADE_BWD_SPLIT=0
+  const bool split = shade_bwd_split();
+  const uint32_t waves = split ? CB_WAVES_SPLIT : CB_WAVES;
+  shade_bwd_geometry(N, rpw, blocks, waves);
   if (M) {
     hipError_t e = hipMemsetAsync(d_h, 0, (size_t)M * 16 * sizeof(float), s);
     if (e != hipSuccess) return -(int32_t)e;
@@ -1015,25 +1020,34 @@ extern "C" int32_t ucsa_march_train_bwd(
                  packed_color_t, packed_sem_t, N, 0u, 0u, n_classes, G, d_h,
                  nullptr, partial_color, partial_sem, rpw, rays, t_all, M, w_min,
                  1.0f};
-  const size_t smem = (7168 + 1024 + (size_t)nrb * 1024 + 6144 +
-                       (16 * (size_t)nrb + 16) * 64 +
-                       (size_t)CB_WAVES * (5 * CB_CAP + 2 * 16 * TILE_LD)) * 4;
-#define LAUNCH_M(NRB)                                                         \
+  const size_t per_wave_b = (size_t)waves * (5 * CB_CAP + 2 * 16 * TILE_LD) * 4;
+  const size_t smem_c = (7168 + 6144) * 4 + per_wave_b;
+  const size_t smem_s = (1024 + (size_t)nrb * 1024 + (16 * (size_t)nrb + 16) * 64) * 4 + per_wave_b;
+  const size_t smem = smem_c + smem_s - per_wave_b;
+#define LAUNCH_M(NRB, NET, SM)                                                \
   do {                                                                        \
     hipError_t e2 = hipFuncSetAttribute(                                      \
-        reinterpret_cast<const void*>(&k_shade_bwd<NRB, true, false>),               \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, true, false, NET>),   \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SM));               \
     if (e2 != hipSuccess) return -(int32_t)e2;                                \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL((k_shade_bwd<NRB, true, false>), dim3(blocks),                \
-                       dim3(64 * CB_WAVES), smem, s, a);                      \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, true, false, NET>), dim3(blocks),    \
+                       dim3(64 * waves), (SM), s, a);                         \
+    int32_t rc2 = ucsa_launch_status();                                       \
+    if (rc2) return rc2;                                                      \
+  } while (0)
+#define LAUNCH_MM(NRB)                                                        \
+  do {                                                                        \
+    if (split) { LAUNCH_M(NRB, 1, smem_c); LAUNCH_M(NRB, 2, smem_s); }        \
+    else LAUNCH_M(NRB, 0, smem);                                              \
   } while (0)
   switch (nrb) {
-    case 1: LAUNCH_M(1); break;
-    case 2: LAUNCH_M(2); break;
-    case 3: LAUNCH_M(3); break;
-    default: LAUNCH_M(4); break;
+    case 1: LAUNCH_MM(1); break;
+    case 2: LAUNCH_MM(2); break;
+    case 3: LAUNCH_MM(3); break;
+    default: LAUNCH_MM(4); break;
   }
+#undef LAUNCH_MM
 #undef LAUNCH_M
   int32_t rc = ucsa_launch_status();
   if (rc) return rc;
