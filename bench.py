@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--nerf-epochs", type=int, default=2, help="cfg5: NeRF-only epochs per scene")
     ap.add_argument("--joint-epochs", type=int, default=1, help="cfg5: joint epochs per scene")
     ap.add_argument("--frames", type=int, default=16, help="cfg5: training frames per scene")
+    ap.add_argument("--pretrain-seg-steps", type=int, default=400,
+                    help="cfg5: Adam steps of the in-harness DeepLab pre-training on eight "
+                         "other rooms before the clock starts (the reference loads a "
+                         "ScanNet-25k checkpoint); 0 = random initialisation")
     ap.add_argument("--mode", choices=["render", "train", "cfg3", "cfg4", "cfg5"],
                     default="render")
     ap.add_argument("--backbone", default=None,
@@ -400,8 +404,9 @@ def main():
     result = None
     if rank == 0:
         assert torch.isfinite(out["image"]).all()
-        # the chunk render() really launches: whole 8-row bands of the image
-        chunk = net.hip_ray_chunk - net.hip_ray_chunk % (8 * W)
+        # the chunk render() really launches (whole 8-row bands of the image,
+        # balanced over the pipelined call's chunks)
+        chunk = net.infer_chunk(H * W, W)[0]
         o, d, nrm = rays[0]
         chunk_in = (o[0, :chunk].contiguous(), d[0, :chunk].contiguous(),
                     nrm[0, :chunk, 0].contiguous(), u[:chunk])

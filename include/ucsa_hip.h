@@ -496,6 +496,29 @@ int32_t ucsa_composite_bwd_f16(
     float density_scale, float f16_scale, float* G, float* d_h_c, float* d_h_f,
     float* partial_color, float* partial_sem, void* stream);
 
+/* The same backward with every contraction of the two nets on the bf16 MFMA
+ * pipe as TWO-term splits ("bf16x2": x = bf16(x) + bf16(x - bf16(x)), three
+ * partial products per product, 2^-16 relative, fp32 range: no loss scale) --
+ * the gradient contractions of `nerf: {train_precision: bf16x3}`, whose forward
+ * is ucsa_composite_train_fwd_x3.  Weights: ucsa_mlp_pack_x3 buffers and their
+ * transposed form ucsa_mlp_pack_t_x3 (fragments of ucsa_mlp_pack_t_f16, three
+ * exact bf16 terms each; ucsa_mlp_pack_t_x3_bytes).  Partials:
+ * ucsa_composite_bwd_parts(N) slots.  Runs as the per-net kernel pair only
+ * (argument 0 error under UCSA_SHADE_BWD_SPLIT=0). */
+uint32_t ucsa_mlp_pack_t_x3_bytes(int32_t kind, uint32_t n_classes);
+int32_t ucsa_mlp_pack_t_x3(int32_t kind, const float* params, void* packed_x3,
+                           uint32_t n_classes, void* stream);
+int32_t ucsa_composite_bwd_x2(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const void* packed_color_x3, const void* packed_sem_x3,
+    const void* packed_color_t_x3, const void* packed_sem_t_x3,
+    const float* d_image, const float* d_depth, const float* d_sem, uint32_t N,
+    uint32_t T, uint32_t t, uint32_t n_classes, float density_scale, float* G,
+    float* d_h_c, float* d_h_f, float* partial_color, float* partial_sem,
+    void* stream);
+
 /* Backward of ucsa_hashgrid_encode_rays: adds into grad_table
  * [total_entries,2] (caller zeroes it).  Autograd of tcnn.Encoding.
  * With a workspace of ucsa_hashgrid_bwd_workspace_bytes() the binned two-pass

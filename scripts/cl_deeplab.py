@@ -80,7 +80,7 @@ def ensure_synthetic_scenes(exp, env, scenes):
             export(root, seed, int(syn.get("n_views", 20)),
                    int(syn.get("H", 240)), int(syn.get("W", 320)),
                    device="cuda" if torch.cuda.is_available() else "cpu",
-                   scene_name=s)
+                   scene_name=s, palette_seed=syn.get("palette_seed"))
     if udist.active():
         torch.distributed.barrier()
 

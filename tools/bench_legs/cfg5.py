@@ -30,6 +30,50 @@ from .common import *  # noqa: F401,F403
 from .common import _tick, finish, max_over_ranks
 
 
+def pretrain_seg(exp, dev, steps, path, palette_seed, B=8):
+    """The reference starts the loop from a DeepLab pre-trained on ScanNet-25k
+    (cfg/exp/multi_step/cl_base.yml `checkpoint_load`; its pseudo-labels are
+    what the NeRF's semantic head learns, joint_train_lightning_net.py:171-176).
+    No checkpoint can be fetched here and a randomly initialised network labels
+    everything with one class (final NeRF mIoU 0.0, measured), so the stand-in
+    is pre-trained in-harness, BEFORE the clock starts: `steps` Adam steps
+    (lr 1e-4, batch 8, CE-on-softmax like the reference) on eight OTHER
+    synthetic rooms (seeds 100-107) that share the class -> colour table of the
+    loop's rooms (`synthetic.palette_seed`), written in the reference's
+    Lightning checkpoint layout.  Returns its mIoU on a ninth room."""
+    from ucsa_neural_rendering_amd import losses as ul, ops
+    from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
+    from ucsa_neural_rendering_amd.network import DeepLabV3
+    from ucsa_neural_rendering_amd.utils.metrics import SemanticsMeter
+    torch.manual_seed(5)
+    m = DeepLabV3(exp["model"]).to(dev).train().to(memory_format=torch.channels_last)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    rooms = [SyntheticSceneDataset(100 + i, n_views=12, H=240, W=320, n_classes=N_CLASSES,
+                                   device=dev, palette_seed=palette_seed) for i in range(8)]
+    frames = [(r[i]["img"], r[i]["label"]) for r in rooms for i in range(12)]
+    g = torch.Generator().manual_seed(6)
+    for it in range(steps):
+        idx = torch.randint(0, len(frames), (B,), generator=g).tolist()
+        x = torch.stack([frames[i][0] for i in idx]).contiguous(memory_format=torch.channels_last)
+        y = torch.stack([frames[i][1] for i in idx])
+        loss = ul.seg_loss(m(x)["out"].float().contiguous(), y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    m.eval()
+    val = SyntheticSceneDataset(200, n_views=8, H=240, W=320, n_classes=N_CLASSES, device=dev,
+                                palette_seed=palette_seed)
+    meter = SemanticsMeter(N_CLASSES)
+    with torch.no_grad():
+        for i in range(8):
+            pred = ops.seg_tail(m(val[i]["img"][None])["out"].float().contiguous(), None,
+                                want_prob=False)["argmax"]
+            meter.update(pred, val[i]["label"][None])
+    sd = {"_model." + k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.save({"state_dict": sd}, path)
+    return float(meter.measure()[0]), float(loss.detach())
+
+
 def main_cfg5(args, dev, dist, world, rank, backend):
     from scripts import cl_deeplab
     from ucsa_neural_rendering_amd import dist as udist
@@ -39,7 +83,8 @@ def main_cfg5(args, dev, dist, world, rank, backend):
 
     exp = load_yaml(os.path.join(ROOT, "cfg/exp/multi_step/cl_base.yml"))
     n_views = int(round(args.frames / 0.8))           # 80 % train / 20 % val split
-    exp["synthetic"].update(n_views=n_views, H=240, W=320)
+    palette_seed = 7 if args.pretrain_seg_steps > 0 else None
+    exp["synthetic"].update(n_views=n_views, H=240, W=320, palette_seed=palette_seed)
     if args.backbone:
         exp["model"]["backbone"] = args.backbone
     if args.seg_amp:
@@ -56,6 +101,19 @@ def main_cfg5(args, dev, dist, world, rank, backend):
     cl_deeplab.ensure_synthetic_scenes(exp, env, scenes)     # rank 0 writes, the rest wait
     export_s = time.perf_counter() - t0
     _tick(f"cfg5: {len(scenes)} synthetic rooms exported ({export_s:.1f} s, not timed)")
+    pre = None
+    if args.pretrain_seg_steps > 0:
+        ck = os.path.join(root, "pretrain_deeplab.ckpt")
+        if rank == 0:
+            t1 = time.perf_counter()
+            miou0, loss0 = pretrain_seg(exp, dev, args.pretrain_seg_steps, ck, palette_seed)
+            pre = {"steps": args.pretrain_seg_steps, "seconds_not_timed": time.perf_counter() - t1,
+                   "miou_on_an_unseen_room": miou0, "final_loss": loss0}
+            _tick(f"cfg5: DeepLab stand-in pre-trained, mIoU {miou0:.3f} on an unseen room "
+                  f"({pre['seconds_not_timed']:.1f} s, not timed)")
+        if dist:
+            dist.barrier()
+        exp["general"]["checkpoint_load"] = ck
 
     # counters: rays through render() with / without grad, training steps
     count = {"rays_trained": 0, "rays_rendered": 0, "nerf_steps": 0, "joint_steps": 0,
@@ -120,12 +178,16 @@ def main_cfg5(args, dev, dist, world, rank, backend):
     stages = []
     for mark, res in zip(stage_marks, results):
         row = dict(mark)
-        for phase in ("test_after_nerf", "test_after_joint"):
+        for phase in ("test_after_nerf", "val", "test_after_joint"):
             for k, v in (res.get(phase) or {}).items():
                 row[f"{phase}.{k}"] = v
         stages.append(row)
     last = results[-1]["test_after_joint"]
-    final = {k: last.get(k) for k in ("test_nerf_mIoU", "test_seg_mIoU", "test_nerf_PSNR")}
+    final = {k: last.get(k) for k in ("test_nerf_mIoU", "test_nerf_PSNR")}
+    # DeepLab on the new scene's validation frames (before its joint epochs: the
+    # network as the previous stages left it; reference train_joint.py:143-146)
+    for k, v in (results[-1].get("val") or {}).items():
+        final["seg_" + k] = v
     result = {
         "metric": "rays/sec", "value": (rays_trained + rays_rendered) / elapsed,
         "unit": "rays/s", "n_gpus": world, "steps": int(joint_steps + nerf_steps),
@@ -148,6 +210,7 @@ def main_cfg5(args, dev, dist, world, rank, backend):
             "frames_per_scene": args.frames, "seg_precision": args.seg_amp or "fp32",
             "nerf_render_nets": args.nerf_precision,
         },
+        "seg_pretraining": pre,
         "quality": {"final_stage": final,
                     "note": "test pass after the last stage's joint epochs (reference "
                             "train_joint.py: trainer_joint.test on the NeRF train loader)"},

@@ -20,9 +20,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak
 F16_MFMA_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA (SURVEY 8d's MLP roofline)
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
-PMC_JSON = "profiles/r03_pmc_traffic.json"
-TRAIN_PMC_JSON = "profiles/r03_train_pmc.json"
+PMC_JSON = "profiles/r04_pmc_traffic.json"
+TRAIN_PMC_JSON = "profiles/r04_train_pmc.json"
 SEG_PMC_JSON = "profiles/r03_seg_pmc.json"
+# k_hashgrid_encode_tiled is unchanged since round 3: its binding-unit counters stand
 ENC_BINDING_JSON = "profiles/r03_encoder_binding.json"
 
 

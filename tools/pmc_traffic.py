@@ -49,8 +49,9 @@ def main(d, tag):
                   "TCC_HIT_sum TCC_MISS_sum / --pmc SQ_* (three separate passes, "
                   "tools/refresh_profiles.sh) of `python3 bench.py --steps 2 "
                   "--warmup 1 --no-cpu-baseline --no-train-bench` (the default "
-                  "200 pretrain steps = the field bench.py times); per-dispatch averages of the largest (bench-size: 61440 "
-                  "rays x 96 samples) launches",
+                  "200 pretrain steps = the field bench.py times); per-dispatch averages of the largest launches of "
+                  "each kernel = the bench's chunks (grid_threads / 96 samples / 16 levels "
+                  "= rays per launch for the encoder)",
         "units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are reported in KiB by "
                  "rocprofv3 and multiplied by 1024 here.  gfx950 note "
                  "(MI355X_MICROARCH.md HBM section): FETCH_SIZE under-reports "

@@ -155,6 +155,10 @@ SIGNATURES = {
     "ucsa_mlp_pack_t_f16_halves": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_t_f16": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_composite_bwd_parts_f16": (C.c_uint32, [_u32]),
+    "ucsa_mlp_pack_t_x3_bytes": (C.c_uint32, [C.c_int32, _u32]),
+    "ucsa_mlp_pack_t_x3": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
+    "ucsa_composite_bwd_x2": (C.c_int32, [_p] * 17 + [_u32, _u32, _u32, _u32, _f] +
+                              [_p] * 6),
     "ucsa_composite_bwd_f16": (C.c_int32, [_p] * 17 + [_u32, _u32, _u32, _u32, _f,
                                                         _f] + [_p] * 6),
     "ucsa_adam_step": (C.c_int32, [_p, _p, _p, _p, C.c_uint64, _u32, _f, _f,

@@ -14,6 +14,7 @@
 //                  a reverse suffix scan, times the trunc_exp backward
 //                  (reference nr4seg/nerf/activation.py:17-21), into d_h[:,0].
 #include "composite_common.h"
+#include "mfma_mlp_x3.h"
 
 #define CB_WAVES 4
 // Waves per workgroup of the f16 variant.  Measured: 8 waves (2 per SIMD, a
@@ -160,9 +161,18 @@ __device__ __forceinline__ f32x4 gate4(f32x4 pre, f32x4 v) {
 // dW accumulators (112 / 64 registers) and weights (52 / 32 KB of LDS), so
 // CB_WAVES_SPLIT = 8 waves per workgroup = TWO waves per SIMD fit, and the LDS
 // round trips / global loads of one wave hide behind the MFMAs of the other.
-template <int NRB, bool MARCH, bool HALF, int NET = 0>
+//
+// B2 (round 4, with NET = 1 / 2; "bf16x2"): the same structure as HALF -- fragment
+// layout, chaining, transposed weight fragments -- with every f16 operand
+// replaced by a two-term bf16 split (mfma_mlp_x3.h "bf16x2": 2^-16 per
+// product, fp32 range, no loss scale) and every f16 MFMA by three bf16 passes:
+// 512 f32-input MFMAs (32 cycles each, vector-ALU rate) per 16 samples become
+// 276 bf16 ones (16 cycles).  The weights come as ucsa_mlp_pack_x3 /
+// ucsa_mlp_pack_t_x3 buffers; LDS keeps their terms 0 and 1.
+template <int NRB, bool MARCH, bool HALF, int NET = 0, bool B2 = false>
 __global__ void __launch_bounds__(64 * (NET ? CB_WAVES_SPLIT : (HALF ? CB_WAVES_H : CB_WAVES)))
 k_shade_bwd(ShadeBwdArgs a) {
+  static_assert(!(B2 && HALF), "one reduced-precision mode at a time");
   constexpr uint32_t NW = NET ? CB_WAVES_SPLIT : (HALF ? CB_WAVES_H : CB_WAVES);
   constexpr bool DO_C = NET != 2, DO_S = NET != 1;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -170,10 +180,11 @@ k_shade_bwd(ShadeBwdArgs a) {
   const uint32_t T = a.T, t = a.t, S = a.T + a.t, C = a.C;
   constexpr int NS = (NRB + 1) / 2;  // half8 k-steps covering the class logits
 
-  constexpr uint32_t WC = !DO_C ? 0 : HALF ? COLOR_H_FRAGS * 256 : 7168;
-  constexpr uint32_t WS = !DO_S ? 0 : HALF ? SEM_H_FRAGS(NRB) * 256 : 1024 + NRB * 1024;
-  constexpr uint32_t WTC = !DO_C ? 0 : HALF ? 14 * 256 : 6144;
-  constexpr uint32_t WTS = !DO_S ? 0 : HALF ? (4 * NS + 2) * 256 : (16 * NRB + 16) * 64;
+  constexpr uint32_t XT = B2 ? 2 : 1;   // bf16 terms kept per fragment
+  constexpr uint32_t WC = !DO_C ? 0 : (HALF || B2) ? COLOR_H_FRAGS * 256 * XT : 7168;
+  constexpr uint32_t WS = !DO_S ? 0 : (HALF || B2) ? SEM_H_FRAGS(NRB) * 256 * XT : 1024 + NRB * 1024;
+  constexpr uint32_t WTC = !DO_C ? 0 : (HALF || B2) ? 14 * 256 * XT : 6144;
+  constexpr uint32_t WTS = !DO_S ? 0 : (HALF || B2) ? (4 * NS + 2) * 256 * XT : (16 * NRB + 16) * 64;
   float* w_color = cb_smem;
   float* w_sem = w_color + WC;
   float* wt_color = w_sem + WS;
@@ -189,12 +200,29 @@ k_shade_bwd(ShadeBwdArgs a) {
   float* dy_tile = lz + CB_CAP;
   float* x_tile = dy_tile + 16 * TILE_LD;
 
-  for (uint32_t i = threadIdx.x; i < WC; i += blockDim.x) w_color[i] = a.packed_color[i];
-  for (uint32_t i = threadIdx.x; i < WS; i += blockDim.x) w_sem[i] = a.packed_sem[i];
-  for (uint32_t i = threadIdx.x; i < WTC; i += blockDim.x) wt_color[i] = a.packed_color_t[i];
-  for (uint32_t i = threadIdx.x; i < WTS; i += blockDim.x) wt_sem[i] = a.packed_sem_t[i];
+  if constexpr (B2) {
+    // terms 0 and 1 of the three-term global pack: [(f*3+term)*64+lane] (16 B)
+    auto copy2 = [&](float* dst, const float* src, uint32_t n_floats) {
+      const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+      u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+      for (uint32_t i = threadIdx.x; i < n_floats / 4; i += blockDim.x) {
+        const uint32_t f = i >> 7, term = (i >> 6) & 1u, l = i & 63u;
+        d4[i] = s4[(f * 3 + term) * 64 + l];
+      }
+    };
+    copy2(w_color, a.packed_color, WC);
+    copy2(w_sem, a.packed_sem, WS);
+    copy2(wt_color, a.packed_color_t, WTC);
+    copy2(wt_sem, a.packed_sem_t, WTS);
+  } else {
+    for (uint32_t i = threadIdx.x; i < WC; i += blockDim.x) w_color[i] = a.packed_color[i];
+    for (uint32_t i = threadIdx.x; i < WS; i += blockDim.x) w_sem[i] = a.packed_sem[i];
+    for (uint32_t i = threadIdx.x; i < WTC; i += blockDim.x) wt_color[i] = a.packed_color_t[i];
+    for (uint32_t i = threadIdx.x; i < WTS; i += blockDim.x) wt_sem[i] = a.packed_sem_t[i];
+  }
   __syncthreads();
   const float gs = HALF ? a.f16_scale : 1.0f, inv_gs = 1.0f / gs;
+  const X3Sel sel = x3_selectors();
 
   const uint64_t gwave = (uint64_t)blockIdx.x * NW + wid;
   f32x4 dwc1[4][2], dwc2[4][4], dwc3[1][4], dws1[4][1], dws2[NRB][4];
@@ -277,7 +305,25 @@ k_shade_bwd(ShadeBwdArgs a) {
       // forward (recompute)
       f32x4 a1c[4], a2c[4], o3[1];
       f32x4 geo_c = geo;
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        X2 b1;
+        split2_pair(sh[0], sh[1], b1, 0, sel);
+        split2_pair(sh[2], sh[3], b1, 1, sel);
+        split2_pair(geo[0], geo[1], b1, 2, sel);
+        split2_pair(geo[2], geo[3], b1, 3, sel);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1c[rb] = mfma_x2(frag_x2(w_color, rb, lane), b1, z4);
+        X2 h0 = chain_relu_x2(a1c[0], a1c[1], sel), h1 = chain_relu_x2(a1c[2], a1c[3], sel);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          a2c[rb] = mfma_x2(frag_x2(w_color, 4 + 2 * rb, lane), h0, z4);
+          a2c[rb] = mfma_x2(frag_x2(w_color, 5 + 2 * rb, lane), h1, a2c[rb]);
+        }
+        h0 = chain_relu_x2(a2c[0], a2c[1], sel);
+        h1 = chain_relu_x2(a2c[2], a2c[3], sel);
+        o3[0] = mfma_x2(frag_x2(w_color, 12, lane), h0, z4);
+        o3[0] = mfma_x2(frag_x2(w_color, 13, lane), h1, o3[0]);
+      } else if constexpr (HALF) {
         half8 b1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -328,11 +374,16 @@ k_shade_bwd(ShadeBwdArgs a) {
       for (int rb = 0; rb < 4; ++rb)
         tile_store(x_tile, g, j, rb, HALF ? relu_q4(a2c[rb]) : relu4(a2c[rb]));
       cb_sync();
-      if constexpr (HALF) dw_accumulate_h<1, 4>(dy_tile, x_tile, lane, dwc3);
+      if constexpr (B2) dw_accumulate_b2<1, 4>(dy_tile, x_tile, lane, dwc3, sel);
+      else if constexpr (HALF) dw_accumulate_h<1, 4>(dy_tile, x_tile, lane, dwc3);
       else dw_accumulate<1, 4>(dy_tile, x_tile, lane, dwc3);
       cb_sync();
       f32x4 dh2[4];
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        const X2 bd = chain_x2(dy3, z4, sel);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) dh2[rb] = mfma_x2(frag_x2(wt_color, rb, lane), bd, z4);
+      } else if constexpr (HALF) {
         const half8 bd = chain_h(dy3, z4);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) dh2[rb] = mfma_h(frag_h(wt_color, rb, lane), bd, z4);
@@ -349,11 +400,19 @@ k_shade_bwd(ShadeBwdArgs a) {
         tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1c[rb]) : relu4(a1c[rb]));
       }
       cb_sync();
-      if constexpr (HALF) dw_accumulate_h<4, 4>(dy_tile, x_tile, lane, dwc2);
+      if constexpr (B2) dw_accumulate_b2<4, 4>(dy_tile, x_tile, lane, dwc2, sel);
+      else if constexpr (HALF) dw_accumulate_h<4, 4>(dy_tile, x_tile, lane, dwc2);
       else dw_accumulate<4, 4>(dy_tile, x_tile, lane, dwc2);
       cb_sync();
       f32x4 dh1[4];
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        const X2 d0 = chain_x2(dh2[0], dh2[1], sel), d1 = chain_x2(dh2[2], dh2[3], sel);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          dh1[rb] = mfma_x2(frag_x2(wt_color, 4 + 2 * rb, lane), d0, z4);
+          dh1[rb] = mfma_x2(frag_x2(wt_color, 5 + 2 * rb, lane), d1, dh1[rb]);
+        }
+      } else if constexpr (HALF) {
         const half8 d0 = chain_h(dh2[0], dh2[1]), d1 = chain_h(dh2[2], dh2[3]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
@@ -380,10 +439,14 @@ k_shade_bwd(ShadeBwdArgs a) {
         x_tile[j * TILE_LD + (m == 0 ? 31u : 15u + m)] = geo_c[r];
       }
       cb_sync();
-      if constexpr (HALF) dw_accumulate_h<4, 2>(dy_tile, x_tile, lane, dwc1);
+      if constexpr (B2) dw_accumulate_b2<4, 2>(dy_tile, x_tile, lane, dwc1, sel);
+      else if constexpr (HALF) dw_accumulate_h<4, 2>(dy_tile, x_tile, lane, dwc1);
       else dw_accumulate<4, 2>(dy_tile, x_tile, lane, dwc1);
       cb_sync();
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        dslot[0] = mfma_x2(frag_x2(wt_color, 12, lane), chain_x2(dh1[0], dh1[1], sel), z4);
+        dslot[0] = mfma_x2(frag_x2(wt_color, 13, lane), chain_x2(dh1[2], dh1[3], sel), dslot[0]);
+      } else if constexpr (HALF) {
         dslot[0] = mfma_h(frag_h(wt_color, 12, lane), chain_h(dh1[0], dh1[1]), z4);
         dslot[0] = mfma_h(frag_h(wt_color, 13, lane), chain_h(dh1[2], dh1[3]), dslot[0]);
       } else {
@@ -400,7 +463,20 @@ k_shade_bwd(ShadeBwdArgs a) {
     if constexpr (DO_S) {
       f32x4 a1s[4], lg[NRB];
       f32x4 geo_s = geo;
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        X2 bs;
+        split2_pair(geo[0], geo[1], bs, 0, sel);
+        split2_pair(geo[2], geo[3], bs, 1, sel);
+        bs.t[0][2] = bs.t[0][3] = bs.t[1][2] = bs.t[1][3] = 0u;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a1s[rb] = mfma_x2(frag_x2(w_sem, rb, lane), bs, z4);
+        const X2 h0 = chain_relu_x2(a1s[0], a1s[1], sel), h1 = chain_relu_x2(a1s[2], a1s[3], sel);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+          lg[rb] = mfma_x2(frag_x2(w_sem, 4 + 2 * rb, lane), h0, z4);
+          lg[rb] = mfma_x2(frag_x2(w_sem, 5 + 2 * rb, lane), h1, lg[rb]);
+        }
+      } else if constexpr (HALF) {
         half8 bs;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -472,11 +548,24 @@ k_shade_bwd(ShadeBwdArgs a) {
       for (int rb = 0; rb < 4; ++rb)
         tile_store(x_tile, g, j, rb, HALF ? relu_q4(a1s[rb]) : relu4(a1s[rb]));
       cb_sync();
-      if constexpr (HALF) dw_accumulate_h<NRB, 4>(dy_tile, x_tile, lane, dws2);
+      if constexpr (B2) dw_accumulate_b2<NRB, 4>(dy_tile, x_tile, lane, dws2, sel);
+      else if constexpr (HALF) dw_accumulate_h<NRB, 4>(dy_tile, x_tile, lane, dws2);
       else dw_accumulate<NRB, 4>(dy_tile, x_tile, lane, dws2);
       cb_sync();
       f32x4 dhs[4];
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        X2 ld[NS];
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx)
+          ld[sx] = chain_x2(dlg[2 * sx], (2 * sx + 1 < NRB) ? dlg[(2 * sx + 1 < NRB) ? 2 * sx + 1 : 0] : z4, sel);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          dhs[rb] = z4;
+#pragma unroll
+          for (int sx = 0; sx < NS; ++sx)
+            dhs[rb] = mfma_x2(frag_x2(wt_sem, NS * rb + sx, lane), ld[sx], dhs[rb]);
+        }
+      } else if constexpr (HALF) {
         half8 ld[NS];
 #pragma unroll
         for (int sx = 0; sx < NS; ++sx)
@@ -507,10 +596,14 @@ k_shade_bwd(ShadeBwdArgs a) {
         x_tile[j * TILE_LD + (m == 0 ? 15u : m - 1u)] = geo_s[r];
       }
       cb_sync();
-      if constexpr (HALF) dw_accumulate_h<4, 1>(dy_tile, x_tile, lane, dws1);
+      if constexpr (B2) dw_accumulate_b2<4, 1>(dy_tile, x_tile, lane, dws1, sel);
+      else if constexpr (HALF) dw_accumulate_h<4, 1>(dy_tile, x_tile, lane, dws1);
       else dw_accumulate<4, 1>(dy_tile, x_tile, lane, dws1);
       cb_sync();
-      if constexpr (HALF) {
+      if constexpr (B2) {
+        dslot_s[0] = mfma_x2(frag_x2(wt_sem, 4 * NS, lane), chain_x2(dhs[0], dhs[1], sel), z4);
+        dslot_s[0] = mfma_x2(frag_x2(wt_sem, 4 * NS + 1, lane), chain_x2(dhs[2], dhs[3], sel), dslot_s[0]);
+      } else if constexpr (HALF) {
         dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS, lane), chain_h(dhs[0], dhs[1]), z4);
         dslot_s[0] = mfma_h(frag_h(wt_sem, 4 * NS + 1, lane), chain_h(dhs[2], dhs[3]), dslot_s[0]);
       } else {
@@ -777,7 +870,7 @@ k_weights_bwd(const float* __restrict__ z_c, const float* __restrict__ z_f,
 
 // ---------------------------------------------------------------------------
 static int32_t composite_bwd_impl(
-    bool half, float f16_scale, const float* rays_d, const float* norms,
+    int mode, float f16_scale, const float* rays_d, const float* norms,
     const float* z_c, const float* sigma_c, const float* h_c, const float* z_f,
     const float* sigma_f, const float* h_f, const int32_t* src,
     const float* weights, const float* packed_color, const float* packed_sem,
@@ -797,7 +890,9 @@ static int32_t composite_bwd_impl(
   UCSA_CHECK_ARG(n_classes >= 1 && n_classes <= 61, 20);
   UCSA_CHECK_ARG(G && d_h_c && (t == 0 || d_h_f), 22);
   UCSA_CHECK_ARG(partial_color && partial_sem, 25);
+  const bool half = mode == 1, x2 = mode == 2;
   UCSA_CHECK_ARG(!half || f16_scale > 0.f, 28);
+  UCSA_CHECK_ARG(!x2 || shade_bwd_split(), 0);   // bf16x2 exists as the per-net pair only
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t nrb = cb_pad16(n_classes) / 16;
@@ -822,26 +917,29 @@ static int32_t composite_bwd_impl(
   const size_t smem = w_floats * 4 + per_wave_b;
   if (split) {
     const size_t ns = (nrb + 1) / 2;
-    const size_t smem_c = (half ? (size_t)(COLOR_H_FRAGS + 14) * 256 : 7168 + 6144) * 4 + per_wave_b;
-    const size_t smem_s = (half ? (size_t)(SEM_H_FRAGS(nrb) + 4 * ns + 2) * 256
-                                : 1024 + (size_t)nrb * 1024 + (16 * (size_t)nrb + 16) * 64) * 4 +
+    const size_t xt = x2 ? 2 : 1;
+    const size_t smem_c = ((half || x2) ? (size_t)(COLOR_H_FRAGS + 14) * 256 * xt : 7168 + 6144) * 4 +
                           per_wave_b;
-#define LAUNCH_NET(NRB, H, NET, SM)                                           \
+    const size_t smem_s = ((half || x2) ? (size_t)(SEM_H_FRAGS(nrb) + 4 * ns + 2) * 256 * xt
+                                        : 1024 + (size_t)nrb * 1024 + (16 * (size_t)nrb + 16) * 64) * 4 +
+                          per_wave_b;
+#define LAUNCH_NET(NRB, H, NET, XX, SM)                                       \
   do {                                                                        \
     hipError_t e2 = hipFuncSetAttribute(                                      \
-        reinterpret_cast<const void*>(&k_shade_bwd<NRB, false, H, NET>),      \
+        reinterpret_cast<const void*>(&k_shade_bwd<NRB, false, H, NET, XX>),  \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SM));               \
     if (e2 != hipSuccess) return -(int32_t)e2;                                \
     UCSA_CLEAR_ERR();                                                         \
-    hipLaunchKernelGGL((k_shade_bwd<NRB, false, H, NET>), dim3(blocks),       \
+    hipLaunchKernelGGL((k_shade_bwd<NRB, false, H, NET, XX>), dim3(blocks),   \
                        dim3(64 * waves), (SM), s, a);                         \
     int32_t rc2 = ucsa_launch_status();                                       \
     if (rc2) return rc2;                                                      \
   } while (0)
 #define LAUNCH_PAIR(NRB)                                                      \
   do {                                                                        \
-    if (half) { LAUNCH_NET(NRB, true, 1, smem_c); LAUNCH_NET(NRB, true, 2, smem_s); } \
-    else { LAUNCH_NET(NRB, false, 1, smem_c); LAUNCH_NET(NRB, false, 2, smem_s); }    \
+    if (x2) { LAUNCH_NET(NRB, false, 1, true, smem_c); LAUNCH_NET(NRB, false, 2, true, smem_s); } \
+    else if (half) { LAUNCH_NET(NRB, true, 1, false, smem_c); LAUNCH_NET(NRB, true, 2, false, smem_s); } \
+    else { LAUNCH_NET(NRB, false, 1, false, smem_c); LAUNCH_NET(NRB, false, 2, false, smem_s); }    \
   } while (0)
     switch (nrb) {
       case 1: LAUNCH_PAIR(1); break;
@@ -899,7 +997,7 @@ extern "C" int32_t ucsa_composite_bwd(
     uint32_t T, uint32_t t, uint32_t n_classes, float density_scale, float* G,
     float* d_h_c, float* d_h_f, float* partial_color, float* partial_sem,
     void* stream) {
-  return composite_bwd_impl(false, 1.0f, rays_d, norms, z_c, sigma_c, h_c, z_f,
+  return composite_bwd_impl(0, 1.0f, rays_d, norms, z_c, sigma_c, h_c, z_f,
                             sigma_f, h_f, src, weights, packed_color,
                             packed_sem, packed_color_t, packed_sem_t, d_image,
                             d_depth, d_sem, N, T, t, n_classes, density_scale,
@@ -916,7 +1014,7 @@ extern "C" int32_t ucsa_composite_bwd_f16(
     const float* d_sem, uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes,
     float density_scale, float f16_scale, float* G, float* d_h_c, float* d_h_f,
     float* partial_color, float* partial_sem, void* stream) {
-  return composite_bwd_impl(true, f16_scale, rays_d, norms, z_c, sigma_c, h_c,
+  return composite_bwd_impl(1, f16_scale, rays_d, norms, z_c, sigma_c, h_c,
                             z_f, sigma_f, h_f, src, weights,
                             (const float*)packed_color_half,
                             (const float*)packed_sem_half,
@@ -924,6 +1022,29 @@ extern "C" int32_t ucsa_composite_bwd_f16(
                             (const float*)packed_sem_t_half, d_image, d_depth,
                             d_sem, N, T, t, n_classes, density_scale, G, d_h_c,
                             d_h_f, partial_color, partial_sem, stream);
+}
+
+// The colour / semantics backward with every contraction on the bf16 MFMA pipe
+// as two-term splits (k_shade_bwd<.., B2>): fp32 range, 2^-16 per product.
+// Weights: ucsa_mlp_pack_x3 / ucsa_mlp_pack_t_x3 buffers.  Needs the per-net
+// kernel pair (UCSA_SHADE_BWD_SPLIT != 0).
+extern "C" int32_t ucsa_composite_bwd_x2(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const int32_t* src,
+    const float* weights, const void* packed_color_x3, const void* packed_sem_x3,
+    const void* packed_color_t_x3, const void* packed_sem_t_x3,
+    const float* d_image, const float* d_depth, const float* d_sem, uint32_t N,
+    uint32_t T, uint32_t t, uint32_t n_classes, float density_scale, float* G,
+    float* d_h_c, float* d_h_f, float* partial_color, float* partial_sem,
+    void* stream) {
+  return composite_bwd_impl(2, 1.0f, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f,
+                            h_f, src, weights, (const float*)packed_color_x3,
+                            (const float*)packed_sem_x3,
+                            (const float*)packed_color_t_x3,
+                            (const float*)packed_sem_t_x3, d_image, d_depth, d_sem,
+                            N, T, t, n_classes, density_scale, G, d_h_c, d_h_f,
+                            partial_color, partial_sem, stream);
 }
 
 // ===========================================================================

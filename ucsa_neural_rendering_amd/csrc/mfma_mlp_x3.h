@@ -123,3 +123,117 @@ __device__ __forceinline__ f32x4 mfma_x3(const W3& w, const X3& x, f32x4 acc) {
   acc = mfma_b(w.t[0], x.t[0], acc);
   return acc;
 }
+
+// ---------------------------------------------------------------------------
+// "bf16x2": the two-term form, for GRADIENT contractions (round 4,
+// k_shade_bwd<.., B2>).  x = x0 + x1 with x0 = bf16(x), x1 = bf16(x - x0)
+// carries 16 significant bits; a product is accumulated from the three partial
+// products of order <= 1 (x1*w0 + x0*w1 + x0*w0), what is dropped is at most
+// 2^-16 |x*w|.  Gradients are compared with the oracle at 2e-3 relative L2
+// (tests/test_gpu_backward.py, test_gpu_configs.py); the forward stays bf16x3.
+// Weight fragments in LDS keep terms 0 and 1 of the x3 pack:
+// lds[(f * 2 + term) * 64 + lane].
+// ---------------------------------------------------------------------------
+struct X2 {
+  u32x4 t[2];
+};
+struct W2 {
+  u32x4 t[2];
+};
+
+__device__ __forceinline__ void split2_pair(float a, float b, X2& x, int d,
+                                            const X3Sel& sel) {
+  const uint32_t p0 = bf16_pair(a, b);
+  const float ra = resid_lo(p0, a, sel), rb = resid_hi(p0, b, sel);
+  x.t[0][d] = p0;
+  x.t[1][d] = bf16_pair(ra, rb);
+}
+
+// two accumulator blocks -> one 32-wide k-step operand, with / without ReLU
+__device__ __forceinline__ X2 chain_relu_x2(f32x4 lo, f32x4 hi, const X3Sel& sel) {
+  X2 x;
+  split2_pair(relu1(lo[0]), relu1(lo[1]), x, 0, sel);
+  split2_pair(relu1(lo[2]), relu1(lo[3]), x, 1, sel);
+  split2_pair(relu1(hi[0]), relu1(hi[1]), x, 2, sel);
+  split2_pair(relu1(hi[2]), relu1(hi[3]), x, 3, sel);
+  return x;
+}
+__device__ __forceinline__ X2 chain_x2(f32x4 lo, f32x4 hi, const X3Sel& sel) {
+  X2 x;
+  split2_pair(lo[0], lo[1], x, 0, sel);
+  split2_pair(lo[2], lo[3], x, 1, sel);
+  split2_pair(hi[0], hi[1], x, 2, sel);
+  split2_pair(hi[2], hi[3], x, 3, sel);
+  return x;
+}
+
+// A fragment f of a two-term weight buffer in LDS
+__device__ __forceinline__ W2 frag_x2(const void* lds2, int f, uint32_t lane) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(lds2) + (f * 2) * 64 + lane;
+  W2 w;
+  w.t[0] = p[0];
+  w.t[1] = p[64];
+  return w;
+}
+
+// acc += W * x, three partial products, smallest first
+__device__ __forceinline__ f32x4 mfma_x2(const W2& w, const X2& x, f32x4 acc) {
+  acc = mfma_b(w.t[1], x.t[0], acc);
+  acc = mfma_b(w.t[0], x.t[1], acc);
+  acc = mfma_b(w.t[0], x.t[0], acc);
+  return acc;
+}
+
+// dW[ob][ib] += dY_tile^T X_tile over the 16 samples of the tile
+// (v_mfma_f32_16x16x16_bf16, three passes): lane (k = lane >> 4, i = lane & 15)
+// holds samples 4k .. 4k+3 of neuron 16*ob + i (A) resp. 16*ib + i (B), the
+// LDS words dw_accumulate reads, each split into two bf16 terms.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct B2x4 {  // four values, two bf16 terms each
+  u32x2 t[2];
+};
+__device__ __forceinline__ B2x4 split2_quad(float a, float b, float c, float d,
+                                            const X3Sel& sel) {
+  B2x4 q;
+  const uint32_t p0 = bf16_pair(a, b), p1 = bf16_pair(c, d);
+  q.t[0][0] = p0;
+  q.t[0][1] = p1;
+  q.t[1][0] = bf16_pair(resid_lo(p0, a, sel), resid_hi(p0, b, sel));
+  q.t[1][1] = bf16_pair(resid_lo(p1, c, sel), resid_hi(p1, d, sel));
+  return q;
+}
+__device__ __forceinline__ f32x4 mfma_b16(u32x2 a, u32x2 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a),
+                                                   __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+template <int OB, int IB>
+__device__ __forceinline__ void dw_accumulate_b2(const float* dy_tile,
+                                                 const float* x_tile, uint32_t lane,
+                                                 f32x4 (&dw)[OB][IB],
+                                                 const X3Sel& sel) {
+  const uint32_t i = lane & 15u, k = lane >> 4;
+  B2x4 a[OB], b[IB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    const float* p = dy_tile + (4 * k) * TILE_LD + 16 * ob + i;
+    a[ob] = split2_quad(p[0], p[TILE_LD], p[2 * TILE_LD], p[3 * TILE_LD], sel);
+  }
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib) {
+    const float* p = x_tile + (4 * k) * TILE_LD + 16 * ib + i;
+    b[ib] = split2_quad(p[0], p[TILE_LD], p[2 * TILE_LD], p[3 * TILE_LD], sel);
+  }
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+      f32x4 acc = dw[ob][ib];
+      acc = mfma_b16(a[ob].t[1], b[ib].t[0], acc);
+      acc = mfma_b16(a[ob].t[0], b[ib].t[1], acc);
+      acc = mfma_b16(a[ob].t[0], b[ib].t[0], acc);
+      dw[ob][ib] = acc;
+    }
+}

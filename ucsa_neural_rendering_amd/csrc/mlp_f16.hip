@@ -126,13 +126,9 @@ extern "C" int32_t ucsa_mlp_pack_x3(int32_t kind, const float* params,
 //   sem   : [L2^T 4*NS (rb, s), NS = ceil(nrb/2), classes >= 16*nrb -> 0
 //            | L1^T (h-row slots) 2]
 // ---------------------------------------------------------------------------
-__global__ void k_mlp_pack_t_f16(int kind, const float* __restrict__ params,
-                                 _Float16* __restrict__ packed,
-                                 uint32_t n_total, uint32_t nrb) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_total) return;
-  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u;
-  uint32_t f = idx >> 9;
+__device__ __forceinline__ float pack_t_value(int kind, const float* __restrict__ params,
+                                              uint32_t f, uint32_t l, uint32_t e,
+                                              uint32_t nrb) {
   const uint32_t g = l >> 4, i = l & 15u;
   float v = 0.f;
   if (kind == UCSA_MLP_COLOR) {
@@ -156,7 +152,32 @@ __global__ void k_mlp_pack_t_f16(int kind, const float* __restrict__ params,
       v = params[chain_col_h(f - 4 * ns, g, e) * 16 + col];
     }
   }
-  packed[idx] = (_Float16)v;
+  return v;
+}
+
+__global__ void k_mlp_pack_t_f16(int kind, const float* __restrict__ params,
+                                 _Float16* __restrict__ packed,
+                                 uint32_t n_total, uint32_t nrb) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total) return;
+  packed[idx] = (_Float16)pack_t_value(kind, params, idx >> 9, (idx >> 3) & 63u, idx & 7u, nrb);
+}
+
+// the same transposed fragments as three exact bf16 terms (layout of
+// k_mlp_pack_x3): dX = W^T dY of k_shade_bwd's bf16x2 mode reads terms 0, 1
+__global__ void k_mlp_pack_t_x3(int kind, const float* __restrict__ params,
+                                uint16_t* __restrict__ packed, uint32_t n_total,
+                                uint32_t nrb) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total) return;
+  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u, f = idx >> 9;
+  float r = pack_t_value(kind, params, f, l, e, nrb);
+#pragma unroll
+  for (uint32_t term = 0; term < 3; ++term) {
+    const uint32_t bits = bf16_pair(r, 0.f) & 0xFFFFu;
+    packed[((f * 3 + term) * 64 + l) * 8 + e] = (uint16_t)bits;
+    r -= __uint_as_float(bits << 16);
+  }
 }
 
 extern "C" uint32_t ucsa_mlp_pack_t_f16_halves(int32_t kind, uint32_t n_classes) {
@@ -178,6 +199,26 @@ extern "C" int32_t ucsa_mlp_pack_t_f16(int32_t kind, const float* params,
   hipLaunchKernelGGL(k_mlp_pack_t_f16, dim3(ucsa_div_up(n_total, 256)), dim3(256),
                      0, (hipStream_t)stream, (int)kind, params,
                      (_Float16*)packed_half, n_total, nrb);
+  return ucsa_launch_status();
+}
+
+extern "C" uint32_t ucsa_mlp_pack_t_x3_bytes(int32_t kind, uint32_t n_classes) {
+  return ucsa_mlp_pack_t_f16_halves(kind, n_classes) * 2u * 3u;
+}
+
+extern "C" int32_t ucsa_mlp_pack_t_x3(int32_t kind, const float* params,
+                                      void* packed_x3, uint32_t n_classes,
+                                      void* stream) {
+  UCSA_CHECK_ARG(kind == UCSA_MLP_COLOR || kind == UCSA_MLP_SEM, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed_x3, 2);
+  UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
+  const uint32_t n_total = ucsa_mlp_pack_t_f16_halves(kind, n_classes);
+  const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack_t_x3, dim3(ucsa_div_up(n_total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (int)kind, params, (uint16_t*)packed_x3,
+                     n_total, nrb);
   return ucsa_launch_status();
 }
 

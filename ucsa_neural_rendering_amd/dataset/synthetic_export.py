@@ -22,10 +22,11 @@ def ngp_to_nerf_matrix(n):
 
 
 def export(root, scene_seed=0, n_views=10, H=240, W=320, device="cuda",
-           scene_name=None):
+           scene_name=None, palette_seed=None):
     from PIL import Image
     from .synthetic_scene import SyntheticSceneDataset
-    ds = SyntheticSceneDataset(scene_seed, n_views, H, W, device=device)
+    ds = SyntheticSceneDataset(scene_seed, n_views, H, W, device=device,
+                               palette_seed=palette_seed)
     name = scene_name or f"scene{scene_seed:04d}_00"
     sroot = os.path.join(root, name)
     for sub in ("color", "label_40", "depth"):

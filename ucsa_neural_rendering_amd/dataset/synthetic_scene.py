@@ -47,7 +47,12 @@ def _slerp_loop_poses(n, radius=1.8, height=0.2, seed=123):
 class SyntheticRoom:
     """Room = inside of the box [-3,3]^3; objects = solid axis-aligned boxes."""
 
-    def __init__(self, seed=0, n_boxes=4, n_classes=40):
+    def __init__(self, seed=0, n_boxes=4, n_classes=40, palette_seed=None):
+        """``palette_seed``: None = every room draws its own class colours (the
+        benchmarks' rooms); an int = ONE class -> colour table shared by all
+        rooms built with it, so that appearance predicts the class ACROSS
+        rooms -- what a segmentation network pre-trained on other rooms needs
+        (the continual loop, cfg5: `synthetic: {palette_seed: ...}`)."""
         g = torch.Generator().manual_seed(1000 + seed)
         self.n_classes = n_classes
         self.room = torch.tensor([[-3.0, -3.0, -3.0], [3.0, 3.0, 3.0]])
@@ -66,6 +71,9 @@ class SyntheticRoom:
         self.boxes = torch.stack(boxes) if boxes else torch.zeros(0, 2, 3)
         self.box_cls = torch.tensor(cls, dtype=torch.int64)
         self.palette = torch.rand(n_classes, 3, generator=g) * 0.7 + 0.2
+        if palette_seed is not None:
+            gp = torch.Generator().manual_seed(77000 + int(palette_seed))
+            self.palette = torch.rand(n_classes, 3, generator=gp) * 0.7 + 0.2
 
     def to(self, device):
         for k in ("room", "room_cls", "boxes", "box_cls", "palette"):
@@ -104,10 +112,11 @@ class SyntheticSceneDataset(torch.utils.data.Dataset):
     """One synthetic scene: n_views posed images with rays, rgb, depth, label."""
 
     def __init__(self, scene_seed=0, n_views=16, H=240, W=320, n_classes=40,
-                 device="cuda", scene_name=None, label_noise=0.0):
+                 device="cuda", scene_name=None, label_noise=0.0, palette_seed=None):
         self.H, self.W = H, W
         self.device = torch.device(device)
-        self.room = SyntheticRoom(scene_seed, n_classes=n_classes).to(self.device)
+        self.room = SyntheticRoom(scene_seed, n_classes=n_classes,
+                                  palette_seed=palette_seed).to(self.device)
         self.poses = _slerp_loop_poses(n_views, seed=123 + scene_seed).to(self.device)
         # ScanNet-like pinhole scaled to W x H (SURVEY 8d)
         self.intrinsics = torch.tensor([0.89 * W, 0.89 * W, W / 2.0, H / 2.0])

@@ -79,6 +79,9 @@ class JointTrainLightningNet(nn.Module):
         # the split pair with the bf16x3 nets (fp32-grade, 1e-7 from the
         # f32-input MFMA chain that "fp32" selects); the backward is the same.
         self.nerf_model.train_precision = str(nerf_cfg.get("train_precision", "bf16x3"))
+        # `nerf: {bwd_precision: fp32}`: keep the f32-input MFMA kernels for the
+        # backward of the bf16x3 mode (default bf16x2: renderer_semantics.py)
+        self.nerf_model.bwd_precision = str(nerf_cfg.get("bwd_precision", "bf16x2"))
         self.nerf_model.f16_bwd_scale = float(nerf_cfg.get("f16_bwd_scale", 1.0))
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last

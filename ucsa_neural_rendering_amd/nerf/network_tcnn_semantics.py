@@ -73,16 +73,24 @@ class _RenderFn(torch.autograd.Function):
             # the bf16x3 nets (fp32-grade, the dense bf16 MFMA pipe): same
             # values as the f32-input MFMA chain to ~1e-7; the backward
             # recomputes the nets with the f32-input MFMA as before
+            pcx, psx = net._pack_x3("color", net.color_net), net._pack_x3("sem", net.semantics_net)
             image, depth, sem, src, w = ops.composite_train_fwd_x3(
-                d, nrm, z_c, s_c, h_c, z_f, s_f, h_f,
-                net._pack_x3("color", net.color_net),
-                net._pack_x3("sem", net.semantics_net), C, ds)
+                d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, pcx, psx, C, ds)
+            # ... and (round 4) the backward's contractions on the bf16 pipe as
+            # two-term splits (2^-16 per product; `nerf: {bwd_precision: fp32}`
+            # keeps the f32-input MFMA kernels)
+            if net.bwd_precision == "bf16x2" and ops.shade_bwd_split():
+                ctx.x2 = True
+                f = dict(f, packed_color=pcx, packed_sem=psx,
+                         packed_color_t=net._pack_t_x3("color", net.color_net),
+                         packed_sem_t=net._pack_t_x3("sem", net.semantics_net))
         else:
             image, depth, sem, src, w = ops.composite_fwd(
                 d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, f["packed_color"],
                 f["packed_sem"], C, ds, want_aux=True, half=half)
         ctx.half = half
         ctx.tcnn = tcnn
+        ctx.x2 = bool(getattr(ctx, "x2", False))
         ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t = net, f, aabb, T, t
         ctx.saved = (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f,
                      src, w)
@@ -99,7 +107,7 @@ class _RenderFn(torch.autograd.Function):
             d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, src, w, f["packed_color"],
             f["packed_sem"], f["packed_color_t"], f["packed_sem_t"],
             d_image.contiguous(), d_depth.contiguous(), d_sem.contiguous(), C,
-            ds, half=ctx.half, f16_scale=float(net.f16_bwd_scale))
+            ds, half=ctx.half, f16_scale=float(net.f16_bwd_scale), x2=ctx.x2)
         g_color = torch.empty_like(net.color_net.params)
         g_sem = torch.empty_like(net.semantics_net.params)
         ops.reduce_partials(pc, g_color, False)
@@ -287,6 +295,18 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
                                      out=out)
             self._packed[name + "_x3"] = (key, packed)
         return self._packed[name + "_x3"][1]
+
+    def _pack_t_x3(self, name: str, net: FullyFusedMLP):
+        """Transposed fragments of ``net`` as bf16 terms (the dX contractions
+        of the bf16x2 backward), refreshed when the parameters change."""
+        p = net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get(name + "_t_x3")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            packed = ops.mlp_pack_t_x3(net.kind, p, self.num_semantic_classes, out=out)
+            self._packed[name + "_t_x3"] = (key, packed)
+        return self._packed[name + "_t_x3"][1]
 
     def _table_half(self):
         """fp16 copy of the hash table (what tiny-cuda-nn stores), refreshed

@@ -13,8 +13,10 @@ value-for-value.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -60,7 +62,9 @@ class SemanticNeRFRenderer(nn.Module):
         self.hip_streams = 1
         # no-grad renders of >= 2 chunks as one software-pipelined call
         # (ucsa_render_view: density half of chunk k+1 || shading half of chunk k)
-        self.hip_pipeline = True
+        self.hip_pipeline = os.environ.get("UCSA_RENDER_PIPELINE", "1") != "0"
+        # the pipelined call balances its chunks: ceil(N / min(hip_ray_chunk, this)) of them
+        self.hip_pipeline_rays = int(os.environ.get("UCSA_PIPELINE_RAYS", "65536"))
         # inference (no-grad render) arithmetic of the three MLPs:
         #   "fp32"   f32-input MFMA, bit for bit a k-ordered fmaf chain (the
         #            same kernels arithmetic as the training forward);
@@ -83,6 +87,11 @@ class SemanticNeRFRenderer(nn.Module):
         # is tiny-cuda-nn's loss scale for the f16 gradient operands (set it to
         # 1 when the incoming gradients already carry a GradScaler scale).
         self.train_precision = "fp32"
+        # with train_precision="bf16x3": the backward's contractions of the
+        # colour / semantics nets -- "bf16x2" (default: bf16 MFMA pipe, two-term
+        # operand splits, 2^-16 per product; gradients within the 2e-3 of the
+        # oracle the fp32 kernels are held to) or "fp32" (f32-input MFMA)
+        self.bwd_precision = "bf16x2"
         self.f16_bwd_scale = 1024.0
         # with train_precision="fp16": the hash-grid backward's bin records
         # carry half2 values (8 instead of 16 bytes per record)
@@ -461,6 +470,30 @@ class SemanticNeRFRenderer(nn.Module):
             "semantics": sem.view(*prefix, C),
         }
 
+    def infer_chunk(self, N: int, image_width: int = 0):
+        """(rays per enqueue, image_width or 0) of a no-grad render of N rays:
+        ``hip_ray_chunk`` at most; whole 8-row bands of 8x8 pixel tiles when the
+        rays are full image rows; and, for the pipelined call, >= 2 BALANCED
+        chunks (a 320x240 frame is 2 x 38 400 rays, not 65 536 + 11 264).
+        Measured on the 640x480 view (tools/chunk_sweep.py): 15.7 - 16.1 M
+        rays/s for any chunk between 20 k and 150 k rays, one 307 k chunk 15.3;
+        the joint step: 192 ms unpipelined, 187 / 184 ms with 2 / 3 chunks per
+        frame.  Larger launches keep the encoder's per-launch efficiency (the
+        bench's roofline figure), hence hip_ray_chunk as the cap.  Results do
+        not depend on any of it."""
+        chunk = max(1, int(self.hip_ray_chunk))
+        band = 8 * image_width if (image_width and N % image_width == 0) else 0
+        if self.hip_pipeline and int(self.hip_streams) <= 1 and N > 16384:
+            n = max(2, -(-N // min(chunk, max(64, self.hip_pipeline_rays))))
+            chunk = -(-N // n)
+            unit = band if band and chunk >= band else 64
+            chunk = -(-chunk // unit) * unit
+        if band and chunk >= band:
+            chunk -= chunk % band  # whole 8-row bands of tiles
+        else:
+            image_width = 0
+        return chunk, image_width
+
     def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near,
                    image_width=0):
         if self.precision not in ("fp32", "fp16", "bf16x3"):
@@ -484,11 +517,7 @@ class SemanticNeRFRenderer(nn.Module):
         image = torch.empty(N, 3, device=dev)
         depth = torch.empty(N, device=dev)
         sem = torch.empty(N, C, device=dev)
-        chunk = max(1, int(self.hip_ray_chunk))
-        if image_width and N % image_width == 0 and chunk >= 8 * image_width:
-            chunk -= chunk % (8 * image_width)  # whole 8-row bands of tiles
-        else:
-            image_width = 0
+        chunk, image_width = self.infer_chunk(N, image_width)
         n_chunks = (N + chunk - 1) // chunk
         if self.hip_pipeline and n_chunks >= 2 and int(self.hip_streams) <= 1:
             # ONE call for the whole batch: density half of chunk k+1 next to

@@ -7,6 +7,7 @@ on torch's current stream.  No arithmetic happens here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -602,13 +603,32 @@ def mlp_pack_t_f16(kind: int, params: torch.Tensor, n_classes: int = 0,
     return out
 
 
+def mlp_pack_t_x3(kind: int, params: torch.Tensor, n_classes: int = 0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Transposed weight fragments (dX = W^T dY) as three bf16 terms."""
+    params = _f32(params.detach(), "params")
+    n = int(lib().ucsa_mlp_pack_t_x3_bytes(kind, n_classes))
+    if out is None:
+        out = torch.empty(n // 2, dtype=torch.bfloat16, device=params.device)
+    check(lib().ucsa_mlp_pack_t_x3(kind, _ptr(params), _ptr(out), n_classes,
+                                   _stream()), "ucsa_mlp_pack_t_x3")
+    return out
+
+
+def shade_bwd_split() -> bool:
+    """The colour / semantics backward runs as the per-net kernel pair
+    (default; UCSA_SHADE_BWD_SPLIT=0 keeps the single kernel)."""
+    return os.environ.get("UCSA_SHADE_BWD_SPLIT", "1")[:1] != "0"
+
+
 def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
                   weights, packed_color, packed_sem, packed_color_t,
                   packed_sem_t, d_image, d_depth, d_sem, n_classes: int,
                   density_scale: float = 1.0, half: bool = False,
-                  f16_scale: float = 1024.0):
+                  f16_scale: float = 1024.0, x2: bool = False):
     """-> d_h_c [N*T,16], d_h_f [N*t,16] | None, partial_color, partial_sem.
-    half=True: packed weights from mlp_pack_f16 / mlp_pack_t_f16."""
+    half=True: packed weights from mlp_pack_f16 / mlp_pack_t_f16; x2=True:
+    from mlp_pack_x3 / mlp_pack_t_x3 (bf16x2 contractions)."""
     N, T = z_c.shape
     t = 0 if z_f is None else z_f.shape[1]
     dev = z_c.device
@@ -629,7 +649,9 @@ def composite_bwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f, src,
             _ptr(packed_sem_t), _ptr(d_image), _ptr(d_depth), _ptr(d_sem), N, T,
             t, n_classes, float(density_scale))
     tail = (_ptr(G), _ptr(d_h_c), _ptr(d_h_f), _ptr(pc), _ptr(ps), _stream())
-    if half:
+    if x2:
+        check(lib().ucsa_composite_bwd_x2(*head, *tail), "ucsa_composite_bwd_x2")
+    elif half:
         check(lib().ucsa_composite_bwd_f16(*head, float(f16_scale), *tail),
               "ucsa_composite_bwd_f16")
     else:
