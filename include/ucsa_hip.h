@@ -460,6 +460,15 @@ int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
                            const float* packed_sigma_t, uint32_t M,
                            uint32_t n_levels, float* d_feat, float* partial,
                            void* stream);
+/* The same backward with its contractions on the bf16 MFMA pipe as two-term
+ * splits (bf16x2, see ucsa_composite_bwd_x2): packed_sigma_x3 from
+ * ucsa_mlp_pack_x3(UCSA_MLP_SIGMA), packed_sigma_t_x3 from ucsa_mlp_pack_t_x3
+ * (8 fragments).  Same inputs, outputs and partial-slot count. */
+int32_t ucsa_sigma_mlp_bwd_x2(const float* feat, const float* d_h,
+                              const void* packed_sigma_x3,
+                              const void* packed_sigma_t_x3, uint32_t M,
+                              uint32_t n_levels, float* d_feat, float* partial,
+                              void* stream);
 
 /* ucsa_hashgrid_bwd_rays with 8-byte bin records: the (entry, vx, vy) records
  * of the fine levels carry their value pair as half2 x rec_scale (a power of

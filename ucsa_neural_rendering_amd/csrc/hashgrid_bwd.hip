@@ -452,6 +452,9 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
   }
 }
 
+#ifndef ACC_INFLIGHT
+#define ACC_INFLIGHT 8
+#endif
 extern __shared__ __attribute__((aligned(16))) float binacc_smem[];
 
 template <bool HREC>
@@ -493,14 +496,14 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
     }
   } else {
   const float4* rec = records + ((size_t)level * BIN_COUNT + bin) * bg.cap;
-  // 4 record loads in flight per thread before the LDS adds
+  // ACC_INFLIGHT record loads in flight per thread before the LDS adds
   uint32_t i = threadIdx.x;
-  for (; i + 3 * 512 < n; i += 4 * 512) {
-    float4 r[4];
+  for (; i + (ACC_INFLIGHT - 1) * 512 < n; i += ACC_INFLIGHT * 512) {
+    float4 r[ACC_INFLIGHT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = rec[i + k * 512];
+    for (int k = 0; k < ACC_INFLIGHT; ++k) r[k] = rec[i + k * 512];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < ACC_INFLIGHT; ++k)
       lds_add_pair(&acc[2 * __float_as_uint(r[k].x)], r[k].y, r[k].z);
   }
   for (; i < n; i += 512) {

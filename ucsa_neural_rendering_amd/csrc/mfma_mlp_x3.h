@@ -131,6 +131,10 @@ __device__ __forceinline__ f32x4 mfma_x3(const W3& w, const X3& x, f32x4 acc) {
 // products of order <= 1 (x1*w0 + x0*w1 + x0*w0), what is dropped is at most
 // 2^-16 |x*w|.  Gradients are compared with the oracle at 2e-3 relative L2
 // (tests/test_gpu_backward.py, test_gpu_configs.py); the forward stays bf16x3.
+// The backward kernels RECOMPUTE the hidden layers with these products: a
+// unit whose pre-activation is within ~1e-5 of zero may get the other ReLU
+// gate than in the forward -- the other subgradient at a kink, on ~1e-5 of the
+// units (as in any reduced-precision backward, tiny-cuda-nn's fp16 included).
 // Weight fragments in LDS keep terms 0 and 1 of the x3 pack:
 // lds[(f * 2 + term) * 64 + lane].
 // ---------------------------------------------------------------------------

@@ -131,7 +131,15 @@ __device__ __forceinline__ float pack_t_value(int kind, const float* __restrict_
                                               uint32_t nrb) {
   const uint32_t g = l >> 4, i = l & 15u;
   float v = 0.f;
-  if (kind == UCSA_MLP_COLOR) {
+  if (kind == UCSA_MLP_SIGMA) {
+    // [L2^T 4 frags (k-slots e<4 = output row 4g+e, rest 0) | L1^T (rb, s): 4]
+    if (f < 4) {
+      if (e < 4) v = params[64 * 32 + (4u * g + e) * 64 + 16u * f + i];
+    } else {
+      const uint32_t rb = (f - 4) >> 1, sidx = (f - 4) & 1u;
+      v = params[chain_col_h(sidx, g, e) * 32 + 16u * rb + i];
+    }
+  } else if (kind == UCSA_MLP_COLOR) {
     if (f < 4) {
       if (e < 4) v = params[64 * 32 + 64 * 64 + (4u * g + e) * 64 + 16u * f + i];
     } else if (f < 12) {
@@ -202,18 +210,21 @@ extern "C" int32_t ucsa_mlp_pack_t_f16(int32_t kind, const float* params,
   return ucsa_launch_status();
 }
 
+#define SIGMA_T_FRAGS 8
+
 extern "C" uint32_t ucsa_mlp_pack_t_x3_bytes(int32_t kind, uint32_t n_classes) {
+  if (kind == UCSA_MLP_SIGMA) return SIGMA_T_FRAGS * 64 * 8 * 2u * 3u;
   return ucsa_mlp_pack_t_f16_halves(kind, n_classes) * 2u * 3u;
 }
 
 extern "C" int32_t ucsa_mlp_pack_t_x3(int32_t kind, const float* params,
                                       void* packed_x3, uint32_t n_classes,
                                       void* stream) {
-  UCSA_CHECK_ARG(kind == UCSA_MLP_COLOR || kind == UCSA_MLP_SEM, 0);
+  UCSA_CHECK_ARG(kind >= 0 && kind <= 2, 0);
   UCSA_CHECK_ARG(params, 1);
   UCSA_CHECK_ARG(packed_x3, 2);
   UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
-  const uint32_t n_total = ucsa_mlp_pack_t_f16_halves(kind, n_classes);
+  const uint32_t n_total = ucsa_mlp_pack_t_x3_bytes(kind, n_classes) / 6u;
   const uint32_t nrb = ((n_classes ? n_classes : 1) + 15u) / 16u;
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_mlp_pack_t_x3, dim3(ucsa_div_up(n_total, 256)), dim3(256), 0,
@@ -384,5 +395,145 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_x3(const float* feat,
   hipLaunchKernelGGL(k_sigma_mlp_x3, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_x3,
                      (uint64_t)M, h, sigma);
+  return ucsa_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------
+// sigma MLP backward with every contraction on the bf16 MFMA pipe as two-term
+// splits (mfma_mlp_x3.h "bf16x2"; the f32-input form is k_sigma_mlp_bwd,
+// mlp_bwd.hip -- same inputs, outputs and partial layout).  Per 16 samples:
+// 12 (forward L1 recompute) + 12 + 12 (dX) bf16 16x16x32 MFMAs and 12 + 24
+// (dW, 16x16x16) instead of 128 f32-input MFMAs.
+// ---------------------------------------------------------------------------
+#define SIGX_WAVES 4
+extern __shared__ __attribute__((aligned(16))) float sigx_smem[];
+
+__global__ void __launch_bounds__(64 * SIGX_WAVES)
+k_sigma_mlp_bwd_x2(const float2* __restrict__ feat, const float* __restrict__ d_h,
+                   const void* __restrict__ packed, const void* __restrict__ packed_t,
+                   uint64_t M, float2* __restrict__ d_feat, float* __restrict__ partial) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t g = lane >> 4, j = lane & 15u;
+  const uint64_t wave = (uint64_t)blockIdx.x * SIGX_WAVES + wid;
+  const uint64_t nwaves = (uint64_t)gridDim.x * SIGX_WAVES;
+  float* dy_tile = sigx_smem + (size_t)wid * 2 * 16 * TILE_LD;
+  float* x_tile = dy_tile + 16 * TILE_LD;
+  const X3Sel sel = x3_selectors();
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // terms 0 and 1 of the three-term packs, in registers for the whole kernel
+  auto frag2 = [&](const void* p, int f) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p) + (f * 3) * 64 + lane;
+    W2 w;
+    w.t[0] = q[0];
+    w.t[1] = q[64];
+    return w;
+  };
+  W2 w1[4], w2t[4], w1t[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    w1[rb] = frag2(packed, rb);
+    w2t[rb] = frag2(packed_t, rb);
+    w1t[rb] = frag2(packed_t, 4 + rb);
+  }
+  f32x4 dw1[4][2], dw2[1][4];
+  dw_zero(dw1);
+  dw_zero(dw2);
+
+  for (uint64_t base = wave * 16; base < M; base += nwaves * 16) {
+    uint64_t m = base + j;
+    const bool live = m < M;
+    if (!live) m = M - 1;
+    float xin[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float2 v = feat[(uint64_t)(4 * q + g) * M + m];
+      xin[2 * q] = v.x;
+      xin[2 * q + 1] = v.y;
+    }
+    f32x4 dh = *reinterpret_cast<const f32x4*>(d_h + m * 16 + 4 * g);
+    if (!live) dh = z4;  // padded columns add nothing
+    X2 xb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2_pair(xin[2 * q], xin[2 * q + 1], xb, q, sel);
+    f32x4 acc1[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc1[rb] = mfma_x2(w1[rb], xb, z4);
+
+    // dW2 += dh (x) relu(acc1)
+    tile_store(dy_tile, g, j, 0, dh);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(x_tile, g, j, rb, relu4(acc1[rb]));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate_b2<1, 4>(dy_tile, x_tile, lane, dw2, sel);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // d_hid = W2^T dh, gated by ReLU
+    f32x4 dhid[4];
+    {
+      const X2 bd = chain_x2(dh, z4, sel);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) dhid[rb] = mfma_x2(w2t[rb], bd, z4);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dhid[rb][r] = acc1[rb][r] > 0.f ? dhid[rb][r] : 0.f;
+
+    // dW1 += d_hid (x) x   (x tile in natural feature order 2*level + c)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tile_store(dy_tile, g, j, rb, dhid[rb]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float2*>(x_tile + j * TILE_LD + 8 * q + 2 * g) =
+          make_float2(live ? xin[2 * q] : 0.f, live ? xin[2 * q + 1] : 0.f);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate_b2<4, 2>(dy_tile, x_tile, lane, dw1, sel);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // d_feat = W1^T d_hid
+    const X2 d0 = chain_x2(dhid[0], dhid[1], sel), d1 = chain_x2(dhid[2], dhid[3], sel);
+    f32x4 dx[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      dx[rb] = mfma_x2(w1t[2 * rb], d0, z4);
+      dx[rb] = mfma_x2(w1t[2 * rb + 1], d1, dx[rb]);
+    }
+    if (live) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const uint32_t lv = 8 * rb + 2 * g;
+        d_feat[(uint64_t)lv * M + m] = make_float2(dx[rb][0], dx[rb][1]);
+        d_feat[(uint64_t)(lv + 1) * M + m] = make_float2(dx[rb][2], dx[rb][3]);
+      }
+    }
+  }
+  float* dst = partial + (size_t)wave * 3072;
+  dw_store<4, 2>(dst, 32, lane, dw1);
+  dw_store<1, 4>(dst + 2048, 64, lane, dw2);
+}
+
+// same partial-slot count as ucsa_sigma_mlp_bwd (ucsa_sigma_mlp_bwd_parts)
+extern "C" int32_t ucsa_sigma_mlp_bwd_x2(const float* feat, const float* d_h,
+                                         const void* packed_sigma_x3,
+                                         const void* packed_sigma_t_x3, uint32_t M,
+                                         uint32_t n_levels, float* d_feat,
+                                         float* partial, void* stream) {
+  UCSA_CHECK_ARG(feat, 0);
+  UCSA_CHECK_ARG(d_h, 1);
+  UCSA_CHECK_ARG(packed_sigma_x3 && packed_sigma_t_x3, 2);
+  UCSA_CHECK_ARG(n_levels == 16, 5);
+  UCSA_CHECK_ARG(d_feat && partial, 6);
+  if (M == 0) return 0;
+  const uint32_t blocks = ucsa_sigma_mlp_bwd_parts(M) / SIGX_WAVES;
+  const size_t smem = (size_t)SIGX_WAVES * 2 * 16 * TILE_LD * sizeof(float);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp_bwd_x2, dim3(blocks), dim3(64 * SIGX_WAVES), smem,
+                     (hipStream_t)stream, (const float2*)feat, d_h, packed_sigma_x3,
+                     packed_sigma_t_x3, (uint64_t)M, (float2*)d_feat, partial);
   return ucsa_launch_status();
 }
