@@ -283,7 +283,11 @@ def encoder_roofline(st, chunk, pretrain_steps):
     except ValueError as e:
         raise SystemExit(f"bench.py: {PMC_JSON} / {ENC_BINDING_JSON} malformed: {e!r}")
     kn = "k_hashgrid_encode_tiled"
-    if int(pmc.get("pretrain_steps", -1)) == int(pretrain_steps) and "fetch_bytes" in pmc.get(kn, {}):
+    # ... and on launches of THIS size: 256 threads per (8x8 tile, 16 sample
+    # indices, level) = rays x T / 4 threads per level, 16 levels
+    same_launch = int(pmc.get(kn, {}).get("grid_threads", -1)) == chunk * T_COARSE // 4 * 16
+    if (int(pmc.get("pretrain_steps", -1)) == int(pretrain_steps) and same_launch
+            and "fetch_bytes" in pmc.get(kn, {})):
         tr = pmc[kn]["fetch_bytes"] + pmc[kn]["write_bytes"]
         r["traffic"] = tr
         r["traffic_source"] = PMC_JSON

@@ -540,6 +540,21 @@ int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid_host, const float* rays_o,
                                const float* aabb_host, uint32_t N, uint32_t T,
                                const float* d_feat, float* grad_table,
                                void* workspace, void* stream);
+/* Both density passes of a training step (the coarse samples z_c [N,Tc] and the
+ * resampled ones z_f [N,Tf], renderer_semantics.py:154-236) in ONE call: every
+ * ray's Tc + Tf samples are walked in SORTED depth order -- src [N,Tc+Tf] int32
+ * as ucsa_composite_fwd / _train_fwd_x3 wrote it (e < Tc: coarse sample e, else
+ * fine sample e - Tc).  On the coarse levels the fine samples fall into cells
+ * the coarse samples of the same ray already visit: the merged walk combines
+ * them into the same runs, so the fine pass adds almost no accumulator traffic;
+ * half the launches.  d_feat_c [L][N*Tc][2], d_feat_f [L][N*Tf][2]; workspace
+ * ucsa_hashgrid_bwd_workspace_bytes(N, Tc + Tf, L) (required).  The gradient
+ * of the two single-pass calls up to the order of fp32 additions. */
+int32_t ucsa_hashgrid_bwd_rays_merged(
+    const ucsa_grid* grid, const float* rays_o, const float* rays_d,
+    const float* z_c, const float* z_f, const int32_t* src, const float* aabb_host,
+    uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
+    const float* d_feat_f, float* grad_table, void* workspace, void* stream);
 
 /* Backward of ucsa_hashgrid_encode_points (x [M,3] explicit points; workspace
  * of ucsa_hashgrid_bwd_workspace_bytes(M, 1, n_levels) or NULL). */

@@ -562,3 +562,44 @@ def test_sigma_mlp_backward_bf16x2_matches_autograd(ops):
         assert rel_l2(gW, p.grad) <= 2e-3
         if M <= 1000:
             assert rel_err(got_dx, x.grad) <= 2e-5 and rel_err(gW, p.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("N,Tc,Tf", [(300, 64, 64), (257, 96, 32), (64, 256, 256)])
+def test_merged_grid_backward_equals_the_two_single_pass_calls(ops, N, Tc, Tf):
+    """ucsa_hashgrid_bwd_rays_merged (both density passes in one call, every
+    ray's samples walked in sorted depth order through ``src``) adds the same
+    table gradient as one ucsa_hashgrid_bwd_rays call per pass, up to the order
+    of fp32 additions -- with clustered fine samples, duplicate depths, zero
+    gradients inside runs and identical rays."""
+    from ucsa_neural_rendering_amd._lib import make_grid
+    dev = torch.device("cuda:0")
+    grid = make_grid(4.0)
+    g = torch.Generator().manual_seed(N + Tc)
+    o = ((torch.rand(N, 3, generator=g) * 2 - 1) * 2.0)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    z_c = (0.3 + 5.0 * torch.linspace(0, 1, Tc)[None] + 0.01 * torch.rand(N, Tc, generator=g)).sort(-1).values
+    centre = torch.rand(N, 1, generator=g) * 3.0 + 0.5            # fine samples pile up on a "surface"
+    z_f = (centre + 10.0 ** (-(torch.rand(N, 1, generator=g) * 2 + 1)) * torch.randn(N, Tf, generator=g)).clamp_min(0.25)
+    z_f[:, 1::8] = z_f[:, 0::8][:, :z_f[:, 1::8].shape[1]]      # duplicate depths
+    z_f = z_f.sort(-1).values
+    o[::5], d[::5] = o[0], d[0]
+    src = torch.sort(torch.cat([z_c, z_f], 1), dim=1, stable=True)[1].to(torch.int32)
+    d_c = torch.randn(grid.n_levels, N * Tc, 2, generator=g)
+    d_f = torch.randn(grid.n_levels, N * Tf, 2, generator=g)
+    d_c[:, 3::7] = 0.0
+    d_f[:, 2::5] = 0.0
+    aabb = [-4.0, -4.0, -4.0, 4.0, 4.0, 4.0]
+    o, d, z_c, z_f, src, d_c, d_f = [x.to(dev).contiguous() for x in (o, d, z_c, z_f, src, d_c, d_f)]
+    total = int(grid.total_entries)
+    g_two = torch.zeros(total, 2, device=dev)
+    g_mrg = torch.zeros(total, 2, device=dev)
+    ops.hashgrid_bwd_rays(grid, o, d, z_c, aabb, d_c, g_two)
+    ops.hashgrid_bwd_rays(grid, o, d, z_f, aabb, d_f, g_two)
+    ops.hashgrid_bwd_rays_merged(grid, o, d, z_c, z_f, src, aabb, d_c, d_f, g_mrg)
+    torch.cuda.synchronize()
+    scale = float(g_two.abs().max())
+    assert scale > 0
+    print(f"merged vs two passes: max {float((g_mrg - g_two).abs().max()) / scale:.2e} "
+          f"L1 {float((g_mrg - g_two).abs().sum() / g_two.abs().sum()):.2e}")
+    assert float((g_mrg - g_two).abs().max()) <= 2e-4 * scale
+    assert float((g_mrg - g_two).abs().sum()) <= 1e-5 * float(g_two.abs().sum())

@@ -43,6 +43,47 @@ __device__ __forceinline__ float to_unit_b(float p, float bound, float two_b, fl
   return inv != 0.0f ? (p + bound) * inv : (p + bound) / two_b;
 }
 
+// Where a kernel's sample m comes from.  Single pass (src == nullptr): sample
+// m of z [N*T] / d_feat [L][N*T]; z == nullptr: explicit points (rays_o = x).
+// MERGED (src != nullptr, round 4): m = r * S + s walks the S = Tc + Tf samples
+// of ray r in SORTED depth order -- src[m] = e < Tc: coarse sample e of the
+// ray (z, d_feat), else fine sample e - Tc (z_f, d_feat_f) -- the order the
+// forward composited them in.  Consecutive lanes are then consecutive samples
+// ALONG the ray whichever pass they came from: on the coarse levels the fine
+// samples fall into cells the coarse samples of the same ray already visit, so
+// the merged walk combines them into the same runs and the fine pass adds
+// (almost) no accumulator traffic of its own; one launch instead of two.
+struct MergedSrc {
+  const int32_t* src;
+  const float* z_f;
+  const float2* d_feat_f;
+  uint32_t Tc, Tf, N;
+};
+
+__device__ __forceinline__ void sample_ref(const MergedSrc& mg, uint32_t T, uint64_t M,
+                                           uint64_t m, uint32_t level,
+                                           const float* __restrict__ zs,
+                                           const float2* __restrict__ d_feat,
+                                           uint32_t& r, float& zz, float2& df) {
+  if (mg.src) {
+    r = (uint32_t)(m / T);  // T = S here
+    const uint32_t e = (uint32_t)mg.src[m];
+    if (e < mg.Tc) {
+      const uint64_t i = (uint64_t)r * mg.Tc + e;
+      zz = zs[i];
+      df = d_feat[(uint64_t)level * ((uint64_t)mg.N * mg.Tc) + i];
+    } else {
+      const uint64_t i = (uint64_t)r * mg.Tf + (e - mg.Tc);
+      zz = mg.z_f[i];
+      df = mg.d_feat_f[(uint64_t)level * ((uint64_t)mg.N * mg.Tf) + i];
+    }
+  } else {
+    r = zs ? (uint32_t)(m / T) : 0u;
+    zz = zs ? zs[m] : 0.0f;
+    df = d_feat[(uint64_t)level * M + m];
+  }
+}
+
 // Run-combining: lanes of a wave are consecutive samples of a ray, so on the
 // coarse levels consecutive lanes fall into the same cell and would hammer the
 // same table entry (measured before this: 85 % of a training step).  Equal
@@ -153,7 +194,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
                const float* __restrict__ rays_d, const float* __restrict__ zs,
                Aabb bb, uint32_t T, uint64_t M, uint32_t level0,
                uint32_t tiles, const float2* __restrict__ d_feat,
-               float* __restrict__ grad_table) {
+               float* __restrict__ grad_table, MergedSrc mg) {
   __shared__ uint32_t acc_keys[RUNRED ? ACC_SLOTS : 1];
   __shared__ __attribute__((aligned(8))) float acc_vals[RUNRED ? 2 * ACC_SLOTS : 2];
   const uint32_t level = level0 + blockIdx.y;
@@ -177,13 +218,14 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
     const bool in_range = m < M;
     if (RUNRED && __syncthreads_or(in_range) == 0) break;
     if (!in_range) m = M - 1;
-    const float2 df = d_feat[(uint64_t)level * M + m];
+    float2 df;
+    uint32_t r;
+    float zz;
+    sample_ref(mg, T, M, m, level, zs, d_feat, r, zz, df);
     const bool act = in_range && !(df.x == 0.0f && df.y == 0.0f);
     if (!RUNRED && !act) return;
     float px, py, pz;
     if (zs) {
-      const uint32_t r = (uint32_t)(m / T);
-      const float zz = zs[m];
       const float* o = rays_o + (size_t)r * 3;
       const float* d = rays_d + (size_t)r * 3;
       px = clampf_b(o[0] + d[0] * zz, bb.lo[0], bb.hi[0]);
@@ -265,16 +307,13 @@ struct BinGeom {
 __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
                                             const float* __restrict__ rays_o,
                                             const float* __restrict__ rays_d,
-                                            const float* __restrict__ zs,
-                                            const Aabb& bb, uint32_t T,
-                                            uint64_t m, uint32_t (&gi)[3],
-                                            float (&wf)[3]) {
+                                            bool from_rays, uint32_t r, float zz,
+                                            const Aabb& bb, uint64_t m,
+                                            uint32_t (&gi)[3], float (&wf)[3]) {
   const float two_b = 2.0f * g.bound, inv_b = unit_inv_b(two_b);
   const float scale = g.scale[level];
   float pos[3];
-  if (zs) {
-    const uint32_t r = (uint32_t)(m / T);
-    const float zz = zs[m];
+  if (from_rays) {
     const float* o = rays_o + (size_t)r * 3;
     const float* d = rays_d + (size_t)r * 3;
 #pragma unroll
@@ -309,7 +348,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                Aabb bb, uint32_t T, uint64_t M,
                const float2* __restrict__ d_feat,
                uint32_t* __restrict__ gcount, void* __restrict__ records_v,
-               float* __restrict__ grad_table, float rec_scale) {
+               float* __restrict__ grad_table, float rec_scale, MergedSrc mg) {
   float4* records = reinterpret_cast<float4*>(records_v);
   uint2* records_h = reinterpret_cast<uint2*>(records_v);
   static_assert(BIN_COUNT == 256, "one thread per bin");
@@ -339,13 +378,16 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
   for (int it = 0; it < BIN_TILE; ++it) {
     const uint64_t m = m0 + (uint64_t)it * 256;
     bool act = m < M;
+    uint32_t r = 0;
+    float zz = 0.f;
     if (act) {
-      const float2 df = d_feat[(uint64_t)level * M + m];
+      float2 df;
+      sample_ref(mg, T, M, m, level, zs, d_feat, r, zz, df);
       act = !(df.x == 0.0f && df.y == 0.0f);
     }
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3];
-    if (act) sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
     const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
     if (!(act && plan.tail)) continue;
 #pragma unroll
@@ -372,8 +414,10 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     const uint64_t m = m0 + (uint64_t)it * 256;
     bool act = m < M;
     float2 df = make_float2(0.f, 0.f);
+    uint32_t r = 0;
+    float zz = 0.f;
     if (act) {
-      df = d_feat[(uint64_t)level * M + m];
+      sample_ref(mg, T, M, m, level, zs, d_feat, r, zz, df);
       act = !(df.x == 0.0f && df.y == 0.0f);
     }
     uint32_t key[8];   // bin << 16 | rank inside the bin (this iteration)
@@ -381,7 +425,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     float valx[8], valy[8];
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3] = {0.f, 0.f, 0.f};
-    if (act) sample_cell(g, level, rays_o, rays_d, zs, bb, T, m, gi, wf);
+    if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
     const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
     const bool has_runs = plan.live != 0;  // some lane continues a run
     const bool emit = act && plan.tail;
@@ -609,7 +653,8 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    const float* aabb_host, uint32_t N,
                                    uint32_t T, const float* d_feat,
                                    float* grad_table, void* workspace,
-                                   void* stream, float rec_scale = 0.0f) {
+                                   void* stream, float rec_scale = 0.0f,
+                                   MergedSrc mg = MergedSrc{nullptr, nullptr, nullptr, 0u, 0u, 0u}) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
   // Binning pays where updates are spread over the whole slab (hashed levels
@@ -665,7 +710,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                          dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
                          (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
                          T, M, (const float2*)d_feat, gcount, (void*)records,
-                         grad_table, rec_scale);
+                         grad_table, rec_scale, mg);
       hipLaunchKernelGGL(k_grid_bwd_accum<true>, dim3(BIN_COUNT, nl), dim3(512),
                          (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
                          gd, bg, n_lo, gcount, (const void*)records, grad_table,
@@ -675,7 +720,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                          dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
                          (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
                          T, M, (const float2*)d_feat, gcount, (void*)records,
-                         grad_table, 1.0f);
+                         grad_table, 1.0f, mg);
       hipLaunchKernelGGL(k_grid_bwd_accum<false>, dim3(BIN_COUNT, nl), dim3(512),
                          (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
                          gd, bg, n_lo, gcount, (const void*)records, grad_table,
@@ -705,12 +750,12 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
     hipLaunchKernelGGL(k_hashgrid_bwd<true>,
                        dim3(ucsa_div_up(M, 256 * tiles), n_run),
                        dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
-                       bb, T, M, 0u, tiles, (const float2*)d_feat, grad_table);
+                       bb, T, M, 0u, tiles, (const float2*)d_feat, grad_table, mg);
   if (n_run < n_lo)
     hipLaunchKernelGGL(k_hashgrid_bwd<false>,
                        dim3(ucsa_div_up(M, 256), n_lo - n_run),
                        dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
-                       bb, T, M, n_run, 1u, (const float2*)d_feat, grad_table);
+                       bb, T, M, n_run, 1u, (const float2*)d_feat, grad_table, mg);
   return join(ucsa_launch_status());
 }
 
@@ -729,6 +774,31 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays(const ucsa_grid* grid,
   UCSA_CHECK_ARG(grad_table, 8);
   return hashgrid_bwd_launch(grid, rays_o, rays_d, z, aabb_host, N, T, d_feat,
                              grad_table, workspace, stream);
+}
+
+// Both density passes of a training step in ONE call, walking every ray's
+// Tc + Tf samples in sorted depth order (src [N, Tc+Tf] as the forward
+// composite wrote it: e < Tc coarse sample e, else fine sample e - Tc): see
+// MergedSrc.  d_feat_c [L][N*Tc][2], d_feat_f [L][N*Tf][2]; the workspace is
+// ucsa_hashgrid_bwd_workspace_bytes(N, Tc + Tf, L).  Same gradient as the two
+// single-pass calls up to the order of fp32 additions.
+extern "C" int32_t ucsa_hashgrid_bwd_rays_merged(
+    const ucsa_grid* grid, const float* rays_o, const float* rays_d,
+    const float* z_c, const float* z_f, const int32_t* src, const float* aabb_host,
+    uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
+    const float* d_feat_f, float* grad_table, void* workspace, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(rays_o && rays_d && z_c, 1);
+  UCSA_CHECK_ARG(z_f && src, 4);
+  UCSA_CHECK_ARG(aabb_host, 6);
+  UCSA_CHECK_ARG(Tc >= 1 && Tf >= 1 && (uint64_t)N * (Tc + Tf) < 0x80000000ull, 8);
+  UCSA_CHECK_ARG(d_feat_c && d_feat_f, 10);
+  UCSA_CHECK_ARG(grad_table, 12);
+  UCSA_CHECK_ARG(workspace, 13);
+  const MergedSrc mg{src, z_f, (const float2*)d_feat_f, Tc, Tf, N};
+  return hashgrid_bwd_launch(grid, rays_o, rays_d, z_c, aabb_host, N, Tc + Tf, d_feat_c,
+                             grad_table, workspace, stream, 0.0f, mg);
 }
 
 // The same with 8-byte bin records: value pairs stored as half2 x rec_scale

@@ -131,14 +131,22 @@ class _RenderFn(torch.autograd.Function):
         # f16 training mode: 8-byte bin records (half2 values under the same
         # loss scale as the nets' gradient operands)
         rs = float(net.f16_bwd_scale) if (ctx.half and (net.f16_grid_records or ctx.tcnn)) else 0.0
-        ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid,
-                              rec_scale=rs)
-        if t > 0:
-            d_feat, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
-                                             f["packed_sigma_t"], x2=ctx.x2)
-            ops.reduce_partials(part, g_sigma, True)
-            ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat, g_grid,
+        merged = t > 0 and rs == 0.0 and net.grid_bwd_merged
+        if not merged:
+            ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid,
                                   rec_scale=rs)
+        if t > 0:
+            d_feat_f, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
+                                               f["packed_sigma_t"], x2=ctx.x2)
+            ops.reduce_partials(part, g_sigma, True)
+            if merged:
+                # both passes in one call, the ray's samples in sorted order: the
+                # fine samples join the coarse samples' runs on the coarse levels
+                ops.hashgrid_bwd_rays_merged(f["grid"], o, d, z_c, z_f, src, aabb,
+                                             d_feat, d_feat_f, g_grid)
+            else:
+                ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat_f, g_grid,
+                                      rec_scale=rs)
         ctx.saved = None
         return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
 

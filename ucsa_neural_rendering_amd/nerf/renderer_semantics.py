@@ -92,6 +92,10 @@ class SemanticNeRFRenderer(nn.Module):
         # operand splits, 2^-16 per product; gradients within the 2e-3 of the
         # oracle the fp32 kernels are held to) or "fp32" (f32-input MFMA)
         self.bwd_precision = "bf16x2"
+        # hash-grid backward of a training step: both density passes in ONE call
+        # that walks every ray's samples in sorted depth order
+        # (ucsa_hashgrid_bwd_rays_merged) instead of one call per pass
+        self.grid_bwd_merged = os.environ.get("UCSA_GRID_BWD_MERGED", "1") != "0"
         self.f16_bwd_scale = 1024.0
         # with train_precision="fp16": the hash-grid backward's bin records
         # carry half2 values (8 instead of 16 bytes per record)

@@ -571,6 +571,33 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
           "ucsa_hashgrid_bwd_rays")
 
 
+def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
+                             d_feat_c, d_feat_f, grad_table):
+    """Both density passes in one call, every ray's samples walked in sorted
+    depth order (``src`` [N, Tc+Tf] int32 of the forward composite): adds the
+    table gradient (ucsa_hashgrid_bwd_rays_merged)."""
+    N, Tc = z_c.shape
+    Tf = z_f.shape[1]
+    L = grid.n_levels
+    if (tuple(d_feat_c.shape) != (L, N * Tc, 2) or tuple(d_feat_f.shape) != (L, N * Tf, 2)
+            or not d_feat_c.is_contiguous() or not d_feat_f.is_contiguous()):
+        raise _lib.UcsaError("d_feat_c / d_feat_f must be contiguous [L, N*T, 2] tensors")
+    if tuple(src.shape) != (N, Tc + Tf) or src.dtype != torch.int32 or not src.is_contiguous():
+        raise _lib.UcsaError(f"src must be a contiguous int32 [{N}, {Tc + Tf}] tensor")
+    if tuple(rays_o.shape) != (N, 3) or tuple(rays_d.shape) != (N, 3):
+        raise _lib.UcsaError("rays_o / rays_d must be [N, 3] with N = z_c.shape[0]")
+    need = int(lib().ucsa_hashgrid_bwd_workspace_bytes(N, Tc + Tf, L))
+    key = (z_c.device, _raw_current_stream())
+    ws = _bwd_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=z_c.device)
+        _bwd_ws[key] = ws
+    check(lib().ucsa_hashgrid_bwd_rays_merged(
+        C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z_c), _ptr(z_f), _ptr(src),
+        fvec(aabb), N, Tc, Tf, _ptr(d_feat_c), _ptr(d_feat_f), _ptr(grad_table), _ptr(ws),
+        _stream()), "ucsa_hashgrid_bwd_rays_merged")
+
+
 def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
     """Backward of hashgrid_encode_points: adds into grad_table."""
     x = _f32(x, "x").view(-1, 3)
