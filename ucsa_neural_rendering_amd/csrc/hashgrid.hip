@@ -159,91 +159,69 @@ k_hashgrid_encode_tiled(GridDev g, LevelMap lm,
                         const float* __restrict__ rays_d,
                         const float* __restrict__ zs, Aabb bb, uint32_t T,
                         uint32_t N, uint32_t W, uint32_t s_blocks,
-                        uint32_t sb_per_wg, FT* __restrict__ feat) {
+                        FT* __restrict__ feat) {
   __shared__ float z_s[64][TILE_S + 1];
   __shared__ FT f_s[64][TILE_S + 1];
   const uint32_t level = lm.lv[blockIdx.y * lm.k + blockIdx.x % lm.k];
   const uint32_t bx = blockIdx.x / lm.k;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-  // a workgroup walks `sb_per_wg` consecutive blocks of TILE_S sample indices
-  // of its tile: what depends on the tile and the level only (ray indices,
-  // origins / directions, the level's constants, the staging offsets) is
-  // computed once for all of them.  On the levels whose cells the lanes share
-  // the kernel is bound by VALU issue, and with one sample block per workgroup
-  // a third of its instructions were that preamble (round 4; the host picks
-  // sb_per_wg, see launch_encode_image).
-  const uint32_t groups = (s_blocks + sb_per_wg - 1u) / sb_per_wg;
-  const uint32_t sg = bx % groups, tile = bx / groups;
+  const uint32_t sb = bx % s_blocks, tile = bx / s_blocks;
   const uint32_t tiles_x = (W + 7u) / 8u;
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  const uint32_t M = N * T;  // the host checks N * T < 2^31
+  const uint32_t s0 = sb * TILE_S;
+  const uint64_t M = (uint64_t)N * T;
   FT* feat_level = feat + (uint64_t)level * M;  // wave-uniform
-  // staging role (depths in, features out; ray-major, contiguous in global
-  // memory): thread -> sample index st_s of tile pixels st_l + 16 k, k < 4.
-  // Pixel l = (l & 7, l >> 3), so the four pixels share the column and sit
-  // two rows apart: ray r0 + 2 k W, offset off0 + 2 k W T.
-  const uint32_t st_s = threadIdx.x % TILE_S, st_l = threadIdx.x / TILE_S;
-  const uint32_t st_px = tx * 8u + (st_l & 7u), st_py = ty * 8u + (st_l >> 3);
-  const uint32_t st_r0 = st_py * W + st_px, st_off0 = st_r0 * T + st_s;
-  const uint32_t st_rstep = 2u * W, st_ostep = 2u * W * T;
-  bool st_ok[4];
+  // (32-bit indices: the host checks N * T < 2^31; rows beyond the last one
+  // give r >= N)
+  auto ray_of = [&](uint32_t l) -> uint32_t {
+    const uint32_t px = tx * 8 + (l & 7u), py = ty * 8 + (l >> 3);
+    const uint32_t r = py * W + px;
+    return (px < W && r < N) ? r : 0xFFFFFFFFu;
+  };
+  // depths of the tile, ray-major reads
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    st_ok[k] = st_px < W && st_r0 + st_rstep * k < N;
-  // compute role: lane -> pixel `lane` of the tile, wave -> sample indices
-  // wid + 4 k
-  const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-  const uint32_t ray = py * W + px;
-  const bool ray_ok = px < W && ray < N;
-  float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-  if (ray_ok) {
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t e = threadIdx.x + 256u * k;
+    const uint32_t r = ray_of(e / TILE_S), ss = e % TILE_S;
+    if (r != 0xFFFFFFFFu && s0 + ss < T)
+      z_s[e / TILE_S][ss] = zs[r * T + s0 + ss];
+  }
+  __syncthreads();
+  const uint32_t ray = ray_of(lane);
+  if (ray != 0xFFFFFFFFu) {
     const float* o = rays_o + ray * 3u;
     const float* d = rays_d + ray * 3u;
-    ox = o[0], oy = o[1], oz = o[2];
-    dx = d[0], dy = d[1], dz = d[2];
-  }
-  const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
-  const TT* tab = table + g.offset[level];
-  const float scale = g.scale[level];
-  const uint32_t res = g.res[level], entries = g.entries[level],
-                 hashed = g.hashed[level];
-  const bool xpair = hashed && level >= lm.simple_below;
-  const uint32_t sb_end = min(s_blocks, (sg + 1u) * sb_per_wg);
-  for (uint32_t sb = sg * sb_per_wg; sb < sb_end; ++sb) {
-    const uint32_t s0 = sb * TILE_S;
-    const bool st_in = s0 + st_s < T;
-    // depths of the tile: the four loads go out together
-    float zv[4];
+    const float ox = o[0], oy = o[1], oz = o[2];
+    const float dx = d[0], dy = d[1], dz = d[2];
+    const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
+    const TT* tab = table + g.offset[level];
+    const float scale = g.scale[level];
+    const uint32_t res = g.res[level], entries = g.entries[level],
+                   hashed = g.hashed[level];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      zv[k] = (st_ok[k] && st_in) ? zs[st_off0 + st_ostep * k + s0] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) z_s[st_l + 16u * k][st_s] = zv[k];
-    __syncthreads();
-    if (ray_ok) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t ss = wid + 4u * k;
-        if (s0 + ss >= T) continue;
-        const float zz = z_s[lane][ss];
-        const float qx = clampf(ox + dx * zz, bb.lo[0], bb.hi[0]);
-        const float qy = clampf(oy + dy * zz, bb.lo[1], bb.hi[1]);
-        const float qz = clampf(oz + dz * zz, bb.lo[2], bb.hi[2]);
-        const float x01 = to_unit(qx, g.bound, two_b, inv),
-                    y01 = to_unit(qy, g.bound, two_b, inv),
-                    z01 = to_unit(qz, g.bound, two_b, inv);
-        to_feat(f_s[lane][ss],
-                xpair ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
-                      : encode_level(tab, x01, y01, z01, scale, res, entries, hashed));
-      }
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ss = wid + 4u * k;
+      if (s0 + ss >= T) continue;
+      const float zz = z_s[lane][ss];
+      const float px = clampf(ox + dx * zz, bb.lo[0], bb.hi[0]);
+      const float py = clampf(oy + dy * zz, bb.lo[1], bb.hi[1]);
+      const float pz = clampf(oz + dz * zz, bb.lo[2], bb.hi[2]);
+      const float x01 = to_unit(px, g.bound, two_b, inv),
+                  y01 = to_unit(py, g.bound, two_b, inv),
+                  z01 = to_unit(pz, g.bound, two_b, inv);
+      to_feat(f_s[lane][ss],
+              (hashed && level >= lm.simple_below)
+                  ? encode_level_hashed(tab, x01, y01, z01, scale, entries)
+                  : encode_level(tab, x01, y01, z01, scale, res, entries, hashed));
     }
-    __syncthreads();
-    // (the next round's z_s writes follow this round's z_s reads by one
-    // barrier, its f_s writes follow these f_s reads by another)
+  }
+  __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (st_ok[k] && st_in)
-        feat_store(feat_level + (st_off0 + st_ostep * k + s0), f_s[st_l + 16u * k][st_s]);
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t e = threadIdx.x + 256u * k;
+    const uint32_t r = ray_of(e / TILE_S), ss = e % TILE_S;
+    if (r != 0xFFFFFFFFu && s0 + ss < T)
+      feat_store(feat_level + (r * T + s0 + ss), f_s[e / TILE_S][ss]);
   }
 }
 
@@ -386,23 +364,11 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
       const char* v = getenv("UCSA_ENC_LDS_PAD");
       return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 0u;
     }();
-    // sample blocks per workgroup: TWO, unless that leaves the chip short of
-    // workgroups (small images).  Measured on the bench's chunk (61 440 rays x
-    // 96, tools/encode_sb_sweep.py, round 4): coarse pass 0.765 / 0.675 /
-    // 0.726 ms and fine pass 1.51 / 1.44 / 1.53 ms for 1 / 2 / 6 blocks --
-    // the preamble is amortised after two, and longer-lived workgroups make
-    // consecutive levels overlap more (two 4 MiB table slices in one L2).
-    // UCSA_ENC_SB (experiments only) overrides; results do not depend on it.
-    const uint32_t wgs1 = tiles * grid->n_levels * s_blocks;
-    uint32_t sb_per_wg = wgs1 >= 2u * 4096u ? 2u : 1u;
-    sb_per_wg = simple_gather_below("UCSA_ENC_SB", sb_per_wg);
-    sb_per_wg = sb_per_wg < 1u ? 1u : (sb_per_wg > s_blocks ? s_blocks : sb_per_wg);
-    const uint32_t groups = ucsa_div_up(s_blocks, sb_per_wg);
     hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
-                       dim3(tiles * groups * lm.k, grid->n_levels / lm.k),
+                       dim3(tiles * s_blocks * lm.k, grid->n_levels / lm.k),
                        dim3(256), lds_pad, (hipStream_t)stream, gd, lm,
                        (const TT*)table, rays_o, rays_d, z, bb, T, N,
-                       image_width, s_blocks, sb_per_wg, (FT*)feat);
+                       image_width, s_blocks, (FT*)feat);
   }
   return ucsa_launch_status();
 }
