@@ -18,7 +18,9 @@ aabb = net._aabb_list(False)
 near, far = ops.near_far_from_aabb(o, d, aabb, 0.2)
 T = 96
 z = ops.sample_coarse(near, far, T, None)
-h, sig = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb, image_width=W), f["packed_sigma"])
+# (set-up through the ray-ordered kernel, so that every k_hashgrid_encode_tiled
+# dispatch of a PASS=coarse / PASS=fine run belongs to that pass; same features)
+h, sig = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb), f["packed_sigma"])
 zf = ops.resample(z, sig.view(N, T), torch.rand(N, T, device=dev), 1.0)
 torch.cuda.synchronize()
 which = os.environ.get("PASS", "both")

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: kernel trace + PMC passes (each its own run) of the
 # tiled encoder alone.   usage: encode_pmc.sh <tag>
+# (the TA_* counter set of round 3 is gone: in round 4 it hung rocprofv3 until
+# the timeout on this pool)
 set -u
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -12,7 +14,6 @@ export PASS
 for PMC in "" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU" \
   "SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" \
-  "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" \
   "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
   "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum" \
   "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_BUSY_sum"; do
