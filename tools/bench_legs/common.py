@@ -23,8 +23,9 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregat
 PMC_JSON = "profiles/r04_pmc_traffic.json"
 TRAIN_PMC_JSON = "profiles/r04_train_pmc.json"
 SEG_PMC_JSON = "profiles/r03_seg_pmc.json"
-# k_hashgrid_encode_tiled is unchanged since round 3: its binding-unit counters stand
-ENC_BINDING_JSON = "profiles/r03_encoder_binding.json"
+# k_hashgrid_encode_tiled is unchanged since round 3; counters re-collected in round 4
+# (tools/encode_pmc.sh r04 + tools/encode_binding_json.py)
+ENC_BINDING_JSON = "profiles/r04_encoder_binding.json"
 
 
 _T0 = time.perf_counter()

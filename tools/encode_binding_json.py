@@ -24,8 +24,8 @@ for path in sorted(glob.glob(f"gpurun_out/{tag}_enc_pmc*.txt")):
         d[c.group(1)] = float(c.group(4))
 js = {"source": f"tools/encode_pmc.sh {tag}: PASS={{coarse,fine}} rocprofv3 --kernel-trace [--pmc <set>] -- "
                 "python3 tools/encode_only.py, one run per counter set; k_hashgrid_encode_tiled alone on the "
-                "bench's 61 440-ray chunk (5.9 M samples), fp32 table, plain 8-load gather, two sample blocks "
-                "per workgroup (round-4 default); per launch; tools/encode_binding_json.py",
+                "bench's 61 440-ray chunk (5.9 M samples), fp32 table, plain 8-load gather; per launch; "
+                "tools/encode_binding_json.py",
       "peak_note": "the TCP (per-CU vector L1) looks up one 128-B line per clock: "
                    "TCP_TOTAL_CACHE_ACCESSES / (256 CUs x cycles) is its utilisation"}
 for name, d in res.items():
