@@ -556,6 +556,28 @@ int32_t ucsa_hashgrid_bwd_rays_merged(
     uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
     const float* d_feat_f, float* grad_table, void* workspace, void* stream);
 
+/* ucsa_hashgrid_bwd_rays / ucsa_hashgrid_bwd_rays_merged with 8-byte PACKED bin
+ * records: one 64-bit word = entry index inside its bin (L bits) | vx | vy,
+ * each value the fp32 rounded to nearest-even to its top min(32, (64 - L) / 2)
+ * bits -- 26 bits (2^-18 relative) for the 2^19-entry levels of the
+ * reference's grid.  Half the record bytes of both passes; the sums stay fp32;
+ * non-finite values stay non-finite.  Meant for training modes whose MLP
+ * backward is itself a two-term bf16 split (2^-16): the Python host uses them
+ * for bwd_precision "bf16x2".  Same arguments; the workspace is mandatory.
+ * (No reference counterpart: tiny-cuda-nn scatters with atomics,
+ * nr4seg/nerf/network_tcnn_semantics.py:36-46 is the call site.) */
+int32_t ucsa_hashgrid_bwd_rays_p64(const ucsa_grid* grid, const float* rays_o,
+                                   const float* rays_d, const float* z,
+                                   const float* aabb_host, uint32_t N,
+                                   uint32_t T, const float* d_feat,
+                                   float* grad_table, void* workspace,
+                                   void* stream);
+int32_t ucsa_hashgrid_bwd_rays_merged_p64(
+    const ucsa_grid* grid, const float* rays_o, const float* rays_d,
+    const float* z_c, const float* z_f, const int32_t* src, const float* aabb_host,
+    uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
+    const float* d_feat_f, float* grad_table, void* workspace, void* stream);
+
 /* Backward of ucsa_hashgrid_encode_points (x [M,3] explicit points; workspace
  * of ucsa_hashgrid_bwd_workspace_bytes(M, 1, n_levels) or NULL). */
 int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid_host, const float* x,

@@ -151,6 +151,12 @@ SIGNATURES = {
     "ucsa_hashgrid_bwd_rays_merged": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                                   C.POINTER(_f), _u32, _u32, _u32, _p, _p,
                                                   _p, _p, _p]),
+    "ucsa_hashgrid_bwd_rays_p64": (C.c_int32, [C.POINTER(Grid), _p, _p, _p,
+                                               C.POINTER(_f), _u32, _u32, _p, _p,
+                                               _p, _p]),
+    "ucsa_hashgrid_bwd_rays_merged_p64": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
+                                                      C.POINTER(_f), _u32, _u32, _u32, _p, _p,
+                                                      _p, _p, _p]),
     "ucsa_hashgrid_bwd_points": (C.c_int32, [C.POINTER(Grid), _p, _u32, _p, _p,
                                              _p, _p]),
     "ucsa_composite_bwd_parts": (C.c_uint32, [_u32]),

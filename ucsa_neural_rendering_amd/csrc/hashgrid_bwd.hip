@@ -301,8 +301,44 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
 struct BinGeom {
   uint32_t bin_size[UCSA_MAX_LEVELS];  // table entries per bin
   uint32_t bin_shift[UCSA_MAX_LEVELS]; // log2(bin_size) when a power of two, else 32
+  uint32_t loc_bits[UCSA_MAX_LEVELS];  // bits that hold an entry index inside a bin
   uint32_t cap;                        // records per bin
 };
+
+// REC_P64 records: one 64-bit word = entry index inside the bin (L = loc_bits)
+// | vx | vy, each value the fp32 rounded (to nearest even) to its top
+// V = min(32, (64 - L) / 2) bits.  For the 2^19-entry levels of the reference's
+// grid L = 11, V = 26: sign, exponent and 17 mantissa bits, a relative error of
+// 2^-18 per record -- finer than the two-term bf16 split (2^-16) of the MLP
+// backward that produces the values; the sums stay fp32.  Half the bytes of the
+// 16-byte records through HBM in both passes.  Non-finite values stay
+// non-finite (a NaN may become an infinity), so overflow detection still sees them.
+__device__ __forceinline__ uint32_t p64_value_bits(uint32_t L) {
+  const uint32_t v = (64u - L) >> 1;
+  return v > 32u ? 32u : v;
+}
+__device__ __forceinline__ uint32_t p64_round(float f, uint32_t V) {
+  uint32_t b = __float_as_uint(f);
+  const uint32_t drop = 32u - V;
+  if (drop) {
+    b += ((1u << (drop - 1u)) - 1u) + ((b >> drop) & 1u);
+    b >>= drop;
+  }
+  return b;
+}
+__device__ __forceinline__ uint64_t p64_pack(uint32_t loc, float vx, float vy, uint32_t L) {
+  const uint32_t V = p64_value_bits(L);
+  return (uint64_t)loc | ((uint64_t)p64_round(vx, V) << L) |
+         ((uint64_t)p64_round(vy, V) << (L + V));
+}
+__device__ __forceinline__ void p64_unpack(uint64_t w, uint32_t L, uint32_t& loc,
+                                           float& vx, float& vy) {
+  const uint32_t V = p64_value_bits(L), drop = 32u - V;
+  const uint64_t vmask = V == 32u ? 0xFFFFFFFFull : ((1ull << V) - 1ull);
+  loc = (uint32_t)(w & ((1ull << L) - 1ull));
+  vx = __uint_as_float((uint32_t)((w >> L) & vmask) << drop);
+  vy = __uint_as_float((uint32_t)((w >> (L + V)) & vmask) << drop);
+}
 
 __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
                                             const float* __restrict__ rays_o,
@@ -340,7 +376,12 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
 // of both passes.  Used by the f16 training mode only (train_precision="fp16":
 // tiny-cuda-nn itself accumulates its grid gradient from half2 values); the
 // sums in the accumulate pass stay fp32.
-template <bool HREC>
+// REC: 0 = 16-byte records, REC_H16 = HREC above, REC_P64 = packed 64-bit words
+// (p64_pack; packed before the LDS staging, which shrinks from 32 to 20 KiB).
+#define REC_F32 0
+#define REC_H16 1
+#define REC_P64 2
+template <int REC>
 __global__ void __launch_bounds__(256)
 k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                const float* __restrict__ rays_o,
@@ -349,12 +390,19 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                const float2* __restrict__ d_feat,
                uint32_t* __restrict__ gcount, void* __restrict__ records_v,
                float* __restrict__ grad_table, float rec_scale, MergedSrc mg) {
+  constexpr bool HREC = REC == REC_H16;
+  constexpr bool P64 = REC == REC_P64;
   float4* records = reinterpret_cast<float4*>(records_v);
   uint2* records_h = reinterpret_cast<uint2*>(records_v);
   static_assert(BIN_COUNT == 256, "one thread per bin");
   __shared__ uint32_t hist[BIN_COUNT], base[BIN_COUNT], cursor[BIN_COUNT];
   __shared__ uint32_t it_cnt[BIN_COUNT], it_off[BIN_COUNT], wave_tot[4];
-  __shared__ float4 stage[256 * 8];  // one iteration's records, bin-sorted
+  // one iteration's records, bin-sorted: float4 (loc, vx, vy, bin), or for
+  // REC_P64 the packed word [2048 x 8 B] followed by the bins [2048 x 2 B]
+  __shared__ float4 stage[P64 ? (256 * 8 * 10) / 16 : 256 * 8];
+  uint64_t* stage_w = reinterpret_cast<uint64_t*>(stage);
+  uint16_t* stage_b = reinterpret_cast<uint16_t*>(stage_w + 256 * 8);
+  const uint32_t lbits = bg.loc_bits[level0 + blockIdx.y];
   const uint32_t level = level0 + blockIdx.y;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t res = g.res[level], entries = g.entries[level],
@@ -461,14 +509,36 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint32_t bin = key[c] >> 16;
-        stage[it_off[bin] + (key[c] & 0xFFFFu)] =
-            make_float4(__uint_as_float(loc[c]), valx[c], valy[c],
-                        __uint_as_float(bin));
+        const uint32_t slot = it_off[bin] + (key[c] & 0xFFFFu);
+        if constexpr (P64) {
+          stage_w[slot] = p64_pack(loc[c], valx[c], valy[c], lbits);
+          stage_b[slot] = (uint16_t)bin;
+        } else {
+          stage[slot] = make_float4(__uint_as_float(loc[c]), valx[c], valy[c],
+                                    __uint_as_float(bin));
+        }
       }
     }
     __syncthreads();
     const uint32_t total = it_off[BIN_COUNT - 1] + it_cnt[BIN_COUNT - 1];
     for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 256) {
+      if constexpr (P64) {
+        const uint64_t w = stage_w[sidx];
+        const uint32_t bin = stage_b[sidx];
+        const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
+        if (pos < bg.cap) {
+          reinterpret_cast<uint64_t*>(records_v)[(size_t)level * BIN_COUNT * bg.cap +
+                                                 (size_t)bin * bg.cap + pos] = w;
+        } else {  // bin full: direct atomics (of the rounded values: same sum)
+          uint32_t l;
+          float vx, vy;
+          p64_unpack(w, lbits, l, vx, vy);
+          const size_t idx = (size_t)bin * bsz + l;
+          atomicAdd(gt + idx * 2, vx);
+          atomicAdd(gt + idx * 2 + 1, vy);
+        }
+        continue;
+      }
       const float4 r = stage[sidx];
       const uint32_t bin = __float_as_uint(r.w);
       const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
@@ -501,7 +571,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
 #endif
 extern __shared__ __attribute__((aligned(16))) float binacc_smem[];
 
-template <bool HREC>
+template <int REC>
 __global__ void __launch_bounds__(512)
 k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
                  const uint32_t* __restrict__ gcount,
@@ -513,10 +583,34 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   uint32_t n = gcount[level * BIN_COUNT + bin];
   if (n == 0) return;
   if (n > bg.cap) n = bg.cap;
+  constexpr bool HREC = REC == REC_H16;
   float* acc = binacc_smem;  // [bsz][2]
   for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) acc[e] = 0.f;
   __syncthreads();
-  if constexpr (HREC) {
+  if constexpr (REC == REC_P64) {
+    const uint64_t* rec = reinterpret_cast<const uint64_t*>(records_v) +
+                          ((size_t)level * BIN_COUNT + bin) * bg.cap;
+    const uint32_t lbits = bg.loc_bits[level];
+    uint32_t i = threadIdx.x;
+    for (; i + (ACC_INFLIGHT - 1) * 512 < n; i += ACC_INFLIGHT * 512) {
+      uint64_t r[ACC_INFLIGHT];
+#pragma unroll
+      for (int k = 0; k < ACC_INFLIGHT; ++k) r[k] = rec[i + k * 512];
+#pragma unroll
+      for (int k = 0; k < ACC_INFLIGHT; ++k) {
+        uint32_t l;
+        float vx, vy;
+        p64_unpack(r[k], lbits, l, vx, vy);
+        lds_add_pair(&acc[2 * l], vx, vy);
+      }
+    }
+    for (; i < n; i += 512) {
+      uint32_t l;
+      float vx, vy;
+      p64_unpack(rec[i], lbits, l, vx, vy);
+      lds_add_pair(&acc[2 * l], vx, vy);
+    }
+  } else if constexpr (HREC) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const uint2* rec = reinterpret_cast<const uint2*>(records_v) +
                        ((size_t)level * BIN_COUNT + bin) * bg.cap;
@@ -576,6 +670,8 @@ static BinGeom bin_geometry(const ucsa_grid* grid, uint64_t M) {
     bg.bin_shift[l] = 32;
     for (uint32_t sh = 0; sh < 32; ++sh)
       if (bg.bin_size[l] == (1u << sh)) bg.bin_shift[l] = sh;
+    bg.loc_bits[l] = 0;
+    while ((1ull << bg.loc_bits[l]) < bg.bin_size[l]) ++bg.loc_bits[l];
   }
   uint64_t cap = 2 * (8 * M / BIN_COUNT + 1);
   if (cap < 4096) cap = 4096;
@@ -653,7 +749,8 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    const float* aabb_host, uint32_t N,
                                    uint32_t T, const float* d_feat,
                                    float* grad_table, void* workspace,
-                                   void* stream, float rec_scale = 0.0f,
+                                   void* stream,
+                                   float rec_scale = 0.0f,  // > 0: REC_H16, < 0: REC_P64
                                    MergedSrc mg = MergedSrc{nullptr, nullptr, nullptr, 0u, 0u, 0u}) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
@@ -705,23 +802,33 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
       if (bg.bin_size[l] > max_bsz) max_bsz = bg.bin_size[l];
     const uint32_t nl = grid->n_levels - n_lo;
     UCSA_CLEAR_ERR();
-    if (rec_scale > 0.0f) {
-      hipLaunchKernelGGL(k_grid_bwd_bin<true>,
-                         dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
-                         (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
-                         T, M, (const float2*)d_feat, gcount, (void*)records,
-                         grad_table, rec_scale, mg);
-      hipLaunchKernelGGL(k_grid_bwd_accum<true>, dim3(BIN_COUNT, nl), dim3(512),
-                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
-                         gd, bg, n_lo, gcount, (const void*)records, grad_table,
-                         1.0f / rec_scale);
-    } else {
-      hipLaunchKernelGGL(k_grid_bwd_bin<false>,
+    if (rec_scale < 0.0f) {  // REC_P64
+      hipLaunchKernelGGL(k_grid_bwd_bin<REC_P64>,
                          dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
                          (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
                          T, M, (const float2*)d_feat, gcount, (void*)records,
                          grad_table, 1.0f, mg);
-      hipLaunchKernelGGL(k_grid_bwd_accum<false>, dim3(BIN_COUNT, nl), dim3(512),
+      hipLaunchKernelGGL(k_grid_bwd_accum<REC_P64>, dim3(BIN_COUNT, nl), dim3(512),
+                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
+                         gd, bg, n_lo, gcount, (const void*)records, grad_table,
+                         1.0f);
+    } else if (rec_scale > 0.0f) {
+      hipLaunchKernelGGL(k_grid_bwd_bin<REC_H16>,
+                         dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
+                         (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
+                         T, M, (const float2*)d_feat, gcount, (void*)records,
+                         grad_table, rec_scale, mg);
+      hipLaunchKernelGGL(k_grid_bwd_accum<REC_H16>, dim3(BIN_COUNT, nl), dim3(512),
+                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
+                         gd, bg, n_lo, gcount, (const void*)records, grad_table,
+                         1.0f / rec_scale);
+    } else {
+      hipLaunchKernelGGL(k_grid_bwd_bin<REC_F32>,
+                         dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
+                         (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
+                         T, M, (const float2*)d_feat, gcount, (void*)records,
+                         grad_table, 1.0f, mg);
+      hipLaunchKernelGGL(k_grid_bwd_accum<REC_F32>, dim3(BIN_COUNT, nl), dim3(512),
                          (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
                          gd, bg, n_lo, gcount, (const void*)records, grad_table,
                          1.0f);
@@ -799,6 +906,48 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays_merged(
   const MergedSrc mg{src, z_f, (const float2*)d_feat_f, Tc, Tf, N};
   return hashgrid_bwd_launch(grid, rays_o, rays_d, z_c, aabb_host, N, Tc + Tf, d_feat_c,
                              grad_table, workspace, stream, 0.0f, mg);
+}
+
+// ucsa_hashgrid_bwd_rays / _merged with 8-byte PACKED bin records (REC_P64:
+// every value rounded to its top (64 - L) / 2 bits, 2^-18 relative for the
+// reference's grid; fp32 sums).  For the training modes whose MLP backward is
+// itself a two-term bf16 split (2^-16).  Require the workspace.
+extern "C" int32_t ucsa_hashgrid_bwd_rays_p64(const ucsa_grid* grid,
+                                              const float* rays_o,
+                                              const float* rays_d,
+                                              const float* z,
+                                              const float* aabb_host, uint32_t N,
+                                              uint32_t T, const float* d_feat,
+                                              float* grad_table, void* workspace,
+                                              void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(rays_o && rays_d && z, 1);
+  UCSA_CHECK_ARG(aabb_host, 4);
+  UCSA_CHECK_ARG(d_feat, 7);
+  UCSA_CHECK_ARG(grad_table, 8);
+  UCSA_CHECK_ARG(workspace, 9);
+  return hashgrid_bwd_launch(grid, rays_o, rays_d, z, aabb_host, N, T, d_feat,
+                             grad_table, workspace, stream, -1.0f);
+}
+
+extern "C" int32_t ucsa_hashgrid_bwd_rays_merged_p64(
+    const ucsa_grid* grid, const float* rays_o, const float* rays_d,
+    const float* z_c, const float* z_f, const int32_t* src, const float* aabb_host,
+    uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
+    const float* d_feat_f, float* grad_table, void* workspace, void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(rays_o && rays_d && z_c, 1);
+  UCSA_CHECK_ARG(z_f && src, 4);
+  UCSA_CHECK_ARG(aabb_host, 6);
+  UCSA_CHECK_ARG(Tc >= 1 && Tf >= 1 && (uint64_t)N * (Tc + Tf) < 0x80000000ull, 8);
+  UCSA_CHECK_ARG(d_feat_c && d_feat_f, 10);
+  UCSA_CHECK_ARG(grad_table, 12);
+  UCSA_CHECK_ARG(workspace, 13);
+  const MergedSrc mg{src, z_f, (const float2*)d_feat_f, Tc, Tf, N};
+  return hashgrid_bwd_launch(grid, rays_o, rays_d, z_c, aabb_host, N, Tc + Tf, d_feat_c,
+                             grad_table, workspace, stream, -1.0f, mg);
 }
 
 // The same with 8-byte bin records: value pairs stored as half2 x rec_scale

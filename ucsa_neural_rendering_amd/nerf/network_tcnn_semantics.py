@@ -132,9 +132,12 @@ class _RenderFn(torch.autograd.Function):
         # loss scale as the nets' gradient operands)
         rs = float(net.f16_bwd_scale) if (ctx.half and (net.f16_grid_records or ctx.tcnn)) else 0.0
         merged = t > 0 and rs == 0.0 and net.grid_bwd_merged
+        # bf16x2 backward: 8-byte packed bin records (26-bit values, 2^-18 --
+        # finer than the two-term split that produced them)
+        pk = ctx.x2 and rs == 0.0 and net.grid_records_packed
         if not merged:
             ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid,
-                                  rec_scale=rs)
+                                  rec_scale=rs, packed=pk)
         if t > 0:
             d_feat_f, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
                                                f["packed_sigma_t"], x2=ctx.x2)
@@ -143,10 +146,10 @@ class _RenderFn(torch.autograd.Function):
                 # both passes in one call, the ray's samples in sorted order: the
                 # fine samples join the coarse samples' runs on the coarse levels
                 ops.hashgrid_bwd_rays_merged(f["grid"], o, d, z_c, z_f, src, aabb,
-                                             d_feat, d_feat_f, g_grid)
+                                             d_feat, d_feat_f, g_grid, packed=pk)
             else:
                 ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat_f, g_grid,
-                                      rec_scale=rs)
+                                      rec_scale=rs, packed=pk)
         ctx.saved = None
         return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
 

@@ -96,6 +96,10 @@ class SemanticNeRFRenderer(nn.Module):
         # that walks every ray's samples in sorted depth order
         # (ucsa_hashgrid_bwd_rays_merged) instead of one call per pass
         self.grid_bwd_merged = os.environ.get("UCSA_GRID_BWD_MERGED", "1") != "0"
+        # with the bf16x2 backward: the hash-grid backward's bin records are
+        # 8-byte words with 26-bit values (ucsa_hashgrid_bwd_rays*_p64) instead
+        # of 16-byte (index, fp32, fp32) records -- half the record traffic
+        self.grid_records_packed = os.environ.get("UCSA_GRID_RECORDS_PACKED", "1") != "0"
         self.f16_bwd_scale = 1024.0
         # with train_precision="fp16": the hash-grid backward's bin records
         # carry half2 values (8 instead of 16 bytes per record)

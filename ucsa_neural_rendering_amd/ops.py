@@ -538,11 +538,13 @@ _bwd_ws = {}
 
 
 def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
-                      binned: bool = True, rec_scale: float = 0.0):
+                      binned: bool = True, rec_scale: float = 0.0,
+                      packed: bool = False):
     """Adds the table gradient.  binned=True: two-pass LDS-binned algorithm
     (workspace cached per device); False: direct float atomics.
     rec_scale > 0 (binned only): 8-byte bin records, values as half2 x
-    rec_scale (the f16 training mode)."""
+    rec_scale (the f16 training mode).  packed (binned only): 8-byte records
+    with 26-bit values (ucsa_hashgrid_bwd_rays_p64)."""
     N, T = z.shape
     if tuple(d_feat.shape) != (grid.n_levels, N * T, 2) or not d_feat.is_contiguous():
         raise _lib.UcsaError(
@@ -564,6 +566,12 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
             _ptr(d_feat), _ptr(grad_table), _ptr(ws), float(rec_scale), _stream()),
             "ucsa_hashgrid_bwd_rays_h16")
         return
+    if packed and ws is not None:
+        check(lib().ucsa_hashgrid_bwd_rays_p64(
+            C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
+            _ptr(d_feat), _ptr(grad_table), _ptr(ws), _stream()),
+            "ucsa_hashgrid_bwd_rays_p64")
+        return
     check(lib().ucsa_hashgrid_bwd_rays(C.byref(grid), _ptr(rays_o),
                                        _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
                                        _ptr(d_feat), _ptr(grad_table),
@@ -572,10 +580,11 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
 
 
 def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
-                             d_feat_c, d_feat_f, grad_table):
+                             d_feat_c, d_feat_f, grad_table, packed: bool = False):
     """Both density passes in one call, every ray's samples walked in sorted
     depth order (``src`` [N, Tc+Tf] int32 of the forward composite): adds the
-    table gradient (ucsa_hashgrid_bwd_rays_merged)."""
+    table gradient (ucsa_hashgrid_bwd_rays_merged; packed: its _p64 form with
+    8-byte records of 26-bit values)."""
     N, Tc = z_c.shape
     Tf = z_f.shape[1]
     L = grid.n_levels
@@ -592,10 +601,11 @@ def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=z_c.device)
         _bwd_ws[key] = ws
-    check(lib().ucsa_hashgrid_bwd_rays_merged(
+    fn = lib().ucsa_hashgrid_bwd_rays_merged_p64 if packed else lib().ucsa_hashgrid_bwd_rays_merged
+    check(fn(
         C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z_c), _ptr(z_f), _ptr(src),
         fvec(aabb), N, Tc, Tf, _ptr(d_feat_c), _ptr(d_feat_f), _ptr(grad_table), _ptr(ws),
-        _stream()), "ucsa_hashgrid_bwd_rays_merged")
+        _stream()), "ucsa_hashgrid_bwd_rays_merged" + ("_p64" if packed else ""))
 
 
 def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
