@@ -578,6 +578,67 @@ int32_t ucsa_hashgrid_bwd_rays_merged_p64(
     uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
     const float* d_feat_f, float* grad_table, void* workspace, void* stream);
 
+/* ---- the differentiable render of a training step as TWO calls --------------
+ * SURVEY 8(b)'s ucsa_render_fused_fwd / ucsa_render_fused_bwd.  Replaces
+ * SemanticNeRFRenderer.run under autograd (reference
+ * nr4seg/nerf/renderer_semantics.py:123-299 as driven by
+ * nr4seg/lightning/joint_train_lightning_net.py:473-513): rows a2-a9 for N rays
+ * with T coarse + t fine samples, forward keeping what the backward needs, and
+ * the backward down to the four flat parameter gradients.  Arithmetic of the
+ * default training mode: bf16x3 nets forward (fp32-grade), bf16x2 contractions
+ * and 8-byte packed bin records backward.  Both only SEQUENCE the per-stage
+ * entry points above on `stream` (same launches, order and arguments as the
+ * Python host issues one by one: bit-identical results); they never allocate or
+ * synchronise.  All buffers are the caller's, device memory, fp32 unless noted. */
+typedef struct ucsa_train_buffers {
+  float* z_c;     /* [N,T]  coarse depths */
+  float* feat_c;  /* [L][N*T][2]  their hash-grid features */
+  float* h_c;     /* [N*T,16]  raw sigma-net outputs */
+  float* sigma_c; /* [N,T] */
+  float* z_f;     /* [N,t]  resampled depths (t > 0) */
+  float* feat_f;  /* [L][N*t][2] */
+  float* h_f;     /* [N*t,16] */
+  float* sigma_f; /* [N,t] */
+  int32_t* src;   /* [N,T+t]  sorted order of the merged samples */
+  float* weights; /* [N,T+t]  compositing weights in that order */
+} ucsa_train_buffers;
+
+typedef struct ucsa_train_packs {
+  const void* sigma_x3;   /* ucsa_mlp_pack_x3(UCSA_MLP_SIGMA) */
+  const void* color_x3;   /* ... UCSA_MLP_COLOR */
+  const void* sem_x3;     /* ... UCSA_MLP_SEM */
+  const void* sigma_t_x3; /* ucsa_mlp_pack_t_x3: backward only (may be NULL forward) */
+  const void* color_t_x3;
+  const void* sem_t_x3;
+} ucsa_train_packs;
+
+uint64_t ucsa_render_fused_fwd_workspace_bytes(uint32_t N, uint32_t T, uint32_t t);
+/* t_rand [N,T] or NULL (no perturbation), u [N,t] (t > 0).  Writes `out`
+ * (every member; the *_f ones only when t > 0), image [N,3], depth [N],
+ * semantics [N,n_classes]. */
+int32_t ucsa_render_fused_fwd(
+    const ucsa_grid* grid, const float* table, const ucsa_train_packs* packs,
+    const float* rays_o, const float* rays_d, const float* norms,
+    const float* aabb_host, float min_near, const float* t_rand, const float* u,
+    uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
+    const ucsa_train_buffers* out, float* image, float* depth, float* semantics,
+    void* workspace, void* stream);
+
+uint64_t ucsa_render_fused_bwd_workspace_bytes(uint32_t N, uint32_t T, uint32_t t,
+                                               uint32_t n_classes,
+                                               uint32_t n_levels);
+/* `saved` as ucsa_render_fused_fwd left it.  grad_table [total_entries,2] is
+ * ADDED to (zero it first); grad_sigma [3072], grad_color [7168] and grad_sem
+ * [1024 + 1024 * ceil(n_classes / 16)] are overwritten (layouts of the flat
+ * tcnn parameter tensors, ucsa_mlp_pack). */
+int32_t ucsa_render_fused_bwd(
+    const ucsa_grid* grid, const ucsa_train_packs* packs, const float* rays_o,
+    const float* rays_d, const float* norms, const float* aabb_host,
+    const ucsa_train_buffers* saved, const float* d_image, const float* d_depth,
+    const float* d_sem, uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes,
+    float density_scale, float* grad_table, float* grad_sigma, float* grad_color,
+    float* grad_sem, void* workspace, void* stream);
+
 /* Backward of ucsa_hashgrid_encode_points (x [M,3] explicit points; workspace
  * of ucsa_hashgrid_bwd_workspace_bytes(M, 1, n_levels) or NULL). */
 int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid_host, const float* x,

@@ -664,3 +664,37 @@ def test_packed_bin_records_match_fp32_records(ops, case):
           f"rel L2 {float((gpk - g32).norm() / g32.norm()):.2e}")
     assert worst <= 1.0
     assert torch.equal(gpk == 0, g32 == 0) or float(((gpk == 0) != (g32 == 0)).float().mean()) < 1e-5
+
+
+@pytest.mark.parametrize("N,T,t,C", [(300, 32, 32, 40), (129, 64, 0, 21), (64, 256, 256, 40)])
+def test_fused_train_calls_equal_the_staged_path(N, T, t, C):
+    """ucsa_render_fused_fwd / ucsa_render_fused_bwd (the training
+    render as one C call per direction) against the same step issued stage by
+    stage from Python: the library sequences the SAME launches, so the outputs
+    and the three net gradients are bit-identical; the hash-grid gradient agrees
+    up to the order of its LDS atomic additions (which also differs between
+    two runs of one path)."""
+    fld = lively_oracle_field(C=C)
+    o, d, norms = make_rays(N, 900 + N)
+    g = torch.Generator().manual_seed(N)
+    t_rand = torch.rand(N, T, generator=g).cuda()
+    u = torch.rand(N, t, generator=g).cuda() if t else None
+    ci, cd, cs = (torch.rand(1, N, 3, generator=g).cuda(), torch.rand(1, N, generator=g).cuda(),
+                  torch.rand(1, N, C, generator=g).cuda())
+    got = {}
+    for fused in (True, False):
+        net = hip_network_from_oracle(fld).train()
+        net.train_precision, net.bwd_precision = "bf16x3", "bf16x2"
+        net.fused_train_calls = fused
+        res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(), perturb=True,
+                         num_steps=T, upsample_steps=t, rng_t=t_rand, rng_u=u)
+        ((res["image"] * ci).sum() + (res["depth"] * cd).sum() + (res["semantics"] * cs).sum()).backward()
+        got[fused] = ([res[k].detach().clone() for k in ("image", "depth", "semantics")],
+                      [p.grad.detach().clone() for p in (net.color_net.params, net.semantics_net.params,
+                                                         net.sigma_net.params)],
+                      net.encoder.params.grad.detach().clone())
+    for a, b in zip(got[True][0] + got[True][1], got[False][0] + got[False][1]):
+        assert torch.equal(a, b)
+    ga, gb = got[True][2], got[False][2]
+    assert float(gb.abs().max()) > 0
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())

@@ -37,6 +37,18 @@ class Grid(C.Structure):
                 ("level", GridLevel * MAX_LEVELS)]
 
 
+class TrainBuffers(C.Structure):
+    """ucsa_train_buffers: device pointers of the training forward's saved state."""
+    _fields_ = [(k, C.c_void_p) for k in ("z_c", "feat_c", "h_c", "sigma_c", "z_f",
+                                          "feat_f", "h_f", "sigma_f", "src", "weights")]
+
+
+class TrainPacks(C.Structure):
+    """ucsa_train_packs: bf16x3 weight fragments (forward) and their transposes."""
+    _fields_ = [(k, C.c_void_p) for k in ("sigma_x3", "color_x3", "sem_x3",
+                                          "sigma_t_x3", "color_t_x3", "sem_t_x3")]
+
+
 class AugParams(C.Structure):
     _fields_ = [("order", C.c_int32 * 4), ("brightness", C.c_float),
                 ("contrast", C.c_float), ("saturation", C.c_float),
@@ -157,6 +169,14 @@ SIGNATURES = {
     "ucsa_hashgrid_bwd_rays_merged_p64": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                                       C.POINTER(_f), _u32, _u32, _u32, _p, _p,
                                                       _p, _p, _p]),
+    "ucsa_render_fused_fwd_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32]),
+    "ucsa_render_fused_fwd": (C.c_int32, [C.POINTER(Grid), _p, C.POINTER(TrainPacks), _p, _p, _p,
+                                          C.POINTER(_f), _f, _p, _p, _u32, _u32, _u32, _u32, _f,
+                                          C.POINTER(TrainBuffers), _p, _p, _p, _p, _p]),
+    "ucsa_render_fused_bwd_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32, _u32, _u32]),
+    "ucsa_render_fused_bwd": (C.c_int32, [C.POINTER(Grid), C.POINTER(TrainPacks), _p, _p, _p,
+                                          C.POINTER(_f), C.POINTER(TrainBuffers), _p, _p, _p,
+                                          _u32, _u32, _u32, _u32, _f, _p, _p, _p, _p, _p, _p]),
     "ucsa_hashgrid_bwd_points": (C.c_int32, [C.POINTER(Grid), _p, _u32, _p, _p,
                                              _p, _p]),
     "ucsa_composite_bwd_parts": (C.c_uint32, [_u32]),

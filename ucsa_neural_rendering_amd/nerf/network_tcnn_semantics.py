@@ -25,10 +25,30 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid_p, sigma_p, color_p, sem_p, net, o, d, nrm, aabb, T,
                 t, rng_t, rng_u, min_near):
-        f = net._field(transposed=True)
         N = o.shape[0]
         C = net.num_semantic_classes
         ds = float(net.density_scale)
+        ctx.fused = False
+        if (net.fused_train_calls and net.train_precision == "bf16x3"
+                and net.bwd_precision == "bf16x2" and ops.shade_bwd_split()
+                and net.grid_records_packed and (net.grid_bwd_merged or t == 0)):
+            # the default training mode: forward and backward are ONE C call each
+            # (ucsa_render_fused_fwd / _bwd: the same launches as the staged code
+            # below, sequenced in the library)
+            pk = [net._pack_x3(k, n) for k, n in (("sigma", net.sigma_net), ("color", net.color_net),
+                                                  ("sem", net.semantics_net))]
+            pk += [net._pack_t_x3(k, n) for k, n in (("sigma", net.sigma_net), ("color", net.color_net),
+                                                     ("sem", net.semantics_net))]
+            # (no f32 weight packs in this mode: six small launches less per step)
+            f = dict(grid=net.encoder.grid, table=net.encoder.params.detach())
+            image, depth, sem, sv = ops.render_fused_fwd(
+                f["grid"], f["table"], ops.train_packs(*pk), o, d, nrm, aabb, min_near,
+                rng_t, rng_u, T, t, C, ds)
+            ctx.fused, ctx.pk, ctx.sv = True, pk, sv
+            ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t = net, f, aabb, T, t
+            ctx.rays = (o, d, nrm)
+            return image, depth, sem
+        f = net._field(transposed=True)
         near, far = ops.near_far_from_aabb(o, d, aabb, min_near)
         z_c = ops.sample_coarse(near, far, T, rng_t)
         # train_precision="tcnn": tiny-cuda-nn's numerics end to end -- the
@@ -107,6 +127,18 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_image, d_depth, d_sem):
         net, f, aabb, T, t = ctx.net, ctx.f, ctx.aabb, ctx.T, ctx.t
+        if ctx.fused:
+            o, d, nrm = ctx.rays
+            g_grid = torch.zeros_like(net.encoder.params)
+            g_sigma = torch.empty_like(net.sigma_net.params)
+            g_color = torch.empty_like(net.color_net.params)
+            g_sem = torch.empty_like(net.semantics_net.params)
+            ops.render_fused_bwd(f["grid"], ops.train_packs(*ctx.pk), o, d, nrm, aabb, ctx.sv,
+                                 d_image.contiguous(), d_depth.contiguous(), d_sem.contiguous(),
+                                 net.num_semantic_classes, float(net.density_scale),
+                                 g_grid, g_sigma, g_color, g_sem)
+            ctx.sv = ctx.pk = ctx.rays = None
+            return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
         (o, d, nrm, z_c, feat_c, h_c, s_c, z_f, feat_f, h_f, s_f, src,
          w) = ctx.saved
         C = net.num_semantic_classes

@@ -100,6 +100,10 @@ class SemanticNeRFRenderer(nn.Module):
         # 8-byte words with 26-bit values (ucsa_hashgrid_bwd_rays*_p64) instead
         # of 16-byte (index, fp32, fp32) records -- half the record traffic
         self.grid_records_packed = os.environ.get("UCSA_GRID_RECORDS_PACKED", "1") != "0"
+        # the default training mode (bf16x3 / bf16x2 / packed / merged) as ONE C
+        # call per direction (ucsa_render_fused_fwd / ucsa_render_fused_bwd)
+        # instead of one call per stage from Python; bit-identical
+        self.fused_train_calls = os.environ.get("UCSA_FUSED_TRAIN", "1") != "0"
         self.f16_bwd_scale = 1024.0
         # with train_precision="fp16": the hash-grid backward's bin records
         # carry half2 values (8 instead of 16 bytes per record)

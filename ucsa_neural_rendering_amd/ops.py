@@ -608,6 +608,73 @@ def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
         _stream()), "ucsa_hashgrid_bwd_rays_merged" + ("_p64" if packed else ""))
 
 
+def train_packs(sigma_x3, color_x3, sem_x3, sigma_t_x3=None, color_t_x3=None,
+                sem_t_x3=None) -> "_lib.TrainPacks":
+    """ucsa_train_packs over bf16x3 weight fragments (mlp_pack_x3 / mlp_pack_t_x3);
+    the caller keeps the tensors alive."""
+    return _lib.TrainPacks(*[_ptr(x) for x in (sigma_x3, color_x3, sem_x3, sigma_t_x3,
+                                              color_t_x3, sem_t_x3)])
+
+
+def render_fused_fwd(grid: Grid, table, packs, rays_o, rays_d, norms, aabb,
+                     min_near: float, t_rand, u, T: int, t: int, n_classes: int,
+                     density_scale: float = 1.0):
+    """The training forward (rows a2-a9) as ONE C call (ucsa_render_fused_fwd,
+    bf16x3 nets) -> image [N,3], depth [N], sem [N,C] and the dict of saved
+    tensors (the members of ucsa_train_buffers) the fused backward reads."""
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    norms = _f32(norms, "norms").view(-1)
+    N, dev, L = rays_o.shape[0], rays_o.device, grid.n_levels
+    if t_rand is not None:
+        t_rand = _f32(t_rand, "t_rand")
+        assert t_rand.shape == (N, T)
+    if t > 0:
+        u = _f32(u, "u")
+        assert u.shape == (N, t)
+    e = lambda *shape, **kw: torch.empty(*shape, device=dev, **kw)  # noqa: E731
+    sv = {"z_c": e(N, T), "feat_c": e(L, N * T, 2), "h_c": e(N * T, 16), "sigma_c": e(N, T),
+          "z_f": e(N, t) if t else None, "feat_f": e(L, N * t, 2) if t else None,
+          "h_f": e(N * t, 16) if t else None, "sigma_f": e(N, t) if t else None,
+          "src": e(N, T + t, dtype=torch.int32), "weights": e(N, T + t)}
+    bufs = _lib.TrainBuffers(*[_ptr(sv[k]) for k, _ in _lib.TrainBuffers._fields_])
+    image, depth, sem = e(N, 3), e(N), e(N, n_classes)
+    ws = _scratch_named("render_fused_fwd",
+                        int(lib().ucsa_render_fused_fwd_workspace_bytes(N, T, t)), dev)
+    aabb_h = fvec(aabb.detach().cpu().tolist() if torch.is_tensor(aabb) else aabb)
+    check(lib().ucsa_render_fused_fwd(
+        C.byref(grid), _ptr(table), C.byref(packs), _ptr(rays_o), _ptr(rays_d), _ptr(norms),
+        aabb_h, float(min_near), _ptr(t_rand), _ptr(u) if t else None, N, T, t, n_classes,
+        float(density_scale), C.byref(bufs), _ptr(image), _ptr(depth), _ptr(sem), _ptr(ws),
+        _stream()), "ucsa_render_fused_fwd")
+    return image, depth, sem, sv
+
+
+def render_fused_bwd(grid: Grid, packs, rays_o, rays_d, norms, aabb, saved: dict,
+                     d_image, d_depth, d_sem, n_classes: int, density_scale: float,
+                     grad_table, grad_sigma, grad_color, grad_sem):
+    """The training backward as ONE C call (ucsa_render_fused_bwd: bf16x2
+    contractions, packed bin records).  ADDS to grad_table, overwrites the three
+    net gradients."""
+    N, T = saved["z_c"].shape
+    t = 0 if saved["z_f"] is None else saved["z_f"].shape[1]
+    dev = saved["z_c"].device
+    d_image = _f32(d_image, "d_image").view(N, 3)
+    d_depth = _f32(d_depth, "d_depth").view(N)
+    d_sem = _f32(d_sem, "d_sem").view(N, n_classes)
+    nsem = 1024 + 1024 * ((n_classes + 15) // 16)
+    assert grad_sigma.numel() == 3072 and grad_color.numel() == 7168 and grad_sem.numel() == nsem
+    bufs = _lib.TrainBuffers(*[_ptr(saved[k]) for k, _ in _lib.TrainBuffers._fields_])
+    ws = _scratch_named("render_fused_bwd", int(lib().ucsa_render_fused_bwd_workspace_bytes(
+        N, T, t, n_classes, grid.n_levels)), dev)
+    aabb_h = fvec(aabb.detach().cpu().tolist() if torch.is_tensor(aabb) else aabb)
+    check(lib().ucsa_render_fused_bwd(
+        C.byref(grid), C.byref(packs), _ptr(rays_o), _ptr(rays_d), _ptr(norms), aabb_h,
+        C.byref(bufs), _ptr(d_image), _ptr(d_depth), _ptr(d_sem), N, T, t, n_classes,
+        float(density_scale), _ptr(grad_table), _ptr(grad_sigma), _ptr(grad_color),
+        _ptr(grad_sem), _ptr(ws), _stream()), "ucsa_render_fused_bwd")
+
+
 def hashgrid_bwd_points(grid: Grid, x, d_feat, grad_table, binned: bool = True):
     """Backward of hashgrid_encode_points: adds into grad_table."""
     x = _f32(x, "x").view(-1, 3)
