@@ -422,7 +422,10 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
   // clustered on a surface, the small steps of a marcher near the camera --
   // their updates are summed by a segmented wave scan first and only the last
   // lane of a run emits records (same plan in both passes).
-#pragma unroll
+  // (not unrolled: the fully unrolled pass made the kernel ~80 KB of code, more
+  // than the 64 KB instruction cache two CUs share; rolled: -1 % of the step.
+  // A version with BOTH 32- and 64-bit index paths in the code was +3 %.)
+#pragma unroll 1
   for (int it = 0; it < BIN_TILE; ++it) {
     const uint64_t m = m0 + (uint64_t)it * 256;
     bool act = m < M;
