@@ -335,13 +335,45 @@ int32_t ucsa_mlp_pack_x3(int32_t kind, const float* params, void* packed_x3,
 int32_t ucsa_sigma_mlp_fwd_x3(const float* feat, const void* packed_sigma_x3,
                               uint32_t M, uint32_t n_levels, float* h,
                               float* sigma, void* stream);
+/* ---- "f16x2": the nets on the f16 MFMA pipe with TWO-term operands ----------
+ * x ~ f16(x) + f16((x - f16(x)) * 2^11) * 2^-11: 22 significant bits per
+ * operand, products accumulated in fp32 from three f16 MFMA passes (bf16x3: six)
+ * -- the same 2^-23-per-product error class as bf16x3 and the f32-input MFMA
+ * chain (csrc/mfma_mlp_h2.h).  RANGE: layer inputs and weights must stay below
+ * 65504 in magnitude (f16), hidden activations below 2^20 (ucsa_mlp_pack_h2
+ * scales the first layer by 2^-4 and the last by 2^4, exact for the bias-free
+ * ReLU nets); beyond that the result is inf / NaN, never silently wrong.
+ * Same interfaces as the _x3 entries with packs from ucsa_mlp_pack_h2
+ * (ucsa_mlp_pack_h2_bytes bytes).  Replaces what the _x3 entries replace
+ * (tcnn.Network forward, reference network_tcnn_semantics.py:135,147-207). */
+uint32_t ucsa_mlp_pack_h2_bytes(int32_t kind, uint32_t n_classes);
+int32_t ucsa_mlp_pack_h2(int32_t kind, const float* params, void* packed_h2,
+                         uint32_t n_classes, void* stream);
+int32_t ucsa_sigma_mlp_fwd_h2(const float* feat, const void* packed_sigma_h2,
+                              uint32_t M, uint32_t n_levels, float* h,
+                              float* sigma, void* stream);
+int32_t ucsa_composite_infer_h2(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_h2,
+    const void* packed_sem_h2, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, void* workspace, void* stream);
+int32_t ucsa_render_fwd_h2(
+    const ucsa_grid* grid, const float* table, const void* packed_sigma_h2,
+    const void* packed_color_h2, const void* packed_sem_h2, const float* rays_o,
+    const float* rays_d, const float* norms, const float* aabb_host,
+    float min_near, const float* t_rand, const float* u, uint32_t N, uint32_t T,
+    uint32_t t, uint32_t n_classes, float density_scale, uint32_t image_width,
+    float* image, float* depth, float* semantics, void* ws, void* stream);
+
 /* A whole batch of rays (e.g. one view) in `chunk`-ray pieces, what the
  * reference's staged `render` loop does (renderer_semantics.py:321-342), as ONE
  * call: software-pipelined over two internal streams (density half of chunk
  * k+1 || shading half of chunk k; events fork from / join to `stream`), two
  * workspaces of ucsa_render_workspace_bytes(min(N, chunk), T, t, L) bytes each
  * (ws1 NULL = serial loop).  mode: 0 = ucsa_render_fwd, 1 = _f16, 2 = _x3,
- * 3 = _f16_h16 (their table / packed-weight formats).  Arrays are for all N
+ * 3 = _f16_h16, 4 = _h2 (their table / packed-weight formats).  Arrays are for all N
  * rays; image_width as in ucsa_render_fwd (needs chunk % (8 * image_width) == 0
  * and N % image_width == 0, else the ray-ordered gather is used -- same
  * results).  Bit-identical to calling ucsa_render_fwd* per chunk. */

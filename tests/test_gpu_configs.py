@@ -122,6 +122,20 @@ def test_cfg2_bench_path_640x480_staged_image_ordered(which):
                           upsample_steps=t, rng_u=u, image_width=W)
     net.precision = "fp32"
     _check(res3, ref, fld, rays_sel, T, t, sel, tag=f"cfg2[{which}, bf16x3]")
+    # ... and f16x2 (two-term f16 operands, half the matrix passes; round 4)
+    net.precision = "f16x2"
+    with torch.no_grad():
+        resh = net.render(o, d, nrm, staged=True, perturb=False, num_steps=T,
+                          upsample_steps=t, rng_u=u, image_width=W)
+    net.precision = "fp32"
+    _check(resh, ref, fld, rays_sel, T, t, sel, tag=f"cfg2[{which}, f16x2]")
+    for k in ("image", "semantics"):
+        e = (resh[k][0] - res[k][0]).abs().max(-1)[0]
+        print(f"cfg2[{which}] f16x2 vs f32 MFMA, {k}: median {float(e.median()):.2e} "
+              f"p99 {float(e.quantile(0.99)):.2e} p99.9 {float(e.quantile(0.999)):.2e} "
+              f"max {float(e.max()):.2e}")
+        assert float(e.median()) <= 2e-6 and float(e.quantile(0.999)) <= 2e-4 \
+            and float(e.max()) <= 2e-3, k
     for k in ("image", "semantics"):
         # The nets of the two modes agree to ~1e-7 (test_bf16x3_nets_are_fp32_
         # grade); a whole view also passes the two step functions of the path

@@ -194,7 +194,7 @@ def _hip_render(net, g, chunk=None, staged=None):
     return {k: v.cpu() for k, v in res.items()}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_render_matches_reference_fixture(net, tag, precision):
     """Fixtures = the REFERENCE renderer run on the restated field.  Same
@@ -214,7 +214,7 @@ def test_render_matches_reference_fixture(net, tag, precision):
     assert float(rel.max()) <= 2e-4
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("N,T,t,perturb", [(1, 16, 16, False), (37, 16, 16, True),
                                            (130, 32, 0, False), (64, 96, 96, True),
                                            (50, 256, 256, False)])
@@ -688,3 +688,98 @@ def test_fp16_table_render_matches_the_oracle_with_the_rounded_table():
     assert maxabs(res["semantics"], ref["semantics"]) <= 3e-3
     rel = (res["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-3)
     assert float(rel.max()) <= 3e-3
+
+
+@pytest.mark.parametrize("scale,hmag", [(1.0, 1.5), (6.0, 1.5), (1.0, 1e-3), (30.0, 40.0)])
+def test_f16x2_nets_are_fp32_grade(ops, scale, hmag):
+    """The f16x2 shading kernel (csrc/mfma_mlp_h2.h: two f16 terms per operand,
+    the second scaled by 2^11, three MFMA passes per product) against an fp64
+    evaluation, next to the f32-input MFMA kernel and bf16x3: ordinary weights,
+    large weights (hidden activations of O(10)), TINY inputs (geo features of
+    1e-3: the regime where an unscaled second term would be an f16 subnormal)
+    and large everything (hidden activations of O(1e4): the 2^-4 hidden scale)."""
+    import copy
+    fld = copy.copy(lively_oracle_field())
+    g = torch.Generator().manual_seed(7)
+    fld.color_params = fld.color_params * scale
+    fld.sem_params = fld.sem_params * scale
+    M = 4096 + 37
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    h = torch.randn(M, 16, generator=g) * hmag
+    rgb64, p64 = _nets_fp64(fld, d, h)
+    dev = torch.device("cuda:0")
+    z = torch.ones(M, 1, device=dev)
+    sig = torch.full((M, 1), 50.0, device=dev)
+    nrm = torch.ones(M, device=dev)
+    cp, sp = fld.color_params.to(dev), fld.sem_params.to(dev)
+    args = (d.to(dev), nrm, z, sig, h.to(dev), None, None, None)
+    f32 = ops.composite_infer(*args, ops.mlp_pack(1, cp), ops.mlp_pack(2, sp, 40), 40)
+    x3 = ops.composite_infer(*args, ops.mlp_pack_x3(1, cp), ops.mlp_pack_x3(2, sp, 40), 40, x3=True)
+    h2 = ops.composite_infer(*args, ops.mlp_pack_h2(1, cp), ops.mlp_pack_h2(2, sp, 40), 40, h2=True)
+    torch.cuda.synchronize()
+    err = lambda got, ref: float((got.cpu().double() - ref).abs().max())  # noqa: E731
+    e32 = (err(f32[0], rgb64), err(f32[2], p64))
+    ex3 = (err(x3[0], rgb64), err(x3[2], p64))
+    eh2 = (err(h2[0], rgb64), err(h2[2], p64))
+    print(f"scale {scale} |h| {hmag}: max |. - fp64|  f32 MFMA rgb {e32[0]:.2e} p {e32[1]:.2e} | "
+          f"bf16x3 rgb {ex3[0]:.2e} p {ex3[1]:.2e} | f16x2 rgb {eh2[0]:.2e} p {eh2[1]:.2e}")
+    assert torch.isfinite(h2[0]).all() and torch.isfinite(h2[2]).all()
+    for a, b, c in zip(eh2, e32, ex3):
+        # as good as the exact chain -- or, where logits of O(1e4) make the
+        # softmax ill-conditioned (the last case), as good as bf16x3
+        assert a <= max(2.0 * b, 3e-7, 1.25 * c), (eh2, e32, ex3)
+    assert maxabs(h2[0], f32[0]) <= max(1e-6, 2 * (e32[0] + eh2[0]))
+    assert maxabs(h2[2], f32[2]) <= max(1e-6, 2 * (e32[1] + eh2[1]))
+
+
+@pytest.mark.parametrize("fmag", [0.5, 1e-4])
+def test_f16x2_sigma_mlp_is_fp32_grade(ops, fmag):
+    """sigma MLP on f16x2 against fp64, next to the f32-input MFMA kernel --
+    with features of O(1) and of 1e-4 (tiny-cuda-nn's initialisation scale of
+    the hash table)."""
+    fld = lively_oracle_field()
+    g = torch.Generator().manual_seed(11)
+    M = 5000
+    feat = torch.randn(16, M, 2, generator=g) * fmag
+    x = feat.permute(1, 0, 2).reshape(M, 32).double()
+    h64 = ofield.mlp_forward(fld.sigma_spec, x, fld.sigma_params.double())
+    dev = torch.device("cuda:0")
+    sp = fld.sigma_params.to(dev)
+    h32, s32 = ops.sigma_mlp_fwd(feat.to(dev), ops.mlp_pack(0, sp))
+    hh2, sh2 = ops.sigma_mlp_fwd_h2(feat.to(dev), ops.mlp_pack_h2(0, sp))
+    torch.cuda.synchronize()
+    e32 = float((h32.cpu().double() - h64).abs().max())
+    eh2 = float((hh2.cpu().double() - h64).abs().max())
+    scale = float(h64.abs().max())
+    print(f"sigma MLP |feat| {fmag}: max |h - fp64|  f32 MFMA {e32:.2e}  f16x2 {eh2:.2e}  (|h| max {scale:.2e})")
+    # relative fp32 grade down to activations of ~2^-10; below that the f16 pair's
+    # error is ABSOLUTE: <= 2^-36 per layer input, 2^-32 per hidden activation
+    # (the 2^-4 hidden scale) -- 1e-9 on h, nothing next to sigma = exp(h0)
+    assert eh2 <= max(2.0 * e32, 3e-7 * scale, 2e-9)
+    rel = ((sh2 - s32).abs() / s32.abs().clamp_min(1e-30)).max()
+    assert float(rel) <= 5e-6
+
+
+def test_f16x2_render_matches_the_oracle_like_bf16x3(net, fld):
+    """A whole render with precision f16x2 against the CPU oracle at the
+    tolerance of the other fp32-grade modes (1e-4 / 2e-4 relative depth), and
+    against bf16x3 (both within ordinary fp32 round-off of the truth)."""
+    N, T, t = 700, 32, 32
+    o, d, norms = make_rays(N, 21)
+    g = torch.Generator().manual_seed(5)
+    u = torch.rand(N, t, generator=g)
+    with torch.no_grad():
+        ref = oren.run(fld, o[None], d[None], norms[None], AABB4, num_steps=T,
+                       upsample_steps=t, u=u)
+    out = {}
+    for prec in ("f16x2", "bf16x3"):
+        net.precision = prec
+        with torch.no_grad():
+            out[prec] = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(),
+                                   num_steps=T, upsample_steps=t, rng_u=u.cuda())
+    torch.cuda.synchronize()
+    net.precision = "fp32"
+    for k in ("image", "depth", "semantics"):
+        e = maxabs(out["f16x2"][k], ref[k])
+        print(f"f16x2 render {k}: max |hip - oracle| {e:.2e}, vs bf16x3 {maxabs(out['f16x2'][k], out['bf16x3'][k]):.2e}")
+        assert e <= 2e-4, k

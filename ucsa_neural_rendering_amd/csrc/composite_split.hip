@@ -34,7 +34,7 @@
 #include <cstdlib>
 
 #include "composite_common.h"
-#include "mfma_mlp_x3.h"
+#include "mfma_mlp_h2.h"
 
 extern __shared__ __attribute__((aligned(16))) float cs_smem[];
 
@@ -58,7 +58,7 @@ struct WcArgs {
   uint32_t C;
   void* sh;            // per-ray SH basis of the direction in the form the
                        // shading kernel's MFMA operand wants (null: not wanted)
-  uint32_t sh_mode;    // 1: [N][16] half; 2: [N][3 terms][16] bf16 (bf16x3 split)
+  uint32_t sh_mode;    // 1: [N][16] half; 2: [N][3 terms][16] bf16 (bf16x3 split); 3: [N][2 terms][16] half (f16x2)
   int32_t* src_out;    // training forward: source index of sorted sample s (or null)
   float* w_out;        // training forward: weight of sorted sample s (or null)
 };
@@ -169,6 +169,11 @@ __global__ void __launch_bounds__(64 * WC_WAVES) k_weights_compact(WcArgs a) {
       const float v = q == 0 ? sh[0] : (q == 1 ? sh[1] : (q == 2 ? sh[2] : sh[3]));
       if (a.sh_mode == 1) {
         reinterpret_cast<_Float16*>(a.sh)[(size_t)r * 16 + lane] = (_Float16)v;
+      } else if (a.sh_mode == 3) {  // the two-term f16 split of mfma_mlp_h2.h
+        _Float16* o = reinterpret_cast<_Float16*>(a.sh) + (size_t)r * 32 + lane;
+        const _Float16 hi = (_Float16)v;
+        o[0] = hi;
+        o[16] = (_Float16)((v - (float)hi) * H2_LO_SCALE);
       } else {  // the exact three-term bf16 split of mfma_mlp_x3.h, per value
         uint16_t* o = reinterpret_cast<uint16_t*>(a.sh) + (size_t)r * 48 + lane;
         const uint32_t p0 = bf16_pair(v, 0.0f);
@@ -588,7 +593,7 @@ struct Pre16 {
   float ew[CBS];
   uint32_t eray[CBS];
   f32x4 hv[CBS];
-  u32x2 sh[CBS][PREC == 2 ? 3 : 1];  // this lane's 4 SH k-slots, operand form
+  u32x2 sh[CBS][PREC == 2 ? 3 : (PREC == 3 ? 2 : 1)];  // this lane's 4 SH k-slots, operand form
 };
 
 // The sums of one ray: add the partial sums of the 16 lanes of every row, lane
@@ -636,7 +641,8 @@ __device__ __attribute__((noinline)) void shade16_flush(
 
 template <int NRB_SEM, int CBS, int PREC, int WAVES, bool OFF32>
 __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
-  static_assert(PREC == 1 || PREC == 2, "16-bit MFMA modes");
+  static_assert(PREC >= 1 && PREC <= 3, "16-bit MFMA modes");
+  constexpr int TERMS = PREC == 2 ? 3 : (PREC == 3 ? 2 : 1);
   constexpr uint32_t G = 16u * CBS;
   const X3Sel sel = x3_selectors();  // bf16x3 split constants, once per kernel
   const uint32_t lane = threadIdx.x & 63u;
@@ -644,9 +650,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint32_t S = a.S, C = a.C;
 
-  constexpr uint32_t WC_FLOATS = PREC == 2 ? COLOR_H_FRAGS * 768 : COLOR_H_FRAGS * 256;
-  constexpr uint32_t WS_FLOATS =
-      PREC == 2 ? SEM_H_FRAGS(NRB_SEM) * 768 : SEM_H_FRAGS(NRB_SEM) * 256;
+  constexpr uint32_t WC_FLOATS = COLOR_H_FRAGS * 256 * TERMS;
+  constexpr uint32_t WS_FLOATS = SEM_H_FRAGS(NRB_SEM) * 256 * TERMS;
   float* w_color = cs_smem;
   float* w_sem = w_color + WC_FLOATS;
   for (uint32_t i = threadIdx.x; i < WC_FLOATS; i += blockDim.x)
@@ -666,7 +671,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
   const float* lw = a.list_w + lbase;
   const uint32_t* lrow = a.list_row + lbase;
   const uint32_t* lray = a.list_ray + lbase;
-  constexpr uint32_t SH_BYTES = PREC == 2 ? 96u : 32u;  // per ray
+  constexpr uint32_t SH_BYTES = 32u * TERMS;  // per ray
 
   uint32_t cur_ray = 0xFFFFFFFFu;  // ray whose partial sums sit in accS / accC
   f32x4 accS[NRB_SEM];             // classes 16 rb + 4 g + r, entries j, j+16, ...
@@ -716,7 +721,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
         p.hv[cb] = *reinterpret_cast<const f32x4*>(hb + ((r0 << 6) | (g << 4)));
         const uint32_t so = en.ray[cb] * SH_BYTES + 8u * g;
 #pragma unroll
-        for (int term = 0; term < (PREC == 2 ? 3 : 1); ++term)
+        for (int term = 0; term < TERMS; ++term)
           p.sh[cb][term] = ld_off32<u32x2>(a.sh, so + 32u * term);
       } else {
         const float* hp = (fine ? a.h_f : a.h_c) + (size_t)r0 * 16 + 4 * g;
@@ -724,7 +729,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
         const char* sp = reinterpret_cast<const char*>(a.sh) +
                          (size_t)en.ray[cb] * SH_BYTES + 8u * g;
 #pragma unroll
-        for (int term = 0; term < (PREC == 2 ? 3 : 1); ++term)
+        for (int term = 0; term < TERMS; ++term)
           p.sh[cb][term] = *reinterpret_cast<const u32x2*>(sp + 32 * term);
       }
     }
@@ -828,6 +833,74 @@ __global__ void __launch_bounds__(64 * WAVES) k_shade16(ShArgs a) {
         const W3 wb = frag_x3(w_sem, 5 + 2 * rb, wl);
 #pragma unroll
         for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = mfma_x3(wb, h1[cb], lg[cb][rb]);
+      }
+    } else if constexpr (PREC == 3) {
+      // f16x2 (mfma_mlp_h2.h): the layer structure of the bf16x3 branch with
+      // two-term operands -- 72 MFMAs per column block instead of 144
+      const H2Sel hsel = h2_selectors();
+      H2X b1[CBS];
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+#pragma unroll
+        for (int term = 0; term < 2; ++term) {
+          b1[cb].t[term][0] = p.sh[cb][term][0];
+          b1[cb].t[term][1] = p.sh[cb][term][1];
+        }
+        h2_split_pair(geo[cb][0], geo[cb][1], b1[cb], 2, hsel);
+        h2_split_pair(geo[cb][2], geo[cb][3], b1[cb], 3, hsel);
+      }
+      f32x4 a1[CBS][4], a2[CBS][4];
+      H2X h0[CBS], h1[CBS];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const H2W w = h2_frag(w_color, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a1[cb][rb] = h2_mul1(w, b1[cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = h2_chain_relu(a1[cb][0], a1[cb][1], hsel);
+        h1[cb] = h2_chain_relu(a1[cb][2], a1[cb][3], hsel);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const H2W wa = h2_frag(w_color, 4 + 2 * rb, wl), wb = h2_frag(w_color, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = h2_mul2(wa, h0[cb], wb, h1[cb]);
+      }
+      // semantics L1 reads the h-row slots of b1 (zeros in the SH slots' place)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const H2W w = h2_frag(w_sem, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          H2X bs;
+#pragma unroll
+          for (int term = 0; term < 2; ++term)
+            bs.t[term] = u32x4{b1[cb].t[term][2], b1[cb].t[term][3], 0u, 0u};
+          a1[cb][rb] = h2_mul1(w, bs);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = h2_chain_relu(a2[cb][0], a2[cb][1], hsel);
+        h1[cb] = h2_chain_relu(a2[cb][2], a2[cb][3], hsel);
+      }
+      {
+        const H2W wa = h2_frag(w_color, 12, wl), wb = h2_frag(w_color, 13, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) o3[cb] = h2_mul2(wa, h0[cb], wb, h1[cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = h2_chain_relu(a1[cb][0], a1[cb][1], hsel);
+        h1[cb] = h2_chain_relu(a1[cb][2], a1[cb][3], hsel);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb) {
+        const H2W wa = h2_frag(w_sem, 4 + 2 * rb, wl), wb = h2_frag(w_sem, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = h2_mul2(wa, h0[cb], wb, h1[cb]);
       }
     } else {
       // fp16 weights / layer inputs, fp32 accumulate: 24 MFMAs per column block
@@ -978,7 +1051,7 @@ template <int NRB, int CBS, int PREC, int WAVES>
 static int32_t launch_shade16(const ShArgs& a, uint32_t n_waves, bool off32,
                               hipStream_t s) {
   const size_t smem = (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(NRB)) *
-                      (PREC == 2 ? 768 : 256) * 4;
+                      (PREC == 2 ? 768 : (PREC == 3 ? 512 : 256)) * 4;
   const uint32_t blocks = ucsa_div_up(n_waves, WAVES);
   const void* fn = off32
       ? reinterpret_cast<const void*>(&k_shade16<NRB, CBS, PREC, WAVES, true>)
@@ -1106,6 +1179,12 @@ static int32_t composite_infer(int prec, const float* rays_d,
   //           2 = (12, 1) 1.60   3 = (8, 2) 1.63
 #define SH_GO16(NRB)                                                                \
   do {                                                                              \
+    if (prec == 3) {                                                                \
+      if (variant == 1) return launch_shade16<NRB, 1, 3, 16>(b, n_waves, off32, s); \
+      if (variant == 2) return launch_shade16<NRB, 1, 3, 12>(b, n_waves, off32, s); \
+      if (variant == 3) return launch_shade16<NRB, 2, 3, 8>(b, n_waves, off32, s);  \
+      return launch_shade16<NRB, 1, 3, 8>(b, n_waves, off32, s);                    \
+    }                                                                               \
     if (prec == 2) {                                                                \
       if (variant == 1) return launch_shade16<NRB, 1, 2, 16>(b, n_waves, off32, s); \
       if (variant == 2) return launch_shade16<NRB, 1, 2, 12>(b, n_waves, off32, s); \
@@ -1161,6 +1240,19 @@ extern "C" int32_t ucsa_composite_infer_x3(
     float* semantics, void* workspace, void* stream) {
   return composite_infer(2, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
                          packed_color_x3, packed_sem_x3, N, T, t, n_classes,
+                         density_scale, image, depth, semantics, workspace,
+                         stream);
+}
+
+extern "C" int32_t ucsa_composite_infer_h2(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_h2,
+    const void* packed_sem_h2, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, void* workspace, void* stream) {
+  return composite_infer(3, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                         packed_color_h2, packed_sem_h2, N, T, t, n_classes,
                          density_scale, image, depth, semantics, workspace,
                          stream);
 }

@@ -93,14 +93,15 @@ static int fused_encode_mode() {
 // the split pair wins once the nets run on the 16-bit MFMA pipe (f16, bf16x3).
 // UCSA_SPLIT_COMPOSITE=0/1 overrides (bf16x3 exists as the split pair only).
 static bool split_composite(int prec) {
-  if (prec == 2) return true;
+  if (prec >= 2) return true;
   const char* v = getenv("UCSA_SPLIT_COMPOSITE");
   if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
   return prec == 1;
 }
 
 // prec: 0 = f32-input MFMA nets (packed by ucsa_mlp_pack), 1 = f16 MFMA
-// (ucsa_mlp_pack_f16), 2 = bf16x3 (ucsa_mlp_pack_x3)
+// (ucsa_mlp_pack_f16), 2 = bf16x3 (ucsa_mlp_pack_x3), 3 = f16x2
+// (ucsa_mlp_pack_h2)
 // (table_half is only offered together with the f16 nets: its encoder emits
 // fp16 features, which only the f16 sigma MLP reads)
 // stage: bit 0 = density half (near/far .. sigma of the fine samples, into the
@@ -153,10 +154,13 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
     if (prec == 1 && table_half)  // the h16 encoder wrote fp16 features
       return ucsa_sigma_mlp_fwd_f16_h(w.feat, packed_sigma, N * n,
                                       grid->n_levels, h, sigma, stream);
+    if (prec == 3)
+      return ucsa_sigma_mlp_fwd_h2(w.feat, packed_sigma, N * n, grid->n_levels, h,
+                                   sigma, stream);
     return ucsa_sigma_mlp_fwd_x3(w.feat, packed_sigma, N * n, grid->n_levels, h,
                                  sigma, stream);
   };
-  const int fmode = image_width && grid->n_levels == 16 && prec != 2 && !table_half
+  const int fmode = image_width && grid->n_levels == 16 && prec < 2 && !table_half
                         ? fused_encode_mode() : 0;
   UCSA_TRY(density(w.z_c, T, fmode != 0, w.h_c, w.sigma_c));
   if (t > 0) {
@@ -173,7 +177,8 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
                                   (const float*)packed_sem, N, T, t, n_classes,
                                   density_scale, image, depth, semantics, w.cmp,
                                   stream);
-    const auto infer = prec == 2 ? ucsa_composite_infer_x3 : ucsa_composite_infer_f16;
+    const auto infer = prec == 3 ? ucsa_composite_infer_h2
+                       : prec == 2 ? ucsa_composite_infer_x3 : ucsa_composite_infer_f16;
     return infer(rays_d, norms, w.z_c, w.sigma_c, w.h_c, w.z_f, w.sigma_f, w.h_f,
                  packed_color, packed_sem, N, T, t, n_classes, density_scale,
                  image, depth, semantics, w.cmp, stream);
@@ -248,6 +253,19 @@ extern "C" int32_t ucsa_render_fwd_x3(
                      image, depth, semantics, ws, stream);
 }
 
+extern "C" int32_t ucsa_render_fwd_h2(
+    const ucsa_grid* grid, const float* table, const void* packed_sigma_h2,
+    const void* packed_color_h2, const void* packed_sem_h2, const float* rays_o,
+    const float* rays_d, const float* norms, const float* aabb_host,
+    float min_near, const float* t_rand, const float* u, uint32_t N, uint32_t T,
+    uint32_t t, uint32_t n_classes, float density_scale, uint32_t image_width,
+    float* image, float* depth, float* semantics, void* ws, void* stream) {
+  return render_impl(3, grid, table, false, packed_sigma_h2, packed_color_h2,
+                     packed_sem_h2, rays_o, rays_d, norms, aabb_host, min_near,
+                     t_rand, u, N, T, t, n_classes, density_scale, image_width,
+                     image, depth, semantics, ws, stream);
+}
+
 // ---------------------------------------------------------------------------
 // ucsa_render_view: a whole batch of rays (a view) in chunks, software
 // pipelined over two internal streams -- the density half of chunk k+1 runs
@@ -318,12 +336,12 @@ extern "C" int32_t ucsa_render_view(
     uint32_t N, uint32_t T, uint32_t t, uint32_t n_classes, float density_scale,
     uint32_t image_width, uint32_t chunk, float* image, float* depth,
     float* semantics, void* ws0, void* ws1, void* stream) {
-  UCSA_CHECK_ARG(mode <= 3, 0);
+  UCSA_CHECK_ARG(mode <= 4, 0);
   UCSA_CHECK_ARG(grid, 1);
   UCSA_CHECK_ARG(chunk >= 1, 19);
   UCSA_CHECK_ARG(ws0, 23);
   if (N == 0) return 0;
-  const int prec = mode == 3 ? 1 : (int)mode;
+  const int prec = mode == 3 ? 1 : (mode == 4 ? 3 : (int)mode);
   const bool table_half = mode == 3;
   if (image_width && (N % image_width != 0 || chunk % (8 * image_width) != 0))
     image_width = 0;  // not whole 8-row bands: ray-ordered gather (same results)

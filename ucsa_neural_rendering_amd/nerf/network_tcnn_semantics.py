@@ -347,6 +347,18 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
             self._packed[name + "_x3"] = (key, packed)
         return self._packed[name + "_x3"][1]
 
+    def _pack_h2(self, name: str, net: FullyFusedMLP):
+        """Weights as two f16 terms (csrc/mfma_mlp_h2.h), refreshed when the
+        parameters change."""
+        p = net.params
+        key = (p.data_ptr(), p._version)
+        hit = self._packed.get(name + "_h2")
+        if hit is None or hit[0] != key or hit[1].device != p.device:
+            out = None if hit is None or hit[1].device != p.device else hit[1]
+            packed = ops.mlp_pack_h2(net.kind, p, self.num_semantic_classes, out=out)
+            self._packed[name + "_h2"] = (key, packed)
+        return self._packed[name + "_h2"][1]
+
     def _pack_t_x3(self, name: str, net: FullyFusedMLP):
         """Transposed fragments of ``net`` as bf16 terms (the dX contractions
         of the bf16x2 backward), refreshed when the parameters change."""
@@ -376,6 +388,13 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
                     packed_sigma=self._pack_x3("sigma", self.sigma_net),
                     packed_color=self._pack_x3("color", self.color_net),
                     packed_sem=self._pack_x3("sem", self.semantics_net))
+
+    def _field_h2(self):
+        """Weights as two f16 terms each (csrc/mfma_mlp_h2.h, "f16x2")."""
+        return dict(grid=self.encoder.grid, table=self.encoder.params.detach(),
+                    packed_sigma=self._pack_h2("sigma", self.sigma_net),
+                    packed_color=self._pack_h2("color", self.color_net),
+                    packed_sem=self._pack_h2("sem", self.semantics_net))
 
     def _field_f16(self, transposed: bool = False):
         f = dict(grid=self.encoder.grid, table=self.encoder.params.detach(),

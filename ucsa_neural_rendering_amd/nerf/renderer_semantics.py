@@ -72,6 +72,11 @@ class SemanticNeRFRenderer(nn.Module):
         #            exactly into three bf16 terms, six partial products per
         #            product, fp32 accumulation (csrc/mfma_mlp_x3.h) -- within
         #            1-2 ulp of "fp32", ~25 % less time per view;
+        #   "f16x2"  fp32-grade on the f16 MFMA pipe with HALF the matrix passes
+        #            of bf16x3: every operand as two f16 terms (the second
+        #            scaled by 2^11), three partial products per product
+        #            (csrc/mfma_mlp_h2.h); layer inputs and weights must stay
+        #            below 65504, hidden activations below 2^20 (inf beyond);
         #   "fp16"   what tiny-cuda-nn does (fp16 weights and layer inputs,
         #            fp32 accumulation).
         self.precision = "fp32"
@@ -303,10 +308,10 @@ class SemanticNeRFRenderer(nn.Module):
             }
         aabb = self._aabb_list(self.training)
         nears, fars = ops.near_far_from_aabb(o, d, aabb, min_near)
-        if self.precision not in ("fp32", "fp16", "bf16x3"):
-            raise ValueError("precision must be fp32, bf16x3 or fp16, got "
+        if self.precision not in ("fp32", "fp16", "bf16x3", "f16x2"):
+            raise ValueError("precision must be fp32, bf16x3, f16x2 or fp16, got "
                              f"{self.precision}")
-        # (the marcher has no bf16x3 kernels: that mode shades in fp32 here)
+        # (the marcher has no bf16x3 / f16x2 kernels: those modes shade in fp32 here)
         half = self.precision == "fp16" and schedule == "segments" and fused_shade
         f = self._field_f16() if half else self._field()
         sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
@@ -508,8 +513,8 @@ class SemanticNeRFRenderer(nn.Module):
 
     def _run_infer(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near,
                    image_width=0):
-        if self.precision not in ("fp32", "fp16", "bf16x3"):
-            raise ValueError("precision must be fp32, bf16x3 or fp16, got "
+        if self.precision not in ("fp32", "fp16", "bf16x3", "f16x2"):
+            raise ValueError("precision must be fp32, bf16x3, f16x2 or fp16, got "
                              f"{self.precision}")
         if self.fp16_table and self.precision != "fp16":
             raise ValueError("fp16_table needs precision='fp16' (its encoder emits "
@@ -521,6 +526,8 @@ class SemanticNeRFRenderer(nn.Module):
                 render = ops.render_fwd_f16_h16
         elif self.precision == "bf16x3":
             f, render = self._field_x3(), ops.render_fwd_x3
+        elif self.precision == "f16x2":
+            f, render = self._field_h2(), ops.render_fwd_h2
         else:
             f, render = self._field(), ops.render_fwd
         N = o.shape[0]
@@ -534,7 +541,7 @@ class SemanticNeRFRenderer(nn.Module):
         if self.hip_pipeline and n_chunks >= 2 and int(self.hip_streams) <= 1:
             # ONE call for the whole batch: density half of chunk k+1 next to
             # the shading half of chunk k (ucsa_render_view; bit-identical)
-            mode = {"fp32": "fp32", "bf16x3": "bf16x3"}.get(
+            mode = {"fp32": "fp32", "bf16x3": "bf16x3", "f16x2": "f16x2"}.get(
                 self.precision, "fp16_h16" if self.fp16_table else "fp16")
             ws = self._workspace(
                 ops.render_workspace_bytes(min(N, chunk), T, t, f["grid"].n_levels), dev, 2)

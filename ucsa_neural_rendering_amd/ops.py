@@ -282,11 +282,12 @@ def composite_train_fwd_x3(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
 def composite_infer(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
                     packed_color, packed_sem, n_classes: int,
                     density_scale: float = 1.0, half: bool = False,
-                    x3: bool = False):
+                    x3: bool = False, h2: bool = False):
     """Inference composite as the dense kernel pair (ucsa_composite_infer):
     same outputs as composite_fwd, bit for bit.  half=True: packed weights
     from mlp_pack_f16.  x3=True: bf16x3 nets (fp32-grade, weights from
-    mlp_pack_x3; not bit-identical to the f32-input MFMA)."""
+    mlp_pack_x3; not bit-identical to the f32-input MFMA); h2=True: f16x2
+    nets (mlp_pack_h2)."""
     rays_d = _f32(rays_d, "rays_d").view(-1, 3)
     norms = _f32(norms, "norms").view(-1)
     N, T = z_c.shape
@@ -298,7 +299,7 @@ def composite_infer(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     ws = _scratch_named("composite_infer",
                         int(lib().ucsa_composite_infer_workspace_bytes(N, T, t)),
                         dev)
-    fn = (lib().ucsa_composite_infer_x3 if x3 else
+    fn = (lib().ucsa_composite_infer_h2 if h2 else lib().ucsa_composite_infer_x3 if x3 else
           lib().ucsa_composite_infer_f16 if half else lib().ucsa_composite_infer)
     check(fn(_ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c),
              _ptr(z_f), _ptr(sigma_f), _ptr(h_f), _ptr(packed_color),
@@ -389,6 +390,45 @@ def mlp_pack_x3(kind: int, params: torch.Tensor, n_classes: int = 0,
     return out
 
 
+def mlp_pack_h2(kind: int, params: torch.Tensor, n_classes: int = 0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weights as two f16 terms per value (the second scaled by 2^11) in MFMA
+    fragment order (csrc/mfma_mlp_h2.h, "f16x2")."""
+    params = _f32(params.detach(), "params")
+    n = int(lib().ucsa_mlp_pack_h2_bytes(kind, n_classes))
+    if out is None:
+        out = torch.empty(n // 2, dtype=torch.float16, device=params.device)
+    check(lib().ucsa_mlp_pack_h2(kind, _ptr(params), _ptr(out), n_classes,
+                                 _stream()), "ucsa_mlp_pack_h2")
+    return out
+
+
+def sigma_mlp_fwd_h2(feat, packed_sigma_h2):
+    L, M, _ = feat.shape
+    h = torch.empty(M, 16, device=feat.device)
+    sigma = torch.empty(M, device=feat.device)
+    check(lib().ucsa_sigma_mlp_fwd_h2(_ptr(feat), _ptr(packed_sigma_h2), M, L,
+                                      _ptr(h), _ptr(sigma), _stream()),
+          "ucsa_sigma_mlp_fwd_h2")
+    return h, sigma
+
+
+def render_fwd_h2(grid: Grid, table, packed_sigma_h2, packed_color_h2,
+                  packed_sem_h2, rays_o, rays_d, norms, aabb, min_near: float,
+                  t_rand, u, T: int, t: int, n_classes: int,
+                  density_scale: float, image, depth, semantics,
+                  ws: torch.Tensor, image_width: int = 0):
+    """run() with the three nets as f16x2 (fp32-grade on the f16 MFMA pipe,
+    three passes per product)."""
+    N = rays_o.shape[0]
+    check(lib().ucsa_render_fwd_h2(
+        C.byref(grid), _ptr(table), _ptr(packed_sigma_h2), _ptr(packed_color_h2),
+        _ptr(packed_sem_h2), _ptr(rays_o), _ptr(rays_d), _ptr(norms), fvec(aabb),
+        float(min_near), _ptr(t_rand), _ptr(u), N, T, t, n_classes,
+        float(density_scale), int(image_width), _ptr(image), _ptr(depth),
+        _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_h2")
+
+
 def sigma_mlp_fwd_f16(feat, packed_sigma_half):
     L, M, _ = feat.shape
     h = torch.empty(M, 16, device=feat.device)
@@ -469,7 +509,7 @@ def render_fwd_x3(grid: Grid, table, packed_sigma_x3, packed_color_x3,
         _ptr(semantics), _ptr(ws), _stream()), "ucsa_render_fwd_x3")
 
 
-RENDER_MODES = {"fp32": 0, "fp16": 1, "bf16x3": 2, "fp16_h16": 3}
+RENDER_MODES = {"fp32": 0, "fp16": 1, "bf16x3": 2, "fp16_h16": 3, "f16x2": 4}
 
 
 def render_view(mode: str, grid: Grid, table, packed_sigma, packed_color, packed_sem,
