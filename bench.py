@@ -90,12 +90,14 @@ def parse():
                          "ResNet-50; the reference's model is resnet101); cfg5 default: "
                          "what cfg/exp/multi_step/cl_base.yml says (resnet101)")
     ap.add_argument("--seg-amp", default="", help="cfg3: '' (fp32, the reference) or bf16")
-    ap.add_argument("--nerf-precision", default="bf16x3",
-                    choices=["fp32", "bf16x3", "fp16"],
+    ap.add_argument("--nerf-precision", default="f16x2",
+                    choices=["fp32", "bf16x3", "f16x2", "fp16"],
                     help="arithmetic of the three MLPs in the no-grad renders: "
-                         "bf16x3 (default; fp32-grade on the bf16 MFMA pipe, "
-                         "csrc/mfma_mlp_x3.h), fp32 (f32-input MFMA, an exact "
-                         "fmaf chain), fp16 (tiny-cuda-nn's own numerics)")
+                         "f16x2 (default; fp32-grade on the f16 MFMA pipe, two-term "
+                         "operands, three passes per product, csrc/mfma_mlp_h2.h), "
+                         "bf16x3 (fp32-grade on the bf16 pipe, three-term operands, "
+                         "six passes, csrc/mfma_mlp_x3.h), fp32 (f32-input MFMA, an "
+                         "exact fmaf chain), fp16 (tiny-cuda-nn's own numerics)")
     ap.add_argument("--seg-find", action="store_true",
                     help="DeepLab legs with torch.backends.cudnn.benchmark (MIOpen's "
                          "exhaustive solver search, what scripts/train_joint.py "
@@ -317,7 +319,8 @@ def composite_pmc(roof, mode, pretrain_steps):
         return roof
     if int(pmc.get("pretrain_steps", -1)) != int(pretrain_steps):
         return roof
-    kn = {"fp32": "k_composite", "bf16x3": "k_shade16_x3", "fp16": "k_shade16_f16"}[mode]
+    kn = {"fp32": "k_composite", "bf16x3": "k_shade16_x3", "f16x2": "k_shade16_h2",
+          "fp16": "k_shade16_f16"}[mode]
     k = pmc.get(kn, {})
     if "fetch_bytes" in k:
         tr = k["fetch_bytes"] + k["write_bytes"]

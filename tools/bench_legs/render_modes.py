@@ -28,6 +28,21 @@ def composite_roofline(mode, mlp_tf, sig_tf, launch_ms):
                     "kernel time = MFMA busy + VALU issue); "
                     "frac_of_fp16_dense_peak is the same achieved rate against "
                     "SURVEY 8d's 2.5 PF line"}
+    if mode == "f16x2":
+        return {
+            "kernel": "k_weights_compact + k_shade16<f16x2> (colour + "
+                      "semantics MLPs, three f16 MFMA passes per fp32 product)",
+            "bound": "mfma", "achieved": mlp_tf, "peak": F16_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": mlp_tf / F16_MFMA_PEAK_TF,
+            "issued_mfma_tflops": mlp_tf * 3 * 22528 / 19584,
+            "issued_frac": mlp_tf * 3 * 22528 / 19584 / F16_MFMA_PEAK_TF,
+            "frac_of_fp32_mfma_peak": mlp_tf / F32_MFMA_PEAK_TF,
+            "launch_ms": launch_ms, "traffic": None, "sigma_mlp_tflops": sig_tf,
+            "note": "achieved = ALGORITHMIC fp32 flop of the masked samples / "
+                    "launch time against the 2.5 PF 16-bit dense line "
+                    "(SURVEY 8d); issued_* counts the three f16 passes and the "
+                    "padding (72 MFMAs per 16 samples); the kernel is bound by "
+                    "instruction issue (MFMA + VALU cycles add up on a SIMD)"}
     if mode == "bf16x3":
         return {
             "kernel": "k_weights_compact + k_shade16<bf16x3> (colour + "
@@ -98,6 +113,7 @@ def mlp_error_vs_fp64(net, dev, M=16384):
     for name, pc, ps, kw in (
             ("f32_mfma", ops.mlp_pack(1, cp), ops.mlp_pack(2, sp, C), {}),
             ("bf16x3", ops.mlp_pack_x3(1, cp), ops.mlp_pack_x3(2, sp, C), {"x3": True}),
+            ("f16x2", ops.mlp_pack_h2(1, cp), ops.mlp_pack_h2(2, sp, C), {"h2": True}),
             ("fp16", ops.mlp_pack_f16(1, cp), ops.mlp_pack_f16(2, sp, C), {"half": True})):
         img, _, sem = ops.composite_infer(*args, pc, ps, C, **kw)
         res[name] = {"rgb": float((img.double() - rgb64).abs().max()),
@@ -112,15 +128,17 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
     """Per-kernel durations of one chunk, measured with events on the stream
     the kernels run on (torch's current stream), launched the way
     ucsa_render_fwd[_f16|_x3] launches them.  mode: "fp32" (f32-input MFMA,
-    fused composite), "fp16" / "bf16x3" (sigma MLP and the split composite
-    pair on the 16-bit MFMA pipe)."""
+    fused composite), "fp16" / "bf16x3" / "f16x2" (sigma MLP and the split
+    composite pair on the 16-bit MFMA pipe)."""
     from ucsa_neural_rendering_amd import ops
     mode = mode or ("fp16" if half else "fp32")
     half = mode == "fp16"
     x3 = mode == "bf16x3"
-    f = net._field_f16() if half else (net._field_x3() if x3 else net._field())
-    sigma_mlp = (ops.sigma_mlp_fwd_f16 if half else
-                 ops.sigma_mlp_fwd_x3 if x3 else ops.sigma_mlp_fwd)
+    h2 = mode == "f16x2"
+    f = (net._field_f16() if half else net._field_x3() if x3 else
+         net._field_h2() if h2 else net._field())
+    sigma_mlp = (ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd_x3 if x3 else
+                 ops.sigma_mlp_fwd_h2 if h2 else ops.sigma_mlp_fwd)
     aabb = net._aabb_list(False)
     N = o.shape[0]
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -151,10 +169,10 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
             w = ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
                                   sf.view(N, T_FINE), hf, f32["packed_color"],
                                   f32["packed_sem"], N_CLASSES, 1.0, want_aux=True)[4]
-        elif half or x3:
+        elif half or x3 or h2:
             ops.composite_infer(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
                                 sf.view(N, T_FINE), hf, f["packed_color"],
-                                f["packed_sem"], N_CLASSES, 1.0, half=half, x3=x3)
+                                f["packed_sem"], N_CLASSES, 1.0, half=half, x3=x3, h2=h2)
         else:   # what ucsa_render_fwd launches for fp32: the fused kernel
             ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
                               sf.view(N, T_FINE), hf, f["packed_color"],
@@ -187,7 +205,7 @@ def render_mode_legs(result, net, step, chunk_in, args, world, mlp_flop, samples
         torch.cuda.synchronize()
         return (time.perf_counter() - t1) / n_alt
 
-    for alt in ("fp32", "bf16x3", "fp16"):
+    for alt in ("fp32", "bf16x3", "f16x2", "fp16"):
         if alt == args.nerf_precision:
             continue
         net.precision = alt
@@ -197,9 +215,9 @@ def render_mode_legs(result, net, step, chunk_in, args, world, mlp_flop, samples
         cmp_tf = mlp_flop / (sta["composite"] * 1e-3) / 1e12
         sga_tf = samples * 6144 / (0.5 * (sta["sigma_c"] + sta["sigma_f"]) * 1e-3) / 1e12
         key = {"fp32": "f32_mfma_option", "bf16x3": "bf16x3_option",
-               "fp16": "f16_mlp_option"}[alt]
+               "f16x2": "f16x2_option", "fp16": "f16_mlp_option"}[alt]
         vkey = {"fp32": "value_f32_mfma_nets", "bf16x3": "value_bf16x3_nets",
-                "fp16": "value_fp16_nets"}[alt]
+                "f16x2": "value_f16x2_nets", "fp16": "value_fp16_nets"}[alt]
         result[vkey] = world * H * W / dta if world == 1 else None
         result[key] = {
             "rays_per_s": H * W / dta, "ms_per_view": dta * 1e3,
