@@ -359,6 +359,14 @@ int32_t ucsa_composite_infer_h2(
     const void* packed_sem_h2, uint32_t N, uint32_t T, uint32_t t,
     uint32_t n_classes, float density_scale, float* image, float* depth,
     float* semantics, void* workspace, void* stream);
+/* ucsa_composite_train_fwd_x3 with f16x2 nets (same outputs and aux arrays). */
+int32_t ucsa_composite_train_fwd_h2(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_h2,
+    const void* packed_sem_h2, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, int32_t* src, float* w, void* workspace, void* stream);
 int32_t ucsa_render_fwd_h2(
     const ucsa_grid* grid, const float* table, const void* packed_sigma_h2,
     const void* packed_color_h2, const void* packed_sem_h2, const float* rays_o,
@@ -642,6 +650,9 @@ typedef struct ucsa_train_packs {
   const void* sigma_t_x3; /* ucsa_mlp_pack_t_x3: backward only (may be NULL forward) */
   const void* color_t_x3;
   const void* sem_t_x3;
+  const void* sigma_h2;   /* ucsa_mlp_pack_h2: when all three are non-NULL the FORWARD */
+  const void* color_h2;   /* runs the nets as f16x2 (three MFMA passes per product    */
+  const void* sem_h2;     /* instead of six; same fp32-grade error) -- may be NULL     */
 } ucsa_train_packs;
 
 uint64_t ucsa_render_fused_fwd_workspace_bytes(uint32_t N, uint32_t T, uint32_t t);

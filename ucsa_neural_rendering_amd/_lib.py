@@ -46,7 +46,8 @@ class TrainBuffers(C.Structure):
 class TrainPacks(C.Structure):
     """ucsa_train_packs: bf16x3 weight fragments (forward) and their transposes."""
     _fields_ = [(k, C.c_void_p) for k in ("sigma_x3", "color_x3", "sem_x3",
-                                          "sigma_t_x3", "color_t_x3", "sem_t_x3")]
+                                          "sigma_t_x3", "color_t_x3", "sem_t_x3",
+                                          "sigma_h2", "color_h2", "sem_h2")]
 
 
 class AugParams(C.Structure):
@@ -128,6 +129,9 @@ SIGNATURES = {
                                        _p, _p, _p, _p]),
     "ucsa_composite_infer_h2": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32,
                                                          _f, _p, _p, _p, _p, _p]),
+    "ucsa_composite_train_fwd_h2": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32,
+                                                             _f, _p, _p, _p, _p, _p,
+                                                             _p, _p]),
     "ucsa_mlp_pack_x3_bytes": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_x3": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_sigma_mlp_fwd_x3": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),

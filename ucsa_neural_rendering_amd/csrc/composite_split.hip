@@ -1275,3 +1275,19 @@ extern "C" int32_t ucsa_composite_train_fwd_x3(
                          density_scale, image, depth, semantics, workspace,
                          stream, src, w);
 }
+
+// ... and with the f16x2 nets (mfma_mlp_h2.h): what the default training mode's
+// forward runs since round 4 (the backward recomputes with its own bf16x2 packs)
+extern "C" int32_t ucsa_composite_train_fwd_h2(
+    const float* rays_d, const float* norms, const float* z_c,
+    const float* sigma_c, const float* h_c, const float* z_f,
+    const float* sigma_f, const float* h_f, const void* packed_color_h2,
+    const void* packed_sem_h2, uint32_t N, uint32_t T, uint32_t t,
+    uint32_t n_classes, float density_scale, float* image, float* depth,
+    float* semantics, int32_t* src, float* w, void* workspace, void* stream) {
+  UCSA_CHECK_ARG(src && w, 18);
+  return composite_infer(3, rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
+                         packed_color_h2, packed_sem_h2, N, T, t, n_classes,
+                         density_scale, image, depth, semantics, workspace,
+                         stream, src, w);
+}

@@ -105,7 +105,8 @@ extern "C" int32_t ucsa_render_fused_fwd(
   UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
                      grid->n_levels <= UCSA_MAX_LEVELS, 0);
   UCSA_CHECK_ARG(table, 1);
-  UCSA_CHECK_ARG(packs && packs->sigma_x3 && packs->color_x3 && packs->sem_x3, 2);
+  UCSA_CHECK_ARG(packs && ((packs->sigma_x3 && packs->color_x3 && packs->sem_x3) ||
+                           (packs->sigma_h2 && packs->color_h2 && packs->sem_h2)), 2);
   UCSA_CHECK_ARG(rays_o && rays_d && norms, 3);
   UCSA_CHECK_ARG(aabb_host, 6);
   UCSA_CHECK_ARG(T >= 1 && (uint64_t)N * (T + t) < 0x80000000ull, 11);
@@ -123,16 +124,31 @@ extern "C" int32_t ucsa_render_fused_fwd(
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, out->z_c, stream));
   UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, out->z_c, aabb_host,
                                      N, T, out->feat_c, stream));
-  UCSA_TRY(ucsa_sigma_mlp_fwd_x3(out->feat_c, packs->sigma_x3, N * T, L, out->h_c,
-                                 out->sigma_c, stream));
+  const bool h2 = packs->sigma_h2 && packs->color_h2 && packs->sem_h2;
+  if (h2)
+    UCSA_TRY(ucsa_sigma_mlp_fwd_h2(out->feat_c, packs->sigma_h2, N * T, L, out->h_c,
+                                   out->sigma_c, stream));
+  else
+    UCSA_TRY(ucsa_sigma_mlp_fwd_x3(out->feat_c, packs->sigma_x3, N * T, L, out->h_c,
+                                   out->sigma_c, stream));
   if (t > 0) {
     UCSA_TRY(ucsa_resample(out->z_c, out->sigma_c, u, N, T, t, density_scale, out->z_f,
                            stream));
     UCSA_TRY(ucsa_hashgrid_encode_rays(grid, table, rays_o, rays_d, out->z_f,
                                        aabb_host, N, t, out->feat_f, stream));
-    UCSA_TRY(ucsa_sigma_mlp_fwd_x3(out->feat_f, packs->sigma_x3, N * t, L, out->h_f,
-                                   out->sigma_f, stream));
+    if (h2)
+      UCSA_TRY(ucsa_sigma_mlp_fwd_h2(out->feat_f, packs->sigma_h2, N * t, L, out->h_f,
+                                     out->sigma_f, stream));
+    else
+      UCSA_TRY(ucsa_sigma_mlp_fwd_x3(out->feat_f, packs->sigma_x3, N * t, L, out->h_f,
+                                     out->sigma_f, stream));
   }
+  if (h2)
+    return ucsa_composite_train_fwd_h2(
+        rays_d, norms, out->z_c, out->sigma_c, out->h_c, t ? out->z_f : nullptr,
+        t ? out->sigma_f : nullptr, t ? out->h_f : nullptr, packs->color_h2,
+        packs->sem_h2, N, T, t, n_classes, density_scale, image, depth, semantics,
+        out->src, out->weights, w.cmp, stream);
   return ucsa_composite_train_fwd_x3(
       rays_d, norms, out->z_c, out->sigma_c, out->h_c, t ? out->z_f : nullptr,
       t ? out->sigma_f : nullptr, t ? out->h_f : nullptr, packs->color_x3,

@@ -39,6 +39,9 @@ class _RenderFn(torch.autograd.Function):
                                                   ("sem", net.semantics_net))]
             pk += [net._pack_t_x3(k, n) for k, n in (("sigma", net.sigma_net), ("color", net.color_net),
                                                      ("sem", net.semantics_net))]
+            if net.train_fwd_f16x2:   # forward nets as f16x2 (three passes instead of six)
+                pk += [net._pack_h2(k, n) for k, n in (("sigma", net.sigma_net), ("color", net.color_net),
+                                                       ("sem", net.semantics_net))]
             # (no f32 weight packs in this mode: six small launches less per step)
             f = dict(grid=net.encoder.grid, table=net.encoder.params.detach())
             image, depth, sem, sv = ops.render_fused_fwd(
@@ -64,8 +67,12 @@ class _RenderFn(torch.autograd.Function):
             # fp32-grade on the bf16 pipe, like the colour / semantics forward
             # below (1e-7 from the f32-input MFMA chain, 0.04 instead of 0.07 ms
             # per million samples)
-            table, sig_fwd = f["table"], ops.sigma_mlp_fwd_x3
-            sig_pack = net._pack_x3("sigma", net.sigma_net)
+            if net.train_fwd_f16x2:
+                table, sig_fwd = f["table"], ops.sigma_mlp_fwd_h2
+                sig_pack = net._pack_h2("sigma", net.sigma_net)
+            else:
+                table, sig_fwd = f["table"], ops.sigma_mlp_fwd_x3
+                sig_pack = net._pack_x3("sigma", net.sigma_net)
         else:
             table, sig_fwd, sig_pack = f["table"], ops.sigma_mlp_fwd, f["packed_sigma"]
         feat_c = ops.hashgrid_encode_rays(f["grid"], table, o, d, z_c, aabb)
@@ -100,8 +107,13 @@ class _RenderFn(torch.autograd.Function):
             # values as the f32-input MFMA chain to ~1e-7; the backward
             # recomputes the nets with the f32-input MFMA as before
             pcx, psx = net._pack_x3("color", net.color_net), net._pack_x3("sem", net.semantics_net)
-            image, depth, sem, src, w = ops.composite_train_fwd_x3(
-                d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, pcx, psx, C, ds)
+            if net.train_fwd_f16x2:
+                image, depth, sem, src, w = ops.composite_train_fwd_x3(
+                    d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, net._pack_h2("color", net.color_net),
+                    net._pack_h2("sem", net.semantics_net), C, ds, h2=True)
+            else:
+                image, depth, sem, src, w = ops.composite_train_fwd_x3(
+                    d, nrm, z_c, s_c, h_c, z_f, s_f, h_f, pcx, psx, C, ds)
             # ... and (round 4) the backward's contractions on the bf16 pipe as
             # two-term splits (2^-16 per product; `nerf: {bwd_precision: fp32}`
             # keeps the f32-input MFMA kernels)

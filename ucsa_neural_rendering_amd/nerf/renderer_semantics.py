@@ -109,6 +109,11 @@ class SemanticNeRFRenderer(nn.Module):
         # call per direction (ucsa_render_fused_fwd / ucsa_render_fused_bwd)
         # instead of one call per stage from Python; bit-identical
         self.fused_train_calls = os.environ.get("UCSA_FUSED_TRAIN", "1") != "0"
+        # with train_precision="bf16x3": the FORWARD nets of the training pass as
+        # f16x2 (two-term f16 operands, three MFMA passes per product instead of
+        # six, the same fp32-grade error; csrc/mfma_mlp_h2.h) -- the backward
+        # keeps its bf16 packs
+        self.train_fwd_f16x2 = os.environ.get("UCSA_TRAIN_FWD_F16X2", "1") != "0"
         self.f16_bwd_scale = 1024.0
         # with train_precision="fp16": the hash-grid backward's bin records
         # carry half2 values (8 instead of 16 bytes per record)

@@ -254,7 +254,7 @@ def composite_fwd(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
 
 def composite_train_fwd_x3(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
                            packed_color_x3, packed_sem_x3, n_classes: int,
-                           density_scale: float = 1.0):
+                           density_scale: float = 1.0, h2: bool = False):
     """Training forward of the colour / semantics stage on the split pair with
     the bf16x3 nets -> (image, depth, sem, src, w) like
     composite_fwd(want_aux=True)."""
@@ -271,7 +271,8 @@ def composite_train_fwd_x3(rays_d, norms, z_c, sigma_c, h_c, z_f, sigma_f, h_f,
     ws = _scratch_named("composite_infer",
                         int(lib().ucsa_composite_infer_workspace_bytes(N, T, t)),
                         dev)
-    check(lib().ucsa_composite_train_fwd_x3(
+    fn = lib().ucsa_composite_train_fwd_h2 if h2 else lib().ucsa_composite_train_fwd_x3
+    check(fn(
         _ptr(rays_d), _ptr(norms), _ptr(z_c), _ptr(sigma_c), _ptr(h_c), _ptr(z_f),
         _ptr(sigma_f), _ptr(h_f), _ptr(packed_color_x3), _ptr(packed_sem_x3), N, T,
         t, n_classes, float(density_scale), _ptr(image), _ptr(depth), _ptr(sem),
@@ -649,11 +650,13 @@ def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
 
 
 def train_packs(sigma_x3, color_x3, sem_x3, sigma_t_x3=None, color_t_x3=None,
-                sem_t_x3=None) -> "_lib.TrainPacks":
-    """ucsa_train_packs over bf16x3 weight fragments (mlp_pack_x3 / mlp_pack_t_x3);
-    the caller keeps the tensors alive."""
+                sem_t_x3=None, sigma_h2=None, color_h2=None, sem_h2=None) -> "_lib.TrainPacks":
+    """ucsa_train_packs over bf16x3 weight fragments (mlp_pack_x3 / mlp_pack_t_x3)
+    and, optionally, f16x2 ones for the forward (mlp_pack_h2); the caller keeps
+    the tensors alive."""
     return _lib.TrainPacks(*[_ptr(x) for x in (sigma_x3, color_x3, sem_x3, sigma_t_x3,
-                                              color_t_x3, sem_t_x3)])
+                                              color_t_x3, sem_t_x3, sigma_h2, color_h2,
+                                              sem_h2)])
 
 
 def render_fused_fwd(grid: Grid, table, packs, rays_o, rays_d, norms, aabb,
