@@ -114,7 +114,7 @@ def test_cfg2_bench_path_640x480_staged_image_ordered(which):
         ref = oren.run(fld, *rays_sel, AABB4,
                        num_steps=T, upsample_steps=t, u=u.cpu()[sel], return_aux=True)
     _check(res, ref, fld, rays_sel, T, t, sel, tag=f"cfg2[{which}]")
-    # bench.py's default arithmetic (bf16x3, fp32-grade on the bf16 MFMA pipe):
+    # round 3's default arithmetic (bf16x3, fp32-grade on the bf16 MFMA pipe):
     # the same fp32 tolerances against the oracle, and 1e-6 to the exact chain
     net.precision = "bf16x3"
     with torch.no_grad():
@@ -122,7 +122,8 @@ def test_cfg2_bench_path_640x480_staged_image_ordered(which):
                           upsample_steps=t, rng_u=u, image_width=W)
     net.precision = "fp32"
     _check(res3, ref, fld, rays_sel, T, t, sel, tag=f"cfg2[{which}, bf16x3]")
-    # ... and f16x2 (two-term f16 operands, half the matrix passes; round 4)
+    # ... and bench.py's default since round 4: f16x2 (two-term f16 operands, half
+    # the matrix passes, the same fp32-grade error)
     net.precision = "f16x2"
     with torch.no_grad():
         resh = net.render(o, d, nrm, staged=True, perturb=False, num_steps=T,
