@@ -12,7 +12,7 @@ from .common import *  # noqa: F401,F403
 
 
 def cfg4_job(net, n_views, rank, world, dev, dist=None, backend="nccl", warmup=1,
-             gather=False, precision="bf16x3", keep=()):
+             gather=False, precision="f16x2", keep=()):
     """BASELINE cfg4's render job: `n_views` novel 640x480 views round-robin
     over the ranks (this rank renders views rank, rank+world, ...), per view
     get_rays (a1) + staged render at 96+96 samples, parameters replicated, no
