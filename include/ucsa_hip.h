@@ -339,10 +339,11 @@ int32_t ucsa_sigma_mlp_fwd_x3(const float* feat, const void* packed_sigma_x3,
  * x ~ f16(x) + f16((x - f16(x)) * 2^11) * 2^-11: 22 significant bits per
  * operand, products accumulated in fp32 from three f16 MFMA passes (bf16x3: six)
  * -- the same 2^-23-per-product error class as bf16x3 and the f32-input MFMA
- * chain (csrc/mfma_mlp_h2.h).  RANGE: layer inputs and weights must stay below
- * 65504 in magnitude (f16), hidden activations below 2^20 (ucsa_mlp_pack_h2
- * scales the first layer by 2^-4 and the last by 2^4, exact for the bias-free
- * ReLU nets); beyond that the result is inf / NaN, never silently wrong.
+ * chain (csrc/mfma_mlp_h2.h).  RANGE: that of the reference's own fp16 nets --
+ * layer inputs and weights below 65504 in magnitude, hidden activations below
+ * 2^20 (ucsa_mlp_pack_h2 scales the first layer by 2^-4 and the last by 2^4,
+ * exact for the bias-free ReLU nets).  Values beyond it are not detected (the
+ * _x3 entries have fp32's range).
  * Same interfaces as the _x3 entries with packs from ucsa_mlp_pack_h2
  * (ucsa_mlp_pack_h2_bytes bytes).  Replaces what the _x3 entries replace
  * (tcnn.Network forward, reference network_tcnn_semantics.py:135,147-207). */

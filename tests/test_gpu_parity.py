@@ -783,3 +783,28 @@ def test_f16x2_render_matches_the_oracle_like_bf16x3(net, fld):
         e = maxabs(out["f16x2"][k], ref[k])
         print(f"f16x2 render {k}: max |hip - oracle| {e:.2e}, vs bf16x3 {maxabs(out['f16x2'][k], out['bf16x3'][k]):.2e}")
         assert e <= 2e-4, k
+
+
+def test_f16x2_inputs_up_to_the_f16_range(ops):
+    """f16x2's first terms are f16, so its range is the range of the reference's
+    own fp16 nets (tiny-cuda-nn): |layer input| <= 65504.  Inputs just inside it
+    (6e4, with hidden pre-activations of ~1e5 that only the 2^-4 hidden scale
+    keeps representable) still agree with the f32-input MFMA chain.  Values
+    beyond the range are NOT detected (documented in csrc/mfma_mlp_h2.h)."""
+    fld = lively_oracle_field()
+    g = torch.Generator().manual_seed(3)
+    M = 256
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    h = torch.randn(M, 16, generator=g)
+    h[:128, 7] = 6.0e4
+    dev = torch.device("cuda:0")
+    z = torch.ones(M, 1, device=dev)
+    sig = torch.full((M, 1), 50.0, device=dev)
+    nrm = torch.ones(M, device=dev)
+    cp, sp = fld.color_params.to(dev), fld.sem_params.to(dev)
+    args = (d.to(dev), nrm, z, sig, h.to(dev), None, None, None)
+    h2 = ops.composite_infer(*args, ops.mlp_pack_h2(1, cp), ops.mlp_pack_h2(2, sp, 40), 40, h2=True)
+    f32 = ops.composite_infer(*args, ops.mlp_pack(1, cp), ops.mlp_pack(2, sp, 40), 40)
+    torch.cuda.synchronize()
+    assert torch.isfinite(h2[0]).all() and torch.isfinite(h2[2]).all()
+    assert maxabs(h2[0], f32[0]) <= 2e-5 and maxabs(h2[2], f32[2]) <= 2e-4

@@ -135,8 +135,8 @@ MLP_ARITHMETIC = {
              "three partial products per product (v_mfma_f32_16x16x32_f16), fp32 "
              "accumulation (csrc/mfma_mlp_h2.h); the same 2^-23-per-product error "
              "class as bf16x3 and the f32-input MFMA chain (mlp_error_vs_fp64); "
-             "layer inputs and weights must stay below 65504, hidden activations "
-             "below 2^20",
+             "range = the reference's own fp16 nets (layer inputs and weights "
+             "below 65504), hidden activations below 2^20",
     "bf16x3": "fp32-grade on the bf16 MFMA pipe: every fp32 weight and layer "
               "input split exactly into three bf16 terms, six partial products "
               "per product (v_mfma_f32_16x16x32_bf16), fp32 accumulation "

@@ -23,12 +23,15 @@
 // accumulation) and as the f32-input MFMA chain: tests/test_gpu_parity.py
 // ::test_f16x2_nets_are_fp32_grade.
 //
-// RANGE: the first terms are f16: |x| <= 65504 for every layer input and every
-// weight (inf beyond, which propagates as NaN / inf into the output -- visible,
-// not silent).  The MLPs have no biases and ReLU is positively homogeneous, so
-// ucsa_mlp_pack_h2 stores the first layer's weights times 2^-4 and the last
+// RANGE: the first terms are f16, so the range is that of the reference's own
+// nets (tiny-cuda-nn computes them in fp16): |x| <= 65504 for every layer input
+// and every weight.  The MLPs have no biases and ReLU is positively homogeneous,
+// so ucsa_mlp_pack_h2 stores the first layer's weights times 2^-4 and the last
 // layer's times 2^4: hidden activations 16 x smaller, same outputs (powers of
-// two: exact) -- hidden layers overflow beyond 2^20, inputs beyond 65504.
+// two: exact) -- hidden layers overflow beyond 2^20 only.  Values beyond the
+// range are NOT detected: the f16 conversion gives inf, the two partial sums
+// give inf - inf = NaN, and a NaN pre-activation passes ReLU (v_max_f32) as 0,
+// here as in every other mode of these kernels.  bf16x3 has fp32's range.
 //
 // Fragment layout: as mfma_mlp_x3.h with two terms,
 // packed[(f * 2 + term) * 64 + lane], 16 bytes each.

@@ -76,7 +76,8 @@ class SemanticNeRFRenderer(nn.Module):
         #            of bf16x3: every operand as two f16 terms (the second
         #            scaled by 2^11), three partial products per product
         #            (csrc/mfma_mlp_h2.h); layer inputs and weights must stay
-        #            below 65504, hidden activations below 2^20 (inf beyond);
+        #            below 65504 (the range of the reference's own fp16 nets), hidden activations
+        #            below 2^20; out-of-range values are not detected;
         #   "fp16"   what tiny-cuda-nn does (fp16 weights and layer inputs,
         #            fp32 accumulation).
         self.precision = "fp32"
