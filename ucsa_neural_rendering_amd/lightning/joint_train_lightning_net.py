@@ -62,13 +62,15 @@ class JointTrainLightningNet(nn.Module):
             seed=exp.get("nerf_seed"))
         self.nerf_model.march_training = self.cuda_ray
         # `nerf: {precision: ...}`: arithmetic of the three MLPs in the no-grad
-        # renders.  "bf16x3" (default): fp32-grade on the bf16 MFMA pipe (three
-        # bf16 terms per operand, six partial products, fp32 accumulation:
-        # within 1-2 ulp of "fp32", a quarter less time per view); "fp32": the
-        # f32-input MFMA (an exact fmaf chain, the training forward's kernels);
-        # "fp16": like tiny-cuda-nn (fp16 weights / layer inputs, fp32
-        # accumulate).  Training stays fp32 unless train_precision says so.
-        self.nerf_model.precision = str(nerf_cfg.get("precision", "bf16x3"))
+        # renders.  "f16x2" (default since round 4): fp32-grade on the f16 MFMA
+        # pipe (two f16 terms per operand, the second scaled by 2^11, three
+        # partial products, fp32 accumulation: the f32-input MFMA chain's error
+        # against fp64; the RANGE of the reference's own fp16 nets, 65504);
+        # "bf16x3": fp32-grade with fp32's range (three bf16 terms, six partial
+        # products, ~11 % more time per view); "fp32": the f32-input MFMA (an
+        # exact fmaf chain); "fp16": like tiny-cuda-nn (fp16 weights / layer
+        # inputs, fp32 accumulate).  Training: see train_precision.
+        self.nerf_model.precision = str(nerf_cfg.get("precision", "f16x2"))
         # `nerf: {fp16_table: true}` (with precision: fp16): the renders read the
         # hash grid from an fp16 copy of the table, as tiny-cuda-nn stores it
         self.nerf_model.fp16_table = bool(nerf_cfg.get("fp16_table", False))
