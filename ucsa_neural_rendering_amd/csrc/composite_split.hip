@@ -1177,13 +1177,17 @@ static int32_t composite_infer(int prec, const float* rays_d,
   //           2 = (8, 1) 0.55   3 = (12, 1) 0.57
   //   bf16x3: 0 = (8 waves, 1 block) 1.43 <- default   1 = (16, 1) 1.50
   //           2 = (12, 1) 1.60   3 = (8, 2) 1.63
+  //   f16x2 (round 4, M rays/s of the whole cfg2 view): 0 = (8 waves, 2 blocks)
+  //           17.87 <- default   1 = (16, 1) 17.25   2 = (12, 1) 17.31
+  //           3 = (8, 1) 17.25: with half the MFMAs a weight fragment read from
+  //           LDS is worth sharing between two column blocks
 #define SH_GO16(NRB)                                                                \
   do {                                                                              \
     if (prec == 3) {                                                                \
       if (variant == 1) return launch_shade16<NRB, 1, 3, 16>(b, n_waves, off32, s); \
       if (variant == 2) return launch_shade16<NRB, 1, 3, 12>(b, n_waves, off32, s); \
-      if (variant == 3) return launch_shade16<NRB, 2, 3, 8>(b, n_waves, off32, s);  \
-      return launch_shade16<NRB, 1, 3, 8>(b, n_waves, off32, s);                    \
+      if (variant == 3) return launch_shade16<NRB, 1, 3, 8>(b, n_waves, off32, s);  \
+      return launch_shade16<NRB, 2, 3, 8>(b, n_waves, off32, s);                    \
     }                                                                               \
     if (prec == 2) {                                                                \
       if (variant == 1) return launch_shade16<NRB, 1, 2, 16>(b, n_waves, off32, s); \
