@@ -501,6 +501,15 @@ int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
                            const float* packed_sigma_t, uint32_t M,
                            uint32_t n_levels, float* d_feat, float* partial,
                            void* stream);
+/* The same with the recomputed hidden layer rounded to fp16 before the ReLU
+ * gate and dW2 read it: the backward of tiny-cuda-nn's fp16 sigma net
+ * (`train_precision: tcnn`; packs of the fp16-rounded parameters, fp16 features
+ * widened to fp32).  Reference network_tcnn_semantics.py:48-58,135. */
+int32_t ucsa_sigma_mlp_bwd_h16(const float* feat, const float* d_h,
+                               const float* packed_sigma,
+                               const float* packed_sigma_t, uint32_t M,
+                               uint32_t n_levels, float* d_feat, float* partial,
+                               void* stream);
 /* The same backward with its contractions on the bf16 MFMA pipe as two-term
  * splits (bf16x2, see ucsa_composite_bwd_x2): packed_sigma_x3 from
  * ucsa_mlp_pack_x3(UCSA_MLP_SIGMA), packed_sigma_t_x3 from ucsa_mlp_pack_t_x3

@@ -384,7 +384,8 @@ def test_tcnn_numerics_training_matches_the_fully_fp16_emulating_oracle(N, T, t)
     ``fp16_table``; casts pass gradients straight through).  Forward <= 3e-3;
     gradients of a linear functional <= 3e-2 relative L2, cosine >= 0.999 (the
     kernels also round each layer's incoming gradient to fp16 under a loss
-    scale, and the sigma net's backward keeps its hidden layer in fp32)."""
+    scale; since round 4 the sigma net's backward rounds its recomputed hidden
+    layer to fp16 as tcnn's forward stored it, ucsa_sigma_mlp_bwd_h16)."""
     import copy
     fld = lively_oracle_field().requires_grad_(True)
     f16 = copy.copy(fld)
@@ -416,7 +417,8 @@ def test_tcnn_numerics_training_matches_the_fully_fp16_emulating_oracle(N, T, t)
                             ("grid", net.encoder.params.grad, fld.grid_params.grad)):
         e, c = rel_l2(got, want), cos(got, want)
         print(f"tcnn-train {name}: rel L2 {e:.3e} cos {c:.6f}")
-        assert e <= 3e-2 and c >= 0.999, name
+        # (measured round 4: nets 3e-5 ... 7e-4, grid 2e-3 ... 7e-3)
+        assert e <= (3e-2 if name == "grid" else 3e-3) and c >= 0.999, name
 
 
 def test_f16_training_reduces_the_loss_like_fp32():

@@ -166,6 +166,7 @@ SIGNATURES = {
     "ucsa_sigma_mlp_bwd_parts": (C.c_uint32, [_u32]),
     "ucsa_sigma_mlp_bwd": (C.c_int32, [_p, _p, _p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_sigma_mlp_bwd_x2": (C.c_int32, [_p, _p, _p, _p, _u32, _u32, _p, _p, _p]),
+    "ucsa_sigma_mlp_bwd_h16": (C.c_int32, [_p, _p, _p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_hashgrid_bwd_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32]),
     "ucsa_hashgrid_bwd_rays": (C.c_int32, [C.POINTER(Grid), _p, _p, _p,
                                            C.POINTER(_f), _u32, _u32, _p, _p,

@@ -213,6 +213,10 @@ extern "C" int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,
 
 extern __shared__ __attribute__((aligned(16))) float sigb_smem[];
 
+// ROUND_H (train_precision "tcnn"): the recomputed hidden layer is rounded to
+// fp16 before the ReLU gate and dW2 use it -- tiny-cuda-nn's forward keeps its
+// hidden activations in fp16 (fp32 accumulation), and its backward reads those.
+template <bool ROUND_H>
 __global__ void __launch_bounds__(64 * SIGB_WAVES)
 k_sigma_mlp_bwd(const float2* __restrict__ feat, const float* __restrict__ d_h,
                 const float* __restrict__ packed,
@@ -260,6 +264,12 @@ k_sigma_mlp_bwd(const float2* __restrict__ feat, const float* __restrict__ d_h,
 
     f32x4 acc1[4];
     mfma_layer<8, 4>(xin, [&](int rb, int ks) { return w1[rb][ks]; }, acc1);
+    if constexpr (ROUND_H) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1[rb][r] = (float)(_Float16)acc1[rb][r];
+    }
 
     // dW2 += dh (x) relu(acc1)
     tile_store(dy_tile, g, j, 0, dh);
@@ -334,7 +344,31 @@ extern "C" int32_t ucsa_sigma_mlp_bwd(const float* feat, const float* d_h,
   const uint32_t blocks = ucsa_sigma_mlp_bwd_parts(M) / SIGB_WAVES;
   const size_t smem = (size_t)SIGB_WAVES * 2 * 16 * TILE_LD * sizeof(float);
   UCSA_CLEAR_ERR();
-  hipLaunchKernelGGL(k_sigma_mlp_bwd, dim3(blocks), dim3(64 * SIGB_WAVES), smem,
+  hipLaunchKernelGGL(k_sigma_mlp_bwd<false>, dim3(blocks), dim3(64 * SIGB_WAVES), smem,
+                     (hipStream_t)stream, (const float2*)feat, d_h,
+                     packed_sigma, packed_sigma_t, (uint64_t)M,
+                     (float2*)d_feat, partial);
+  return ucsa_launch_status();
+}
+
+// The same with the recomputed hidden layer rounded to fp16 (k_sigma_mlp_bwd<true>):
+// the backward of tiny-cuda-nn's fp16 sigma net, fed with fp16-rounded weights
+// (ucsa_mlp_pack of the rounded parameters) and the fp16 features widened to fp32.
+extern "C" int32_t ucsa_sigma_mlp_bwd_h16(const float* feat, const float* d_h,
+                                          const float* packed_sigma,
+                                          const float* packed_sigma_t, uint32_t M,
+                                          uint32_t n_levels, float* d_feat,
+                                          float* partial, void* stream) {
+  UCSA_CHECK_ARG(feat, 0);
+  UCSA_CHECK_ARG(d_h, 1);
+  UCSA_CHECK_ARG(packed_sigma && packed_sigma_t, 2);
+  UCSA_CHECK_ARG(n_levels == 16, 5);
+  UCSA_CHECK_ARG(d_feat && partial, 6);
+  if (M == 0) return 0;
+  const uint32_t blocks = ucsa_sigma_mlp_bwd_parts(M) / SIGB_WAVES;
+  const size_t smem = (size_t)SIGB_WAVES * 2 * 16 * TILE_LD * sizeof(float);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp_bwd<true>, dim3(blocks), dim3(64 * SIGB_WAVES), smem,
                      (hipStream_t)stream, (const float2*)feat, d_h,
                      packed_sigma, packed_sigma_t, (uint64_t)M,
                      (float2*)d_feat, partial);

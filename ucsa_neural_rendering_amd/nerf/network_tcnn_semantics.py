@@ -96,9 +96,9 @@ class _RenderFn(torch.autograd.Function):
         if tcnn:
             # the sigma net's backward runs the fp32 kernel on the forward's
             # fp16-rounded operands (rounded weights, rounded features; fp32
-            # accumulation like the f16 MFMA) -- its hidden layer is not
-            # re-rounded to fp16 there (tcnn does), the one place this mode is
-            # "fp16 operands, fp32 arithmetic" rather than tcnn's exact kernel
+            # accumulation like the f16 MFMA) with the recomputed hidden layer
+            # rounded to fp16 as tcnn's forward stored it (round 4:
+            # ucsa_sigma_mlp_bwd_h16)
             ps, pst = net._pack_rounded_sigma()
             f = dict(f, packed_sigma=ps, packed_sigma_t=pst)
         if net.train_precision == "bf16x3":
@@ -170,7 +170,8 @@ class _RenderFn(torch.autograd.Function):
             feat_c = feat_c.float()
             feat_f = None if feat_f is None else feat_f.float()
         d_feat, part = ops.sigma_mlp_bwd(feat_c, d_h_c, f["packed_sigma"],
-                                         f["packed_sigma_t"], x2=ctx.x2)
+                                         f["packed_sigma_t"], x2=ctx.x2,
+                                         round_hidden=ctx.tcnn)
         ops.reduce_partials(part, g_sigma, False)
         # f16 training mode: 8-byte bin records (half2 values under the same
         # loss scale as the nets' gradient operands)
@@ -184,7 +185,8 @@ class _RenderFn(torch.autograd.Function):
                                   rec_scale=rs, packed=pk)
         if t > 0:
             d_feat_f, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
-                                               f["packed_sigma_t"], x2=ctx.x2)
+                                               f["packed_sigma_t"], x2=ctx.x2,
+                                               round_hidden=ctx.tcnn)
             ops.reduce_partials(part, g_sigma, True)
             if merged:
                 # both passes in one call, the ray's samples in sorted order: the

@@ -561,14 +561,17 @@ def reduce_partials_multi(pairs, accumulate: bool = False):
           "ucsa_reduce_partials_multi")
 
 
-def sigma_mlp_bwd(feat, d_h, packed_sigma, packed_sigma_t, x2: bool = False):
+def sigma_mlp_bwd(feat, d_h, packed_sigma, packed_sigma_t, x2: bool = False,
+                  round_hidden: bool = False):
     """-> d_feat [L,M,2], dW partials [parts, 3072].  x2: the bf16x2 kernel
-    (packed weights from mlp_pack_x3 / mlp_pack_t_x3)."""
+    (packed weights from mlp_pack_x3 / mlp_pack_t_x3); round_hidden: the fp32
+    kernel with its recomputed hidden layer rounded to fp16 (tcnn numerics)."""
     L, M, _ = feat.shape
     d_feat = torch.empty_like(feat)
     parts = int(lib().ucsa_sigma_mlp_bwd_parts(M))
     partial = torch.empty(parts, 3072, device=feat.device)
     fn, nm = ((lib().ucsa_sigma_mlp_bwd_x2, "ucsa_sigma_mlp_bwd_x2") if x2 else
+              (lib().ucsa_sigma_mlp_bwd_h16, "ucsa_sigma_mlp_bwd_h16") if round_hidden else
               (lib().ucsa_sigma_mlp_bwd, "ucsa_sigma_mlp_bwd"))
     check(fn(_ptr(feat), _ptr(d_h), _ptr(packed_sigma), _ptr(packed_sigma_t), M, L,
              _ptr(d_feat), _ptr(partial), _stream()), nm)
