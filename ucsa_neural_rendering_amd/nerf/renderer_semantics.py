@@ -493,7 +493,7 @@ class SemanticNeRFRenderer(nn.Module):
             "semantics": sem.view(*prefix, C),
         }
 
-    def infer_chunk(self, N: int, image_width: int = 0):
+    def infer_chunk(self, N: int, image_width: int = 0, samples_per_ray: int = 0):
         """(rays per enqueue, image_width or 0) of a no-grad render of N rays:
         ``hip_ray_chunk`` at most; whole 8-row bands of 8x8 pixel tiles when the
         rays are full image rows; and, for the pipelined call, >= 2 BALANCED
@@ -502,12 +502,19 @@ class SemanticNeRFRenderer(nn.Module):
         rays/s for any chunk between 20 k and 150 k rays, one 307 k chunk 15.3;
         the joint step: 192 ms unpipelined, 187 / 184 ms with 2 / 3 chunks per
         frame.  Larger launches keep the encoder's per-launch efficiency (the
-        bench's roofline figure), hence hip_ray_chunk as the cap.  Results do
-        not depend on any of it."""
+        bench's roofline figure), hence hip_ray_chunk as the cap.  The pipelined
+        call's budget is in SAMPLES beyond 192 per ray (~10 M per chunk): the
+        joint step's 8 frames of 320x240 at 256 + 256 samples go out as 30
+        chunks of 20 480 rays instead of 10 of 61 440 (round 4, with the faster
+        f16x2 shader: 167 -> 163 ms).
+        Results do not depend on any of it."""
         chunk = max(1, int(self.hip_ray_chunk))
         band = 8 * image_width if (image_width and N % image_width == 0) else 0
         if self.hip_pipeline and int(self.hip_streams) <= 1 and N > 16384:
-            n = max(2, -(-N // min(chunk, max(64, self.hip_pipeline_rays))))
+            budget = max(64, self.hip_pipeline_rays)
+            if samples_per_ray > 192:   # ~10 M samples per chunk
+                budget = max(8192, budget * 192 * 4 // (samples_per_ray * 5))
+            n = max(2, -(-N // min(chunk, budget)))
             chunk = -(-N // n)
             unit = band if band and chunk >= band else 64
             chunk = -(-chunk // unit) * unit
@@ -542,7 +549,7 @@ class SemanticNeRFRenderer(nn.Module):
         image = torch.empty(N, 3, device=dev)
         depth = torch.empty(N, device=dev)
         sem = torch.empty(N, C, device=dev)
-        chunk, image_width = self.infer_chunk(N, image_width)
+        chunk, image_width = self.infer_chunk(N, image_width, T + t)
         n_chunks = (N + chunk - 1) // chunk
         if self.hip_pipeline and n_chunks >= 2 and int(self.hip_streams) <= 1:
             # ONE call for the whole batch: density half of chunk k+1 next to
