@@ -25,6 +25,14 @@ recomputed) -- and the result under test must MATCH ONE ALTERNATIVE in all
 three outputs at once: image and semantics within ``ALT_ABS``, depth within
 ``ALT_REL``.  There is no blanket escape: a loose ray that matches no
 alternative fails the test, wherever it sits.
+
+The match tolerance is ``ALT_ABS`` / ``ALT_REL`` or, where the render's ORDINARY
+error is larger than that, the 99.5th percentile of the error of its rays that
+are NOT loose -- never more than half the stated tolerance (``alt_tolerances``):
+once its flipped decision is accounted for, a loose ray must look like every
+other ray of the same render.  (A field trained to sharper class logits has an
+ordinary semantics error of 3e-5 at that percentile on the exact f32 path; a
+fixed 2e-5 then rejected a ray whose explained residual was 2.2e-5.)
 """
 from __future__ import annotations
 
@@ -186,10 +194,22 @@ def _errors(got, ref):
                   ref["depth"].double().abs().clamp_min(1e-3)))
 
 
-def explain_ray(ro: RayOracle, got, window_fn=None):
+def alt_tolerances(e_img, e_sem, rel, loose):
+    """(image, semantics, depth) match tolerances of a render: its ordinary
+    error level (p99.5 over the rays that are not loose), at least ALT_ABS /
+    ALT_REL, at most half the stated tolerance."""
+    ok = ~loose
+    if int(ok.sum()) < 16:
+        return ALT_ABS, ALT_ABS, ALT_REL
+    q = lambda e, lo, hi: min(max(float(e[ok].quantile(0.995)), lo), hi)  # noqa: E731
+    return (q(e_img, ALT_ABS, 0.5 * TOL_ABS), q(e_sem, ALT_ABS, 0.5 * TOL_ABS),
+            q(rel, ALT_REL, 0.5 * TOL_DEPTH_REL))
+
+
+def explain_ray(ro: RayOracle, got, window_fn=None, tol=(ALT_ABS, ALT_ABS, ALT_REL)):
     """Best alternative for one ray: (score, description, errors).  score <= 1
-    means ``got`` matches that alternative within ALT_ABS / ALT_REL in all
-    three outputs.  Alternatives: subsets of the denom-step fine samples
+    means ``got`` matches that alternative within ``tol`` (image, semantics,
+    depth; default ALT_ABS / ALT_REL) in all three outputs.  Alternatives: subsets of the denom-step fine samples
     flipped x subsets of the at-threshold samples toggled."""
     with torch.no_grad():
         denom_cand = []
@@ -221,7 +241,7 @@ def explain_ray(ro: RayOracle, got, window_fn=None):
                             mask[s] = ~mask[s]
                         alt = ro.composite(z, weights, rgbs, probs, mask)
                         ei, es, ed = _errors(got, alt)
-                        score = max(ei / ALT_ABS, es / ALT_ABS, ed / ALT_REL)
+                        score = max(ei / tol[0], es / tol[1], ed / tol[2])
                         n_alt += 1
                         if score < best[0]:
                             best = (score, {"denom_flipped": list(dflip), "mask_toggled": list(tog),
@@ -270,13 +290,15 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
           f"{int(at_denom.sum())} with a fine sample on the denom step = {100 * frac:.1f} % of {n} "
           "(informational: having a candidate excuses nothing)")
     # every loose ray must match one alternative of ITS OWN candidates
+    alt = alt_tolerances(e_img, e_sem, rel, loose)
+    print(f"{tag} match tolerances (image, semantics, depth rel): {alt[0]:.2e} {alt[1]:.2e} {alt[2]:.2e}")
     unexplained = []
     for i in torch.nonzero(loose).flatten().tolist():
         ro = RayOracle(fld, o[i], d[i], nrm[i], aabb, T, t,
                        None if t == 0 else aux["u"][i],
                        None if t_rand is None else t_rand[i])
         g1 = {k: got[k][i] for k in got}
-        score, what, errs, n_alt = explain_ray(ro, g1)
+        score, what, errs, n_alt = explain_ray(ro, g1, tol=alt)
         line = (f"{tag} ray {i}: err img {float(e_img[i]):.2e} sem {float(e_sem[i]):.2e} depth "
                 f"{float(rel[i]):.2e}; best of {n_alt} alternatives {what} -> "
                 f"img {errs[0]:.2e} sem {errs[1]:.2e} depth {errs[2]:.2e}")
@@ -285,7 +307,7 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
             unexplained.append(line)
     assert not unexplained, ("rays above the tolerance that NO alternative decision of the "
                              "reference's two step functions reproduces within "
-                             f"{ALT_ABS:g} / {ALT_REL:g}:\n" + "\n".join(unexplained[:10]))
+                             f"{alt[0]:.2g} / {alt[1]:.2g} / {alt[2]:.2g}:\n" + "\n".join(unexplained[:10]))
     # every loose ray is reproduced by a named alternative above; their NUMBER
     # stays small (0.2 % observed at 4096 rays; 8 allows for the Poisson spread
     # of a 512-ray sample, where 5 were seen once)

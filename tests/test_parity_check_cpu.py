@@ -136,3 +136,41 @@ def test_a_denom_step_sample_placed_by_the_other_branch_passes(case):
         assert done > 0
     finally:
         pc.DENOM_WINDOW = old
+
+
+def test_match_tolerance_follows_the_renders_ordinary_error_but_is_capped(case):
+    """A render with an ordinary semantics error of ~3e-5 (a sharper field on
+    the exact path does that): a genuine flip whose explained residual is
+    2.5e-5 passes -- it looks like every other ray -- while a residual of 7e-5
+    fails even though the noise level were higher still (cap: half of 1e-4)."""
+    fld, rays, u, ref = case
+    i, s = _toggle_case(case)
+    ro = pc.RayOracle(fld, rays[0][0, i], rays[1][0, i], rays[2][0, i], AABB4, T, t, u[i])
+    with torch.no_grad():
+        z, sigma, geo, xyz, _ = ro.sorted_samples()
+        w, rgbs, probs = ro.shade_all(z, sigma, geo, xyz)
+        mask = w > 1e-4
+        mask[s] = ~mask[s]
+        alt = ro.composite(z, w, rgbs, probs, mask)
+    g = torch.Generator().manual_seed(9)
+    # heavy-tailed like the real thing: 3 % of the rays at +-3.2e-5, the rest at 1e-6
+    noise = torch.where(torch.rand(N, generator=g) < 0.03, torch.full((N,), 3.2e-5),
+                        torch.full((N,), 1e-6)) * torch.sign(torch.rand(N, generator=g) - 0.5)
+    for extra, ok in ((2.5e-5, True), (7e-5, False)):
+        res = _res(ref)
+        res["semantics"][0, :, 3] += noise
+        for k in res:
+            res[k][0, i] = alt[k]
+        res["semantics"][0, i, 3] += extra
+        if ok:
+            assert pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="noisy-flip")["loose"] == 1
+        else:
+            with pytest.raises(AssertionError, match="NO alternative"):
+                pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="noisy-flip+error")
+    # the same 2.5e-5 residual on a QUIET render exceeds ALT_ABS and fails
+    res = _res(ref)
+    for k in res:
+        res[k][0, i] = alt[k]
+    res["semantics"][0, i, 3] += 2.5e-5
+    with pytest.raises(AssertionError, match="NO alternative"):
+        pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="quiet-flip+2.5e-5")
