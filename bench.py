@@ -251,6 +251,11 @@ def init_distributed(args):
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # create the communicator now (RCCL prints its banner then) and push the
+        # banner out of libc's buffer on EVERY rank: nothing but rank 0's JSON
+        # line may reach the job's stdout after this
+        dist.barrier()
+        common.flush_c_stdio()
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     return dist, world, rank, dev, backend

@@ -32,8 +32,13 @@ def _run(cmd, tmp_path, env, timeout=900):
     with open(out, "w") as fo, open(err, "w") as fe:
         rc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
                               env=env, cwd=ROOT).wait(timeout=timeout)
-    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    text = out.read_text()
+    lines = [l for l in text.splitlines() if l.startswith("{")]
     assert rc == 0 and lines, (rc, err.read_text()[-3000:])
+    if os.path.basename(cmd[1]) == "bench.py":
+        # the record is the LAST stdout line even though RCCL prints a banner with
+        # C stdio (which a pipe / file buffers until flushed: common.flush_c_stdio)
+        assert text.strip().splitlines()[-1] == lines[-1], text[-600:]
     return json.loads(lines[-1]), err.read_text()
 
 

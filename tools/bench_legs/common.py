@@ -194,13 +194,27 @@ def tuning_tables_matched(dev=None):
                     "tunableop": tu["why"]}}
 
 
+def flush_c_stdio():
+    """fflush(NULL): RCCL prints its banner (version, hostname, library path)
+    with C stdio; redirected to a pipe or a file that sits in libc's buffer
+    until the process exits -- i.e. AFTER the JSON line Python has long written.
+    Flushed where it is produced, the banner stays in front of the line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def finish(dist, rank, result):
-    """Rank 0: full result -> bench_detail.json + stderr, compact line ->
-    stdout (tools/bench_legs/headline.py).  Then tear the group down."""
+    """Tear the group down, then rank 0: full result -> bench_detail.json +
+    stderr, compact line -> stdout (tools/bench_legs/headline.py) as the LAST
+    thing this process writes there."""
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
     if rank == 0:
         from .headline import emit
         result["distributed"] = DIST_RECORD
         emit(result, ROOT)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
