@@ -84,6 +84,16 @@ class JointTrainLightningNet(nn.Module):
         # `nerf: {bwd_precision: fp32}`: keep the f32-input MFMA kernels for the
         # backward of the bf16x3 mode (default bf16x2: renderer_semantics.py)
         self.nerf_model.bwd_precision = str(nerf_cfg.get("bwd_precision", "bf16x2"))
+        # round-4 switches of the default training mode (all default on; the
+        # UCSA_* environment variables of renderer_semantics.py set the defaults):
+        #   train_fwd_f16x2      forward nets as f16x2 instead of bf16x3
+        #   grid_records_packed  8-byte packed bin records in the grid backward
+        #   grid_bwd_merged      both density passes' grid backward in one call
+        #   fused_train_calls    ucsa_render_fused_fwd / _bwd instead of staged calls
+        for key in ("train_fwd_f16x2", "grid_records_packed", "grid_bwd_merged",
+                    "fused_train_calls"):
+            if key in nerf_cfg:
+                setattr(self.nerf_model, key, bool(nerf_cfg[key]))
         self.nerf_model.f16_bwd_scale = float(nerf_cfg.get("f16_bwd_scale", 1.0))
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
