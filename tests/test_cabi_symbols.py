@@ -97,3 +97,30 @@ def test_reference_import_paths_resolve():
                  "composite_rays_train_semantics", "march_rays", "composite_rays",
                  "composite_rays_semantics", "compact_rays"):
         assert callable(getattr(raymarching, name)), name
+
+
+def test_ctypes_structures_match_the_header_layout(built_lib, tmp_path):
+    """The structs that cross the boundary by pointer (ucsa_grid, ucsa_aug_params,
+    ucsa_train_buffers, ucsa_train_packs): size and field offsets of the ctypes
+    mirrors against what a C compiler makes of include/ucsa_hip.h."""
+    structs = {"ucsa_grid": built_lib.Grid, "ucsa_grid_level": built_lib.GridLevel,
+               "ucsa_aug_params": built_lib.AugParams,
+               "ucsa_train_buffers": built_lib.TrainBuffers,
+               "ucsa_train_packs": built_lib.TrainPacks}
+    lines = []
+    for cname, ct in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ucsa_hip.h"\n'
+                   "int main(void) {\n" + "\n".join(lines) + "\nreturn 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    c_layout = dict(l.split() for l in out.strip().splitlines())
+    for cname, ct in structs.items():
+        assert int(c_layout[cname]) == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(c_layout[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
