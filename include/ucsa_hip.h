@@ -692,6 +692,15 @@ int32_t ucsa_render_fused_bwd(
     float density_scale, float* grad_table, float* grad_sigma, float* grad_color,
     float* grad_sem, void* workspace, void* stream);
 
+/* ucsa_hashgrid_bwd_rays_merged with the half2 x rec_scale records of
+ * ucsa_hashgrid_bwd_rays_h16 (training modes fp16 / tcnn). */
+int32_t ucsa_hashgrid_bwd_rays_merged_h16(
+    const ucsa_grid* grid, const float* rays_o, const float* rays_d,
+    const float* z_c, const float* z_f, const int32_t* src, const float* aabb_host,
+    uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
+    const float* d_feat_f, float* grad_table, void* workspace, float rec_scale,
+    void* stream);
+
 /* Backward of ucsa_hashgrid_encode_points (x [M,3] explicit points; workspace
  * of ucsa_hashgrid_bwd_workspace_bytes(M, 1, n_levels) or NULL). */
 int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid_host, const float* x,

@@ -191,6 +191,9 @@ SIGNATURES = {
     "ucsa_render_fused_bwd": (C.c_int32, [C.POINTER(Grid), C.POINTER(TrainPacks), _p, _p, _p,
                                           C.POINTER(_f), C.POINTER(TrainBuffers), _p, _p, _p,
                                           _u32, _u32, _u32, _u32, _f, _p, _p, _p, _p, _p, _p]),
+    "ucsa_hashgrid_bwd_rays_merged_h16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
+                                                      C.POINTER(_f), _u32, _u32, _u32, _p, _p,
+                                                      _p, _p, _f, _p]),
     "ucsa_hashgrid_bwd_points": (C.c_int32, [C.POINTER(Grid), _p, _u32, _p, _p,
                                              _p, _p]),
     "ucsa_composite_bwd_parts": (C.c_uint32, [_u32]),

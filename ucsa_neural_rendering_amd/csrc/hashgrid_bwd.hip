@@ -958,6 +958,29 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays_merged_p64(
                              grad_table, workspace, stream, -1.0f, mg);
 }
 
+// ucsa_hashgrid_bwd_rays_merged with the half2 records of _h16 (the f16 / tcnn
+// training modes): rec_scale > 0, a power of two.
+extern "C" int32_t ucsa_hashgrid_bwd_rays_merged_h16(
+    const ucsa_grid* grid, const float* rays_o, const float* rays_d,
+    const float* z_c, const float* z_f, const int32_t* src, const float* aabb_host,
+    uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
+    const float* d_feat_f, float* grad_table, void* workspace, float rec_scale,
+    void* stream) {
+  UCSA_CHECK_ARG(grid && grid->n_features == 2 && grid->n_levels > 0 &&
+                     grid->n_levels <= UCSA_MAX_LEVELS, 0);
+  UCSA_CHECK_ARG(rays_o && rays_d && z_c, 1);
+  UCSA_CHECK_ARG(z_f && src, 4);
+  UCSA_CHECK_ARG(aabb_host, 6);
+  UCSA_CHECK_ARG(Tc >= 1 && Tf >= 1 && (uint64_t)N * (Tc + Tf) < 0x80000000ull, 8);
+  UCSA_CHECK_ARG(d_feat_c && d_feat_f, 10);
+  UCSA_CHECK_ARG(grad_table, 12);
+  UCSA_CHECK_ARG(workspace, 13);
+  UCSA_CHECK_ARG(rec_scale > 0.0f, 14);
+  const MergedSrc mg{src, z_f, (const float2*)d_feat_f, Tc, Tf, N};
+  return hashgrid_bwd_launch(grid, rays_o, rays_d, z_c, aabb_host, N, Tc + Tf, d_feat_c,
+                             grad_table, workspace, stream, rec_scale, mg);
+}
+
 // The same with 8-byte bin records: value pairs stored as half2 x rec_scale
 // (rec_scale > 0; a power of two).  Requires the workspace.
 extern "C" int32_t ucsa_hashgrid_bwd_rays_h16(const ucsa_grid* grid,

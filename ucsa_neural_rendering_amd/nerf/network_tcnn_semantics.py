@@ -176,7 +176,7 @@ class _RenderFn(torch.autograd.Function):
         # f16 training mode: 8-byte bin records (half2 values under the same
         # loss scale as the nets' gradient operands)
         rs = float(net.f16_bwd_scale) if (ctx.half and (net.f16_grid_records or ctx.tcnn)) else 0.0
-        merged = t > 0 and rs == 0.0 and net.grid_bwd_merged
+        merged = t > 0 and net.grid_bwd_merged
         # bf16x2 backward: 8-byte packed bin records (26-bit values, 2^-18 --
         # finer than the two-term split that produced them)
         pk = ctx.x2 and rs == 0.0 and net.grid_records_packed
@@ -192,7 +192,8 @@ class _RenderFn(torch.autograd.Function):
                 # both passes in one call, the ray's samples in sorted order: the
                 # fine samples join the coarse samples' runs on the coarse levels
                 ops.hashgrid_bwd_rays_merged(f["grid"], o, d, z_c, z_f, src, aabb,
-                                             d_feat, d_feat_f, g_grid, packed=pk)
+                                             d_feat, d_feat_f, g_grid, packed=pk,
+                                             rec_scale=rs)
             else:
                 ops.hashgrid_bwd_rays(f["grid"], o, d, z_f, aabb, d_feat_f, g_grid,
                                       rec_scale=rs, packed=pk)

@@ -624,7 +624,8 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
 
 
 def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
-                             d_feat_c, d_feat_f, grad_table, packed: bool = False):
+                             d_feat_c, d_feat_f, grad_table, packed: bool = False,
+                             rec_scale: float = 0.0):
     """Both density passes in one call, every ray's samples walked in sorted
     depth order (``src`` [N, Tc+Tf] int32 of the forward composite): adds the
     table gradient (ucsa_hashgrid_bwd_rays_merged; packed: its _p64 form with
@@ -645,6 +646,12 @@ def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=z_c.device)
         _bwd_ws[key] = ws
+    if rec_scale > 0.0:   # half2 x rec_scale records (training modes fp16 / tcnn)
+        check(lib().ucsa_hashgrid_bwd_rays_merged_h16(
+            C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z_c), _ptr(z_f), _ptr(src),
+            fvec(aabb), N, Tc, Tf, _ptr(d_feat_c), _ptr(d_feat_f), _ptr(grad_table), _ptr(ws),
+            float(rec_scale), _stream()), "ucsa_hashgrid_bwd_rays_merged_h16")
+        return
     fn = lib().ucsa_hashgrid_bwd_rays_merged_p64 if packed else lib().ucsa_hashgrid_bwd_rays_merged
     check(fn(
         C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z_c), _ptr(z_f), _ptr(src),
