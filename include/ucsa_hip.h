@@ -771,15 +771,20 @@ int32_t ucsa_nerf_loss(const float* rgb, const float* sem, const float* depth,
                        void* stream);
 
 /* Backward of the loss node of reference joint_train_lightning_net.py:497-513
- * (`total.backward()` / `scaler.scale(total).backward()`) in one launch, in
- * place on the gradients ucsa_nerf_loss wrote with the same w_sem / w_depth:
- *   d_rgb *= g_total + g_color,  d_sem *= g_total + g_sem / w_sem,
- *   d_depth *= g_total + g_depth / w_depth
+ * (`total.backward()` / `scaler.scale(total).backward()`) in one launch, from
+ * the gradients ucsa_nerf_loss wrote with the same w_sem / w_depth:
+ *   out_rgb = d_rgb * (g_total + g_color),  out_sem = d_sem * (g_total + g_sem / w_sem),
+ *   out_depth = d_depth * (g_total + g_depth / w_depth)
+ * (out_* may alias d_* for an in-place update; the autograd node writes fresh
+ * buffers so that a second backward through a retained graph sees the stored
+ * gradients unscaled -- ADVICE r4)
  * where g_* are DEVICE scalars (the cotangents autograd hands back: of the
  * total, and of the single terms when a caller combined them itself); NULL = 0.
  * Replaces the ~10 elementwise launches torch's autograd spends on
  * `lc + 0.04 ls + 0.1 ld` and its backward. */
-int32_t ucsa_nerf_loss_apply(float* d_rgb, float* d_sem, float* d_depth,
+int32_t ucsa_nerf_loss_apply(const float* d_rgb, const float* d_sem,
+                             const float* d_depth, float* out_rgb,
+                             float* out_sem, float* out_depth,
                              uint32_t N, uint32_t C, const float* g_total,
                              const float* g_color, const float* g_sem,
                              const float* g_depth, float w_sem, float w_depth,

@@ -62,6 +62,35 @@ def test_nerf_loss_kernel_values_and_gradients(ops):
     assert z2.grad is None or float(z2.grad.abs().max()) == 0.0
 
 
+def test_nerf_loss_second_backward_through_a_retained_graph(ops):
+    """the loss node's backward used to scale its saved gradients
+    IN PLACE (unseen by autograd's version counter); per-term gradient norms
+    with ``torch.autograd.grad(..., retain_graph=True)`` followed by
+    ``.backward()`` then returned gradients scaled twice.  Every backward
+    through the retained node must give the gradient of what was asked."""
+    from ucsa_neural_rendering_amd import losses as ul
+    rgb, sem, depth, gt, labels, gtd = _loss_inputs(300)
+    a = [t.clone().requires_grad_() for t in (rgb, sem, depth)]
+    lc, ls, ld = olosses.nerf_losses(a[0], a[1], a[2], gt, labels, gtd, 0.7)
+    want_c = torch.autograd.grad(lc, a[0], retain_graph=True)[0]
+    want_s = torch.autograd.grad(ls, a[1], retain_graph=True)[0]
+    olosses.nerf_total_loss(lc, ls, ld).backward()
+    b = [t.clone().cuda().requires_grad_() for t in (rgb, sem, depth)]
+    hc, hs, hd = ul.nerf_losses(b[0], b[1], b[2], gt.cuda(), labels.cuda(), gtd.cuda(), 0.7)
+    total = ul.nerf_total_loss(hc, hs, hd)
+    got_c = torch.autograd.grad(hc * 3.0, b[0], retain_graph=True)[0]
+    got_s = torch.autograd.grad(hs, b[1], retain_graph=True)[0]
+    total.backward(retain_graph=True)
+    first = [x.grad.clone() for x in b]
+    total.backward()
+    assert maxabs(got_c / 3.0, want_c) <= 1e-6 * float(want_c.abs().max())
+    assert maxabs(got_s, want_s) <= 2e-6 * float(want_s.abs().max())
+    for x, f, y in zip(b, first, a):
+        tol = 1e-6 * max(1.0, float(y.grad.abs().max()))
+        assert maxabs(f, y.grad) <= tol
+        assert maxabs(x.grad, 2.0 * y.grad) <= 2 * tol   # accumulated, not rescaled
+
+
 def test_semantic_postproc(ops):
     g = torch.Generator().manual_seed(2)
     sem = torch.rand(3, 50, 40, generator=g)

@@ -1,0 +1,69 @@
+"""Round 5 experiment: how much of the fine pass's gather time is DEPTH
+DIVERGENCE inside a wave?  In the coarse pass the 64 pixels of a tile sit at one
+depth per sample index; in the fine pass the i-th sorted sample of neighbouring
+rays is at a different depth for every pixel, so the lanes of a wave share no
+cells.  Proxy for a depth-binned encoder: pool the 64 x T fine depths of every
+8x8 tile, sort them, and deal them back so that sample index i of the tile's 64
+pixels holds the 64 pooled depths of rank 64 i .. 64 i + 63 (same depth
+distribution per tile, coherent across the lanes of a wave), then time the
+shipped tiled encoder per level on both arrays."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from ucsa_neural_rendering_amd import ops
+from ucsa_neural_rendering_amd._lib import Grid
+dev = torch.device("cuda:0")
+net, ds = bench.build_field(dev, train_steps=int(os.environ.get("PRE", 200)))
+f = net._field()
+W, H = 640, 480
+from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
+pose = _slerp_loop_poses(4, seed=999)[1:2].to(dev)
+o, d, n = ops.get_rays(pose, (0.89 * W, 0.89 * W, W / 2, H / 2), H, W)
+ROWS = 96
+N = ROWS * W
+o, d = o[0, :N].contiguous(), d[0, :N].contiguous()
+aabb = net._aabb_list(False)
+near, far = ops.near_far_from_aabb(o, d, aabb, 0.2)
+T = 96
+z = ops.sample_coarse(near, far, T, None)
+os.environ["UCSA_ENC_ML"] = "0"
+h, sig = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb), f["packed_sigma"])
+zf = ops.resample(z, sig.view(N, T), torch.rand(N, T, device=dev), 1.0)
+# pooled + dealt back
+t = zf.view(ROWS // 8, 8, W // 8, 8, T).permute(0, 2, 1, 3, 4).reshape(-1, 64 * T)
+t = t.sort(dim=1).values.view(-1, T, 64).permute(0, 2, 1)          # [tiles, 64, T]
+zc = t.reshape(ROWS // 8, W // 8, 8, 8, T).permute(0, 2, 1, 3, 4).reshape(N, T).contiguous()
+print("fine z spread inside a wave (max-min over the tile's 64 pixels at one sample index), mean: "
+      f"shipped order {float((zf.view(ROWS//8,8,W//8,8,T).amax((1,3)) - zf.view(ROWS//8,8,W//8,8,T).amin((1,3))).mean()):.4f}  "
+      f"depth-binned {float((zc.view(ROWS//8,8,W//8,8,T).amax((1,3)) - zc.view(ROWS//8,8,W//8,8,T).amin((1,3))).mean()):.4f}  "
+      f"coarse-pass spacing {float((z[:,1]-z[:,0]).mean()):.4f}")
+
+
+def timed(fn, n=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+full = f["grid"]
+print("level | coarse pass | fine pass shipped order | fine pass depth-binned   (us, single-level launches)")
+tot = [0.0, 0.0, 0.0]
+for l in range(full.n_levels):
+    g1 = Grid()
+    g1.n_levels, g1.n_features, g1.total_entries, g1.bound = 1, full.n_features, full.total_entries, full.bound
+    g1.level[0] = full.level[l]
+    row = [1e3 * timed(lambda: ops.hashgrid_encode_rays(g1, f["table"], o, d, zz, aabb, image_width=W)) for zz in (z, zf, zc)]
+    tot = [a + b for a, b in zip(tot, row)]
+    print(f"{l:5d} | {row[0]:7.1f} | {row[1]:7.1f} | {row[2]:7.1f}", flush=True)
+print("sum:", [round(x) for x in tot])
+for name, zz in (("coarse", z), ("fine shipped", zf), ("fine depth-binned", zc)):
+    for ml in (0, 9):
+        os.environ["UCSA_ENC_ML"] = str(ml)
+        print(f"{name:18s} UCSA_ENC_ML={ml}: {timed(lambda: ops.hashgrid_encode_rays(full, f['table'], o, d, zz, aabb, image_width=W)):.3f} ms")

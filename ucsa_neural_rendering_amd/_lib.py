@@ -217,7 +217,7 @@ SIGNATURES = {
     "ucsa_loss_partial_floats": (C.c_uint32, [_u32]),
     "ucsa_nerf_loss": (C.c_int32, [_p] * 6 + [_u32, _u32, _f, _f, _f, _f] +
                        [_p] * 6),
-    "ucsa_nerf_loss_apply": (C.c_int32, [_p, _p, _p, _u32, _u32, _p, _p, _p, _p, _f, _f, _p]),
+    "ucsa_nerf_loss_apply": (C.c_int32, [_p, _p, _p, _p, _p, _p, _u32, _u32, _p, _p, _p, _p, _f, _f, _p]),
     "ucsa_semantic_postproc": (C.c_int32, [_p, _u32, _u32, _p, _p, _p]),
     "ucsa_seg_tail": (C.c_int32, [_p, _p, _u32, _u32, _u32, _f, _p, _p, _p, _p,
                                   _p, _p]),

@@ -225,6 +225,201 @@ k_hashgrid_encode_tiled(GridDev g, LevelMap lm,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 5: SEVERAL levels per workgroup for the levels that are bound by
+// instruction issue, not by the gather (per-level times of the kernel above on
+// the bench's chunk: levels 0-8 cost 31-37 us each in the coarse pass whatever
+// their table -- ~205 VALU instructions per sample and level, a third of them
+// the per-workgroup preamble (tile geometry, z staging, ray loads, position) and
+// another ~20 the position -> unit-cube arithmetic, all of it repeated for every
+// level).  Here a workgroup keeps its tile's 4 samples per lane in registers as
+// unit-cube coordinates and walks levels [l_lo, l_hi): per level only cell /
+// fraction, the 8 indices, the gather and the blend remain; the level's
+// features leave through a double-buffered LDS tile (one barrier per level).
+// Same arithmetic per sample (encode_cell below = encode_level's operations in
+// encode_level's order): bit-identical features.  The fine levels stay with
+// k_hashgrid_encode_tiled: they are bound by the L2 -> L1 line fills of their
+// random corners and their time follows the L1 miss count, which every
+// restructuring of the code around the gather made worse.
+// ---------------------------------------------------------------------------
+// table entries addressed as 32-bit BYTE offsets off the level's (wave-uniform)
+// base: one `global_load ... v_off, s[base]` per corner instead of a 64-bit
+// shift-and-add per address
+__device__ __forceinline__ float2 tab_at(const float2* __restrict__ tab, uint32_t off) {
+  return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab) + off);
+}
+__device__ __forceinline__ float2 tab_at(const ucsa_half2* __restrict__ tab, uint32_t off) {
+  const ucsa_half2 v = *reinterpret_cast<const ucsa_half2*>(reinterpret_cast<const char*>(tab) + off);
+  return make_float2((float)v[0], (float)v[1]);
+}
+__device__ __forceinline__ void tab_pair_at(const float2* __restrict__ tab, uint32_t off,
+                                            float2& a, float2& b) {
+  const ucsa_f32x4_u p = *reinterpret_cast<const ucsa_f32x4_u*>(reinterpret_cast<const char*>(tab) + off);
+  a = make_float2(p[0], p[1]);
+  b = make_float2(p[2], p[3]);
+}
+__device__ __forceinline__ void tab_pair_at(const ucsa_half2* __restrict__ tab, uint32_t off,
+                                            float2& a, float2& b) {
+  const ucsa_half4_u p = *reinterpret_cast<const ucsa_half4_u*>(reinterpret_cast<const char*>(tab) + off);
+  a = make_float2((float)p[0], (float)p[1]);
+  b = make_float2((float)p[2], (float)p[3]);
+}
+
+// the far faces of a dense level (tcnn's `% entries` wraps there): rare, kept
+// out of line and rolled so that it costs no instruction-cache space
+template <typename TT>
+__device__ __noinline__ void dense_corners_wrapped(const TT* __restrict__ tab,
+                                                   uint32_t gx, uint32_t gy, uint32_t gz,
+                                                   uint32_t res, uint32_t entries,
+                                                   float2* v) {
+#pragma unroll 1
+  for (int c = 0; c < 8; ++c)
+    v[c] = tab_load(tab, grid_index(gx + (c & 1), gy + ((c >> 1) & 1),
+                                    gz + ((c >> 2) & 1), res, entries, 0u));
+}
+
+template <typename TT>
+__device__ __forceinline__ float2 encode_cell(const TT* __restrict__ tab,
+                                              float x, float y, float z,
+                                              float scale, uint32_t res,
+                                              uint32_t res2, uint32_t entries,
+                                              uint32_t hashed) {
+  constexpr uint32_t SH = sizeof(TT) == 8 ? 3u : 2u;   // log2 of the entry size
+  const float px = x * scale + 0.5f, py = y * scale + 0.5f,
+              pz = z * scale + 0.5f;
+  const float fx0 = floorf(px), fy0 = floorf(py), fz0 = floorf(pz);
+  const float wx = px - fx0, wy = py - fy0, wz = pz - fz0;
+  const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
+                 gz = (uint32_t)(int32_t)fz0;
+  float2 v[8];
+  if (!hashed) {   // wave-uniform
+    const uint32_t b = gx + gy * res + gz * res2;
+    // all four x-pairs inside the slab (false only on the far faces of the
+    // box): one test instead of eight
+    if (__builtin_expect(b + res + res2 + 1u < entries, 1)) {
+      const uint32_t o = b << SH;
+      tab_pair_at(tab, o, v[0], v[1]);
+      tab_pair_at(tab, o + (res << SH), v[2], v[3]);
+      tab_pair_at(tab, o + (res2 << SH), v[4], v[5]);
+      tab_pair_at(tab, o + ((res + res2) << SH), v[6], v[7]);
+    } else {
+      dense_corners_wrapped(tab, gx, gy, gz, res, entries, v);
+    }
+  } else {
+    // byte offset of entry (ix ^ iy P_y ^ iz P_z) & (entries - 1): the shift
+    // by SH commutes with the xor / and, and a product mod 2^32 shifted left
+    // keeps the bits the mask reads -- the same entries as grid_index()
+    const uint32_t mask = (entries - 1u) << SH;
+    constexpr uint32_t PY = PRIME_Y << SH, PZ = PRIME_Z << SH;
+    const uint32_t hy0 = gy * PY, hy1 = hy0 + PY;   // (gy + 1) P = gy P + P mod 2^32
+    const uint32_t hz0 = gz * PZ, hz1 = hz0 + PZ;
+    const uint32_t x0 = gx << SH, x1 = x0 + (1u << SH);
+    const uint32_t h00 = hy0 ^ hz0, h10 = hy1 ^ hz0, h01 = hy0 ^ hz1, h11 = hy1 ^ hz1;
+    v[0] = tab_at(tab, (x0 ^ h00) & mask);
+    v[1] = tab_at(tab, (x1 ^ h00) & mask);
+    v[2] = tab_at(tab, (x0 ^ h10) & mask);
+    v[3] = tab_at(tab, (x1 ^ h10) & mask);
+    v[4] = tab_at(tab, (x0 ^ h01) & mask);
+    v[5] = tab_at(tab, (x1 ^ h01) & mask);
+    v[6] = tab_at(tab, (x0 ^ h11) & mask);
+    v[7] = tab_at(tab, (x1 ^ h11) & mask);
+  }
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float w = (c & 1) ? wx : 1.0f - wx;
+    w = w * ((c & 2) ? wy : 1.0f - wy);
+    w = w * ((c & 4) ? wz : 1.0f - wz);
+    acc.x = acc.x + w * v[c].x;
+    acc.y = acc.y + w * v[c].y;
+  }
+  return acc;
+}
+
+template <typename TT = float2, typename FT = float2>
+__global__ void __launch_bounds__(256)
+k_hashgrid_encode_tiled_ml(GridDev g, uint32_t l_lo, uint32_t l_hi,
+                           const TT* __restrict__ table,
+                           const float* __restrict__ rays_o,
+                           const float* __restrict__ rays_d,
+                           const float* __restrict__ zs, Aabb bb, uint32_t T,
+                           uint32_t N, uint32_t W, uint32_t s_blocks,
+                           FT* __restrict__ feat) {
+  __shared__ float z_s[64][TILE_S + 1];
+  __shared__ FT f_s[2][64][TILE_S + 1];
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
+  const uint32_t tiles_x = (W + 7u) / 8u;
+  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+  const uint32_t s0 = sb * TILE_S;
+  const uint32_t M = N * T;   // the host checks N * T < 2^31
+  auto ray_of = [&](uint32_t l) -> uint32_t {
+    const uint32_t px = tx * 8 + (l & 7u), py = ty * 8 + (l >> 3);
+    const uint32_t r = py * W + px;
+    return (px < W && r < N) ? r : 0xFFFFFFFFu;
+  };
+  // ray-major slots of the tile (depths in, features out): element e of the
+  // workgroup's 1024 = (pixel e / 16, sample index e % 16)
+  uint32_t slot[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t e = threadIdx.x + 256u * k;
+    const uint32_t r = ray_of(e / TILE_S), ss = e % TILE_S;
+    slot[k] = (r != 0xFFFFFFFFu && s0 + ss < T) ? r * T + s0 + ss : 0xFFFFFFFFu;
+    if (slot[k] != 0xFFFFFFFFu) z_s[e / TILE_S][ss] = zs[slot[k]];
+  }
+  __syncthreads();
+  const uint32_t ray = ray_of(lane);
+  float ux[4], uy[4], uz[4];
+  uint32_t live = 0u;   // which of the lane's 4 samples exist
+  if (ray != 0xFFFFFFFFu) {
+    const float* o = rays_o + ray * 3u;
+    const float* d = rays_d + ray * 3u;
+    const float ox = o[0], oy = o[1], oz = o[2];
+    const float dx = d[0], dy = d[1], dz = d[2];
+    const float two_b = 2.0f * g.bound, inv = unit_inv(two_b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ss = wid + 4u * k;
+      ux[k] = uy[k] = uz[k] = 0.f;
+      if (s0 + ss >= T) continue;
+      live |= 1u << k;
+      const float zz = z_s[lane][ss];
+      const float px = clampf(ox + dx * zz, bb.lo[0], bb.hi[0]);
+      const float py = clampf(oy + dy * zz, bb.lo[1], bb.hi[1]);
+      const float pz = clampf(oz + dz * zz, bb.lo[2], bb.hi[2]);
+      ux[k] = to_unit(px, g.bound, two_b, inv);
+      uy[k] = to_unit(py, g.bound, two_b, inv);
+      uz[k] = to_unit(pz, g.bound, two_b, inv);
+    }
+  }
+  uint32_t buf = 0u;
+  for (uint32_t level = l_hi; level-- > l_lo; buf ^= 1u) {   // finest first
+    const TT* tab = table + g.offset[level];
+    const float scale = g.scale[level];
+    const uint32_t res = g.res[level], entries = g.entries[level],
+                   hashed = g.hashed[level];
+    const uint32_t res2 = res * res;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!(live >> k & 1u)) continue;
+      to_feat(f_s[buf][lane][wid + 4u * k],
+              encode_cell(tab, ux[k], uy[k], uz[k], scale, res, res2, entries, hashed));
+    }
+    __syncthreads();
+    // (no second barrier: the next level fills the other buffer, and a thread
+    // reaches the level after that only past the next barrier, i.e. after
+    // every thread has finished these reads)
+    FT* feat_level = feat + (size_t)level * M;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t e = threadIdx.x + 256u * k;
+      if (slot[k] != 0xFFFFFFFFu)
+        feat_store(feat_level + slot[k], f_s[buf][e / TILE_S][e % TILE_S]);
+    }
+  }
+}
+
 // how many leading levels go to the fused coarse kernel: all dense levels plus
 // hashed ones whose cells are still wider than ~2 sample spacings
 static uint32_t coarse_levels(const ucsa_grid* grid) {
@@ -364,11 +559,33 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
       const char* v = getenv("UCSA_ENC_LDS_PAD");
       return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 0u;
     }();
-    hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
-                       dim3(tiles * s_blocks * lm.k, grid->n_levels / lm.k),
-                       dim3(256), lds_pad, (hipStream_t)stream, gd, lm,
-                       (const TT*)table, rays_o, rays_d, z, bb, T, N,
-                       image_width, s_blocks, (FT*)feat);
+    // levels [0, n_ml) through the several-levels-per-workgroup kernel (see
+    // k_hashgrid_encode_tiled_ml); UCSA_ENC_ML overrides (experiments only:
+    // the features do not depend on it), 0 = every level through the
+    // per-level kernel as in rounds 3-4.  Only for the default level order.
+    const char* ml_v = getenv("UCSA_ENC_ML");
+    const int ml_env = ml_v && *ml_v ? (int)strtol(ml_v, nullptr, 10) : -1;
+    // measured on the bench's chunk (tools/encode_ml_sweep.py, ms by n_ml):
+    //   fp32 table  coarse pass 0: 0.702  4: 0.620  8: 0.607  9: 0.603  10: 0.600  12: 0.603  16: 0.824
+    //               fine pass   0: 1.283  4: 1.259  8: 1.248  9: 1.247  10: 1.254  12: 1.298  16: 1.686
+    //   fp16 table  coarse pass 0: 0.588  6: 0.512  10: 0.479 | fine pass 0: 1.035  4: 1.018  6: 1.044  10: 1.123
+    //   (its per-level kernel has the group-of-four gather on the hashed levels)
+    uint32_t n_ml = ml_env >= 0 ? (uint32_t)ml_env : (sizeof(TT) == 8 ? 9u : 6u);
+    if (n_ml > grid->n_levels) n_ml = grid->n_levels;
+    if (lm.k != 1 || getenv("UCSA_ENC_ORDER")) n_ml = 0;
+    const uint32_t n_fine = grid->n_levels - n_ml;
+    if (n_fine > 0)   // lm.lv = finest level first: its first n_fine rows
+      hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),
+                         dim3(tiles * s_blocks * lm.k, n_fine / lm.k),
+                         dim3(256), lds_pad, (hipStream_t)stream, gd, lm,
+                         (const TT*)table, rays_o, rays_d, z, bb, T, N,
+                         image_width, s_blocks, (FT*)feat);
+    if (n_ml > 0)
+      hipLaunchKernelGGL((k_hashgrid_encode_tiled_ml<TT, FT>),
+                         dim3(tiles * s_blocks), dim3(256), 0,
+                         (hipStream_t)stream, gd, 0u, n_ml, (const TT*)table,
+                         rays_o, rays_d, z, bb, T, N, image_width, s_blocks,
+                         (FT*)feat);
   }
   return ucsa_launch_status();
 }

@@ -98,8 +98,9 @@ __global__ void k_nerf_loss_final(const float* __restrict__ partial,
 // of the single terms (g_color / g_sem / g_depth; a term's own gradient is the
 // stored one / its weight).  Device scalars, NULL = 0: no host read-back.
 __global__ void __launch_bounds__(256)
-k_nerf_loss_apply(float* __restrict__ d_rgb, float* __restrict__ d_sem,
-                  float* __restrict__ d_depth, uint32_t N, uint32_t C,
+k_nerf_loss_apply(const float* d_rgb, const float* d_sem, const float* d_depth,
+                  float* o_rgb, float* o_sem, float* o_depth,  // may alias the inputs
+                  uint32_t N, uint32_t C,
                   const float* __restrict__ g_total,
                   const float* __restrict__ g_color,
                   const float* __restrict__ g_sem,
@@ -113,29 +114,33 @@ k_nerf_loss_apply(float* __restrict__ d_rgb, float* __restrict__ d_sem,
   const uint64_t total = n_rgb + n_sem + N;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (uint64_t)gridDim.x * blockDim.x) {
-    if (i < n_rgb) d_rgb[i] *= kc;
-    else if (i < n_rgb + n_sem) d_sem[i - n_rgb] *= ks;
-    else d_depth[i - n_rgb - n_sem] *= kd;
+    if (i < n_rgb) o_rgb[i] = d_rgb[i] * kc;
+    else if (i < n_rgb + n_sem) o_sem[i - n_rgb] = d_sem[i - n_rgb] * ks;
+    else o_depth[i - n_rgb - n_sem] = d_depth[i - n_rgb - n_sem] * kd;
   }
 }
 
-extern "C" int32_t ucsa_nerf_loss_apply(float* d_rgb, float* d_sem,
-                                        float* d_depth, uint32_t N, uint32_t C,
+extern "C" int32_t ucsa_nerf_loss_apply(const float* d_rgb, const float* d_sem,
+                                        const float* d_depth, float* out_rgb,
+                                        float* out_sem, float* out_depth,
+                                        uint32_t N, uint32_t C,
                                         const float* g_total,
                                         const float* g_color,
                                         const float* g_sem, const float* g_depth,
                                         float w_sem, float w_depth,
                                         void* stream) {
   UCSA_CHECK_ARG(d_rgb && d_sem && d_depth, 0);
-  UCSA_CHECK_ARG(N > 0 && C >= 1, 3);
-  UCSA_CHECK_ARG(g_total || g_color || g_sem || g_depth, 5);
-  UCSA_CHECK_ARG((!g_sem || w_sem != 0.f) && (!g_depth || w_depth != 0.f), 9);
+  UCSA_CHECK_ARG(out_rgb && out_sem && out_depth, 3);
+  UCSA_CHECK_ARG(N > 0 && C >= 1, 6);
+  UCSA_CHECK_ARG(g_total || g_color || g_sem || g_depth, 8);
+  UCSA_CHECK_ARG((!g_sem || w_sem != 0.f) && (!g_depth || w_depth != 0.f), 12);
   const uint64_t total = (uint64_t)N * (4 + C);
   uint32_t blocks = (uint32_t)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_nerf_loss_apply, dim3(blocks), dim3(256), 0,
-                     (hipStream_t)stream, d_rgb, d_sem, d_depth, N, C, g_total,
+                     (hipStream_t)stream, d_rgb, d_sem, d_depth, out_rgb, out_sem,
+                     out_depth, N, C, g_total,
                      g_color, g_sem, g_depth, g_sem ? 1.0f / w_sem : 0.f,
                      g_depth ? 1.0f / w_depth : 0.f);
   return ucsa_launch_status();

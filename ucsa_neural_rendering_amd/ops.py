@@ -882,11 +882,18 @@ def nerf_loss(rgb, sem, depth, gt_rgb, labels, gt_depth, uom: float,
 
 def nerf_loss_apply(grads, g_total, g_color, g_sem, g_depth, w_sem: float,
                     w_depth: float):
-    """In place on ``grads`` = (d_rgb [N,3], d_sem [N,C], d_depth [N]) of
-    ``nerf_loss``: times the loss node's cotangents (0-d / 1-element device
-    tensors or None), one launch (ucsa_nerf_loss_apply)."""
+    """``grads`` = (d_rgb [N,3], d_sem [N,C], d_depth [N]) of ``nerf_loss``
+    times the loss node's cotangents (0-d / 1-element device tensors or None),
+    one launch (ucsa_nerf_loss_apply) into FRESH tensors: ``grads`` are the
+    tensors the autograd node saved and a second backward through a retained
+    graph must find them unscaled (the in-place form scaled them
+    twice, unseen by autograd's version counter)."""
     d_rgb, d_sem, d_depth = grads
     N, Cn = d_sem.shape
+    out = torch.empty(N * (4 + Cn), dtype=torch.float32, device=d_rgb.device)
+    o_rgb = out[:N * 3].view(N, 3)
+    o_sem = out[N * 3:N * (3 + Cn)].view(N, Cn)
+    o_depth = out[N * (3 + Cn):]
 
     def sc(t):
         if t is None:
@@ -897,11 +904,12 @@ def nerf_loss_apply(grads, g_total, g_color, g_sem, g_depth, w_sem: float,
         return t.contiguous()
 
     gt, gc, gs, gd = sc(g_total), sc(g_color), sc(g_sem), sc(g_depth)
-    check(lib().ucsa_nerf_loss_apply(_ptr(d_rgb), _ptr(d_sem), _ptr(d_depth), N, Cn,
+    check(lib().ucsa_nerf_loss_apply(_ptr(d_rgb), _ptr(d_sem), _ptr(d_depth),
+                                     _ptr(o_rgb), _ptr(o_sem), _ptr(o_depth), N, Cn,
                                      _ptr(gt), _ptr(gc), _ptr(gs), _ptr(gd),
                                      float(w_sem), float(w_depth), _stream()),
           "ucsa_nerf_loss_apply")
-    return grads
+    return o_rgb, o_sem, o_depth
 
 
 def semantic_postproc(sem, want_normalised: bool = True):
