@@ -300,6 +300,45 @@ int32_t ucsa_hashgrid_encode_rays_hf(const ucsa_grid* grid, const float* table,
                                      uint32_t N, uint32_t T,
                                      uint32_t image_width, void* feat_half,
                                      void* stream);
+/* ---- depth-ordered encoding of the FINE samples of image-ordered rays ----
+ * Replaces, for rays that are the pixels of whole image rows, the
+ * `self.encoder(x)` + `self.sigma_net(x)` of the second `density()` call of
+ * run() (nr4seg/nerf/renderer_semantics.py:214-226 ->
+ * network_tcnn_semantics.py:130-144).  The fine samples of neighbouring rays sit
+ * at unrelated depths (importance sampling with independent uniforms), so a wave
+ * that holds one sample index of an 8x8 pixel tile shares no cells; dealt to the
+ * lanes in DEPTH order the same samples share their cache lines as in the coarse
+ * pass.  Three calls, bit-identical h / sigma to ucsa_hashgrid_encode_rays_image
+ * + ucsa_sigma_mlp_fwd*:
+ *   ucsa_tile_depth_order: counting sort of every tile's 64 x T samples by
+ *     depth -> z_sorted [N*T] (depths), pix [N*T] (pixel inside the 8x8 tile),
+ *     slot [N*T] (ray-major index r * T + s), tiles back to back.  N must be a
+ *     multiple of image_width (whole rows), T <= 1024.
+ *   ucsa_hashgrid_encode_sorted[_hf]: features [L][N*T] (float2 / half2) in that
+ *     order.
+ *   ucsa_sigma_mlp_fwd_scatter: the sigma MLP on such an array, h [N*T,16] and
+ *     sigma [N*T] written at the ray-major slots.  mode 0 = f32-input MFMA
+ *     (ucsa_mlp_pack), 1 = f16 nets on fp16 features (ucsa_mlp_pack_f16),
+ *     2 = bf16x3 (ucsa_mlp_pack_x3), 3 = f16x2 (ucsa_mlp_pack_h2). */
+int32_t ucsa_tile_depth_order(const float* z, uint32_t N, uint32_t T,
+                              uint32_t image_width, float* z_sorted,
+                              uint8_t* pix, uint32_t* slot, void* stream);
+int32_t ucsa_hashgrid_encode_sorted(const ucsa_grid* grid, const float* table,
+                                    const float* rays_o, const float* rays_d,
+                                    const float* z_sorted, const uint8_t* pix,
+                                    const float* aabb_host, uint32_t N,
+                                    uint32_t T, uint32_t image_width,
+                                    float* feat, void* stream);
+int32_t ucsa_hashgrid_encode_sorted_hf(const ucsa_grid* grid, const float* table,
+                                       const float* rays_o, const float* rays_d,
+                                       const float* z_sorted, const uint8_t* pix,
+                                       const float* aabb_host, uint32_t N,
+                                       uint32_t T, uint32_t image_width,
+                                       void* feat_half, void* stream);
+int32_t ucsa_sigma_mlp_fwd_scatter(int32_t mode, const void* feat,
+                                   const void* packed_sigma, uint32_t M,
+                                   uint32_t n_levels, const uint32_t* slot,
+                                   float* h, float* sigma, void* stream);
 /* ucsa_sigma_mlp_fwd_f16 on fp16 features (same h / sigma) */
 int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
                                  const void* packed_sigma_half, uint32_t M,

@@ -293,6 +293,11 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
     # every loose ray must match one alternative of ITS OWN candidates
     alt = alt_tolerances(e_img, e_sem, rel, loose)
     print(f"{tag} match tolerances (image, semantics, depth rel): {alt[0]:.2e} {alt[1]:.2e} {alt[2]:.2e}")
+    # the match tolerance follows the render's own ordinary error, so
+    # a regression of that error must not be able to loosen it without bound --
+    # it never exceeds HALF the stated tolerance (a constant), and the ordinary
+    # error itself is held by the median / loose-count assertions here
+    assert alt[0] <= 0.5 * TOL_ABS and alt[1] <= 0.5 * TOL_ABS and alt[2] <= 0.5 * TOL_DEPTH_REL, alt
     unexplained = []
     for i in torch.nonzero(loose).flatten().tolist():
         ro = RayOracle(fld, o[i], d[i], nrm[i], aabb, T, t,

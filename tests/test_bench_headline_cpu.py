@@ -33,7 +33,11 @@ def _canned():
                      "binding_resource": {"resource": "TCP " + note, "frac": 0.785,
                                           "fine_pass": big, "coarse_pass": big}},
         "roofline_composite": {"note": note, "by_kernel": big},
-        "train": {"roofline": {"traffic": {"fetch_by_kernel_bytes": big,
+        "train": {"ms_per_step": 3.4012345678, "rays_per_s": 1204280.123456,
+                  "workload": "NeRF train step, 4096 rays x (256+256) samples " + note,
+                  "ms_per_step_blocks": [3.4] * 20,
+                  "roofline": {"hbm": {"frac": 0.1712345678, "algorithmic_bytes": 4.66e9},
+                               "traffic": {"fetch_by_kernel_bytes": big,
                                            "write_by_kernel_bytes": big}}, "note": note},
         "seg": {m: {"note": note, "k": big} for m in ("fp32", "bf16", "g1", "g2")},
         "march_option": {"note": note, "fp32": big, "fp16": big},
@@ -66,7 +70,13 @@ def test_headline_fits_and_round_trips():
     assert abs(back["speedup_vs_cpu"] - 3003.33) < 1e-6
     assert back["tuning_tables_matched"]["miopen"] is True
     assert back["distributed"]["world_size"] == 8 and len(back["distributed"]["devices"]) == 8
-    for k in ("train", "seg", "march_option", "roofline_composite"):
+    # BASELINE.json's metric is train + render: the training step's figures are
+    # in the line, its per-kernel dictionaries are not
+    t = back["train"]
+    assert set(t) == {"ms_per_step", "rays_per_s", "workload", "hbm_frac_algorithmic"}
+    assert abs(t["ms_per_step"] - 3.40123) < 1e-4 and abs(t["rays_per_s"] - 1204280) < 1
+    assert len(t["workload"]) <= 160
+    for k in ("seg", "march_option", "roofline_composite"):
         assert k not in back                     # detail file only
 
 

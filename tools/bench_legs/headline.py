@@ -71,6 +71,16 @@ def headline(result: dict, text: int = 300) -> dict:
     for k in ("quality", "tuning_tables_matched"):
         if k in result:
             out[k] = result[k]
+    # BASELINE.json's metric is "rays/sec (train+render)": the NeRF training
+    # step measured in the same run (tools/bench_legs/train.py)
+    tr = result.get("train")
+    if isinstance(tr, dict) and "ms_per_step" in tr:
+        t = {"ms_per_step": tr["ms_per_step"], "rays_per_s": tr.get("rays_per_s"),
+             "workload": _short(tr.get("workload"), min(text, 160))}
+        hbm = (tr.get("roofline") or {}).get("hbm") or {}
+        if "frac" in hbm:
+            t["hbm_frac_algorithmic"] = hbm["frac"]
+        out["train"] = t
     d = result.get("distributed")
     if d:
         dd = {k: d.get(k) for k in ("world_size", "backend", "launcher", "forced_world_1")

@@ -142,7 +142,12 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
     aabb = net._aabb_list(False)
     N = o.shape[0]
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    names = ["near_far+coarse", "encode_c", "sigma_c", "resample", "encode_f",
+    # the fine pass as ucsa_render_fwd* runs it for image-ordered rays (round 5):
+    # depth order per tile, encoder and sigma MLP in that order, h / sigma
+    # scattered back (csrc/hashgrid_sorted.hip); UCSA_ENC_SORTED=0: as the coarse pass
+    sorted_f = bool(image_width) and os.environ.get("UCSA_ENC_SORTED", "1") != "0"
+    smode = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16x2": 3}[mode]
+    names = ["near_far+coarse", "encode_c", "sigma_c", "resample", "sort_f", "encode_f",
              "sigma_f", "composite"]
     acc = {k: 0.0 for k in names}
     rho = 0.0
@@ -159,11 +164,20 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
         marks[3].record()
         zf = ops.resample(zc, sc.view(N, T_COARSE), u)
         marks[4].record()
-        feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb,
-                                        image_width=image_width, half_features=half)
-        marks[5].record()
-        hf, sf = sigma_mlp(feat, f["packed_sigma"])
-        marks[6].record()
+        if sorted_f:
+            zs, pix, slot = ops.tile_depth_order(zf, image_width)
+            marks[5].record()
+            feat = ops.hashgrid_encode_sorted(f["grid"], f["table"], o, d, zs, pix, aabb,
+                                              T_FINE, image_width, half_features=half)
+            marks[6].record()
+            hf, sf = ops.sigma_mlp_fwd_scatter(smode, feat, f["packed_sigma"], slot)
+        else:
+            marks[5].record()
+            feat = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zf, aabb,
+                                            image_width=image_width, half_features=half)
+            marks[6].record()
+            hf, sf = sigma_mlp(feat, f["packed_sigma"])
+        marks[7].record()
         if it == 0:   # the weights, for the masked fraction rho
             f32 = net._field()
             w = ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
@@ -177,7 +191,7 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
             ops.composite_fwd(d, nrm, zc, sc.view(N, T_COARSE), hc, zf,
                               sf.view(N, T_FINE), hf, f["packed_color"],
                               f["packed_sem"], N_CLASSES, 1.0)
-        marks[7].record()
+        marks[8].record()
         torch.cuda.synchronize()
         if it == 0:
             rho = float((w > 1e-4).float().mean())

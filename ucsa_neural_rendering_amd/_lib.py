@@ -115,6 +115,15 @@ SIGNATURES = {
     "ucsa_hashgrid_encode_rays_hf": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
                                                  C.POINTER(_f), _u32, _u32, _u32,
                                                  _p, _p]),
+    "ucsa_tile_depth_order": (C.c_int32, [_p, _u32, _u32, _u32, _p, _p, _p, _p]),
+    "ucsa_hashgrid_encode_sorted": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
+                                                C.POINTER(_f), _u32, _u32, _u32,
+                                                _p, _p]),
+    "ucsa_hashgrid_encode_sorted_hf": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
+                                                   C.POINTER(_f), _u32, _u32, _u32,
+                                                   _p, _p]),
+    "ucsa_sigma_mlp_fwd_scatter": (C.c_int32, [C.c_int32, _p, _p, _u32, _u32, _p,
+                                               _p, _p, _p]),
     "ucsa_sigma_mlp_fwd_f16_h": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_render_fwd_f16_h16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                             _p, _p, C.POINTER(_f), _f, _p, _p,

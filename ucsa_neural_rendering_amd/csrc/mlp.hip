@@ -104,7 +104,8 @@ extern "C" int32_t ucsa_mlp_pack(int32_t kind, const float* params,
 
 __global__ void __launch_bounds__(256)
 k_sigma_mlp(const float2* __restrict__ feat, const float* __restrict__ packed,
-            uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+            uint64_t M, float* __restrict__ h, float* __restrict__ sigma,
+            const uint32_t* __restrict__ slot) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -142,8 +143,11 @@ k_sigma_mlp(const float2* __restrict__ feat, const float* __restrict__ packed,
       mfma_layer<16, 1>(hid, [&](int, int ks) { return w2[ks]; }, out);
       const uint64_t m = base + sb * 16 + j;
       if (m < M) {
-        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out[0];
-        if (g == 0) sigma[m] = expf(out[0][0]);
+        // slot: where sample m of a depth-ordered feature array lives in the
+        // ray-major outputs (hashgrid_sorted.hip); NULL = in place
+        const uint64_t mo = slot ? slot[m] : m;
+        *reinterpret_cast<f32x4*>(h + mo * 16 + 4 * g) = out[0];
+        if (g == 0) sigma[mo] = expf(out[0][0]);
       }
     }
   }
@@ -164,6 +168,19 @@ extern "C" int32_t ucsa_sigma_mlp_fwd(const float* feat,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma,
-                     (uint64_t)M, h, sigma);
+                     (uint64_t)M, h, sigma, (const uint32_t*)nullptr);
+  return ucsa_launch_status();
+}
+
+// (mlp_f16.hip: ucsa_sigma_mlp_fwd_scatter)
+int32_t ucsa_sigma_mlp_fwd_f32_slot(const float* feat, const float* packed_sigma,
+                                    uint32_t M, const uint32_t* slot, float* h,
+                                    float* sigma, void* stream) {
+  const uint32_t need = ucsa_div_up(M, 16 * SIG_UNROLL * 4);
+  const uint32_t blocks = need < 2048u ? need : 2048u;
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_sigma_mlp, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)feat, packed_sigma,
+                     (uint64_t)M, h, sigma, slot);
   return ucsa_launch_status();
 }

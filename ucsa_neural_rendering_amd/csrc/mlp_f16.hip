@@ -1,6 +1,7 @@
 // fp16-MFMA inference option: weight packing and the sigma MLP.
 // (call sites: reference nr4seg/nerf/network_tcnn_semantics.py:48-58,133-139;
 // tiny-cuda-nn itself computes these nets in fp16 with fp32 accumulation.)
+#include <cstdlib>
 #include "mfma_mlp_h2.h"
 
 __device__ __forceinline__ uint32_t chain_col_h(uint32_t s, uint32_t g,
@@ -289,7 +290,8 @@ __device__ __forceinline__ void feat_to_h(const sig_half2 v, _Float16& a, _Float
 template <typename FT>
 __global__ void __launch_bounds__(256)
 k_sigma_mlp_f16(const FT* __restrict__ feat, const void* __restrict__ packed,
-                uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+                uint64_t M, float* __restrict__ h, float* __restrict__ sigma,
+                const uint32_t* __restrict__ slot) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -324,8 +326,9 @@ k_sigma_mlp_f16(const FT* __restrict__ feat, const void* __restrict__ packed,
       out = mfma_h(w2[1], chain_relu_h(a1[2], a1[3]), out);
       const uint64_t m = base + sb * 16 + j;
       if (m < M) {
-        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out;
-        if (g == 0) sigma[m] = expf(out[0]);
+        const uint64_t mo = slot ? slot[m] : m;   // see k_sigma_mlp (mlp.hip)
+        *reinterpret_cast<f32x4*>(h + mo * 16 + 4 * g) = out;
+        if (g == 0) sigma[mo] = expf(out[0]);
       }
     }
   }
@@ -346,7 +349,7 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_f16(const float* feat,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp_f16<float2>, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_half,
-                     (uint64_t)M, h, sigma);
+                     (uint64_t)M, h, sigma, (const uint32_t*)nullptr);
   return ucsa_launch_status();
 }
 
@@ -365,7 +368,7 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp_f16<sig_half2>, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const sig_half2*)feat_half,
-                     packed_sigma_half, (uint64_t)M, h, sigma);
+                     packed_sigma_half, (uint64_t)M, h, sigma, (const uint32_t*)nullptr);
   return ucsa_launch_status();
 }
 
@@ -376,7 +379,8 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
 
 __global__ void __launch_bounds__(256)
 k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
-               uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+               uint64_t M, float* __restrict__ h, float* __restrict__ sigma,
+               const uint32_t* __restrict__ slot) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -410,8 +414,9 @@ k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
       out = mfma_x3(w2[1], chain_relu_x3(a1[2], a1[3], sel), out);
       const uint64_t m = base + sb * 16 + j;
       if (m < M) {
-        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out;
-        if (g == 0) sigma[m] = expf(out[0]);
+        const uint64_t mo = slot ? slot[m] : m;   // see k_sigma_mlp (mlp.hip)
+        *reinterpret_cast<f32x4*>(h + mo * 16 + 4 * g) = out;
+        if (g == 0) sigma[mo] = expf(out[0]);
       }
     }
   }
@@ -421,7 +426,8 @@ k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
 // 18 MFMAs per 16 samples instead of 36
 __global__ void __launch_bounds__(256)
 k_sigma_mlp_h2(const float2* __restrict__ feat, const void* __restrict__ packed,
-               uint64_t M, float* __restrict__ h, float* __restrict__ sigma) {
+               uint64_t M, float* __restrict__ h, float* __restrict__ sigma,
+               const uint32_t* __restrict__ slot, int exp_mode = 0) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -454,8 +460,10 @@ k_sigma_mlp_h2(const float2* __restrict__ feat, const void* __restrict__ packed,
                                 h2_chain_relu(a1[2], a1[3], sel));
       const uint64_t m = base + sb * 16 + j;
       if (m < M) {
-        *reinterpret_cast<f32x4*>(h + m * 16 + 4 * g) = out;
-        if (g == 0) sigma[m] = expf(out[0]);
+        const uint64_t mo = slot ? slot[m] : m;   // see k_sigma_mlp (mlp.hip)
+        const uint64_t mh = exp_mode == 1 ? m : mo;
+        *reinterpret_cast<f32x4*>(h + mh * 16 + 4 * g) = out;
+        if (g == 0) sigma[exp_mode == 2 ? m : mo] = expf(out[0]);
       }
     }
   }
@@ -475,7 +483,7 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_h2(const float* feat,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp_h2, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_h2,
-                     (uint64_t)M, h, sigma);
+                     (uint64_t)M, h, sigma, (const uint32_t*)nullptr, 0);
   return ucsa_launch_status();
 }
 
@@ -493,10 +501,51 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_x3(const float* feat,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp_x3, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_x3,
-                     (uint64_t)M, h, sigma);
+                     (uint64_t)M, h, sigma, (const uint32_t*)nullptr);
   return ucsa_launch_status();
 }
 
+
+// The sigma MLP of any arithmetic reading a DEPTH-ORDERED feature array
+// (ucsa_tile_depth_order / ucsa_hashgrid_encode_sorted) and writing h / sigma
+// to the ray-major slots: sample m of the feature array -> row slot[m].
+int32_t ucsa_sigma_mlp_fwd_f32_slot(const float* feat, const float* packed_sigma,
+                                    uint32_t M, const uint32_t* slot, float* h,
+                                    float* sigma, void* stream);   // mlp.hip
+extern "C" int32_t ucsa_sigma_mlp_fwd_scatter(int32_t mode, const void* feat,
+                                              const void* packed_sigma,
+                                              uint32_t M, uint32_t n_levels,
+                                              const uint32_t* slot, float* h,
+                                              float* sigma, void* stream) {
+  UCSA_CHECK_ARG(mode >= 0 && mode <= 3, 0);
+  UCSA_CHECK_ARG(feat, 1);
+  UCSA_CHECK_ARG(packed_sigma, 2);
+  UCSA_CHECK_ARG(n_levels == 16, 4);
+  UCSA_CHECK_ARG(slot, 5);
+  UCSA_CHECK_ARG(h && sigma, 6);
+  if (M == 0) return 0;
+  if (mode == 0)
+    return ucsa_sigma_mlp_fwd_f32_slot((const float*)feat, (const float*)packed_sigma,
+                                       M, slot, h, sigma, stream);
+  UCSA_CLEAR_ERR();
+  if (mode == 1) {   // f16 nets on fp16 features
+    const uint32_t need = ucsa_div_up(M, 16 * SIGH_UNROLL * 4);
+    hipLaunchKernelGGL(k_sigma_mlp_f16<sig_half2>, dim3(need < 2048u ? need : 2048u),
+                       dim3(256), 0, (hipStream_t)stream, (const sig_half2*)feat,
+                       packed_sigma, (uint64_t)M, h, sigma, slot);
+  } else {
+    const uint32_t need = ucsa_div_up(M, 16 * SIGX_UNROLL * 4);
+    const dim3 g(need < 4096u ? need : 4096u);
+    if (mode == 2)
+      hipLaunchKernelGGL(k_sigma_mlp_x3, g, dim3(256), 0, (hipStream_t)stream,
+                         (const float2*)feat, packed_sigma, (uint64_t)M, h, sigma, slot);
+    else
+      hipLaunchKernelGGL(k_sigma_mlp_h2, g, dim3(256), 0, (hipStream_t)stream,
+                         (const float2*)feat, packed_sigma, (uint64_t)M, h, sigma, slot,
+                         getenv("UCSA_SCATTER_EXP") ? atoi(getenv("UCSA_SCATTER_EXP")) : 0);
+  }
+  return ucsa_launch_status();
+}
 
 // ---------------------------------------------------------------------------
 // sigma MLP backward with every contraction on the bf16 MFMA pipe as two-term

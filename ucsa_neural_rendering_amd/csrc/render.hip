@@ -15,6 +15,10 @@
 namespace {
 struct Ws {
   float *nears, *fars, *z_c, *z_f, *feat, *h_c, *sigma_c, *h_f, *sigma_f;
+  // depth order of the fine samples (hashgrid_sorted.hip)
+  float* zs_sorted;
+  uint32_t* slot;
+  uint8_t* pix;
   void* cmp;  // ucsa_composite_infer's survivor lists
   uint64_t bytes;
 };
@@ -41,6 +45,10 @@ Ws carve(void* base, uint32_t N, uint32_t T, uint32_t t, uint32_t L) {
   w.sigma_c = take(Mc);
   w.h_f = take(Mf ? Mf * 16 : 1);
   w.sigma_f = take(Mf ? Mf : 1);
+  const uint64_t Ms = Mmax;   // (UCSA_ENC_SORTED=2 orders the coarse pass too)
+  w.zs_sorted = take(Ms);
+  w.slot = (uint32_t*)take(Ms);
+  w.pix = (uint8_t*)take((Ms + 3) / 4);
   w.cmp = take(ucsa_composite_infer_workspace_bytes(N, T, t) / 4 + 64);
   w.bytes = off;
   return w;
@@ -128,9 +136,31 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
+  // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays:
+  // UCSA_ENC_SORTED = 0 off, 1 the fine pass (default), 2 both passes.  Same
+  // h / sigma bits either way.
+  const char* es = getenv("UCSA_ENC_SORTED");
+  const int sorted_mode = es && es[0] >= '0' && es[0] <= '2' ? es[0] - '0' : 1;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
   auto density = [&](const float* z, uint32_t n, bool fused, float* h,
                      float* sigma) -> int32_t {
+    const bool fine = z == w.z_f;
+    if (image_width && !table_half && !fused && n <= 1024u &&
+        N % image_width == 0 && grid->n_levels == 16 &&
+        (sorted_mode == 2 || (sorted_mode == 1 && fine))) {
+      UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
+                                     w.slot, stream));
+      if (prec == 1)
+        UCSA_TRY(ucsa_hashgrid_encode_sorted_hf(grid, table, rays_o, rays_d,
+                                                w.zs_sorted, w.pix, aabb_host, N, n,
+                                                image_width, w.feat, stream));
+      else
+        UCSA_TRY(ucsa_hashgrid_encode_sorted(grid, table, rays_o, rays_d,
+                                             w.zs_sorted, w.pix, aabb_host, N, n,
+                                             image_width, w.feat, stream));
+      return ucsa_sigma_mlp_fwd_scatter(prec, w.feat, packed_sigma, N * n,
+                                        grid->n_levels, w.slot, h, sigma, stream);
+    }
     if (fused && prec == 0)
       return ucsa_encode_sigma_rays_image(grid, table, (const float*)packed_sigma,
                                           rays_o, rays_d, z, aabb_host, N, n,

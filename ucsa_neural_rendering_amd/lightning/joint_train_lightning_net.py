@@ -95,6 +95,12 @@ class JointTrainLightningNet(nn.Module):
             if key in nerf_cfg:
                 setattr(self.nerf_model, key, bool(nerf_cfg[key]))
         self.nerf_model.f16_bwd_scale = float(nerf_cfg.get("f16_bwd_scale", 1.0))
+        # `nerf: {h2_guard: off | weights | full}`: range guard of the f16x2 nets
+        # (default weights: max|W| checked at every refreshed pack; full also the
+        # activations of a sample of every no-grad render) -- out-of-range values
+        # raise instead of turning into zeros (network_tcnn_semantics.py)
+        if "h2_guard" in nerf_cfg:
+            self.nerf_model.h2_guard = str(nerf_cfg["h2_guard"])
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
         # (MIOpen's fast path on MI355X: 49 -> 34 ms per 8-image train step)

@@ -541,6 +541,8 @@ class SemanticNeRFRenderer(nn.Module):
             f, render = self._field_x3(), ops.render_fwd_x3
         elif self.precision == "f16x2":
             f, render = self._field_h2(), ops.render_fwd_h2
+            if self._h2_guard_mode() == "full":
+                self._h2_check_activations(o, d, aabb, T, min_near)
         else:
             f, render = self._field(), ops.render_fwd
         N = o.shape[0]

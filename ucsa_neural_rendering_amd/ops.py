@@ -165,6 +165,56 @@ def hashgrid_encode_rays(grid: Grid, table, rays_o, rays_d, z, aabb,
     return feat
 
 
+def tile_depth_order(z, image_width: int):
+    """z [N,T] of image-ordered rays (whole rows, N % image_width == 0) ->
+    (z_sorted [N*T] f32, pix [N*T] u8, slot [N*T] int32): every 8x8 pixel
+    tile's samples in depth order, tiles back to back; ``slot`` = the ray-major
+    index r * T + s of each (ucsa_tile_depth_order)."""
+    z = _f32(z, "z")
+    N, T = z.shape
+    z_sorted = torch.empty(N * T, device=z.device)
+    pix = torch.empty(N * T, dtype=torch.uint8, device=z.device)
+    slot = torch.empty(N * T, dtype=torch.int32, device=z.device)
+    check(lib().ucsa_tile_depth_order(_ptr(z), N, T, int(image_width), _ptr(z_sorted),
+                                      _ptr(pix), _ptr(slot), _stream()),
+          "ucsa_tile_depth_order")
+    return z_sorted, pix, slot
+
+
+def hashgrid_encode_sorted(grid: Grid, table, rays_o, rays_d, z_sorted, pix, aabb,
+                           T: int, image_width: int, half_features: bool = False):
+    """-> feat [L, N*T, 2] in the order of ``tile_depth_order`` (fp32 table)."""
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    N = rays_o.shape[0]
+    z_sorted = _f32(z_sorted, "z_sorted")
+    if z_sorted.numel() != N * T or pix.numel() != N * T or pix.dtype != torch.uint8:
+        raise UcsaError("hashgrid_encode_sorted: z_sorted / pix must hold N*T entries (pix uint8)")
+    feat = torch.empty(grid.n_levels, N * T, 2, device=z_sorted.device,
+                       dtype=torch.float16 if half_features else torch.float32)
+    fn = (lib().ucsa_hashgrid_encode_sorted_hf if half_features
+          else lib().ucsa_hashgrid_encode_sorted)
+    check(fn(C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z_sorted),
+             _ptr(pix), fvec(aabb), N, int(T), int(image_width), _ptr(feat), _stream()),
+          "ucsa_hashgrid_encode_sorted")
+    return feat
+
+
+def sigma_mlp_fwd_scatter(mode: int, feat, packed_sigma, slot):
+    """The sigma MLP (mode 0 f32-input MFMA, 1 f16 nets on fp16 features,
+    2 bf16x3, 3 f16x2) on a depth-ordered feature array; h [M,16] / sigma [M]
+    land at the ray-major rows ``slot``."""
+    L, M, _ = feat.shape
+    if slot.numel() != M or slot.dtype != torch.int32:
+        raise UcsaError("sigma_mlp_fwd_scatter: slot must be int32 [M]")
+    h = torch.empty(M, 16, device=feat.device)
+    sigma = torch.empty(M, device=feat.device)
+    check(lib().ucsa_sigma_mlp_fwd_scatter(int(mode), _ptr(feat), _ptr(packed_sigma), M, L,
+                                           _ptr(slot), _ptr(h), _ptr(sigma), _stream()),
+          "ucsa_sigma_mlp_fwd_scatter")
+    return h, sigma
+
+
 def encode_sigma_rays_image(grid: Grid, table, packed_sigma, rays_o, rays_d, z,
                             aabb, image_width: int, half: bool = False):
     """hashgrid_encode_rays(image_width=...) + sigma_mlp_fwd in one kernel
