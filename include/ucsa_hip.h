@@ -645,6 +645,23 @@ int32_t ucsa_hashgrid_bwd_rays_merged(
     uint32_t N, uint32_t Tc, uint32_t Tf, const float* d_feat_c,
     const float* d_feat_f, float* grad_table, void* workspace, void* stream);
 
+/* Deterministic form of ucsa_hashgrid_bwd_rays (debug / reproducibility mode,
+ * `UCSA_DETERMINISTIC=1`; SURVEY 5 "race detection": the reference relies on
+ * torch.use_deterministic_algorithms for this, scripts/train_joint.py seeds
+ * only): every contribution w * d_feat as 64-bit fixed point (2^-44 units) added
+ * with integer atomics -- the sum does not depend on the order of the additions,
+ * so two runs of a step give the same bits.  `fix`: int64
+ * [ucsa_hashgrid_bwd_det_workspace_bytes / 8], zeroed by the caller, accumulates
+ * over any number of _det calls (both density passes); _finish adds it into
+ * grad_table (NaN everywhere if a contribution was non-finite or >= 2^18). */
+uint64_t ucsa_hashgrid_bwd_det_workspace_bytes(const ucsa_grid* grid);
+int32_t ucsa_hashgrid_bwd_rays_det(const ucsa_grid* grid, const float* rays_o,
+                                   const float* rays_d, const float* z,
+                                   const float* aabb_host, uint32_t N, uint32_t T,
+                                   const float* d_feat, void* fix, void* stream);
+int32_t ucsa_hashgrid_bwd_det_finish(const ucsa_grid* grid, const void* fix,
+                                     float* grad_table, void* stream);
+
 /* ucsa_hashgrid_bwd_rays / ucsa_hashgrid_bwd_rays_merged with 8-byte PACKED bin
  * records: one 64-bit word = entry index inside its bin (L bits) | vx | vy,
  * each value the fp32 rounded to nearest-even to its top min(32, (64 - L) / 2)

@@ -700,3 +700,52 @@ def test_fused_train_calls_equal_the_staged_path(N, T, t, C):
     ga, gb = got[True][2], got[False][2]
     assert float(gb.abs().max()) > 0
     assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
+
+
+@pytest.mark.parametrize("N,T,t,C,prec", [(300, 32, 32, 40, "bf16x3"), (129, 64, 0, 21, "fp32"),
+                                          (64, 256, 256, 40, "bf16x3")])
+def test_deterministic_mode_repeats_bit_for_bit(N, T, t, C, prec):
+    """`UCSA_DETERMINISTIC=1` / net.deterministic (SURVEY 5 "race detection"
+    build note, VERDICT r4 "missing" item 4): the hash-grid gradient through the
+    order-independent fixed-point reduction (ucsa_hashgrid_bwd_rays_det).  Two
+    runs of one step give the SAME BITS in every gradient (the default path's
+    grid gradient differs in the last bits from run to run: float atomics, bin
+    records in reservation order), and they agree with the default path's to the
+    fixed point's 2^-44 per contribution + fp32 round-off."""
+    fld = lively_oracle_field(C=C)
+    o, d, norms = make_rays(N, 700 + N)
+    g = torch.Generator().manual_seed(N)
+    t_rand = torch.rand(N, T, generator=g).cuda()
+    u = torch.rand(N, t, generator=g).cuda() if t else None
+    ci, cd, cs = (torch.rand(1, N, 3, generator=g).cuda(), torch.rand(1, N, generator=g).cuda(),
+                  torch.rand(1, N, C, generator=g).cuda())
+
+    def grads(det):
+        net = hip_network_from_oracle(fld).train()
+        net.train_precision = prec
+        net.deterministic = det
+        res = net.render(o[None].cuda(), d[None].cuda(), norms[None].cuda(), perturb=True,
+                         num_steps=T, upsample_steps=t, rng_t=t_rand, rng_u=u)
+        ((res["image"] * ci).sum() + (res["depth"] * cd).sum() + (res["semantics"] * cs).sum()).backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in (net.encoder.params, net.sigma_net.params,
+                                                  net.color_net.params, net.semantics_net.params)]
+
+    a, b, ref = grads(True), grads(True), grads(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float(ref[0].abs().max()) > 0
+    assert float((a[0] - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
+    for x, y in zip(a[1:], ref[1:]):       # the nets' gradients do not go through it
+        assert torch.equal(x, y)
+    # a non-finite contribution poisons the whole table gradient (found_inf semantics)
+    from ucsa_neural_rendering_amd import ops
+    net = hip_network_from_oracle(fld)
+    grid = net.encoder.grid
+    z = torch.rand(8, 4).cuda() + 0.5
+    df = torch.zeros(grid.n_levels, 32, 2).cuda()
+    df[3, 5, 1] = float("inf")
+    fix = ops.hashgrid_bwd_rays_det(grid, o[:8].cuda(), d[:8].cuda(), z, net._aabb_list(True), df)
+    gt = torch.zeros_like(net.encoder.params)
+    ops.hashgrid_bwd_det_finish(grid, fix, gt)
+    assert torch.isnan(gt).all()

@@ -22,14 +22,14 @@ def _port():
     return p
 
 
-def _run2(extra, tmp_path, timeout=600):
+def _run2(extra, tmp_path, timeout=600, ranks=2):
     """Output goes to FILES, not pipes: a helper process the ranks leave behind
     for a while keeps an inherited pipe open, and `communicate()` would then
     block until it is gone although torchrun itself exited after seconds."""
-    env = dict(os.environ, UCSA_BENCH_BACKEND="gloo", UCSA_BENCH_WATCHDOG="500")
+    env = dict(os.environ, UCSA_BENCH_BACKEND="gloo", UCSA_BENCH_WATCHDOG=str(timeout - 20))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+           "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port",
+           str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks)] + extra
     out, err = tmp_path / "out.txt", tmp_path / "err.txt"
     with open(out, "w") as fo, open(err, "w") as fe:
         proc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
@@ -88,6 +88,61 @@ def test_cfg4_mode_two_ranks_with_gather(tmp_path):
                  "--pretrain-steps", "30"], tmp_path)
     assert res["config"]["mode"] == "cfg4" and res["_full"]["config"]["views_per_rank"] == 2
     assert res["scaling"] == "strong" and res["value"] > 0
+
+
+# ---- width 8: the driver's SCALE run is `bench.py --gpus 8`
+# under torchrun; no 8-GPU node has ever been available, so the same command
+# lines run here with eight ranks on ONE GPU over gloo -- a code-path check at
+# that width (round-robin shards, max-over-ranks timing, aggregate `value`, the
+# 8-way ShardedHipAdam slices), not a measurement.
+def test_default_render_line_at_eight_ranks(tmp_path):
+    res = _run2(["--steps", "2", "--warmup", "1", "--pretrain-steps", "20"], tmp_path,
+                timeout=1500, ranks=8)
+    assert res["n_gpus"] == 8 and res["scaling"] == "weak" and res["distributed"]["world_size"] == 8
+    assert len(res["distributed"]["devices"]) == 8
+    # whole-job aggregate: 8 ranks x 2 views x 640 x 480 rays in 2 x ms_per_step
+    assert res["value"] == pytest.approx(8 * 640 * 480 / (res["ms_per_step"] * 1e-3), rel=1e-4)
+    dp = res["_full"]["train_dp"]
+    assert dp["collective_ranks"] == 8 and dp["replicas_identical"] is True
+    assert dp["rays_per_step_total"] == 8 * 4096
+    _check_shards(dp["adam_shards"], 8)
+
+
+def _check_shards(sh, world):
+    """The ranks' Adam slices of the hash grid tile it: 13 074 912 fp32 values
+    (6 537 456 entries x 2 features) = 8 x 1 634 364, no tail at width 8."""
+    assert sh["grid_numel"] == 13074912 and sh["params_total"] > sh["grid_numel"]
+    assert len(sh["by_rank"]) == world
+    spans = sorted((r[0][1], r[0][2]) for r in sh["by_rank"])
+    assert all(len(r) == 1 and r[0][0] == sh["grid_numel"] for r in sh["by_rank"])
+    assert spans[0][0] == 0
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0 and a1 > a0          # back to back, none empty
+    body = sh["by_rank"][0][0][3]
+    assert spans[-1][1] == body and 0 <= sh["grid_numel"] - body < 4 * world
+    assert all(s % 4 == 0 for a in spans for s in a)    # 16-byte aligned slices
+
+
+def test_train_mode_eight_ranks(tmp_path):
+    res = _run2(["--mode", "train", "--steps", "2", "--warmup", "1", "--pretrain-steps", "20"],
+                tmp_path, timeout=1500, ranks=8)
+    dp = res["_full"]["train_dp"]
+    assert res["n_gpus"] == 8 and dp["collective_ranks"] == 8 and dp["replicas_identical"] is True
+    assert res["value"] == pytest.approx(8 * 4096 / (res["ms_per_step"] * 1e-3), rel=1e-4)
+    assert dp["optimizer"].startswith("ShardedHipAdam")
+    _check_shards(dp["adam_shards"], 8)
+
+
+def test_cfg4_mode_eight_ranks_every_view_once(tmp_path):
+    res = _run2(["--mode", "cfg4", "--views", "16", "--warmup", "1", "--gather",
+                 "--pretrain-steps", "20"], tmp_path, timeout=1500, ranks=8)
+    cfg = res["_full"]["config"]
+    assert res["n_gpus"] == 8 and cfg["views_per_rank"] == 2 and res["scaling"] == "strong"
+    by_rank = cfg["views_by_rank"]
+    assert len(by_rank) == 8 and all(len(v) == 2 for v in by_rank)
+    assert sorted(v for vs in by_rank for v in vs) == list(range(16))     # each view exactly once
+    assert all(vs == [r, r + 8] for r, vs in enumerate(by_rank))           # round-robin
+    assert res["value"] == pytest.approx(16 * 640 * 480 / cfg["total_s"], rel=1e-4)
 
 
 def test_plain_bench_gpus_2_launches_its_own_ranks(tmp_path):

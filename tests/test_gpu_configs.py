@@ -81,6 +81,46 @@ def test_cfg1_4096_rays_16_plus_16():
     _check(res, ref, fld, (o, d, nrm), 16, 16, tag="cfg1")
 
 
+def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
+    """the test below compares 4 096 of a view's 307 200
+    rays.  Here EVERY ray of one 640x480 view rendered exactly as bench.py times
+    it (f16x2 nets, one pipelined ucsa_render_view call, depth-ordered fine pass)
+    goes against the oracle, in blocks of 32 768 rays (~6 s of CPU each), with the
+    same stated tolerance and the same causal explanation of every ray above it."""
+    import bench
+    from ucsa_neural_rendering_amd import ops
+    from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
+    dev = torch.device("cuda:0")
+    H, W, T, t = bench.H, bench.W, bench.T_COARSE, bench.T_FINE
+    net, _ = bench.build_field(dev, train_steps=200)
+    fld = _oracle_from_net(net)
+    net.hip_ray_chunk = 65536
+    net.precision = "f16x2"
+    intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
+    pose = _slerp_loop_poses(23, seed=999)[11:12].to(dev)
+    o, d, nrm = ops.get_rays(pose, intr, H, W)
+    g = torch.Generator(device=dev).manual_seed(1001)
+    u = torch.rand(H * W, t, device=dev, generator=g)
+    with torch.no_grad():
+        res = net.render(o, d, nrm, staged=True, perturb=False, num_steps=T,
+                         upsample_steps=t, rng_u=u, image_width=W)
+    torch.cuda.synchronize()
+    oc, dc, nc, uc = o.cpu(), d.cpu(), nrm.cpu(), u.cpu()
+    loose = n = 0
+    for head in range(0, H * W, 32768):
+        sel = torch.arange(head, min(head + 32768, H * W))
+        rays_sel = (oc[:, sel], dc[:, sel], nc[:, sel])
+        with torch.no_grad():
+            ref = oren.run(fld, *rays_sel, AABB4, num_steps=T, upsample_steps=t, u=uc[sel],
+                           return_aux=True)
+        r = _check(res, ref, fld, rays_sel, T, t, sel, tag=f"cfg2-whole[{head}]")
+        loose += r["loose"]
+        n += sel.numel()
+    print(f"cfg2 whole view: {loose} of {n} rays above the stated tolerance, each reproduced "
+          "by a named alternative decision")
+    assert n == H * W
+
+
 @pytest.mark.parametrize("which", ["bench_field", "lively_field"])
 def test_cfg2_bench_path_640x480_staged_image_ordered(which):
     import bench

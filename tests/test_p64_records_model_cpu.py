@@ -13,7 +13,10 @@ def rnd(f, V):
     b = np.asarray(f, np.float32).view(np.uint32).astype(np.uint64)
     drop = 32 - V
     if drop:
-        b = (b + ((1 << (drop - 1)) - 1) + ((b >> drop) & 1)) >> drop      # nearest even
+        r = b + ((1 << (drop - 1)) - 1) + ((b >> drop) & 1)               # nearest even
+        # non-finite values are truncated instead: the add would carry an all-ones
+        # NaN payload into the sign bit or wrap it around in 32 bits
+        b = np.where((b & 0x7F800000) == 0x7F800000, b, r) >> drop
     return b
 
 
@@ -54,9 +57,12 @@ def test_reference_grid_records_round_to_26_bits():
 def test_non_finite_values_stay_non_finite_and_zero_stays_zero():
     L = 11
     v = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 3.4e38], np.float32)
-    # a NaN with only low mantissa bits set rounds to an infinity: still non-finite
+    # a NaN with only low mantissa bits set truncates to an infinity: still non-finite
     low_nan = np.array([0x7F800001], np.uint32).view(np.float32)
-    v = np.concatenate([v, low_nan])
+    # ... and NaNs with an all-ones payload (either sign) stay NaNs: a 32-bit
+    # rounding add would wrap 0xFFFFFFFF around to +0.0
+    ones_nan = np.array([0xFFFFFFFF, 0x7FFFFFFF, 0xFFFFFFE0], np.uint32).view(np.float32)
+    v = np.concatenate([v, low_nan, ones_nan])
     _, x2, _ = unpack(pack(np.zeros(len(v), np.uint64), v, v, L), L)
     assert np.array_equal(np.isfinite(x2), np.isfinite(v))
     assert x2[3] == 0.0 and x2[4] == 0.0

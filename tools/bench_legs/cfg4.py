@@ -86,6 +86,10 @@ def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
     elapsed, mine, _ = cfg4_job(net, args.views, rank, world, dev, dist, backend,
                                 warmup=args.warmup, gather=args.gather,
                                 precision=args.nerf_precision)
+    views_by_rank = [list(map(int, mine))]
+    if dist:
+        views_by_rank = [None] * world
+        dist.all_gather_object(views_by_rank, list(map(int, mine)))
     result = {
         "metric": "rays/sec", "value": args.views * H * W / elapsed,
         "unit": "rays/s", "n_gpus": world, "steps": args.views,
@@ -97,6 +101,7 @@ def main_cfg4(args, net, scene_ds, dev, dist, world, rank, backend, prelog):
                                "get_rays + render per group of 4 views (one call, as "
                                "forward_nerf_test renders its batch of frames)",
                    "mode": "cfg4", "views_per_rank": len(mine),
+                   "views_by_rank": views_by_rank,
                    "gather_to_rank0": bool(args.gather), "pretrain": prelog,
                    "mlp_arithmetic": MLP_ARITHMETIC[args.nerf_precision],
                    "total_s": elapsed},

@@ -201,6 +201,14 @@ def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
         res["reduce_scatter_allgather_ms"] = timed(lambda: (
             dist.reduce_scatter_tensor(shard, buf[:per * world]),
             dist.all_gather_into_tensor(buf[:per * world], shard)))
+        # which slice of the hash grid each rank's Adam owns (ShardedHipAdam):
+        # together they must tile the parameter (tests/test_gpu_bench_modes.py)
+        mine = [list(x) for x in getattr(opt, "last_shards", [])]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        res["adam_shards"] = {"by_rank": everyone,
+                              "params_total": int(sum(p.numel() for p in params)),
+                              "grid_numel": int(n_grid)}
         res["collective_ranks"] = dist.get_world_size()
         res["collective_backend"] = dist.get_backend()
         res["grad_payload_bytes"] = n_grid * 4

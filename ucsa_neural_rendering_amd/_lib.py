@@ -115,6 +115,10 @@ SIGNATURES = {
     "ucsa_hashgrid_encode_rays_hf": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
                                                  C.POINTER(_f), _u32, _u32, _u32,
                                                  _p, _p]),
+    "ucsa_hashgrid_bwd_det_workspace_bytes": (C.c_uint64, [C.POINTER(Grid)]),
+    "ucsa_hashgrid_bwd_rays_det": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, C.POINTER(_f),
+                                               _u32, _u32, _p, _p, _p]),
+    "ucsa_hashgrid_bwd_det_finish": (C.c_int32, [C.POINTER(Grid), _p, _p, _p]),
     "ucsa_tile_depth_order": (C.c_int32, [_p, _u32, _u32, _u32, _p, _p, _p, _p]),
     "ucsa_hashgrid_encode_sorted": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                                 C.POINTER(_f), _u32, _u32, _u32,

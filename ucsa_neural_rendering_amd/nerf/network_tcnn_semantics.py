@@ -31,7 +31,7 @@ class _RenderFn(torch.autograd.Function):
         C = net.num_semantic_classes
         ds = float(net.density_scale)
         ctx.fused = False
-        if (net.fused_train_calls and net.train_precision == "bf16x3"
+        if (not net.deterministic and net.fused_train_calls and net.train_precision == "bf16x3"
                 and net.bwd_precision == "bf16x2" and ops.shade_bwd_split()
                 and net.grid_records_packed and (net.grid_bwd_merged or t == 0)):
             # the default training mode: forward and backward are ONE C call each
@@ -182,6 +182,20 @@ class _RenderFn(torch.autograd.Function):
         # bf16x2 backward: 8-byte packed bin records (26-bit values, 2^-18 --
         # finer than the two-term split that produced them)
         pk = ctx.x2 and rs == 0.0 and net.grid_records_packed
+        if net.deterministic:
+            # `UCSA_DETERMINISTIC=1` / net.deterministic: order-independent
+            # fixed-point accumulation of the table gradient (two runs of a step
+            # give the same bits; ucsa_hashgrid_bwd_rays_det)
+            fix = ops.hashgrid_bwd_rays_det(f["grid"], o, d, z_c, aabb, d_feat)
+            if t > 0:
+                d_feat_f, part = ops.sigma_mlp_bwd(feat_f, d_h_f, f["packed_sigma"],
+                                                   f["packed_sigma_t"], x2=ctx.x2,
+                                                   round_hidden=ctx.tcnn)
+                ops.reduce_partials(part, g_sigma, True)
+                ops.hashgrid_bwd_rays_det(f["grid"], o, d, z_f, aabb, d_feat_f, fix)
+            ops.hashgrid_bwd_det_finish(f["grid"], fix, g_grid)
+            ctx.saved = None
+            return (g_grid, g_sigma, g_color, g_sem) + (None,) * 10
         if not merged:
             ops.hashgrid_bwd_rays(f["grid"], o, d, z_c, aabb, d_feat, g_grid,
                                   rec_scale=rs, packed=pk)
@@ -299,6 +313,11 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
         # UCSA_H2_GUARD overrides.
         self.h2_guard = "weights"
         self._h2_pending = []
+        # reproducibility mode: the hash-grid gradient through an
+        # order-independent fixed-point reduction instead of float atomics / bin
+        # records -- two runs of a training step then give the same bits.  ~8 x
+        # slower backward: for debugging and for the trajectory-parity test.
+        self.deterministic = os.environ.get("UCSA_DETERMINISTIC", "0") == "1"
 
     # f16x2's first terms are f16 and ucsa_mlp_pack_h2 stores the last layer
     # times 2^4: a weight of 65504 / 16 or more becomes inf, the two partial sums

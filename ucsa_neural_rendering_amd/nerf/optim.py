@@ -228,6 +228,9 @@ class ShardedHipAdam(HipAdam):
         small = []  # (group, p_view, g_view, exp_avg, exp_avg_sq, step)
         large = []  # (group, p, pf, g_shard, state, per, body)
         comm = 0
+        # what this rank's Adam owns of every sharded parameter (read by the
+        # bench / the width-8 test): (numel, first, last + 1, first of the tail)
+        self.last_shards = []
         # phase 1: every gradient collective of the large parameters
         for group in self.param_groups:
             for p in group["params"]:
@@ -264,6 +267,7 @@ class ShardedHipAdam(HipAdam):
                     udist.reduce_scatter_sum_(g_shard, g[:body])
                     comm += body * 4
                 large.append((group, p, pf, g_shard, st, per, body))
+                self.last_shards.append((n, rank * per, (rank + 1) * per, body))
                 if n > body:
                     small.append((group, pf[body:], g[body:], st["tail_exp_avg"],
                                   st["tail_exp_avg_sq"], st["step"]))

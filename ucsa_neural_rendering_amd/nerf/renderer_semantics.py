@@ -432,11 +432,20 @@ class SemanticNeRFRenderer(nn.Module):
         return self._aabb_host[key][1]
 
     def _workspace(self, nbytes: int, device, slots: int = 1):
-        if (self._ws is None or self._ws.shape[0] < slots or
-                self._ws.shape[1] < nbytes or self._ws.device != device):
-            self._ws = torch.empty(slots, nbytes, dtype=torch.uint8,
-                                   device=device)
-        return self._ws
+        # one workspace per (device, caller stream): two streams rendering with
+        # one module at the same time must not share the intermediates
+        # ucsa_render_view / ucsa_render_fwd* write; at most four are
+        # kept (a module is normally driven from one or two streams)
+        if self._ws is None:
+            self._ws = {}
+        key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+        ws = self._ws.get(key)
+        if ws is None or ws.shape[0] < slots or ws.shape[1] < nbytes:
+            if ws is None and len(self._ws) >= 4:
+                self._ws.pop(next(iter(self._ws)))
+            ws = torch.empty(slots, nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
 
     def run(self, rays_o, rays_d, direction_norms, num_steps=256,
             upsample_steps=256, bg_color=None, perturb=False, epoch=None,

@@ -673,6 +673,28 @@ def hashgrid_bwd_rays(grid: Grid, rays_o, rays_d, z, aabb, d_feat, grad_table,
           "ucsa_hashgrid_bwd_rays")
 
 
+def hashgrid_bwd_rays_det(grid: Grid, rays_o, rays_d, z, aabb, d_feat, fix=None):
+    """Deterministic accumulation of the table gradient of one density pass
+    into the int64 fixed-point buffer ``fix`` (created zeroed when None;
+    ucsa_hashgrid_bwd_rays_det).  Finish with ``hashgrid_bwd_det_finish``."""
+    N, T = z.shape
+    if tuple(d_feat.shape) != (grid.n_levels, N * T, 2) or not d_feat.is_contiguous():
+        raise _lib.UcsaError("d_feat must be a contiguous [L, N*T, 2] tensor")
+    if fix is None:
+        n = int(lib().ucsa_hashgrid_bwd_det_workspace_bytes(C.byref(grid))) // 8
+        fix = torch.zeros(n, dtype=torch.int64, device=z.device)
+    check(lib().ucsa_hashgrid_bwd_rays_det(
+        C.byref(grid), _ptr(rays_o), _ptr(rays_d), _ptr(z), fvec(aabb), N, T,
+        _ptr(d_feat), _ptr(fix), _stream()), "ucsa_hashgrid_bwd_rays_det")
+    return fix
+
+
+def hashgrid_bwd_det_finish(grid: Grid, fix, grad_table):
+    """grad_table += fix * 2^-44 (NaN everywhere after a non-finite contribution)."""
+    check(lib().ucsa_hashgrid_bwd_det_finish(C.byref(grid), _ptr(fix), _ptr(grad_table),
+                                             _stream()), "ucsa_hashgrid_bwd_det_finish")
+
+
 def hashgrid_bwd_rays_merged(grid: Grid, rays_o, rays_d, z_c, z_f, src, aabb,
                              d_feat_c, d_feat_f, grad_table, packed: bool = False,
                              rec_scale: float = 0.0):
