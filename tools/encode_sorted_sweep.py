@@ -57,3 +57,7 @@ for name, zz in (("coarse", z), ("fine", zf)):
             t_s = timed(lambda: ops.sigma_mlp_fwd_scatter(3, got, f2["packed_sigma"], slot))
             print(f"{name:6s} depth-ordered lean={lean} ml={ml:2d}: sort {t_sort:.3f} + encode {t_e:.3f} + sigma/scatter {t_s:.3f} = "
                   f"{t_sort + t_e + t_s:.3f} ms  bit-identical {same}", flush=True)
+    hF, sF = ops.encode_sigma_sorted(3, f["grid"], f["table"], o, d, zs, pix, slot, aabb, T, W, f2["packed_sigma"])
+    t_f = timed(lambda: ops.encode_sigma_sorted(3, f["grid"], f["table"], o, d, zs, pix, slot, aabb, T, W, f2["packed_sigma"]))
+    print(f"{name:6s} depth-ordered, levels 0-7 inside the sigma MLP: sort {t_sort:.3f} + encode(8-15)+sigma {t_f:.3f} = "
+          f"{t_sort + t_f:.3f} ms  bit-identical {bool(torch.equal(h0, hF) and torch.equal(s0, sF))}", flush=True)

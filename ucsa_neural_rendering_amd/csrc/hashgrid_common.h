@@ -313,12 +313,16 @@ __device__ __noinline__ void dense_corners_wrapped(const TT* __restrict__ tab,
                                     gz + ((c >> 2) & 1), res, entries, 0u));
 }
 
+// base_off: byte offset of the level inside `tab` when the level is not
+// wave-uniform (encode_sigma_sorted.hip: one scalar base for the whole table,
+// the level's offset per lane); 0 with `tab` already at the level.
 template <typename TT>
 __device__ __forceinline__ float2 encode_cell(const TT* __restrict__ tab,
                                               float x, float y, float z,
                                               float scale, uint32_t res,
                                               uint32_t res2, uint32_t entries,
-                                              uint32_t hashed) {
+                                              uint32_t hashed,
+                                              uint32_t base_off = 0u) {
   constexpr uint32_t SH = sizeof(TT) == 8 ? 3u : 2u;   // log2 of the entry size
   const float px = x * scale + 0.5f, py = y * scale + 0.5f,
               pz = z * scale + 0.5f;
@@ -332,13 +336,13 @@ __device__ __forceinline__ float2 encode_cell(const TT* __restrict__ tab,
     // all four x-pairs inside the slab (false only on the far faces of the
     // box): one test instead of eight
     if (__builtin_expect(b + res + res2 + 1u < entries, 1)) {
-      const uint32_t o = b << SH;
+      const uint32_t o = (b << SH) + base_off;
       tab_pair_at(tab, o, v[0], v[1]);
       tab_pair_at(tab, o + (res << SH), v[2], v[3]);
       tab_pair_at(tab, o + (res2 << SH), v[4], v[5]);
       tab_pair_at(tab, o + ((res + res2) << SH), v[6], v[7]);
     } else {
-      dense_corners_wrapped(tab, gx, gy, gz, res, entries, v);
+      dense_corners_wrapped(tab + (base_off >> SH), gx, gy, gz, res, entries, v);
     }
   } else {
     // byte offset of entry (ix ^ iy P_y ^ iz P_z) & (entries - 1): the shift
@@ -350,14 +354,14 @@ __device__ __forceinline__ float2 encode_cell(const TT* __restrict__ tab,
     const uint32_t hz0 = gz * PZ, hz1 = hz0 + PZ;
     const uint32_t x0 = gx << SH, x1 = x0 + (1u << SH);
     const uint32_t h00 = hy0 ^ hz0, h10 = hy1 ^ hz0, h01 = hy0 ^ hz1, h11 = hy1 ^ hz1;
-    v[0] = tab_at(tab, (x0 ^ h00) & mask);
-    v[1] = tab_at(tab, (x1 ^ h00) & mask);
-    v[2] = tab_at(tab, (x0 ^ h10) & mask);
-    v[3] = tab_at(tab, (x1 ^ h10) & mask);
-    v[4] = tab_at(tab, (x0 ^ h01) & mask);
-    v[5] = tab_at(tab, (x1 ^ h01) & mask);
-    v[6] = tab_at(tab, (x0 ^ h11) & mask);
-    v[7] = tab_at(tab, (x1 ^ h11) & mask);
+    v[0] = tab_at(tab, ((x0 ^ h00) & mask) + base_off);
+    v[1] = tab_at(tab, ((x1 ^ h00) & mask) + base_off);
+    v[2] = tab_at(tab, ((x0 ^ h10) & mask) + base_off);
+    v[3] = tab_at(tab, ((x1 ^ h10) & mask) + base_off);
+    v[4] = tab_at(tab, ((x0 ^ h01) & mask) + base_off);
+    v[5] = tab_at(tab, ((x1 ^ h01) & mask) + base_off);
+    v[6] = tab_at(tab, ((x0 ^ h11) & mask) + base_off);
+    v[7] = tab_at(tab, ((x1 ^ h11) & mask) + base_off);
   }
   float2 acc = make_float2(0.f, 0.f);
 #pragma unroll

@@ -25,33 +25,8 @@
 // changes.  Per sample the arithmetic is encode_level's: bit-identical results.
 #include <cstdlib>
 
-#include "hashgrid_common.h"
+#include "hashgrid_sorted.h"
 
-
-namespace {
-struct TileGeom {
-  uint32_t base;    // first sorted position of the tile (samples of earlier tiles)
-  uint32_t count;   // samples of the tile
-  uint32_t wt, ht;  // valid pixels of the tile in x / y
-  uint32_t px0, py0;
-};
-}  // namespace
-
-// rays = the pixels of `rows` full image rows, W wide; tiles row-major
-__device__ __forceinline__ TileGeom tile_geom(uint32_t tile, uint32_t rows,
-                                              uint32_t W, uint32_t T) {
-  const uint32_t tiles_x = (W + 7u) / 8u;
-  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  TileGeom t;
-  t.px0 = tx * 8u;
-  t.py0 = ty * 8u;
-  t.wt = W - t.px0 < 8u ? W - t.px0 : 8u;
-  t.ht = rows - t.py0 < 8u ? rows - t.py0 : 8u;
-  // every earlier tile of this band is 8 wide, every earlier band W x 8 pixels
-  t.base = T * (t.py0 * W + t.px0 * t.ht);
-  t.count = t.wt * t.ht * T;
-  return t;
-}
 
 // Sort key of a sample: (depth slab, pixel).  The tile's depth range is cut
 // into `nbins` slabs (about one per 64 samples) and a slab holds its samples in
@@ -295,37 +270,6 @@ k_tile_depth_order2(const float* __restrict__ z, uint32_t rows, uint32_t T,
   }
 }
 
-// the tile's rays in LDS: lane -> (origin, direction) by pixel id
-__device__ __forceinline__ void load_tile_rays(float (*ray_s)[8], const TileGeom& tg,
-                                               uint32_t W,
-                                               const float* __restrict__ rays_o,
-                                               const float* __restrict__ rays_d) {
-  for (uint32_t e = threadIdx.x; e < 64u * 6u; e += blockDim.x) {
-    const uint32_t p = e / 6u, c = e % 6u;
-    const uint32_t lx = p & 7u, ly = p >> 3;
-    float v = 0.f;
-    if (lx < tg.wt && ly < tg.ht) {
-      const uint32_t r = (tg.py0 + ly) * W + tg.px0 + lx;
-      v = c < 3u ? rays_o[r * 3u + c] : rays_d[r * 3u + c - 3u];
-    }
-    ray_s[p][c < 3u ? c : c + 1u] = v;   // o in [0..2], d in [4..6]
-  }
-}
-
-__device__ __forceinline__ void unit_position(const float (*ray_s)[8], uint32_t p,
-                                              float zz, const Aabb& bb, float bound,
-                                              float two_b, float inv, float& ux,
-                                              float& uy, float& uz) {
-  const float4 o = *reinterpret_cast<const float4*>(&ray_s[p][0]);
-  const float4 d = *reinterpret_cast<const float4*>(&ray_s[p][4]);
-  const float px = clampf(o.x + d.x * zz, bb.lo[0], bb.hi[0]);
-  const float py = clampf(o.y + d.y * zz, bb.lo[1], bb.hi[1]);
-  const float pz = clampf(o.z + d.z * zz, bb.lo[2], bb.hi[2]);
-  ux = to_unit(px, bound, two_b, inv);
-  uy = to_unit(py, bound, two_b, inv);
-  uz = to_unit(pz, bound, two_b, inv);
-}
-
 // One level per grid row (finest level first: level = l_top - blockIdx.y), a
 // workgroup = 1024 consecutive samples of a tile's depth order.
 template <typename TT, typename FT, bool LEAN>
@@ -460,7 +404,7 @@ static int32_t launch_sorted(const ucsa_grid* grid, const float* table,
                              const float* rays_o, const float* rays_d,
                              const float* z_sorted, const uint8_t* pix, Aabb bb,
                              uint32_t N, uint32_t T, uint32_t image_width,
-                             void* feat, void* stream) {
+                             void* feat, void* stream, uint32_t first_level = 0u) {
   const GridDev gd = ucsa_grid_dev(grid);
   const uint32_t rows = N / image_width;
   const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
@@ -475,6 +419,9 @@ static int32_t launch_sorted(const ucsa_grid* grid, const float* table,
   };
   uint32_t n_ml = env_u("UCSA_ENC_SORTED_ML", 9u);
   if (n_ml > grid->n_levels) n_ml = grid->n_levels;
+  // first_level > 0: only levels [first_level, L), one level per grid row (the
+  // levels below are computed by the consumer, encode_sigma_sorted.hip)
+  if (first_level > 0u) n_ml = first_level;
   const bool lean = env_u("UCSA_ENC_SORTED_LEAN", 1u) != 0u;
   UCSA_CLEAR_ERR();
   if (n_ml < grid->n_levels) {
@@ -490,7 +437,7 @@ static int32_t launch_sorted(const ucsa_grid* grid, const float* table,
                          (const float2*)table, rays_o, rays_d, z_sorted, pix, bb, T,
                          rows, image_width, s_blocks, M, (FT*)feat);
   }
-  if (n_ml > 0)
+  if (n_ml > 0 && first_level == 0u)
     hipLaunchKernelGGL((k_hashgrid_encode_sorted_ml<float2, FT>), dim3(tiles * s_blocks),
                        dim3(256), 0, (hipStream_t)stream, gd, 0u, n_ml,
                        (const float2*)table, rays_o, rays_d, z_sorted, pix, bb, T,
@@ -538,4 +485,19 @@ extern "C" int32_t ucsa_hashgrid_encode_sorted_hf(
   return launch_sorted<ucsa_half2>(grid, table, rays_o, rays_d, z_sorted, pix,
                                    ucsa_aabb(aabb_host), N, T, image_width, feat_half,
                                    stream);
+}
+
+// levels [first_level, L) only (see encode_sigma_sorted.hip)
+int32_t ucsa_hashgrid_encode_sorted_from(const ucsa_grid* grid, const float* table,
+                                         const float* rays_o, const float* rays_d,
+                                         const float* z_sorted, const uint8_t* pix,
+                                         const float* aabb_host, uint32_t N, uint32_t T,
+                                         uint32_t image_width, uint32_t first_level,
+                                         float* feat, void* stream) {
+  const int32_t rc = check_sorted_args(grid, table, rays_o, rays_d, z_sorted, pix,
+                                       aabb_host, N, T, image_width, feat);
+  if (rc != 0 || N == 0) return rc;
+  return launch_sorted<float2>(grid, table, rays_o, rays_d, z_sorted, pix,
+                               ucsa_aabb(aabb_host), N, T, image_width, feat, stream,
+                               first_level);
 }

@@ -150,6 +150,15 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
         (sorted_mode == 2 || (sorted_mode == 1 && fine))) {
       UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
                                      w.slot, stream));
+      // UCSA_ENC_FUSED_ML=1 (bf16x3 / f16x2 nets): the sigma MLP encodes levels
+      // 0-7 itself (encode_sigma_sorted.hip).  Measured SLOWER as built (one
+      // 16-sample block per iteration at 128 VGPRs: fine pass 1.34 ms against
+      // 0.94 + 0.27 for the two calls, bit-identical) -- off by default.
+      const char* fm = getenv("UCSA_ENC_FUSED_ML");
+      if (prec >= 2 && fm && fm[0] == '1')
+        return ucsa_encode_sigma_sorted(prec, grid, table, rays_o, rays_d, w.zs_sorted,
+                                        w.pix, w.slot, aabb_host, N, n, image_width,
+                                        packed_sigma, w.feat, h, sigma, stream);
       if (prec == 1)
         UCSA_TRY(ucsa_hashgrid_encode_sorted_hf(grid, table, rays_o, rays_d,
                                                 w.zs_sorted, w.pix, aabb_host, N, n,
