@@ -261,55 +261,79 @@ def init_distributed(args):
     return dist, world, rank, dev, backend
 
 
+# the encoder launches of one density pass (round 5): the coarse samples stay in
+# image order, the fine samples are encoded in per-tile depth order
+ENC_PASS_KERNELS = {
+    "coarse": ("k_hashgrid_encode_tiled", "k_hashgrid_encode_tiled_ml"),
+    "fine": ("k_hashgrid_encode_sorted", "k_hashgrid_encode_sorted_ml"),
+}
+
+
 def encoder_roofline(st, chunk, pretrain_steps):
-    """`roofline` of the dominant kernel, k_hashgrid_encode_tiled: algorithmic
-    gather bytes per launch (L x 8 corners x F x 4 B = 1024 B per
-    sample x the samples of one launch) / the launch's duration, event-timed
-    live in this process (stage_times) / the 8 TB/s HBM line.  `traffic` and
-    the binding unit come from the committed PMC passes (rocprofv3 cannot run
-    inside this process), only when collected on the same parameter state."""
+    """`roofline` of the dominant stage, the hash-grid encoder of one density
+    pass: algorithmic gather bytes (L x 8 corners x F x 4 B = 1024 B
+    per sample x the samples of one pass) / the pass's duration, event-timed live
+    in this process (stage_times) / the 8 TB/s HBM line.  Since round 5 a pass is
+    TWO launches back to back -- levels 9-15 one level per grid row, levels 0-8 in
+    the several-levels kernel (ENC_PASS_KERNELS; the fine pass on the depth-ordered
+    samples, after the per-tile sort `sort_f`) -- `launch_ms` is their sum, the
+    mean of the coarse and the fine pass; the rocprofv3 summary
+    (profiles/r05_bench_kernel_trace.txt) lists the kernels singly.  `traffic`
+    and the binding unit come from the committed PMC passes (rocprofv3 cannot run
+    inside this process), only when collected on the same parameter state and
+    launch size."""
     samples = chunk * T_COARSE
     enc_bytes = samples * 16 * 8 * 2 * 4
     enc_ms = 0.5 * (st["encode_c"] + st["encode_f"])
     enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
-    r = {"kernel": "k_hashgrid_encode_tiled", "bound": "hbm", "achieved": enc_gbs,
+    r = {"kernel": "hash-grid encoder, one density pass = 2 launches: k_hashgrid_encode_tiled + "
+                   "_tiled_ml (coarse samples) / k_hashgrid_encode_sorted + _sorted_ml "
+                   "(depth-ordered fine samples)",
+         "bound": "hbm", "achieved": enc_gbs,
          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
          "traffic": None, "launch_ms": enc_ms, "algorithmic_bytes_per_launch": enc_bytes,
-         "timing": "HIP events on the launch stream, mean of coarse+fine pass, 5 iterations",
-         "note": "achieved = ALGORITHMIC gather bytes (1024 B/sample) / launch time: a "
+         "pass_ms": {"coarse": st["encode_c"], "fine": st["encode_f"],
+                     "fine_sort": st.get("sort_f", 0.0)},
+         "timing": "HIP events on the launch stream around the two encoder launches of a pass, "
+                   "mean of coarse+fine pass, 5 iterations",
+         "note": "achieved = ALGORITHMIC gather bytes (1024 B/sample) / pass time: a "
                  "nominal figure against the HBM line, NOT HBM utilisation "
                  "(hbm_utilisation is: measured traffic / time / peak).  The table slice a "
-                 "launch phase works on is L2/MALL resident; what binds the kernel is the "
-                 "per-CU L1's line look-up rate (binding_resource)"}
+                 "launch phase works on is L2/MALL resident; what binds the fine levels is the "
+                 "L2 -> L1 fill of one 128-B line per 8-byte corner pair (binding_resource)"}
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_JSON)))
         eb = json.load(open(os.path.join(ROOT, ENC_BINDING_JSON)))
     except OSError as e:
-        raise SystemExit(f"bench.py: the committed PMC passes the roofline's `traffic` "
-                         f"comes from are missing: {e}")
+        # (only while a round's PMC passes are being re-collected: tools/
+        # refresh_profiles.sh runs this very program under rocprofv3)
+        print(f"[bench] WARNING: committed PMC passes missing ({e}): roofline.traffic and "
+              "binding_resource are not reported", file=sys.stderr)
+        return r
     except ValueError as e:
         raise SystemExit(f"bench.py: {PMC_JSON} / {ENC_BINDING_JSON} malformed: {e!r}")
-    kn = "k_hashgrid_encode_tiled"
-    # ... and on launches of THIS size: 256 threads per (8x8 tile, 16 sample
-    # indices, level) = rays x T / 4 threads per level, 16 levels
-    same_launch = int(pmc.get(kn, {}).get("grid_threads", -1)) == chunk * T_COARSE // 4 * 16
-    if (int(pmc.get("pretrain_steps", -1)) == int(pretrain_steps) and same_launch
-            and "fetch_bytes" in pmc.get(kn, {})):
-        tr = pmc[kn]["fetch_bytes"] + pmc[kn]["write_bytes"]
+    # ... on launches of THIS size: 256 threads per 1024 samples and level
+    per_level = chunk * T_COARSE // 4
+    names = [k for ks in ENC_PASS_KERNELS.values() for k in ks]
+    same_launch = all(
+        "fetch_bytes" in pmc.get(k, {}) and int(pmc[k].get("grid_threads", -1)) % per_level == 0
+        for k in names)
+    if int(pmc.get("pretrain_steps", -1)) == int(pretrain_steps) and same_launch:
+        tr = 0.5 * sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in names)
         r["traffic"] = tr
-        r["traffic_source"] = PMC_JSON
+        r["traffic_source"] = PMC_JSON + " (mean over the two passes of the sum of their launches)"
+        r["traffic_by_kernel"] = {k: pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in names}
         r["hbm_utilisation"] = tr / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        for k in ("tcc_hit_rate", "valu_issue_frac"):
-            if k in pmc[kn]:
-                r[k] = pmc[kn][k]
-    acc = 0.5 * (eb["coarse"]["tcp_accesses_per_clock_per_cu"] +
-                 eb["fine"]["tcp_accesses_per_clock_per_cu"])
-    keys = ("tcp_accesses_per_clock_per_cu", "l1_hit_rate", "l2_latency_cycles",
+    l2 = 0.5 * (eb["coarse"]["l2_request_frac_of_34500"] + eb["fine"]["l2_request_frac_of_34500"])
+    keys = ("launch_us", "tcp_accesses_per_clock_per_cu", "l1_hit_rate", "l2_latency_cycles",
             "misses_in_flight_per_tcp", "tcp_pending_stall_frac", "valu_issue_frac",
             "l2_request_frac_of_34500")
+    fine_top = eb["fine"].get("kernels", {}).get("k_hashgrid_encode_sorted", {})
     r["binding_resource"] = {
-        "resource": "TCP (per-CU vector L1) line look-ups of divergent gathers, 1 per clock and CU",
-        "achieved": acc, "peak": 1.0, "unit": "line accesses / clock / CU", "frac": acc,
+        "resource": "L2 -> L1 line fills of the gathers (128-B lines, ~34.5 TB/s): the levels-9-15 "
+                    "launches; TCP look-ups 1 per clock and CU next",
+        "achieved": l2, "peak": 1.0, "unit": "fraction of the L2 request rate", "frac": l2,
+        "fine_levels_kernel": {k: fine_top[k] for k in keys if k in fine_top},
         "fine_pass": {k: eb["fine"][k] for k in keys if k in eb["fine"]},
         "coarse_pass": {k: eb["coarse"][k] for k in keys if k in eb["coarse"]},
         "source": ENC_BINDING_JSON + " (tools/encode_pmc.sh)"}

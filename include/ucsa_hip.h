@@ -660,9 +660,10 @@ int32_t ucsa_hashgrid_bwd_rays_merged(
     const float* d_feat_f, float* grad_table, void* workspace, void* stream);
 
 /* Deterministic form of ucsa_hashgrid_bwd_rays (debug / reproducibility mode,
- * `UCSA_DETERMINISTIC=1`; SURVEY 5 "race detection": the reference relies on
- * torch.use_deterministic_algorithms for this, scripts/train_joint.py seeds
- * only): every contribution w * d_feat as 64-bit fixed point (2^-44 units) added
+ * `UCSA_DETERMINISTIC=1`; SURVEY 5 "race detection": the reference only seeds,
+ * scripts/train_joint.py:48 `seed_everything`; this is what
+ * torch.use_deterministic_algorithms would ask of its backward,
+ * joint_train_lightning_net.py:509-513): every contribution w * d_feat as 64-bit fixed point (2^-44 units) added
  * with integer atomics -- the sum does not depend on the order of the additions,
  * so two runs of a step give the same bits.  `fix`: int64
  * [ucsa_hashgrid_bwd_det_workspace_bytes / 8], zeroed by the caller, accumulates

@@ -265,10 +265,16 @@ def flagged_a_priori(aux):
 
 
 def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
-                 max_loose_frac=5e-3):
+                 max_loose_frac=5e-3, collect_unexplained=None):
     """``res``: the outputs under test ([1, N(, C)] tensors, any device);
     ``ref``: ``oracle.renderer.run(..., return_aux=True)`` on ``rays`` = (o, d,
-    nrm) [1, n, .] CPU tensors (the rows ``sel`` of what ``res`` rendered)."""
+    nrm) [1, n, .] CPU tensors (the rows ``sel`` of what ``res`` rendered).
+
+    ``collect_unexplained`` (a list, whole-view test only): loose rays that match
+    no alternative are appended to it as (line, residuals, errors) instead of
+    failing here -- the caller bounds their number and size over the whole view
+    (one view has ~550 loose rays: a handful of them lie in the tail of the
+    ordinary error distribution the match tolerance is a percentile of)."""
     o, d, nrm = rays[0].reshape(-1, 3), rays[1].reshape(-1, 3), rays[2].reshape(-1)
     aux = ref["aux"]
     pick = (lambda x: x[0].cpu()) if sel is None else (lambda x: x[0][sel.to(x.device)].cpu())
@@ -310,7 +316,10 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
                 f"img {errs[0]:.2e} sem {errs[1]:.2e} depth {errs[2]:.2e}")
         print(line)
         if not (score <= 1.0 and (what["denom_flipped"] or what["mask_toggled"])):
-            unexplained.append(line)
+            if collect_unexplained is not None:
+                collect_unexplained.append((line, errs, (float(e_img[i]), float(e_sem[i]), float(rel[i]))))
+            else:
+                unexplained.append(line)
     assert not unexplained, ("rays above the tolerance that NO alternative decision of the "
                              "reference's two step functions reproduces within "
                              f"{alt[0]:.2g} / {alt[1]:.2g} / {alt[2]:.2g}:\n" + "\n".join(unexplained[:10]))

@@ -158,7 +158,18 @@ def main_cfg5(args, dev, dist, world, rank, backend):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        results = cl_deeplab.main(argv, exp=exp, env=env)
+        prof_to = os.environ.get("UCSA_CFG5_PROFILE")   # host-side profile of the loop
+        if prof_to and rank == 0:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            results = pr.runcall(cl_deeplab.main, argv, exp=exp, env=env)
+            with open(prof_to, "w") as fh:
+                st = pstats.Stats(pr, stream=fh)
+                st.sort_stats("cumulative").print_stats(70)
+                st.sort_stats("tottime").print_stats(40)
+        else:
+            results = cl_deeplab.main(argv, exp=exp, env=env)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()

@@ -1,6 +1,10 @@
-"""The tiled hash-grid encoder alone on the bench's 61 440-ray chunk (coarse
-pass then fine pass, 5 launches each after warm-up): the program the
-`--pmc` passes of tools/encode_pmc.sh profile."""
+"""The hash-grid encoder alone on the bench's 61 440-ray chunk, as
+ucsa_render_view runs it (round 5): coarse pass = k_hashgrid_encode_tiled (levels
+9-15) + k_hashgrid_encode_tiled_ml (levels 0-8) on the image-ordered samples; fine
+pass = k_tile_depth_order2, then k_hashgrid_encode_sorted (9-15) +
+k_hashgrid_encode_sorted_ml (0-8) on the depth-ordered samples.  6 launches of
+each after the set-up: the program the `--pmc` passes of tools/encode_pmc.sh
+profile."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -24,9 +28,12 @@ h, sig = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d,
 zf = ops.resample(z, sig.view(N, T), torch.rand(N, T, device=dev), 1.0)
 torch.cuda.synchronize()
 which = os.environ.get("PASS", "both")
-for name, zz in (("coarse", z), ("fine", zf)):
-    if which not in ("both", name):
-        continue
+if which in ("both", "coarse"):
     for _ in range(6):
-        ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zz, aabb, image_width=W)
+        ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb, image_width=W)
+    torch.cuda.synchronize()
+if which in ("both", "fine"):
+    for _ in range(6):
+        zs, pix, slot = ops.tile_depth_order(zf, W)
+        ops.hashgrid_encode_sorted(f["grid"], f["table"], o, d, zs, pix, aabb, T, W)
     torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: kernel trace + PMC passes (each its own run) of the
-# tiled encoder alone.   usage: encode_pmc.sh <tag>
+# encoder alone (tools/encode_only.py: round 5's four encoder kernels + the sort).   usage: encode_pmc.sh <tag>
 # (the TA_* counter set of round 3 is gone: in round 4 it hung rocprofv3 until
 # the timeout on this pool)
 set -u
@@ -23,7 +23,7 @@ for PMC in "" \
   else
     timeout 600 rocprofv3 --kernel-trace --pmc $PMC -d /tmp/ep$i -o p -- python3 tools/encode_only.py > $OUT/${TAG}_enc_pmc$i.log 2>&1
   fi
-  (echo "# PASS=$PASS  pmc: $PMC"; python3 tools/rocpd_summary.py $(find /tmp/ep$i -name "*.db" | head -1) 2>/dev/null | grep -E "^#|hashgrid_encode_tiled") > $OUT/${TAG}_enc_pmc$i.txt
+  (echo "# PASS=$PASS  pmc: $PMC"; python3 tools/rocpd_summary.py $(find /tmp/ep$i -name "*.db" | head -1) 2>/dev/null | grep -E "^#|hashgrid_encode_tiled|hashgrid_encode_sorted|tile_depth_order") > $OUT/${TAG}_enc_pmc$i.txt
   i=$((i+1))
 done
 done

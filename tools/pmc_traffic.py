@@ -61,6 +61,13 @@ def main(d, tag):
     }
     for key, prefix in (("k_composite", "void k_composite<3, 2, false, false>"),
                         ("k_hashgrid_encode_tiled", "void k_hashgrid_encode_tiled<HIP_vector_t"),
+                        # round 5: the encoder is four kernels (coarse pass: _tiled levels
+                        # 9-15 + _tiled_ml levels 0-8; fine pass: _sorted + _sorted_ml on the
+                        # depth-ordered samples) and the per-tile sort
+                        ("k_hashgrid_encode_tiled_ml", "void k_hashgrid_encode_tiled_ml<"),
+                        ("k_hashgrid_encode_sorted", "void k_hashgrid_encode_sorted<"),
+                        ("k_hashgrid_encode_sorted_ml", "void k_hashgrid_encode_sorted_ml<"),
+                        ("k_tile_depth_order2", "k_tile_depth_order2("),
                         ("k_weights_compact", "k_weights_compact"),
                         ("k_shade16_f16", "void k_shade16<3, 1, 1,"),
                         ("k_shade16_x3", "void k_shade16<3, 1, 2,"),
