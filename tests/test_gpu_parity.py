@@ -935,13 +935,14 @@ def test_f16x2_guard_raises_instead_of_zeroing():
         net.encoder.params.mul_(200.0)
         with pytest.raises(UcsaError, match="sigma net|features"):
             net.render(o, d, norms, **kw)
-    # training: the check of step k is read at the pack of step k + 1
+    # training: sampled (the first pack of a net, then every 16th), read back
+    # asynchronously at a later pack
     net2 = hip_network_from_oracle(fld).train()
     net2.train_precision = "bf16x3"          # the LightningModule's default: f16x2 forward nets
     with torch.no_grad():
         net2.semantics_net.params[3] = 1.0e5
     with pytest.raises(UcsaError, match="sem"):
-        for _ in range(3):
+        for _ in range(20):
             out = net2.render(o, d, norms, **kw)
             (out["image"].sum() + out["semantics"].sum()).backward()
             torch.cuda.synchronize()

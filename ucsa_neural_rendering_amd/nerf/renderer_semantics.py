@@ -573,6 +573,8 @@ class SemanticNeRFRenderer(nn.Module):
                             f["packed_color"], f["packed_sem"], o, d, nrm, aabb, min_near,
                             rng_t, rng_u, T, t, C, float(self.density_scale), image, depth,
                             sem, chunk, ws[0], ws[1], image_width)
+            if self.precision == "f16x2":
+                self._h2_finish_render()
             return image, depth, sem
         n_str = max(1, min(int(self.hip_streams), n_chunks))
         ws = self._workspace(
@@ -601,6 +603,8 @@ class SemanticNeRFRenderer(nn.Module):
                     image_width)
         for st in streams[1:]:
             main.wait_stream(st)
+        if self.precision == "f16x2":
+            self._h2_finish_render()
         return image, depth, sem
 
     def _run_train(self, o, d, nrm, aabb, T, t, rng_t, rng_u, min_near):

@@ -779,10 +779,36 @@ def render_fused_fwd(grid: Grid, table, packs, rays_o, rays_d, norms, aabb,
         u = _f32(u, "u")
         assert u.shape == (N, t)
     e = lambda *shape, **kw: torch.empty(*shape, device=dev, **kw)  # noqa: E731
-    sv = {"z_c": e(N, T), "feat_c": e(L, N * T, 2), "h_c": e(N * T, 16), "sigma_c": e(N, T),
-          "z_f": e(N, t) if t else None, "feat_f": e(L, N * t, 2) if t else None,
-          "h_f": e(N * t, 16) if t else None, "sigma_f": e(N, t) if t else None,
-          "src": e(N, T + t, dtype=torch.int32), "weights": e(N, T + t)}
+    # The saved tensors of a step are carved from ONE allocation at fixed, skewed
+    # offsets (array i starts 256 * (2 i + 1) bytes past a 4 KiB boundary).  As
+    # ten separate torch.empty calls their relative placement was whatever the
+    # caching allocator's history made it, and the step time followed it: +0.15 ms
+    # (3.40 -> 3.55 ms) after ONE extra device synchronisation earlier in the
+    # process (round 5, tools/gpu notes in the notebook); the C side already
+    # skews its own workspace for the same reason (render_train.hip).
+    shapes = [("z_c", (N, T), 4), ("feat_c", (L, N * T, 2), 4), ("h_c", (N * T, 16), 4),
+              ("sigma_c", (N, T), 4)]
+    if t:
+        shapes += [("z_f", (N, t), 4), ("feat_f", (L, N * t, 2), 4), ("h_f", (N * t, 16), 4),
+                   ("sigma_f", (N, t), 4)]
+    shapes += [("src", (N, T + t), 4), ("weights", (N, T + t), 4)]
+    offs, end = [], 0
+    for i, (_, shp, b) in enumerate(shapes):
+        start = (end + 4095) // 4096 * 4096 + 256 * (2 * i + 1)
+        n = b
+        for d_ in shp:
+            n *= d_
+        offs.append(start)
+        end = start + n
+    slab = torch.empty(end + 4096, dtype=torch.uint8, device=dev)
+    base = (-slab.data_ptr()) % 4096          # 4 KiB-aligned origin inside the slab
+    sv = {k: None for k in ("z_f", "feat_f", "h_f", "sigma_f")}
+    for (k, shp, b), off in zip(shapes, offs):
+        n = b
+        for d_ in shp:
+            n *= d_
+        raw = slab[base + off: base + off + n]
+        sv[k] = raw.view(torch.int32 if k == "src" else torch.float32).view(*shp)
     bufs = _lib.TrainBuffers(*[_ptr(sv[k]) for k, _ in _lib.TrainBuffers._fields_])
     image, depth, sem = e(N, 3), e(N), e(N, n_classes)
     ws = _scratch_named("render_fused_fwd",
