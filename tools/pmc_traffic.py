@@ -71,7 +71,9 @@ def main(d, tag):
                         ("k_weights_compact", "k_weights_compact"),
                         ("k_shade16_f16", "void k_shade16<3, 1, 1,"),
                         ("k_shade16_x3", "void k_shade16<3, 1, 2,"),
-                        ("k_shade16_h2", "void k_shade16<3, 1, 3,")):
+                        ("k_shade16_h2", "void k_shade16<3, 1, 3,"),
+                        # (two column blocks per group since round 4's last step)
+                        ("k_shade16_h2", "void k_shade16<3, 2, 3,")):
         f, w, s = pick(fetch, prefix), pick(wr, prefix), pick(sq, prefix)
         if not (f and w):
             continue

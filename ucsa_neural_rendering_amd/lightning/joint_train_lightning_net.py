@@ -207,7 +207,10 @@ class JointTrainLightningNet(nn.Module):
         """reference :108-157 -> rays_o, rays_d [1,N,3], direction_norms
         [1,N,1], inds [1,N]."""
         N = self.n_rays_train if N is None else N
-        poses = batch["pose"][[bs], ...]
+        # (a slice, not `[[bs], ...]`: indexing a device tensor with a Python list
+        # uploads the index with a blocking copy -- one device synchronisation per
+        # training step, 15 ms of host time each in the continual loop's profile)
+        poses = batch["pose"][bs:bs + 1]
         device = poses.device
         fx, fy, cx, cy = [float(v) for v in batch["intrinsics"][bs]]
         H, W = int(batch["H"][bs]), int(batch["W"][bs])
@@ -310,9 +313,9 @@ class JointTrainLightningNet(nn.Module):
         same total and gradients, without a host read-back per step
         (``losses.nerf_losses``)."""
         rays_o, rays_d, direction_norms, inds = self.get_rays_train(batch, bs)
-        images = batch["img_fp16"][[bs], ...]
-        label_nerf = output_seg["seg_semantics"][[bs], ...]
-        depths = batch["depth"][[bs], ...]
+        images = batch["img_fp16"][bs:bs + 1]
+        label_nerf = output_seg["seg_semantics"][bs:bs + 1]
+        depths = batch["depth"][bs:bs + 1]
         uom = batch["one_m_to_scene_uom"][bs]
         uom = float(uom)
         B, C, H, W = images.shape
@@ -626,7 +629,8 @@ class JointTrainLightningNet(nn.Module):
             out = self.forward_nerf_test(batch)
             self._meter["test_nerf"].update(out["nerf_semantics"], batch["label"])
             mse = torch.mean((out["nerf_rgb"] - batch["img"]) ** 2)
-            self._psnr.append(float(-10.0 * torch.log10(mse)))
+            # (kept on the device: a float() here is one synchronisation per frame)
+            self._psnr.append((-10.0 * torch.log10(mse)).detach().double().reshape(1))
         else:
             tail = ops.seg_tail(self.seg_model(batch["img"])["out"].contiguous(),
                                 None, want_prob=False)
@@ -644,8 +648,8 @@ class JointTrainLightningNet(nn.Module):
                 self.log(f"test/{net_name}_mean_IoU", m_iou)
                 out[f"test_{net_name}_mIoU"] = m_iou
                 m.clear()
-        tot = torch.tensor([sum(self._psnr), float(len(self._psnr))],
-                           dtype=torch.float64)
+        psnr_sum = float(torch.cat(self._psnr).sum()) if self._psnr else 0.0
+        tot = torch.tensor([psnr_sum, float(len(self._psnr))], dtype=torch.float64)
         if udist.active():  # the ranks evaluated disjoint frames
             tot = udist.allreduce_sum_tensor(tot.to(self._reduce_device()))
         if float(tot[1]) > 0:
@@ -703,14 +707,16 @@ class JointTrainLightningNet(nn.Module):
             from PIL import Image
             import numpy as np
             sub = "novel_viewpoints" if novel else ""
+            # one read-back per batch and array (quantised on the device), not three
+            # per frame
+            rgb8 = (res["nerf_image"].permute(0, 2, 3, 1).detach() * 255).to(torch.uint8).cpu().numpy()
+            lab8 = {name: res[name].detach().to(torch.uint8).cpu().numpy()
+                    for name in ("nerf_label", "seg_label")}
             for i, idx in enumerate(batch["current_index"]):
-                rgb = (res["nerf_image"][i].permute(1, 2, 0).detach().cpu()
-                       .numpy() * 255).astype(np.uint8)
-                Image.fromarray(rgb).save(os.path.join(
+                Image.fromarray(rgb8[i]).save(os.path.join(
                     self.root_new_scene, sub, "nerf_image", idx + ".png"))
                 for name in ("nerf_label", "seg_label"):
-                    lab = res[name][i].detach().cpu().numpy().astype(np.uint8)
-                    Image.fromarray(lab).save(os.path.join(
+                    Image.fromarray(lab8[name][i]).save(os.path.join(
                         self.root_new_scene, sub, name, idx + ".png"))
         return res
 

@@ -13,28 +13,50 @@ import torch
 
 
 class SemanticsMeter:
+    """``conf_mat`` (numpy int64 [C,C] or None) as in the reference; counts of
+    GPU label maps accumulate in a device tensor and are folded into it only
+    when it is read (``conf_mat`` / ``measure``): an ``update`` per evaluated
+    frame no longer costs a device synchronisation (3.7 s of a 63 s continual-loop
+    profile, round 5)."""
 
     def __init__(self, number_classes):
-        self.conf_mat = None
+        self._host = None
+        self._dev = None
         self.number_classes = number_classes
 
     def clear(self):
-        self.conf_mat = None
+        self._host = None
+        self._dev = None
+
+    @property
+    def conf_mat(self):
+        if self._dev is not None:
+            cm = self._dev.cpu().numpy().astype(np.int64)
+            self._dev = None
+            self._host = cm if self._host is None else self._host + cm
+        return self._host
+
+    @conf_mat.setter
+    def conf_mat(self, value):
+        self._dev = None
+        self._host = value
 
     def update(self, preds, truths):
         C = self.number_classes
         if torch.is_tensor(preds) and preds.is_cuda:
             from .. import ops
             cm = ops.confusion_matrix(preds, truths.to(preds.device), C)
-            cm = cm.cpu().numpy()
-        else:
-            p = preds.detach().cpu().numpy() if torch.is_tensor(preds) else np.asarray(preds)
-            t = truths.detach().cpu().numpy() if torch.is_tensor(truths) else np.asarray(truths)
-            p, t = p.reshape(-1), t.reshape(-1)
-            ok = (t >= 0) & (t < C) & (p >= 0) & (p < C)
-            cm = np.zeros((C, C), dtype=np.int64)
-            np.add.at(cm, (t[ok].astype(np.int64), p[ok].astype(np.int64)), 1)
-        self.conf_mat = cm if self.conf_mat is None else self.conf_mat + cm
+            if self._dev is not None and self._dev.device != cm.device:
+                self.conf_mat       # fold the other device's counts first
+            self._dev = cm if self._dev is None else self._dev + cm
+            return
+        p = preds.detach().cpu().numpy() if torch.is_tensor(preds) else np.asarray(preds)
+        t = truths.detach().cpu().numpy() if torch.is_tensor(truths) else np.asarray(truths)
+        p, t = p.reshape(-1), t.reshape(-1)
+        ok = (t >= 0) & (t < C) & (p >= 0) & (p < C)
+        cm = np.zeros((C, C), dtype=np.int64)
+        np.add.at(cm, (t[ok].astype(np.int64), p[ok].astype(np.int64)), 1)
+        self._host = cm if self._host is None else self._host + cm
 
     def measure(self):
         cm = self.conf_mat.astype(np.int64)
