@@ -403,6 +403,18 @@ int32_t ucsa_sigma_mlp_fwd_x3(const float* feat, const void* packed_sigma_x3,
 uint32_t ucsa_mlp_pack_h2_bytes(int32_t kind, uint32_t n_classes);
 int32_t ucsa_mlp_pack_h2(int32_t kind, const float* params, void* packed_h2,
                          uint32_t n_classes, void* stream);
+/* The same, and *range_bits (uint32 in device memory or in pinned host memory
+ * the device can address -- hipHostMalloc / torch pin_memory --, caller-zeroed,
+ * accumulated over calls: the waves raise a device word, the last workgroup
+ * publishes it with ONE system-scope atomic max) = the largest |value| it converted to f16, as an fp32
+ * bit pattern: >= 0x477FE000 (65504.0f) means a weight outside f16x2's range or
+ * not finite -- values the kernels would turn into zeros silently
+ * (mfma_mlp_h2.h).  The range guard of `nerf: {precision: f16x2}`
+ * (network_tcnn_semantics.py `h2_guard`) without a launch of its own. */
+int32_t ucsa_mlp_pack_h2_checked(int32_t kind, const float* params, void* packed_h2,
+                                 uint32_t n_classes, uint32_t* range_bits,
+                                 uint32_t* scratch /* 2 device uint32, zeroed once */,
+                                 void* stream);
 int32_t ucsa_sigma_mlp_fwd_h2(const float* feat, const void* packed_sigma_h2,
                               uint32_t M, uint32_t n_levels, float* h,
                               float* sigma, void* stream);

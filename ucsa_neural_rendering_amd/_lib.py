@@ -138,6 +138,7 @@ SIGNATURES = {
                                             _p, _p, _p, _p]),
     "ucsa_mlp_pack_h2_bytes": (C.c_uint32, [C.c_int32, _u32]),
     "ucsa_mlp_pack_h2": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
+    "ucsa_mlp_pack_h2_checked": (C.c_int32, [C.c_int32, _p, _p, _u32, _p, _p, _p]),
     "ucsa_sigma_mlp_fwd_h2": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_render_fwd_h2": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                        _p, _p, C.POINTER(_f), _f, _p, _p,

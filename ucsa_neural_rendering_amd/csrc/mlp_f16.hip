@@ -76,18 +76,48 @@ __global__ void k_mlp_pack_x3(int kind, const float* __restrict__ params,
 // 2^11; fragment (f, term) at [(f * 2 + term) * 64 + lane].  First-layer
 // fragments carry the weights x 2^-4, last-layer ones x 2^4 (exact; the hidden
 // activations are 16 x smaller, the outputs unchanged).
+// range_host (may be NULL): the largest |value| this pack converted to f16, as
+// its fp32 bit pattern (non-negative floats order like unsigned integers; a
+// NaN's pattern is above every finite one).  The waves raise a DEVICE word
+// (scratch[0]) with device-scope atomics; the last workgroup to finish
+// (scratch[1] counts them) publishes it with ONE system-scope atomic max to
+// range_host, which may live in pinned host memory: the host then simply reads
+// it -- no copy, stream, event or wait on its side.  (One system-scope atomic per
+// WAVE, ~110 per pack over PCIe, cost 0.1 ms per pack.)  Neither word is reset
+// here: the host sees the worst pack since it last cleared range_host.
 __global__ void k_mlp_pack_h2(int kind, const float* __restrict__ params,
-                              _Float16* __restrict__ packed, uint32_t n_total) {
+                              _Float16* __restrict__ packed, uint32_t n_total,
+                              uint32_t* __restrict__ range_host,
+                              uint32_t* __restrict__ scratch) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_total) return;
-  const uint32_t e = idx & 7u, l = (idx >> 3) & 63u, f = idx >> 9;
-  const bool first = f < 4;
-  const bool last = kind == UCSA_MLP_COLOR ? f >= 12 : f >= 4;
-  const float v = pack_h_value(kind, params, f, l, e) *
-                  (first ? H2_HIDDEN_SCALE : (last ? 1.0f / H2_HIDDEN_SCALE : 1.0f));
-  const _Float16 hi = (_Float16)v;
-  packed[((f * 2 + 0) * 64 + l) * 8 + e] = hi;
-  packed[((f * 2 + 1) * 64 + l) * 8 + e] = (_Float16)((v - (float)hi) * H2_LO_SCALE);
+  uint32_t b = 0u;
+  if (idx < n_total) {
+    const uint32_t e = idx & 7u, l = (idx >> 3) & 63u, f = idx >> 9;
+    const bool first = f < 4;
+    const bool last = kind == UCSA_MLP_COLOR ? f >= 12 : f >= 4;
+    const float v = pack_h_value(kind, params, f, l, e) *
+                    (first ? H2_HIDDEN_SCALE : (last ? 1.0f / H2_HIDDEN_SCALE : 1.0f));
+    const _Float16 hi = (_Float16)v;
+    packed[((f * 2 + 0) * 64 + l) * 8 + e] = hi;
+    packed[((f * 2 + 1) * 64 + l) * 8 + e] = (_Float16)((v - (float)hi) * H2_LO_SCALE);
+    b = __float_as_uint(v) & 0x7FFFFFFFu;
+  }
+  if (!range_host) return;   // (kernel-uniform)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)b, d, 64);
+    b = o > b ? o : b;
+  }
+  if ((threadIdx.x & 63u) == 0u) atomicMax(&scratch[0], b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&scratch[1], 1u) == gridDim.x - 1u) {   // the last workgroup
+      scratch[1] = 0u;
+      const uint32_t m = atomicMax(&scratch[0], 0u);
+      __hip_atomic_fetch_max(range_host, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 extern "C" uint32_t ucsa_mlp_pack_f16_halves(int32_t kind, uint32_t n_classes) {
@@ -128,7 +158,31 @@ extern "C" int32_t ucsa_mlp_pack_h2(int32_t kind, const float* params,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_mlp_pack_h2, dim3(ucsa_div_up(n_total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (int)kind, params, (_Float16*)packed_h2,
-                     n_total);
+                     n_total, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  return ucsa_launch_status();
+}
+
+// ucsa_mlp_pack_h2 that also records the range of what it packed: *range_bits
+// (uint32 in pinned, device-mapped host memory -- or device memory --, zeroed by
+// the caller) = max over every value converted to f16 of its |.| as an fp32 bit
+// pattern, accumulated over calls; scratch: two device uint32, zeroed by the
+// caller once.  A pattern >= 0x477FE000 (65504.0f) means a weight left f16x2's
+// range (or is not finite).
+extern "C" int32_t ucsa_mlp_pack_h2_checked(int32_t kind, const float* params,
+                                            void* packed_h2, uint32_t n_classes,
+                                            uint32_t* range_bits, uint32_t* scratch,
+                                            void* stream) {
+  UCSA_CHECK_ARG(kind >= 0 && kind <= 2, 0);
+  UCSA_CHECK_ARG(params, 1);
+  UCSA_CHECK_ARG(packed_h2, 2);
+  UCSA_CHECK_ARG(kind != UCSA_MLP_SEM || (n_classes >= 1 && n_classes <= 61), 3);
+  UCSA_CHECK_ARG(range_bits, 4);
+  UCSA_CHECK_ARG(scratch, 5);
+  const uint32_t n_total = ucsa_mlp_pack_f16_halves(kind, n_classes);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_mlp_pack_h2, dim3(ucsa_div_up(n_total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (int)kind, params, (_Float16*)packed_h2,
+                     n_total, range_bits, scratch);
   return ucsa_launch_status();
 }
 

@@ -103,11 +103,12 @@ class JointTrainLightningNet(nn.Module):
         # raise instead of turning into zeros (network_tcnn_semantics.py)
         if "h2_guard" in nerf_cfg:
             self.nerf_model.h2_guard = str(nerf_cfg["h2_guard"])
-        # `nerf: {joint_overlap: false}`: the joint step on one stream (default:
-        # renders || pseudo-label forward, NeRF updates || DeepLab step on two
-        # streams, training_step_joint); UCSA_JOINT_OVERLAP sets the default
+        # `nerf: {joint_overlap: true}` / UCSA_JOINT_OVERLAP=1: the joint step's
+        # independent halves on two streams (training_step_joint).  OFF by
+        # default: measured SLOWER (R-101: 177 -> 187 ms) -- every kernel of either
+        # half fills the chip, co-scheduling them only makes them contend
         self.joint_overlap = bool(nerf_cfg.get(
-            "joint_overlap", os.environ.get("UCSA_JOINT_OVERLAP", "1") != "0"))
+            "joint_overlap", os.environ.get("UCSA_JOINT_OVERLAP", "0") == "1"))
         self._joint_side = None
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
@@ -481,8 +482,9 @@ class JointTrainLightningNet(nn.Module):
     def training_step_joint(self, batch):
         """reference :363-471.
 
-        Round 5: the step's independent halves run on two streams
-        (`nerf: {joint_overlap: false}` / UCSA_JOINT_OVERLAP=0: one stream).  The
+        Round 5: the step's independent halves CAN run on two streams
+        (`nerf: {joint_overlap: true}` / UCSA_JOINT_OVERLAP=1; off by default:
+        measured slower, 177 -> 187 ms on the R-101 step, see __init__).  The
         reference's data flow (:363-461): the renders of the new-scene frames read
         the NeRF, the pseudo-label forward reads DeepLab -- independent; the NeRF
         updates need the pseudo-labels and must follow the renders (they write

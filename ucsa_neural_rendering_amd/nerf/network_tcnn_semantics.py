@@ -315,6 +315,8 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
         self._h2_pending = []
         self._h2_seen, self._h2_pinned, self._h2_slot, self._h2_stream = {}, None, -1, None
         self._h2_eval_pending = False
+        self._h2_flags = {}
+        self._h2_scratch = {}
         # reproducibility mode: the hash-grid gradient through an
         # order-independent fixed-point reduction instead of float atomics / bin
         # records -- two runs of a training step then give the same bits.  ~8 x
@@ -327,14 +329,14 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
         (gigabytes of scratch) and pinned read-back slots should not be."""
         st = dict(self.__dict__)
         st.update(_h2_pending=[], _h2_pinned=None, _h2_stream=None, _h2_slot=-1,
-                  _h2_eval_pending=False, _side_streams=[], _ws=None)
+                  _h2_eval_pending=False, _h2_flags={}, _h2_scratch={}, _h2_seen={}, _side_streams=[],
+                  _ws=None)
         return st
 
     # f16x2's first terms are f16 and ucsa_mlp_pack_h2 stores the last layer
     # times 2^4: a weight of 65504 / 16 or more becomes inf, the two partial sums
     # give inf - inf = NaN and a NaN pre-activation passes ReLU as 0 -- silently
     # (csrc/mfma_mlp_h2.h).  The guard makes that loud.
-    H2_WEIGHT_LIMIT = 65504.0 / 16.0
     H2_INPUT_LIMIT = 65504.0
     H2_HIDDEN_LIMIT = float(2 ** 20)
 
@@ -346,78 +348,61 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
 
     def _h2_fail(self, name: str, amax: float):
         raise _lib.UcsaError(
-            f"f16x2 nets: max|weight| of the {name} net is {amax!r}, outside the range of "
-            f"precision 'f16x2' (|w| < {self.H2_WEIGHT_LIMIT:g}, finite; csrc/mfma_mlp_h2.h): "
-            "the kernels would turn the overflow into zeros silently.  Use "
-            "nerf: {precision: bf16x3} (fp32 range) for this field.")
+            f"f16x2 nets: the {name} net holds a weight that packs to {amax!r} (first / last "
+            "layer scaled by 2^-4 / 2^4), outside the range of precision 'f16x2' (< 65504, "
+            "finite; csrc/mfma_mlp_h2.h): the kernels would turn the overflow into zeros "
+            "silently.  Use nerf: {precision: bf16x3} (fp32 range) for this field.")
+
+    H2_BITS_LIMIT = 0x477FE000     # 65504.0f as an fp32 bit pattern
+
+    def _h2_flag(self, name: str, device):
+        """The net's range word: ONE int32 of pinned host memory that the device
+        addresses directly (ucsa_mlp_pack_h2_checked raises it with a system-scope
+        atomic max, nothing lowers it).  The host reads it like any memory."""
+        f = self._h2_flags.get(name)
+        if f is None:
+            f = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._h2_flags[name] = f
+        return f
 
     def _h2_poll(self, block: bool = False):
-        """Raise for any finished weight check that found an out-of-range net."""
-        keep = []
-        for name, host, ev in self._h2_pending:
-            if block:
-                ev.synchronize()
-            if ev.query():
-                a = float(host[0])
-                if not a < self.H2_WEIGHT_LIMIT:      # also NaN
-                    self._h2_pending = []
-                    self._h2_fail(name, a)
-            else:
-                keep.append((name, host, ev))
-        self._h2_pending = keep
+        """Raise if a net's range word shows an out-of-range pack.  ``block``:
+        wait for the device first, so that every pack launched so far is in."""
+        if block and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for name, f in self._h2_flags.items():
+            bits = int(f[0]) & 0xFFFFFFFF
+            if bits >= self.H2_BITS_LIMIT:
+                import struct
+                f.zero_()                      # reported once: both words start over
+                if name in self._h2_scratch:
+                    self._h2_scratch[name].zero_()
+                self._h2_fail(name, struct.unpack("<f", struct.pack("<I", bits))[0])
 
-    def _h2_check_weights(self, name: str, p):
-        """One reduce per refreshed pack, never a device synchronisation HERE: the
-        maximum goes to a pinned slot through a side stream and is looked at
-        later.  No-grad renders (packs are rare): at the END of the render call
-        that refreshed the pack (``_h2_finish_render``: the error is raised before
-        any output is handed back).  Training (a pack per net and step): the first
-        pack and then every 16th one of a net, looked at when a later pack is made
-        -- weights move by <= lr per step, 16 steps cannot carry a net from |w| ~ 1
-        to 4094 unseen, and a non-finite value reaches the check through the next
-        sampled pack.  Why so careful: a blocking read-back between the pack
-        launches made every LATER training step of the process 0.15 ms (4 %)
-        slower, a synchronisation after the render does not (round 5, measured
-        A/B in alternation; kernel durations are unchanged, the step's launch
-        pacing is not)."""
-        training = self.training and torch.is_grad_enabled()
-        if training:
-            # (the training step is paced by the host as much as by the GPU: on
-            # 15 of 16 packs nothing but this counter is touched)
-            n = self._h2_seen.get(name, 0)
-            self._h2_seen[name] = n + 1
-            if n % 16 != 0 and not (n % 16 == 1 and self._h2_pending):
-                return
-        if self._h2_guard_mode() == "off" or torch.cuda.is_current_stream_capturing():
-            return
-        if training:
-            self._h2_poll()
-            if n % 16 != 0:
-                return
-        if self._h2_pinned is None:
-            self._h2_pinned = torch.empty(64, dtype=torch.float32, pin_memory=True)
-        k = self._h2_slot = (self._h2_slot + 1) % 64
-        host = self._h2_pinned[k:k + 1]
-        amax = torch.linalg.vector_norm(p.detach(), ord=float("inf")).reshape(1)
-        if self._h2_stream is None or self._h2_stream.device != p.device:
-            self._h2_stream = torch.cuda.Stream(device=p.device)
-        ready = torch.cuda.Event()
-        ready.record()
-        amax.record_stream(self._h2_stream)
-        with torch.cuda.stream(self._h2_stream):
-            self._h2_stream.wait_event(ready)
-            host.copy_(amax, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        self._h2_pending.append((name, host, ev))
-        if not training:
+    def _h2_read(self, name: str):   # (kept for callers of the earlier interface)
+        return None
+
+    def _h2_after_pack(self, name: str):
+        """The range guard's host side (`h2_guard: weights`, the default).  The
+        pack kernel itself keeps the largest |value| it converted to f16 in the
+        net's word in pinned host memory -- no launch, allocation, copy, stream,
+        event or wait per pack (round 5 measured every one of those: a blocking
+        read between the pack launches made each later training step of the
+        process 0.15 ms slower; a norm + copy per pack, and even one more stream in
+        the process, the joint step 177 -> 231-245 ms).  The word only grows and
+        the host can read it at any time: it looks at every pack (a memory read; a
+        pack launched a few steps ago has landed by then), and a net packed for
+        the FIRST time in this process -- a loaded checkpoint -- is judged before
+        its first render returns (``_h2_finish_render``)."""
+        n = self._h2_seen.get(name, 0)
+        self._h2_seen[name] = n + 1
+        self._h2_poll()
+        if n == 0 and not (self.training and torch.is_grad_enabled()):
             self._h2_eval_pending = True
-        if len(self._h2_pending) > 32:   # never grow without bound (64 slots)
-            self._h2_poll(block=True)
 
     def _h2_finish_render(self):
-        """End of a no-grad render: if this call refreshed an f16x2 pack, wait for
-        its range check and raise before the outputs are returned."""
+        """End of a no-grad render that packed a net for the first time: wait for
+        the device and raise before the outputs are returned."""
         if self._h2_eval_pending:
             self._h2_eval_pending = False
             self._h2_poll(block=True)
@@ -537,9 +522,15 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
         hit = self._packed.get(name + "_h2")
         if hit is None or hit[0] != key or hit[1].device != p.device:
             out = None if hit is None or hit[1].device != p.device else hit[1]
-            self._h2_check_weights(name, p)
-            packed = ops.mlp_pack_h2(net.kind, p, self.num_semantic_classes, out=out)
+            guard = self._h2_guard_mode() != "off"
+            if guard and (name not in self._h2_scratch or self._h2_scratch[name].device != p.device):
+                self._h2_scratch[name] = torch.zeros(2, dtype=torch.int32, device=p.device)
+            packed = ops.mlp_pack_h2(net.kind, p, self.num_semantic_classes, out=out,
+                                     range_bits=self._h2_flag(name, p.device) if guard else None,
+                                     scratch=self._h2_scratch.get(name) if guard else None)
             self._packed[name + "_h2"] = (key, packed)
+            if guard:
+                self._h2_after_pack(name)
         return self._packed[name + "_h2"][1]
 
     def _pack_t_x3(self, name: str, net: FullyFusedMLP):

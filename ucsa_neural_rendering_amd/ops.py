@@ -463,13 +463,25 @@ def mlp_pack_x3(kind: int, params: torch.Tensor, n_classes: int = 0,
 
 
 def mlp_pack_h2(kind: int, params: torch.Tensor, n_classes: int = 0,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None,
+                range_bits: Optional[torch.Tensor] = None,
+                scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weights as two f16 terms per value (the second scaled by 2^11) in MFMA
-    fragment order (csrc/mfma_mlp_h2.h, "f16x2")."""
+    fragment order (csrc/mfma_mlp_h2.h, "f16x2").  ``range_bits`` (int32 [1] in
+    pinned host or device memory, zeroed by the caller) accumulates the largest
+    |value| converted to f16 as an fp32 bit pattern; ``scratch``: int32 [2] on
+    the device, zeroed once (ucsa_mlp_pack_h2_checked)."""
     params = _f32(params.detach(), "params")
     n = int(lib().ucsa_mlp_pack_h2_bytes(kind, n_classes))
     if out is None:
         out = torch.empty(n // 2, dtype=torch.float16, device=params.device)
+    if range_bits is not None:
+        if scratch is None or not scratch.is_cuda or scratch.numel() < 2:
+            raise UcsaError("mlp_pack_h2: range_bits needs a 2-word int32 device scratch")
+        check(lib().ucsa_mlp_pack_h2_checked(kind, _ptr(params), _ptr(out), n_classes,
+                                             _ptr(range_bits), _ptr(scratch), _stream()),
+              "ucsa_mlp_pack_h2_checked")
+        return out
     check(lib().ucsa_mlp_pack_h2(kind, _ptr(params), _ptr(out), n_classes,
                                  _stream()), "ucsa_mlp_pack_h2")
     return out
