@@ -103,6 +103,9 @@ def _train(exp, env, args, rank, local_rank, world, model_path):
 
     kw = dict(default_root_dir=model_path if rank == 0 else None,
               limit_batches=args.limit_batches,
+              # `trainer: {prefetch: N}`: batches produced by a background thread
+              # (the reference's DataLoader workers; lightning/trainer.py)
+              prefetch=int(exp["trainer"].get("prefetch", 0) or 0),
               device=f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu")
     trainer_nerf = Trainer(max_epochs=args.nerf_train_epoch, **kw)
     trainer_joint = Trainer(max_epochs=args.joint_train_epoch,

@@ -78,6 +78,24 @@ for seed in [int(x) for x in os.environ.get("SEEDS", "3,4,7,8,9,10").split(",")]
             hs = outs[prec]["semantics"][0, gi].cpu().double()
             print(f"    HIP {prec:7s}: max |sem - oracle32| {float((hs - sem32).abs().max()):.3e}   max |sem - oracle64nets| {float((hs - sem64).abs().max()):.3e}"
                   f"   img err {float((outs[prec]['image'][0, gi].cpu() - c32['image']).abs().max()):.2e}")
+        # per sample: the HIP field (fp32 pointwise ops) on the ORACLE's sample positions
+        net.precision = "fp32"
+        with torch.no_grad():
+            den = net.density(xyz.reshape(-1, 3).to(dev))
+            hp = net.semantics(xyz.reshape(-1, 3).to(dev), dirs.float().to(dev), geo_feat=den["geo_feat"])
+        d_sig = (den["sigma"].cpu() - sigma.reshape(-1)).abs() / sigma.reshape(-1).abs().clamp_min(1e-12)
+        d_geo = (den["geo_feat"].cpu() - geo.reshape(S, -1)).abs().max(-1)[0]
+        d_p = (hp.cpu().double() - p64).abs().max(-1)[0]
+        contrib = w * (hp.cpu().double() - p64).abs().max(-1)[0]
+        j = int(contrib.argmax())
+        print(f"    HIP field on the oracle's positions: max rel |d sigma| {float(d_sig.max()):.2e}, max |d geo| {float(d_geo.max()):.2e}, "
+              f"max |d p| {float(d_p.max()):.2e}; largest w*|dp| at sample {j}: w {float(w[j]):.3e} dp {float(d_p[j]):.3e} "
+              f"|d geo| {float(d_geo[j]):.2e} z {float(z[0, j]):.5f}; sum_s w*dp (signed, class argmax) "
+              f"{float((w[:, None] * (hp.cpu().double() - p64)).sum(0).abs().max()):.3e}")
+        zz = z[0]
+        gaps = (zz[1:] - zz[:-1])
+        print(f"    smallest gaps between sorted depths: {[float(x) for x in gaps.topk(3, largest=False).values]}; "
+              f"z[-3:] {[float(x) for x in zz[-3:]]}")
         k = int((outs["f16x2"]["semantics"][0, gi].cpu().double() - sem32).abs().argmax())
         contrib = (w * p64[:, k])
         top = torch.topk(contrib, 4)

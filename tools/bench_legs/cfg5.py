@@ -90,6 +90,8 @@ def main_cfg5(args, dev, dist, world, rank, backend):
     if args.seg_amp:
         exp["model"]["amp"] = args.seg_amp
     exp["nerf"]["precision"] = args.nerf_precision
+    if os.environ.get("UCSA_CFG5_PREFETCH"):       # `trainer: {prefetch: N}` (lightning/trainer.py)
+        exp["trainer"]["prefetch"] = int(os.environ["UCSA_CFG5_PREFETCH"])
     exp["trainer"]["cudnn_benchmark"] = (True if args.seg_find else
                                          False if args.no_seg_find else None)
     if exp["trainer"]["cudnn_benchmark"] is None:
@@ -220,6 +222,7 @@ def main_cfg5(args, dev, dist, world, rank, backend):
             "nerf_epochs": args.nerf_epochs, "joint_epochs": args.joint_epochs,
             "frames_per_scene": args.frames, "seg_precision": args.seg_amp or "fp32",
             "nerf_render_nets": args.nerf_precision,
+            "trainer_prefetch": int(exp["trainer"].get("prefetch", 0) or 0),
         },
         "seg_pretraining": pre,
         "quality": {"final_stage": final,

@@ -81,7 +81,7 @@ class Trainer:
 
     def __init__(self, max_epochs=1, default_root_dir=None, logger=None,
                  callbacks=None, check_val_every_n_epoch=1, device=None,
-                 limit_batches=None, **unused):
+                 limit_batches=None, prefetch=0, **unused):
         self.max_epochs = int(max_epochs)
         self.root = default_root_dir
         self.logger = logger or JsonlLogger(default_root_dir)
@@ -89,6 +89,14 @@ class Trainer:
         self.device = torch.device(device or (
             "cuda" if torch.cuda.is_available() else "cpu"))
         self.limit_batches = limit_batches
+        # `trainer: {prefetch: N}`: the next N batches are produced (PNG decode,
+        # device rays, replay augmentation, host -> device copies) by a background
+        # thread while the current step runs -- the role of the reference's
+        # DataLoader workers (cfg `num_workers`), which cannot be forked here: the
+        # datasets work on the device.  Off by default: the loader's random draws
+        # then interleave with the step's on the shared generator (as with worker
+        # processes, runs are no longer reproducible draw for draw).
+        self.prefetch = int(prefetch or 0)
         self.current_epoch = 0
         self.global_step = 0
 
@@ -120,11 +128,57 @@ class Trainer:
     def _loaders(self, dl):
         return dl if isinstance(dl, (list, tuple)) else [dl]
 
-    def _batches(self, loader, limited=True):
+    def _batches_serial(self, loader, limited=True):
         for i, b in enumerate(loader):
             if limited and self.limit_batches is not None and i >= self.limit_batches:
                 break
             yield i, self._to_device(b)
+
+    def _batches(self, loader, limited=True):
+        if self.prefetch <= 0:
+            yield from self._batches_serial(loader, limited)
+            return
+        import queue
+        import threading
+        q, done, failed = queue.Queue(maxsize=self.prefetch), object(), []
+        stop = threading.Event()
+
+        def work():
+            try:
+                if self.device.type == "cuda":
+                    torch.cuda.set_device(self.device)     # thread-local in HIP
+                for item in self._batches_serial(loader, limited):
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the consumer
+                failed.append(e)
+            finally:
+                while True:
+                    try:
+                        q.put(done, timeout=0.2)
+                        break
+                    except queue.Full:
+                        if stop.is_set():
+                            break
+
+        t = threading.Thread(target=work, name="ucsa-prefetch", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    break
+                yield item
+        finally:
+            stop.set()
+        if failed:
+            raise failed[0]
 
     def _flush_logs(self):
         flush = getattr(self.logger, "flush", None)
