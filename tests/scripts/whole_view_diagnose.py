@@ -92,6 +92,30 @@ for seed in [int(x) for x in os.environ.get("SEEDS", "3,4,7,8,9,10").split(",")]
               f"max |d p| {float(d_p.max()):.2e}; largest w*|dp| at sample {j}: w {float(w[j]):.3e} dp {float(d_p[j]):.3e} "
               f"|d geo| {float(d_geo[j]):.2e} z {float(z[0, j]):.5f}; sum_s w*dp (signed, class argmax) "
               f"{float((w[:, None] * (hp.cpu().double() - p64)).sum(0).abs().max()):.3e}")
+        # the HIP pipeline on this ONE ray, stage by stage (fp32 ops), against the oracle's
+        fpk = net._field()
+        ro_, rd_, rn_ = oc[0, gi:gi + 1].to(dev), dc[0, gi:gi + 1].to(dev), nc[0, gi:gi + 1].to(dev).reshape(1)
+        aabb_l = net._aabb_list(False)
+        with torch.no_grad():
+            nr, fr = ops.near_far_from_aabb(ro_, rd_, aabb_l, 0.2)
+            zc_h = ops.sample_coarse(nr, fr, T)
+            hc_h, sc_h = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(fpk["grid"], fpk["table"], ro_, rd_, zc_h, aabb_l), fpk["packed_sigma"])
+            zf_h = ops.resample(zc_h, sc_h.view(1, T), uc[gi:gi + 1].to(dev), 1.0)
+            hf_h, sf_h = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(fpk["grid"], fpk["table"], ro_, rd_, zf_h, aabb_l), fpk["packed_sigma"])
+            im_h, dp_h, se_h, src_h, w_h = ops.composite_fwd(rd_, rn_, zc_h, sc_h.view(1, T), hc_h, zf_h, sf_h.view(1, t), hf_h,
+                                                           fpk["packed_color"], fpk["packed_sem"], 40, 1.0, want_aux=True)
+        zcat = torch.cat([zc_h, zf_h], 1)[0].cpu()
+        z_hip = zcat[src_h[0].long().cpu()]
+        w_hip = w_h[0].cpu()
+        print(f"    single-ray HIP (fp32, ray-ordered): sem vs oracle32 {float((se_h[0].cpu().double() - sem32).abs().max()):.3e}, "
+              f"vs the view's render {float((se_h[0].cpu() - outs['fp32']['semantics'][0, gi].cpu()).abs().max()):.3e}")
+        print(f"    coarse z max |d| {float((zc_h[0].cpu() - ro.zc[0]).abs().max()):.2e}; sorted z max |d| {float((z_hip - z[0]).abs().max()):.2e}; "
+              f"weights max |d| {float((w_hip - weights).abs().max()):.3e} at sample {int((w_hip - weights).abs().argmax())}; "
+              f"masks differ at {[int(i) for i in torch.nonzero((w_hip > 1e-4) != (weights > 1e-4)).flatten()]}")
+        dw = (w_hip - weights)
+        for i in dw.abs().topk(4).indices.tolist():
+            print(f"      sample {i}: z hip {float(z_hip[i]):.6f} oracle {float(z[0, i]):.6f}  w hip {float(w_hip[i]):.6e} oracle {float(weights[i]):.6e}  "
+                  f"sigma oracle {float(sigma[0, i]):.4f}  p(class k) oracle {float(p64[i, int((se_h[0].cpu().double() - sem32).abs().argmax())]):.4f}")
         zz = z[0]
         gaps = (zz[1:] - zz[:-1])
         print(f"    smallest gaps between sorted depths: {[float(x) for x in gaps.topk(3, largest=False).values]}; "

@@ -481,7 +481,7 @@ k_sigma_mlp_x3(const float2* __restrict__ feat, const void* __restrict__ packed,
 __global__ void __launch_bounds__(256)
 k_sigma_mlp_h2(const float2* __restrict__ feat, const void* __restrict__ packed,
                uint64_t M, float* __restrict__ h, float* __restrict__ sigma,
-               const uint32_t* __restrict__ slot, int exp_mode = 0) {
+               const uint32_t* __restrict__ slot) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane >> 4, j = lane & 15u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -515,9 +515,8 @@ k_sigma_mlp_h2(const float2* __restrict__ feat, const void* __restrict__ packed,
       const uint64_t m = base + sb * 16 + j;
       if (m < M) {
         const uint64_t mo = slot ? slot[m] : m;   // see k_sigma_mlp (mlp.hip)
-        const uint64_t mh = exp_mode == 1 ? m : mo;
-        *reinterpret_cast<f32x4*>(h + mh * 16 + 4 * g) = out;
-        if (g == 0) sigma[exp_mode == 2 ? m : mo] = expf(out[0]);
+        *reinterpret_cast<f32x4*>(h + mo * 16 + 4 * g) = out;
+        if (g == 0) sigma[mo] = expf(out[0]);
       }
     }
   }
@@ -537,7 +536,7 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_h2(const float* feat,
   UCSA_CLEAR_ERR();
   hipLaunchKernelGGL(k_sigma_mlp_h2, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)feat, packed_sigma_h2,
-                     (uint64_t)M, h, sigma, (const uint32_t*)nullptr, 0);
+                     (uint64_t)M, h, sigma, (const uint32_t*)nullptr);
   return ucsa_launch_status();
 }
 
@@ -595,8 +594,7 @@ extern "C" int32_t ucsa_sigma_mlp_fwd_scatter(int32_t mode, const void* feat,
                          (const float2*)feat, packed_sigma, (uint64_t)M, h, sigma, slot);
     else
       hipLaunchKernelGGL(k_sigma_mlp_h2, g, dim3(256), 0, (hipStream_t)stream,
-                         (const float2*)feat, packed_sigma, (uint64_t)M, h, sigma, slot,
-                         getenv("UCSA_SCATTER_EXP") ? atoi(getenv("UCSA_SCATTER_EXP")) : 0);
+                         (const float2*)feat, packed_sigma, (uint64_t)M, h, sigma, slot);
   }
   return ucsa_launch_status();
 }

@@ -312,8 +312,7 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
         # the activations of a sample of every no-grad render, "off" nothing.
         # UCSA_H2_GUARD overrides.
         self.h2_guard = "weights"
-        self._h2_pending = []
-        self._h2_seen, self._h2_pinned, self._h2_slot, self._h2_stream = {}, None, -1, None
+        self._h2_seen = {}
         self._h2_eval_pending = False
         self._h2_flags = {}
         self._h2_scratch = {}
@@ -328,9 +327,8 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
         behind -- streams and events cannot be copied, and the render workspaces
         (gigabytes of scratch) and pinned read-back slots should not be."""
         st = dict(self.__dict__)
-        st.update(_h2_pending=[], _h2_pinned=None, _h2_stream=None, _h2_slot=-1,
-                  _h2_eval_pending=False, _h2_flags={}, _h2_scratch={}, _h2_seen={}, _side_streams=[],
-                  _ws=None)
+        st.update(_h2_eval_pending=False, _h2_flags={}, _h2_scratch={}, _h2_seen={},
+                  _side_streams=[], _ws=None)
         return st
 
     # f16x2's first terms are f16 and ucsa_mlp_pack_h2 stores the last layer
@@ -378,9 +376,6 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
                 if name in self._h2_scratch:
                     self._h2_scratch[name].zero_()
                 self._h2_fail(name, struct.unpack("<f", struct.pack("<I", bits))[0])
-
-    def _h2_read(self, name: str):   # (kept for callers of the earlier interface)
-        return None
 
     def _h2_after_pack(self, name: str):
         """The range guard's host side (`h2_guard: weights`, the default).  The
