@@ -287,8 +287,7 @@ def encoder_roofline(st, chunk, pretrain_steps):
     enc_ms = 0.5 * (st["encode_c"] + st["encode_f"])
     enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
     r = {"kernel": "hash-grid encoder, one density pass = 2 launches: k_hashgrid_encode_tiled + "
-                   "_tiled_ml (coarse samples) / k_hashgrid_encode_sorted + _sorted_ml "
-                   "(depth-ordered fine samples)",
+                   "_tiled_ml (coarse) / k_hashgrid_encode_sorted + _sorted_ml (fine, depth-ordered)",
          "bound": "hbm", "achieved": enc_gbs,
          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
          "traffic": None, "launch_ms": enc_ms, "algorithmic_bytes_per_launch": enc_bytes,

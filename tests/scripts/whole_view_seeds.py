@@ -14,7 +14,9 @@ for seed in [int(x) for x in os.environ.get("SEEDS", "1,2,3,4,5,6").split(",")]:
             t.test_cfg2_whole_view_f16x2_every_ray_against_the_oracle()
         print(f"seed {seed}: PASS  " + buf.getvalue().strip().splitlines()[-1], flush=True)
     except AssertionError as e:
+        import traceback
         lines = buf.getvalue().strip().splitlines()
-        print(f"seed {seed}: FAIL  {str(e)[:1500]}", flush=True)
-        for l in lines[-12:]:
-            print("    " + l[:300])
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        print(f"seed {seed}: FAIL at {tb.filename.split('/')[-1]}:{tb.lineno} `{tb.line}`  {str(e)[:600]}", flush=True)
+        for l in lines[-6:]:
+            print("    " + l[:400])

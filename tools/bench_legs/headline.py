@@ -55,7 +55,7 @@ def headline(result: dict, text: int = 300) -> dict:
     roof = result.get("roofline")
     if roof:
         r = {k: roof[k] for k in ROOFLINE_KEYS if k in roof}
-        r["kernel"] = _short(r.get("kernel"), 120)
+        r["kernel"] = _short(r.get("kernel"), 200)
         r.setdefault("traffic", None)
         b = roof.get("binding_resource")
         if b:
