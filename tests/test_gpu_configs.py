@@ -130,26 +130,28 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
         print("   TAIL " + line)
     assert n == H * W
     assert loose <= 0.005 * n, (loose, n)     # >= 99.5 % of the view's rays within the stated tolerance
-    # The match tolerance is a PERCENTILE of the view's ordinary error (twice its
-    # p99.5, parity_check.alt_tolerances): of the ~550 loose rays of a view a few
-    # sit in the tail of that distribution.  Measured over 16 fields
-    # (profiles/r05_whole_view_tail.txt): 0 or 1 ray per view, of two kinds --
-    # (i) marginal: 2.75e-5 / 3.24e-5 / 3.5e-5 of residual against a tolerance of
-    # 2.1e-5 / 3.2e-5 / 2.0e-5 once the ray's mask flip is accounted for (rays whose
-    # last sample carries ~0.55 of the weight at class probability 1.0: transmittance
-    # round-off of that one weight);  (ii) three semantics-only residuals of 7e-5 ...
-    # 1.15e-4 next to image / depth residuals of 3e-6: all three HIP arithmetics agree
-    # with each other to 1e-5 on such a ray, and the HIP FIELD evaluated on the
-    # oracle's own sample positions agrees with the oracle to |sum w dp| = 9e-9 --
-    # so it is neither the nets nor the encoder but the placement / weight of a
-    # sample (a pair of fine samples 3e-5 apart at depth 5: 1.6 % of round-off in
-    # its interval -- beyond the 2 % cap of the candidate window when the pair is
-    # closer still) that no single-decision alternative models.  Open; bounded below.
-    # (Inside the full suite the test still failed 2 runs of 5 with "at most 3, each
-    # within twice the tolerance" -- on fields the standalone scripts did not draw,
-    # 21 of which gave 0 or 1 such ray; the suite's log kept only the test name.
-    # The bound is therefore 8 rays = 2.6e-5 of the view, each inside the hard cap
-    # that check_render asserts for EVERY ray, and every one of them is printed.)
+    # The handful that matches no alternative (profiles/r05_whole_view_tail.txt, 40
+    # fields): 0-2 rays per view, of two kinds --
+    # (i) marginal: a mask flip accounts for the ray down to a residual of 2.2e-5 ...
+    # 3.5e-5 against a match tolerance of 2.0e-5 ... 3.2e-5 (the tolerance is a
+    # PERCENTILE of the view's ordinary error: of ~550 loose rays one in its tail is
+    # expected every second view), or the flipped sample sat 1.3 % from the threshold
+    # against a window of 1.29 %;
+    # (ii) semantics-only residuals of 7e-5 ... 1.7e-4 next to 3e-6 in image and
+    # depth, on rays whose LAST sample carries ~0.53 of the weight at class
+    # probability 1.0000: all three HIP arithmetics agree with each other to 1e-5 on
+    # such a ray, and the HIP FIELD evaluated on the oracle's own sample positions
+    # agrees with the oracle to |sum w dp| = 9e-9 -- neither the nets nor the
+    # encoder; not a depth moved within its round-off either (parity_check
+    # ._depth_jitter explains none of them).  OPEN.
+    # Until the window had a floor at the render's own error level (parity_check
+    # .window_floor, round 5) a third kind existed: on fields with ~1200 loose rays
+    # (haze: many weights of 1e-4 behind empty space) up to 7 single flips of a
+    # p = 1.0 sample, error 1.00e-4 ... 1.02e-4, had NO candidate in the depth-only
+    # window -- that is what failed 2 runs in 5 of the suite.  With the floor: 0 or 1
+    # tail ray on 8 further views, two of them such fields (1239 / 842 loose rays).
+    # Bound: at most 8 rays = 2.6e-5 of the view, each inside the hard cap that
+    # check_render asserts for EVERY ray, every one of them printed.
     assert len(tail) <= 8, [x[0] for x in tail]
     for line, resid, errs in tail:
         assert errs[0] <= pc.CAP_ABS and errs[1] <= pc.CAP_ABS and errs[2] <= pc.CAP_DEPTH_REL, line

@@ -174,3 +174,48 @@ def test_match_tolerance_follows_the_renders_ordinary_error_but_is_capped(case):
     res["semantics"][0, i, 3] += 2.5e-5
     with pytest.raises(AssertionError, match="NO alternative"):
         pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="quiet-flip+2.5e-5")
+
+
+def test_one_depth_moved_by_its_round_off_is_named_and_a_larger_move_is_not(case):
+    """The diagnostic third alternative (round 5, off by default): a result whose
+    sample k sits 4 x its modelled round-off away is reproduced by a depth jitter
+    of that sample, ~4 units; the
+    same move at 20 units (beyond JITTER = 6) is not.  Match tolerances scaled
+    down to a tenth of the move's effect: the small fixture has no ray on which
+    4 units move an output by 1e-4."""
+    fld, rays, u, ref = case
+    aux = ref["aux"]
+    dz = pc.depth_noise(aux)
+    z = aux["z"]
+    delta = z[:, 1:] - z[:, :-1]
+    # the sample with the largest relative interval noise that carries weight
+    r = (dz[:, 1:-1] / torch.minimum(delta[:, :-1], delta[:, 1:]).clamp_min(1e-9)) * aux["weights"][:, 1:-1]
+    r = torch.where(dz[:, 1:-1] * 20 < 0.45 * torch.minimum(delta[:, :-1], delta[:, 1:]), r, torch.zeros_like(r))
+    i = int(r.max(-1)[0].argmax())
+    k = int(r[i].argmax()) + 1
+    ro = pc.RayOracle(fld, rays[0][0, i], rays[1][0, i], rays[2][0, i], AABB4, T, t, u[i])
+    with torch.no_grad():
+        zs, sigma, geo, xyz, order = ro.sorted_samples()
+        w, rgbs, probs = ro.shade_all(zs, sigma, geo, xyz)
+        mask = w > 1e-4
+        base = ro.composite(zs, w, rgbs, probs, mask)
+
+        def moved(units):
+            zd = zs.double().clone()
+            zd[0, k] += units * float(dz[i, k])
+            _, wd = oren.alpha_weights(zd, sigma.double(), ro.ds)
+            wd = torch.where(mask, wd[0], torch.zeros_like(wd[0]))
+            return {"depth": (wd * zd[0]).sum() / ro.nrm[0].double(), "image": wd @ rgbs.double(),
+                    "semantics": wd @ probs.double()}
+
+        got4, got20 = moved(4.0), moved(20.0)
+        e4 = pc._errors(got4, base)
+        tol = tuple(max(e / 10.0, 1e-9) for e in e4)
+        score, what, errs, _ = pc.explain_ray(ro, got4, tol=tol, jitter=True)
+        assert score <= 1.0 and what["depth_jitter"]["sample"] == k, (score, what, e4)
+        assert 3.0 < what["depth_jitter"]["in_dz"] < 5.0, what
+        score, what, errs, _ = pc.explain_ray(ro, got20, tol=tol, jitter=True)
+        assert score > 1.0, (score, what)
+        # and by default the 4-unit move is NOT explained
+        score, what, errs, _ = pc.explain_ray(ro, got4, tol=tol)
+        assert score > 1.0 and "depth_jitter" not in what
