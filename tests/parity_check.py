@@ -185,15 +185,19 @@ class RayOracle:
             self.z_mid = self.zc[:, :-1] + 0.5 * deltas[:, :-1]
             self.w_c = w
 
-    def sorted_samples(self, denom_flip=None):
+    def sorted_samples(self, denom_flip=None, shift=None):
         """(z, sigma, geo, xyz) of the merged, sorted samples; ``denom_flip``:
-        indices of fine samples placed by the other branch of the denom step."""
+        indices of fine samples placed by the other branch of the denom step;
+        ``shift`` {fine sample: eps}: those fine samples moved by eps along the ray
+        (the field is re-evaluated there)."""
         if self.t == 0:
             return self.zc, self.sig_c, self.geo_c, self.xyz_c, None
         flip = torch.zeros(1, self.t, dtype=torch.bool)
         for j in (denom_flip or ()):
             flip[0, j] = True
         new_z = _inverse_cdf_flipped(self.z_mid, self.w_c[:, 1:-1], self.u, flip)
+        for j, eps in (shift or {}).items():
+            new_z[0, j] = (new_z[0, j].double() + eps).float()
         new_xyz = oren.positions(self.o, self.d, new_z, self.aabb)
         den2 = self.fld.density(new_xyz.reshape(-1, 3))
         z = torch.cat([self.zc, new_z], 1)
@@ -261,7 +265,6 @@ def explain_ray(ro: RayOracle, got, window_fn=None, tol=(ALT_ABS, ALT_ABS, ALT_R
         best = (float("inf"), None, None)
         n_alt = 0
         nearest = []
-        stage2 = []
         for kd in range(len(denom_cand) + 1):
             for dflip in itertools.combinations(denom_cand, kd):
                 z, sigma, geo, xyz, order = ro.sorted_samples(dflip)
@@ -286,22 +289,17 @@ def explain_ray(ro: RayOracle, got, window_fn=None, tol=(ALT_ABS, ALT_ABS, ALT_R
                         ei, es, ed = _errors(got, alt)
                         score = max(ei / tol[0], es / tol[1], ed / tol[2])
                         n_alt += 1
-                        if len(tog) <= 1 and not dflip:
-                            stage2.append((list(tog), z, sigma, rgbs, probs, mask, aux))
                         if score < best[0]:
                             best = (score, {"denom_flipped": list(dflip), "mask_toggled": list(tog),
                                             "toggled_weights": [float(weights[s]) for s in tog]},
                                     (ei, es, ed))
-        if best[0] > 1.0 and jitter:
-            for tog, z, sigma, rgbs, probs, mask, aux in stage2:
-                for score, k, eps, units, errs in _depth_jitter(ro, z, sigma, rgbs, probs, mask,
-                                                                depth_noise(aux)[0], got, tol):
-                    n_alt += 1
-                    if score < best[0]:
-                        best = (score, {"denom_flipped": [], "mask_toggled": tog,
-                                        "toggled_weights": [],
-                                        "depth_jitter": {"sample": k, "eps": eps, "in_dz": round(units, 2)}},
-                                errs)
+        if best[0] > 1.0 and jitter and ro.t > 0:
+            for score, j, eps, units, errs in _moved_fine_sample(ro, got, tol):
+                n_alt += 1
+                if score < best[0]:
+                    best = (score, {"denom_flipped": [], "mask_toggled": [], "toggled_weights": [],
+                                    "moved_fine_sample": {"sample": j, "eps": eps, "in_dz": round(units, 2)}},
+                            errs)
         best[1]["nearest_w_win"] = [(round(a * 1e4, 4), round(b * 1e4, 4)) for a, b in nearest]
         return best + (n_alt,)
 
@@ -309,55 +307,69 @@ def explain_ray(ro: RayOracle, got, window_fn=None, tol=(ALT_ABS, ALT_ABS, ALT_R
 JITTER = 6.0        # the same multiple of the modelled round-off as the mask window
 
 
-def _depth_jitter(ro, z, sigma, rgbs, probs, mask, dz, got, tol, top=3):
-    """A candidate third cause, OFF by default (round 5; `explain_ray(jitter=True)`,
-    tests/scripts/whole_view_diagnose.py): ONE sample's depth moved by at most
-    ``JITTER`` x its modelled round-off ``depth_noise``.  Moving sorted sample k by
-    eps lengthens interval k-1 and shortens interval k, so weight passes between the
-    two samples.  Built to test whether the whole view's semantics-only residuals
-    (7e-5 ... 1.7e-4 next to 3e-6 in image and depth) are such a transfer across a
-    class edge: they are NOT -- on four views it explained no ray (the weight that
-    6 dz can move is w * 6 dz / delta ~ 1e-6), and on those rays 0.53 of the weight
-    sits on the LAST sample at class probability 1.0000.  Kept with its CPU test as
-    a diagnostic.  Yields (score, k, eps, eps / dz_k, errors) of the ``top`` samples
-    by linear prediction, each verified exactly."""
-    S = z.shape[1]
-    z, sig64, dz = z.double(), sigma.double(), dz.double()    # (eps is below an ulp of z)
-    delta = z[0, 1:] - z[0, :-1]
-    room = torch.full((S,), 1e10, dtype=torch.float64)
-    room[1:] = torch.minimum(room[1:], delta)
-    room[:-1] = torch.minimum(room[:-1], delta)
-    h = torch.minimum(JITTER * dz, 0.45 * room).clamp_min(0.0)
+def fine_depth_noise(ro):
+    """Per fine sample of one ray: ``depth_noise``'s round-off of its depth -- 2 ulp(z)
+    plus ``4 * 2^-23 / denom * (b1 - b0)``: a sample drawn into a nearly EMPTY bin
+    (pdf = 1e-5 / sum, cdf interval ~2e-5 on a ray that is not opaque) is placed by
+    the ratio of two differences of cdf values near 0.5, and 4 ulp of the cdf's
+    running sum move it by ~2 % of the bin: 1e-3 at a bin width of 0.06."""
+    aux1 = {"w_coarse": ro.w_c, "z_mid_coarse": ro.z_mid, "u": ro.u}
+    denom, width = fine_sample_cdf(aux1)
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    z = _inverse_cdf_flipped(ro.z_mid, ro.w_c[:, 1:-1], ro.u, torch.zeros(1, ro.t, dtype=torch.bool))
+    ulp = torch.exp2(torch.floor(torch.log2(z.abs().clamp_min(1e-30))) - 23)
+    return (2 * ulp + 4 * 2.0 ** -23 / denom * width.abs())[0]
 
-    def outputs(zb):      # [B, S] depths -> [B, 3 + C + 1] outputs scaled by the tolerances
-        _, w = oren.alpha_weights(zb, sig64.expand(zb.shape[0], -1), ro.ds)
-        w = torch.where(mask[None], w, torch.zeros_like(w))
-        return w @ rgbs.double(), w @ probs.double(), (w * zb).sum(-1, keepdim=True) / float(ro.nrm[0])
 
-    def scaled(img, sem, dep, dep_ref):
-        return torch.cat([img / tol[0], sem / tol[1],
-                          dep / (tol[2] * dep_ref.abs().clamp_min(1e-3))], -1)
+def _moved_fine_sample(ro, got, tol, top=4):
+    """Third named cause (round 5), after the two step functions: ONE fine sample
+    sits elsewhere in its bin, by at most ``JITTER`` x the modelled round-off of its
+    depth (``fine_depth_noise``), and the FIELD is re-evaluated there -- density,
+    sort, weights, masks, colour, class probabilities.  Such a sample has moved by up
+    to 1e-3 between a sequential and a parallel running sum of the same pdf (measured:
+    the oracle against itself with the cdf summed in the other order); where it
+    carries a weight of 1e-2 next to a class boundary (probability 0.87, logits
+    steep), the semantics move by 1e-4 while colour and depth barely do.  Not a
+    decision but a one-parameter family, bounded by the fp32 round-off of the
+    reference's own formula, that must reproduce all three outputs at once.  Yields
+    (score, fine sample, eps, eps / dz, errors) for the ``top`` samples by weight x
+    round-off, the step from a linear estimate refined once, verified exactly."""
+    dz = fine_depth_noise(ro).double()
+    z0, sigma0, geo0, xyz0, order0 = ro.sorted_samples()
+    w0, _, _ = ro.shade_all(z0, sigma0, geo0, xyz0)
+    rank_of = torch.empty(ro.T + ro.t, dtype=torch.long)
+    rank_of[order0[0]] = torch.arange(ro.T + ro.t)
+    impact = dz * w0[rank_of[ro.T:]].double().clamp_min(1e-6)
 
-    i0, s0, d0 = outputs(z)
-    g = scaled(got["image"].double()[None] - i0, got["semantics"].double()[None] - s0,
-               got["depth"].double().view(1, 1) - d0, d0)[0]
-    zb = z.expand(S, -1).clone()
-    zb[torch.arange(S), torch.arange(S)] += h
-    i1, s1, d1 = outputs(zb)
-    J = scaled(i1 - i0, s1 - s0, d1 - d0, d0)            # [S, .]: effect of +h_k on sample k
-    jj = (J * J).sum(-1).clamp_min(1e-300)
-    step = ((J @ g) / jj).clamp(-1.0, 1.0)
-    left = ((g[None] - step[:, None] * J) ** 2).sum(-1)
-    left[h <= 0] = float("inf")
-    for k in torch.argsort(left)[:top].tolist():
-        eps = float(step[k] * h[k])
-        zk = z.clone()
-        zk[0, k] += eps
-        ik, sk, dk = outputs(zk)
-        alt = {"image": ik[0], "semantics": sk[0], "depth": dk[0, 0]}
-        ei, es, ed = _errors(got, alt)
-        yield (max(ei / tol[0], es / tol[1], ed / tol[2]), k, eps,
-               eps / max(float(dz[k]), 1e-30), (ei, es, ed))
+    def outputs(shift):
+        z, sigma, geo, xyz, _ = ro.sorted_samples(shift=shift)
+        w, rgbs, probs = ro.shade_all(z, sigma, geo, xyz)
+        return ro.composite(z, w, rgbs, probs, w > 1e-4)
+
+    def vec(a, b):      # (a - b) in units of the tolerances
+        return torch.cat([(a["image"].double() - b["image"].double()) / tol[0],
+                          (a["semantics"].double() - b["semantics"].double()) / tol[1],
+                          ((a["depth"].double() - b["depth"].double()) /
+                           (tol[2] * b["depth"].double().abs().clamp_min(1e-3))).view(1)])
+
+    base = outputs(None)
+    g = vec(got, base)
+    for j in torch.argsort(impact, descending=True)[:top].tolist():
+        h = JITTER * float(dz[j])
+        eps, best_j = 0.0, None
+        for _ in range(2):       # linear estimate around eps, then once more around the result
+            here = base if eps == 0.0 else outputs({j: eps})
+            probe = eps + (0.5 * h if eps <= 0 else -0.5 * h)
+            J = vec(outputs({j: probe}), here) / (probe - eps)
+            step = float((J @ vec(got, here)) / (J @ J).clamp_min(1e-300))
+            eps = min(max(eps + step, -h), h)
+            alt = outputs({j: eps})
+            ei, es, ed = _errors(got, alt)
+            cand = (max(ei / tol[0], es / tol[1], ed / tol[2]), j, eps, eps / max(float(dz[j]), 1e-30),
+                    (ei, es, ed))
+            if best_j is None or cand[0] < best_j[0]:
+                best_j = cand
+        yield best_j
 
 
 def flagged_a_priori(aux, floor=WINDOW_MIN):
@@ -426,9 +438,9 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
                 f"{float(rel[i]):.2e}; best of {n_alt} alternatives {what} -> "
                 f"img {errs[0]:.2e} sem {errs[1]:.2e} depth {errs[2]:.2e}")
         print(line)
-        if score <= 1.0 and what.get("depth_jitter"):
+        if score <= 1.0 and what.get("moved_fine_sample"):
             n_jitter += 1
-        if not (score <= 1.0 and (what["denom_flipped"] or what["mask_toggled"] or what.get("depth_jitter"))):
+        if not (score <= 1.0 and (what["denom_flipped"] or what["mask_toggled"] or what.get("moved_fine_sample"))):
             if collect_unexplained is not None:
                 collect_unexplained.append((line, errs, (float(e_img[i]), float(e_sem[i]), float(rel[i]))))
             else:

@@ -176,46 +176,45 @@ def test_match_tolerance_follows_the_renders_ordinary_error_but_is_capped(case):
         pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="quiet-flip+2.5e-5")
 
 
-def test_one_depth_moved_by_its_round_off_is_named_and_a_larger_move_is_not(case):
-    """The diagnostic third alternative (round 5, off by default): a result whose
-    sample k sits 4 x its modelled round-off away is reproduced by a depth jitter
-    of that sample, ~4 units; the
-    same move at 20 units (beyond JITTER = 6) is not.  Match tolerances scaled
-    down to a tenth of the move's effect: the small fixture has no ray on which
-    4 units move an output by 1e-4."""
+def test_a_fine_sample_moved_within_its_round_off_is_named_and_a_larger_move_is_not(case):
+    """The third alternative (round 5, `jitter=True`): a result in which ONE fine
+    sample sits 4 x its modelled depth round-off away (field re-evaluated there) is
+    reproduced by moving that sample, ~4 units; the same at 20 units (beyond
+    JITTER = 6) is not; and by default neither is.  Match tolerances scaled down to
+    a quarter of the move's effect: the small fixture has no ray on which 4 units move
+    an output by 1e-4."""
     fld, rays, u, ref = case
-    aux = ref["aux"]
-    dz = pc.depth_noise(aux)
-    z = aux["z"]
-    delta = z[:, 1:] - z[:, :-1]
-    # the sample with the largest relative interval noise that carries weight
-    r = (dz[:, 1:-1] / torch.minimum(delta[:, :-1], delta[:, 1:]).clamp_min(1e-9)) * aux["weights"][:, 1:-1]
-    r = torch.where(dz[:, 1:-1] * 20 < 0.45 * torch.minimum(delta[:, :-1], delta[:, 1:]), r, torch.zeros_like(r))
-    i = int(r.max(-1)[0].argmax())
-    k = int(r[i].argmax()) + 1
-    ro = pc.RayOracle(fld, rays[0][0, i], rays[1][0, i], rays[2][0, i], AABB4, T, t, u[i])
-    with torch.no_grad():
-        zs, sigma, geo, xyz, order = ro.sorted_samples()
-        w, rgbs, probs = ro.shade_all(zs, sigma, geo, xyz)
-        mask = w > 1e-4
-        base = ro.composite(zs, w, rgbs, probs, mask)
+    tried = 0
+    for i in range(0, N, 37):
+        ro = pc.RayOracle(fld, rays[0][0, i], rays[1][0, i], rays[2][0, i], AABB4, T, t, u[i])
+        with torch.no_grad():
+            dz = pc.fine_depth_noise(ro)
+            z0, sigma0, geo0, xyz0, order0 = ro.sorted_samples()
+            w0, rgbs0, probs0 = ro.shade_all(z0, sigma0, geo0, xyz0)
+            base = ro.composite(z0, w0, rgbs0, probs0, w0 > 1e-4)
+            rank_of = torch.empty(T + t, dtype=torch.long)
+            rank_of[order0[0]] = torch.arange(T + t)
+            j = int((dz * w0[rank_of[T:]]).argmax())
 
-        def moved(units):
-            zd = zs.double().clone()
-            zd[0, k] += units * float(dz[i, k])
-            _, wd = oren.alpha_weights(zd, sigma.double(), ro.ds)
-            wd = torch.where(mask, wd[0], torch.zeros_like(wd[0]))
-            return {"depth": (wd * zd[0]).sum() / ro.nrm[0].double(), "image": wd @ rgbs.double(),
-                    "semantics": wd @ probs.double()}
+            def moved(units):
+                z, sigma, geo, xyz, _ = ro.sorted_samples(shift={j: units * float(dz[j])})
+                w, rgbs, probs = ro.shade_all(z, sigma, geo, xyz)
+                return ro.composite(z, w, rgbs, probs, w > 1e-4)
 
-        got4, got20 = moved(4.0), moved(20.0)
-        e4 = pc._errors(got4, base)
-        tol = tuple(max(e / 10.0, 1e-9) for e in e4)
-        score, what, errs, _ = pc.explain_ray(ro, got4, tol=tol, jitter=True)
-        assert score <= 1.0 and what["depth_jitter"]["sample"] == k, (score, what, e4)
-        assert 3.0 < what["depth_jitter"]["in_dz"] < 5.0, what
-        score, what, errs, _ = pc.explain_ray(ro, got20, tol=tol, jitter=True)
-        assert score > 1.0, (score, what)
-        # and by default the 4-unit move is NOT explained
-        score, what, errs, _ = pc.explain_ray(ro, got4, tol=tol)
-        assert score > 1.0 and "depth_jitter" not in what
+            got4, got20 = moved(4.0), moved(20.0)
+            e4, e20 = pc._errors(got4, base), pc._errors(got20, base)
+            if max(e4[:2]) < 1.5e-6 or max(e20) < 3 * max(e4):
+                continue            # nothing to see on this ray / the response saturates
+            tried += 1
+            # (a third of the effect, and not below the fp32 noise of the composite itself)
+            tol = (max(e4[0] / 3, 4e-7), max(e4[1] / 3, 4e-7), max(e4[2] / 3, 2e-6))
+            score, what, errs, _ = pc.explain_ray(ro, got4, tol=tol, jitter=True)
+            assert score <= 1.0 and what["moved_fine_sample"]["sample"] == j, (i, score, what, e4)
+            assert 2.5 < what["moved_fine_sample"]["in_dz"] < 5.5, what
+            score, what, errs, _ = pc.explain_ray(ro, got20, tol=tol, jitter=True)
+            assert score > 1.0, (i, score, what)
+            score, what, errs, _ = pc.explain_ray(ro, got4, tol=tol)
+            assert score > 1.0 and "moved_fine_sample" not in what
+        if tried == 3:
+            break
+    assert tried == 3
