@@ -87,7 +87,9 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
     it (f16x2 nets, one pipelined ucsa_render_view call, depth-ordered fine pass)
     goes against the oracle, in blocks of 32 768 rays (~6 s of CPU each), with the
     same stated tolerance and the same causal explanation of the rays above it
-    (all but a bounded handful of a view's ~550: see the end of the test)."""
+    (a decision of one of the two step functions, or -- this test only -- one fine
+    sample moved inside its depth round-off; all but a bounded handful of a view's
+    ~550: see the end of the test)."""
     import bench
     from ucsa_neural_rendering_amd import ops
     from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
@@ -107,7 +109,7 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
                          upsample_steps=t, rng_u=u, image_width=W)
     torch.cuda.synchronize()
     oc, dc, nc, uc = o.cpu(), d.cpu(), nrm.cpu(), u.cpu()
-    loose = n = 0
+    loose = n = moved = 0
     tail = []
     for head in range(0, H * W, 32768):
         sel = torch.arange(head, min(head + 32768, H * W))
@@ -121,11 +123,13 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
         # threshold weight 1.0e-4, i.e. the stated tolerance itself)
         r = pc.check_render(res, ref, fld, rays_sel, AABB4, T, t, sel=sel,
                             tag=f"cfg2-whole[{head}]", collect_unexplained=tail,
-                            max_loose_frac=1.0)
+                            max_loose_frac=1.0, jitter=True)
         loose += r["loose"]
+        moved += r["by_jitter"]
         n += sel.numel()
     print(f"cfg2 whole view: {loose} of {n} rays above the stated tolerance; {loose - len(tail)} of them "
-          f"reproduced by a named alternative decision within the match tolerance, {len(tail)} not:")
+          f"reproduced by a named alternative within the match tolerance ({moved} by one fine sample moved "
+          f"inside its depth round-off, the others by a decision of a step function), {len(tail)} not:")
     for line, resid, errs in tail:
         print("   TAIL " + line)
     assert n == H * W
@@ -138,12 +142,14 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
     # expected every second view), or the flipped sample sat 1.3 % from the threshold
     # against a window of 1.29 %;
     # (ii) semantics-only residuals of 7e-5 ... 1.7e-4 next to 3e-6 in image and
-    # depth, on rays whose LAST sample carries ~0.53 of the weight at class
-    # probability 1.0000: all three HIP arithmetics agree with each other to 1e-5 on
-    # such a ray, and the HIP FIELD evaluated on the oracle's own sample positions
-    # agrees with the oracle to |sum w dp| = 9e-9 -- neither the nets nor the
-    # encoder; not a depth moved within its round-off either (parity_check
-    # ._depth_jitter explains none of them).  OPEN.
+    # depth: ONE fine sample next to a class boundary sits a few times its depth
+    # round-off away (a sample drawn into a nearly empty bin is placed by the ratio
+    # of two cdf differences: 4 ulp of the running sum are ~2 % of the bin); the
+    # weights hardly move, the class probabilities AT the sample do.  Reproduced
+    # without a GPU (tests/scripts/oracle_self_noise.py: the oracle against itself
+    # with another summation order and 1e-5 of density noise shows two such rays on
+    # a view) and matched by parity_check._moved_fine_sample -- that sample moved by
+    # <= 6 dz, the field re-evaluated there -- to 9e-7; counted and bounded below.
     # Until the window had a floor at the render's own error level (parity_check
     # .window_floor, round 5) a third kind existed: on fields with ~1200 loose rays
     # (haze: many weights of 1e-4 behind empty space) up to 7 single flips of a
@@ -153,6 +159,7 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
     # Bound: at most 8 rays = 2.6e-5 of the view, each inside the hard cap that
     # check_render asserts for EVERY ray, every one of them printed.
     assert len(tail) <= 8, [x[0] for x in tail]
+    assert moved <= 8, moved      # the odd ray, not a second tolerance
     for line, resid, errs in tail:
         assert errs[0] <= pc.CAP_ABS and errs[1] <= pc.CAP_ABS and errs[2] <= pc.CAP_DEPTH_REL, line
 
