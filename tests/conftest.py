@@ -37,3 +37,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_runtest_logreport(report):
+    """Every failure's traceback and captured output also go to
+    gpurun_out/pytest_failures.txt (merged back from the GPU box): in round 5 two
+    leases went into a flaky test of which the `-q` log kept only the name."""
+    if not report.failed:
+        return
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "pytest_failures.txt"), "a") as f:
+            f.write(f"=== {report.nodeid} [{report.when}]\n{report.longreprtext[-6000:]}\n")
+            for name, text in report.sections:
+                f.write(f"--- {name}\n{text[-6000:]}\n")
+    except OSError:
+        pass
