@@ -218,3 +218,51 @@ def test_a_fine_sample_moved_within_its_round_off_is_named_and_a_larger_move_is_
         if tried == 3:
             break
     assert tried == 3
+
+
+def test_the_oracle_with_its_cdf_summed_in_another_order_is_fully_explained():
+    """Real round-off instead of an injected error: the oracle against itself,
+    the second render with sample_pdf's cdf as a sequential fp32 running sum
+    (torch.cumsum accumulates in double on the CPU; a GPU's parallel scan rounds
+    differently again).  4096 rays: a few end up above the stated tolerance -- a
+    mask flip, and fine samples in nearly empty bins that sit up to 2e-3 elsewhere --
+    and every one of them must be matched by a named alternative (the moved-sample
+    one included: what the whole-view GPU test runs with)."""
+    n_rays, T2, t2 = 4096, 48, 48
+    fld = lively_oracle_field()
+    o, d, n = make_rays(n_rays, 5)
+    u = torch.rand(n_rays, t2, generator=torch.Generator().manual_seed(1))
+    rays = (o[None], d[None], n[None])
+
+    def seq_cdf(bins, weights, uu):
+        w = weights + 1e-5
+        pdf = w / torch.sum(w, -1, keepdim=True)
+        acc, cols = torch.zeros_like(pdf[:, 0]), []
+        for k in range(pdf.shape[1]):
+            acc = acc + pdf[:, k]
+            cols.append(acc)
+        cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.stack(cols, -1)], -1)
+        hi = torch.searchsorted(cdf, uu.contiguous(), right=True)
+        lo = torch.clamp(hi - 1, min=0)
+        hi = torch.clamp(hi, max=cdf.shape[-1] - 1)
+        c0, c1 = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+        b0, b1 = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+        denom = c1 - c0
+        denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+        return b0 + (uu - c0) / denom * (b1 - b0)
+
+    orig = oren.inverse_cdf
+    with torch.no_grad():
+        ref = oren.run(fld, *rays, AABB4, num_steps=T2, upsample_steps=t2, u=u, return_aux=True)
+        try:
+            oren.inverse_cdf = seq_cdf
+            alt = oren.run(fld, *rays, AABB4, num_steps=T2, upsample_steps=t2, u=u)
+        finally:
+            oren.inverse_cdf = orig
+    moved = (alt["depth"] != ref["depth"]).float().mean()
+    assert float(moved) > 0.2, "the two summation orders gave the same render"
+    out = pc.check_render(_res(alt), ref, fld, rays, AABB4, T2, t2, tag="seq-cdf", jitter=True)
+    assert out["loose"] >= 1 and out["by_jitter"] >= 1, out
+    # ... and without the moved-sample alternative the same render does NOT pass
+    with pytest.raises(AssertionError, match="NO alternative"):
+        pc.check_render(_res(alt), ref, fld, rays, AABB4, T2, t2, tag="seq-cdf-no-moved-sample")
