@@ -675,6 +675,239 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   }
 }
 
+// ---------------------------------------------------------------------------
+// x-PAIR records (written at the end of round 5; OFF unless UCSA_BWD_XPAIR=1 and
+// NOT YET RUN ON A GPU -- the round's GPU budget was spent; tests/
+// test_gpu_backward.py::test_xpair_bin_records_match_packed_records is the test
+// to switch on first, docs/DESIGN_NOTEBOOK.md "R6-plan" the reasoning).
+//
+// The bin kernel is issue- and LDS-atomic-bound (~82 VALU instructions per
+// record, profiles/r04_train_sq_counters.txt), not byte-bound: what costs is the
+// NUMBER of records.  The corners x and x + 1 of a cell differ in the low bits of
+// the index only (idx = x ^ y P1 ^ z P2: x ^ (x + 1) = 2^(k+1) - 1 with k the
+// number of trailing ones of x; dense rows: idx + 1), so with 2048-entry bins
+// they fall into the SAME bin unless x ends in eleven 1-bits -- never below
+// resolution 2048, 2^-11 of the pairs at the finest level (checked on 4 M random
+// cells per level).  One 16-byte record per x-pair = two REC_P64 words,
+// p64(loc0, v0) and p64(loc0 ^ loc1, v1): 4 hashes' worth of bin counters, LDS
+// ranks and stage slots per sample and level instead of 8, the same bytes, the
+// same 26-bit values and fp32 sums as REC_P64 (so the same gradient up to the
+// order of additions).  A pair that straddles two bins goes to the table by direct
+// atomics (unrounded).  The workspace is the REC_F32 one (16 bytes x cap per bin).
+__global__ void __launch_bounds__(256)
+k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
+                     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                     const float* __restrict__ zs, Aabb bb, uint32_t T, uint64_t M,
+                     const float2* __restrict__ d_feat, uint32_t* __restrict__ gcount,
+                     ulonglong2* __restrict__ records, float* __restrict__ grad_table,
+                     MergedSrc mg) {
+  __shared__ uint32_t hist[BIN_COUNT], base[BIN_COUNT], cursor[BIN_COUNT];
+  __shared__ uint32_t it_cnt[BIN_COUNT], it_off[BIN_COUNT], wave_tot[4];
+  __shared__ ulonglong2 stage_w[256 * 4];   // one iteration's records, bin-sorted
+  __shared__ uint16_t stage_b[256 * 4];
+  const uint32_t level = level0 + blockIdx.y;
+  const uint32_t lbits = bg.loc_bits[level];
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t res = g.res[level], entries = g.entries[level],
+                 hashed = g.hashed[level], bsz = bg.bin_size[level],
+                 bshift = bg.bin_shift[level];
+  auto bin_of = [&](uint32_t idx) -> uint32_t {
+    return bshift < 32 ? idx >> bshift : idx / bsz;
+  };
+  hist[threadIdx.x] = 0;
+  cursor[threadIdx.x] = 0;
+  it_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t m0 = (uint64_t)blockIdx.x * (256 * BIN_TILE) + threadIdx.x;
+  // pass 1: the workgroup's x-pair records per bin
+#pragma unroll 1
+  for (int it = 0; it < BIN_TILE; ++it) {
+    const uint64_t m = m0 + (uint64_t)it * 256;
+    bool act = m < M;
+    uint32_t r = 0;
+    float zz = 0.f;
+    if (act) {
+      float2 df;
+      sample_ref(mg, T, M, m, level, zs, d_feat, r, zz, df);
+      act = !(df.x == 0.0f && df.y == 0.0f);
+    }
+    uint32_t gi[3] = {0u, 0u, 0u};
+    float wf[3];
+    if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    if (!(act && plan.tail)) continue;
+    // index of the corner at x + 1 from the corner at x: one xor on a hashed level
+    // ((x ^ h) & (E - 1) with E a power of two), the next entry on a dense one
+    const uint32_t xflip = (gi[0] ^ (gi[0] + 1u)) & (entries - 1u);
+    auto x_neighbour = [&](uint32_t i0) -> uint32_t {
+      return hashed ? (i0 ^ xflip) : (i0 + 1u == entries ? 0u : i0 + 1u);
+    };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t i0 = grid_index_b(gi[0], gi[1] + (p & 1), gi[2] + (p >> 1), res, entries, hashed);
+      const uint32_t i1 = x_neighbour(i0);
+      const uint32_t b0 = bin_of(i0);
+      if (b0 == bin_of(i1)) atomicAdd(&hist[b0], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t h = hist[threadIdx.x];
+    base[threadIdx.x] = h ? atomicAdd(&gcount[level * BIN_COUNT + threadIdx.x], h) : 0u;
+  }
+  __syncthreads();
+  float* gt = grad_table + (size_t)g.offset[level] * 2;
+  ulonglong2* rec_level = records + (size_t)level * BIN_COUNT * bg.cap;
+  // pass 2, 256 samples at a time (as k_grid_bwd_bin: counting sort by bin in
+  // LDS, consecutive lanes store consecutive records of a bin)
+#pragma unroll 1
+  for (int it = 0; it < BIN_TILE; ++it) {
+    const uint64_t m = m0 + (uint64_t)it * 256;
+    bool act = m < M;
+    float2 df = make_float2(0.f, 0.f);
+    uint32_t r = 0;
+    float zz = 0.f;
+    if (act) {
+      sample_ref(mg, T, M, m, level, zs, d_feat, r, zz, df);
+      act = !(df.x == 0.0f && df.y == 0.0f);
+    }
+    uint32_t gi[3] = {0u, 0u, 0u};
+    float wf[3] = {0.f, 0.f, 0.f};
+    if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    const bool has_runs = plan.live != 0;
+    const bool emit = act && plan.tail;
+    float valx[8], valy[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {   // c = x | y << 1 | z << 2, as in k_grid_bwd_bin
+      float w = (c & 1) ? wf[0] : 1.0f - wf[0];
+      w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
+      w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
+      float vx = act ? w * df.x : 0.0f, vy = act ? w * df.y : 0.0f;
+      if (has_runs) run_sum(plan, vx, vy);
+      valx[c] = vx;
+      valy[c] = vy;
+    }
+    uint32_t key[4];       // bin << 16 | rank inside the bin; ~0u: no record
+    uint64_t w0[4], w1[4];
+    const uint32_t xflip = (gi[0] ^ (gi[0] + 1u)) & (entries - 1u);
+    auto x_neighbour = [&](uint32_t i0) -> uint32_t {
+      return hashed ? (i0 ^ xflip) : (i0 + 1u == entries ? 0u : i0 + 1u);
+    };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      key[p] = 0xFFFFFFFFu;
+      w0[p] = w1[p] = 0ull;
+      if (emit) {
+        const uint32_t i0 = grid_index_b(gi[0], gi[1] + (p & 1), gi[2] + (p >> 1), res, entries, hashed);
+        const uint32_t i1 = x_neighbour(i0);
+        const uint32_t b0 = bin_of(i0);
+        if (b0 == bin_of(i1)) {
+          const uint32_t l0 = i0 - b0 * bsz, l1 = i1 - b0 * bsz;
+          w0[p] = p64_pack(l0, valx[2 * p], valy[2 * p], lbits);
+          w1[p] = p64_pack(l0 ^ l1, valx[2 * p + 1], valy[2 * p + 1], lbits);
+          key[p] = (b0 << 16) | atomicAdd(&it_cnt[b0], 1u);
+        } else {   // the pair straddles two bins: rare, straight to the table
+          atomicAdd(gt + (size_t)i0 * 2, valx[2 * p]);
+          atomicAdd(gt + (size_t)i0 * 2 + 1, valy[2 * p]);
+          atomicAdd(gt + (size_t)i1 * 2, valx[2 * p + 1]);
+          atomicAdd(gt + (size_t)i1 * 2 + 1, valy[2 * p + 1]);
+        }
+      }
+    }
+    __syncthreads();
+    {  // exclusive prefix of it_cnt over the bins (thread = bin)
+      const uint32_t v = it_cnt[threadIdx.x];
+      const uint32_t inc = wave_incl_scan_add_u32(v, lane);
+      if (lane == 63) wave_tot[wid] = inc;
+      __syncthreads();
+      uint32_t before = 0;
+      for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
+      it_off[threadIdx.x] = before + inc - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (key[p] != 0xFFFFFFFFu) {
+        const uint32_t bin = key[p] >> 16;
+        const uint32_t slot = it_off[bin] + (key[p] & 0xFFFFu);
+        stage_w[slot] = make_ulonglong2(w0[p], w1[p]);
+        stage_b[slot] = (uint16_t)bin;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = it_off[BIN_COUNT - 1] + it_cnt[BIN_COUNT - 1];
+    for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 256) {
+      const ulonglong2 w = stage_w[sidx];
+      const uint32_t bin = stage_b[sidx];
+      const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
+      if (pos < bg.cap) {
+        rec_level[(size_t)bin * bg.cap + pos] = w;
+      } else {  // bin full: direct atomics (of the rounded values: same sum)
+        uint32_t l0, mk;
+        float ax, ay, bx, by;
+        p64_unpack(w.x, lbits, l0, ax, ay);
+        p64_unpack(w.y, lbits, mk, bx, by);
+        const size_t e0 = (size_t)bin * bsz + l0, e1 = (size_t)bin * bsz + (l0 ^ mk);
+        atomicAdd(gt + e0 * 2, ax);
+        atomicAdd(gt + e0 * 2 + 1, ay);
+        atomicAdd(gt + e1 * 2, bx);
+        atomicAdd(gt + e1 * 2 + 1, by);
+      }
+    }
+    __syncthreads();
+    cursor[threadIdx.x] += it_cnt[threadIdx.x];
+    it_cnt[threadIdx.x] = 0;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(512)
+k_grid_bwd_accum_xpair(GridDev g, BinGeom bg, uint32_t level0,
+                       const uint32_t* __restrict__ gcount,
+                       const ulonglong2* __restrict__ records,
+                       float* __restrict__ grad_table) {
+  const uint32_t level = level0 + blockIdx.y, bin = blockIdx.x;
+  const uint32_t bsz = bg.bin_size[level];
+  uint32_t n = gcount[level * BIN_COUNT + bin];
+  if (n == 0) return;
+  if (n > bg.cap) n = bg.cap;
+  float* acc = binacc_smem;  // [bsz][2]
+  for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) acc[e] = 0.f;
+  __syncthreads();
+  const ulonglong2* rec = records + ((size_t)level * BIN_COUNT + bin) * bg.cap;
+  const uint32_t lbits = bg.loc_bits[level];
+  auto add = [&](const ulonglong2& w) {
+    uint32_t l0, mk;
+    float ax, ay, bx, by;
+    p64_unpack(w.x, lbits, l0, ax, ay);
+    p64_unpack(w.y, lbits, mk, bx, by);
+    lds_add_pair(&acc[2 * l0], ax, ay);
+    lds_add_pair(&acc[2 * (l0 ^ mk)], bx, by);
+  };
+  constexpr int INF = ACC_INFLIGHT / 2;   // 16-byte loads: the same bytes in flight
+  uint32_t i = threadIdx.x;
+  for (; i + (INF - 1) * 512 < n; i += INF * 512) {
+    ulonglong2 r[INF];
+#pragma unroll
+    for (int k = 0; k < INF; ++k) r[k] = rec[i + k * 512];
+#pragma unroll
+    for (int k = 0; k < INF; ++k) add(r[k]);
+  }
+  for (; i < n; i += 512) add(rec[i]);
+  __syncthreads();
+  const uint32_t first = bin * bsz;
+  const uint32_t entries = g.entries[level];
+  float* gt = grad_table + (size_t)g.offset[level] * 2;
+  for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) {
+    const uint32_t ent = first + (e >> 1);
+    if (ent < entries) {
+      const float v = acc[e];
+      if (v != 0.f) gt[(size_t)ent * 2 + (e & 1)] += v;  // exclusive owner
+    }
+  }
+}
+
 static BinGeom bin_geometry(const ucsa_grid* grid, uint64_t M) {
   BinGeom bg;
   for (uint32_t l = 0; l < UCSA_MAX_LEVELS; ++l) {
@@ -815,7 +1048,16 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
       if (bg.bin_size[l] > max_bsz) max_bsz = bg.bin_size[l];
     const uint32_t nl = grid->n_levels - n_lo;
     UCSA_CLEAR_ERR();
-    if (rec_scale < 0.0f) {  // REC_P64
+    const char* xp = rec_scale < 0.0f ? getenv("UCSA_BWD_XPAIR") : nullptr;
+    if (xp && xp[0] == '1') {  // x-pair records (experimental, see k_grid_bwd_bin_xpair)
+      hipLaunchKernelGGL(k_grid_bwd_bin_xpair, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
+                         dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
+                         bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
+                         grad_table, mg);
+      hipLaunchKernelGGL(k_grid_bwd_accum_xpair, dim3(BIN_COUNT, nl), dim3(512),
+                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream, gd, bg,
+                         n_lo, gcount, (const ulonglong2*)records, grad_table);
+    } else if (rec_scale < 0.0f) {  // REC_P64
       hipLaunchKernelGGL(k_grid_bwd_bin<REC_P64>,
                          dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
                          (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
