@@ -141,6 +141,72 @@ __device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
   }
 }
 
+// The same run structure on the DPP data path (experimental, used by
+// k_grid_bwd_bin_xpair<true> only: UCSA_BWD_XPAIR=2; not yet run on a GPU).  A
+// __shfl_up is a ds_bpermute_b32 -- an LDS instruction with its latency in a
+// dependent chain -- and run_sum issues two per live step for each of the 16
+// values of a sample; a DPP step is one VALU instruction (wave_ops.h: 3.5 x the scan
+// rate).  Ladder: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, row_bcast15 into
+// rows 1 and 3, row_bcast31 into rows 2 and 3 -- a segmented scan under the
+// associative operator (f1, v1) o (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2), so the
+// tail lane of a run ends up with the run's sum as with the shuffle ladder (other
+// association of the fp32 additions).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_src_i(int v, int identity) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_src_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ __forceinline__ RunPlan run_plan_dpp(uint32_t cx, uint32_t cy, uint32_t cz,
+                                                bool act, uint32_t lane) {
+  const uint32_t kx = act ? cx : 0xFFFFFFFFu;
+  // previous lane's cell (wave_shr:1; lane 0 is a head anyway)
+  const uint32_t px = (uint32_t)dpp_src_i<0x138, 0xf>((int)kx, 0);
+  const uint32_t py = (uint32_t)dpp_src_i<0x138, 0xf>((int)cy, 0);
+  const uint32_t pz = (uint32_t)dpp_src_i<0x138, 0xf>((int)cz, 0);
+  const bool head = lane == 0 || px != kx || py != cy || pz != cz || !act;
+  int f = head ? 1 : 0;
+  RunPlan p;
+  p.live = 0;
+  const uint32_t in_row = lane & 15u;
+  auto step = [&](int s, int of, bool has_src) {
+    p.add[s] = has_src && !f;
+    if (p.add[s]) f |= of;
+    if (__any(p.add[s])) p.live |= 1u << s;
+  };
+  step(0, dpp_src_i<0x111, 0xf>(f, 1), in_row >= 1u);          // row_shr:1
+  step(1, dpp_src_i<0x112, 0xf>(f, 1), in_row >= 2u);          // row_shr:2
+  step(2, dpp_src_i<0x114, 0xf>(f, 1), in_row >= 4u);          // row_shr:4
+  step(3, dpp_src_i<0x118, 0xf>(f, 1), in_row >= 8u);          // row_shr:8
+  step(4, dpp_src_i<0x142, 0xa>(f, 1), ((lane >> 4) & 1u) != 0u);  // row_bcast:15 -> rows 1, 3
+  step(5, dpp_src_i<0x143, 0xc>(f, 1), lane >= 32u);           // row_bcast:31 -> rows 2, 3
+  const int next_head = __shfl_down(head ? 1 : 0, 1, 64);
+  p.tail = act && (lane == 63 || next_head);
+  return p;
+}
+
+__device__ __forceinline__ void run_sum_dpp(const RunPlan& p, float& vx, float& vy) {
+#define UCSA_RUN_STEP(S, CTRL, MASK)                         \
+  if ((p.live >> S) & 1u) {                                  \
+    const float ox = dpp_src_f<CTRL, MASK>(vx);              \
+    const float oy = dpp_src_f<CTRL, MASK>(vy);              \
+    if (p.add[S]) {                                          \
+      vx += ox;                                              \
+      vy += oy;                                              \
+    }                                                        \
+  }
+  UCSA_RUN_STEP(0, 0x111, 0xf)
+  UCSA_RUN_STEP(1, 0x112, 0xf)
+  UCSA_RUN_STEP(2, 0x114, 0xf)
+  UCSA_RUN_STEP(3, 0x118, 0xf)
+  UCSA_RUN_STEP(4, 0x142, 0xa)
+  UCSA_RUN_STEP(5, 0x143, 0xc)
+#undef UCSA_RUN_STEP
+}
+
 // (x, y) += (vx, vy) on an 8-byte aligned pair of LDS floats.  ds_add_f32 is
 // serialised per lane on gfx950 (measured, tools/ubench/lds_atomic.hip: two of
 // them per record retire at 100 G records/s chip-wide, integer LDS atomics at
@@ -694,6 +760,7 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
 // same 26-bit values and fp32 sums as REC_P64 (so the same gradient up to the
 // order of additions).  A pair that straddles two bins goes to the table by direct
 // atomics (unrounded).  The workspace is the REC_F32 one (16 bytes x cap per bin).
+template <bool DPPSCAN>   // run plan / run sums on the DPP data path (UCSA_BWD_XPAIR=2)
 __global__ void __launch_bounds__(256)
 k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
                      const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -734,7 +801,8 @@ k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3];
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
+                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
     if (!(act && plan.tail)) continue;
     // index of the corner at x + 1 from the corner at x: one xor on a hashed level
     // ((x ^ h) & (E - 1) with E a power of two), the next entry on a dense one
@@ -774,7 +842,8 @@ k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3] = {0.f, 0.f, 0.f};
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
+                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
     const bool has_runs = plan.live != 0;
     const bool emit = act && plan.tail;
     float valx[8], valy[8];
@@ -784,7 +853,10 @@ k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
       w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
       w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
       float vx = act ? w * df.x : 0.0f, vy = act ? w * df.y : 0.0f;
-      if (has_runs) run_sum(plan, vx, vy);
+      if (has_runs) {
+        if constexpr (DPPSCAN) run_sum_dpp(plan, vx, vy);
+        else run_sum(plan, vx, vy);
+      }
       valx[c] = vx;
       valy[c] = vy;
     }
@@ -1049,11 +1121,17 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
     const uint32_t nl = grid->n_levels - n_lo;
     UCSA_CLEAR_ERR();
     const char* xp = rec_scale < 0.0f ? getenv("UCSA_BWD_XPAIR") : nullptr;
-    if (xp && xp[0] == '1') {  // x-pair records (experimental, see k_grid_bwd_bin_xpair)
-      hipLaunchKernelGGL(k_grid_bwd_bin_xpair, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
-                         dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
-                         bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
-                         grad_table, mg);
+    if (xp && (xp[0] == '1' || xp[0] == '2')) {  // x-pair records (experimental, see k_grid_bwd_bin_xpair)
+      if (xp[0] == '2')
+        hipLaunchKernelGGL(k_grid_bwd_bin_xpair<true>, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
+                           dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
+                           bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
+                           grad_table, mg);
+      else
+        hipLaunchKernelGGL(k_grid_bwd_bin_xpair<false>, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
+                           dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
+                           bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
+                           grad_table, mg);
       hipLaunchKernelGGL(k_grid_bwd_accum_xpair, dim3(BIN_COUNT, nl), dim3(512),
                          (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream, gd, bg,
                          n_lo, gcount, (const ulonglong2*)records, grad_table);
