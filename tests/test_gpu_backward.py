@@ -673,14 +673,16 @@ def test_packed_bin_records_match_fp32_records(ops, case):
 @pytest.mark.skipif(os.environ.get("UCSA_TEST_XPAIR") != "1",
                     reason="x-pair bin records (UCSA_BWD_XPAIR=1, off by default) were written after round 5's GPU "
                            "budget was spent: set UCSA_TEST_XPAIR=1 to run this first in round 6")
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "dpp"])
 @pytest.mark.parametrize("case", ["rays", "merged", "overflow", "nonfinite"])
 def test_xpair_bin_records_match_packed_records(ops, case, mode, monkeypatch):
     """k_grid_bwd_bin_xpair / _accum_xpair (one 16-byte record per x-pair of
     corners = two REC_P64 words) against the REC_P64 path: the same 26-bit values
     and fp32 sums, so entries agree up to the order of additions -- except pairs
     that straddle two bins, which go to the table unrounded (2^-18 per value).
-    mode 2: the run sums on the DPP data path as well (other association)."""
+    mode 2: the run sums on the DPP data path as well (other association);
+    mode dpp: UCSA_BWD_DPP=1 -- the SHIPPED kernels (k_hashgrid_bwd<true>,
+    k_grid_bwd_bin<REC_P64>) with their run plans / run sums as DPP scans."""
     from ucsa_neural_rendering_amd._lib import make_grid
     dev = torch.device("cuda:0")
     grid = make_grid(4.0)
@@ -703,7 +705,8 @@ def test_xpair_bin_records_match_packed_records(ops, case, mode, monkeypatch):
     gpk, gxp, gabs = (torch.zeros(total, 2, device=dev) for _ in range(3))
 
     def run(out, df, xpair, **kw):
-        monkeypatch.setenv("UCSA_BWD_XPAIR", mode if xpair else "0")
+        monkeypatch.setenv("UCSA_BWD_XPAIR", mode if xpair and mode != "dpp" else "0")
+        monkeypatch.setenv("UCSA_BWD_DPP", "1" if xpair and mode == "dpp" else "0")
         if case == "merged":
             ops.hashgrid_bwd_rays_merged(grid, o, d, z, kw["z_f"], kw["src"], aabb, df, kw["d_f"], out, packed=True)
         else:

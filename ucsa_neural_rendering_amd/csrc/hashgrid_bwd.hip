@@ -259,7 +259,7 @@ __device__ __forceinline__ void lds_accumulate(uint32_t* keys, float* vals,
   atomicAdd(gt + (size_t)idx * 2 + 1, vy);
 }
 
-template <bool RUNRED>
+template <bool RUNRED, bool DPPSCAN = false>   // DPPSCAN: run_plan_dpp / run_sum_dpp (UCSA_BWD_DPP=1, experimental)
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
                const float* __restrict__ rays_d, const float* __restrict__ zs,
@@ -316,7 +316,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
     const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
                    gz = (uint32_t)(int32_t)fz0;
     RunPlan plan;
-    if (RUNRED) plan = run_plan(gx, gy, gz, act, lane);
+    if (RUNRED) plan = DPPSCAN ? run_plan_dpp(gx, gy, gz, act, lane) : run_plan(gx, gy, gz, act, lane);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float w = (c & 1) ? wx : 1.0f - wx;
@@ -327,7 +327,8 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
       float vx = w * df.x, vy = w * df.y;
       if (RUNRED) {
         if (!act) { vx = 0.f; vy = 0.f; }
-        run_sum(plan, vx, vy);
+        if constexpr (DPPSCAN) run_sum_dpp(plan, vx, vy);
+        else run_sum(plan, vx, vy);
         if (plan.tail) lds_accumulate(acc_keys, acc_vals, idx, vx, vy, gt);
       } else {
         atomicAdd(gt + (size_t)idx * 2, vx);
@@ -457,7 +458,7 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
 #define REC_F32 0
 #define REC_H16 1
 #define REC_P64 2
-template <int REC>
+template <int REC, bool DPPSCAN = false>
 __global__ void __launch_bounds__(256)
 k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                const float* __restrict__ rays_o,
@@ -515,7 +516,8 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3];
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
+                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
     if (!(act && plan.tail)) continue;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -553,7 +555,8 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3] = {0.f, 0.f, 0.f};
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
+                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
     const bool has_runs = plan.live != 0;  // some lane continues a run
     const bool emit = act && plan.tail;
 #pragma unroll
@@ -562,7 +565,10 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
       w = w * ((c & 2) ? wf[1] : 1.0f - wf[1]);
       w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
       float vx = act ? w * df.x : 0.0f, vy = act ? w * df.y : 0.0f;
-      if (has_runs) run_sum(plan, vx, vy);
+      if (has_runs) {
+        if constexpr (DPPSCAN) run_sum_dpp(plan, vx, vy);
+        else run_sum(plan, vx, vy);
+      }
       valx[c] = vx;
       valy[c] = vy;
       if (emit) {
@@ -1072,6 +1078,10 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    MergedSrc mg = MergedSrc{nullptr, nullptr, nullptr, 0u, 0u, 0u}) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
+  // UCSA_BWD_DPP=1 (experimental, not yet run on a GPU): the run plans / run sums
+  // of the coarse kernel and of the packed bin kernel on the DPP data path
+  const char* dpp_env = getenv("UCSA_BWD_DPP");
+  const bool dpp_scan = dpp_env && dpp_env[0] == '1';
   // Binning pays where updates are spread over the whole slab (hashed levels
   // with cells finer than ~2 sample spacings: 170 us vs 800 us per level and
   // million samples).  On the dense coarse levels the records pile up in a
@@ -1136,6 +1146,13 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                          (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream, gd, bg,
                          n_lo, gcount, (const ulonglong2*)records, grad_table);
     } else if (rec_scale < 0.0f) {  // REC_P64
+      if (dpp_scan)
+        hipLaunchKernelGGL((k_grid_bwd_bin<REC_P64, true>),
+                           dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
+                           (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
+                           T, M, (const float2*)d_feat, gcount, (void*)records,
+                           grad_table, 1.0f, mg);
+      else
       hipLaunchKernelGGL(k_grid_bwd_bin<REC_P64>,
                          dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
                          (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
@@ -1186,7 +1203,12 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
   // (a marched training batch has ~0.3 M points: 34 workgroups per level)
   uint32_t tiles = ACC_TILES;
   while (tiles > 1 && ucsa_div_up(M, 256 * tiles) * n_run < 1024) tiles >>= 1;
-  if (n_run > 0)
+  if (n_run > 0 && dpp_scan)
+    hipLaunchKernelGGL((k_hashgrid_bwd<true, true>),
+                       dim3(ucsa_div_up(M, 256 * tiles), n_run),
+                       dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
+                       bb, T, M, 0u, tiles, (const float2*)d_feat, grad_table, mg);
+  else if (n_run > 0)
     hipLaunchKernelGGL(k_hashgrid_bwd<true>,
                        dim3(ucsa_div_up(M, 256 * tiles), n_run),
                        dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
