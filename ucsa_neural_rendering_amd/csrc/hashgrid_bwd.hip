@@ -141,8 +141,9 @@ __device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
   }
 }
 
-// The same run structure on the DPP data path (experimental, used by
-// k_grid_bwd_bin_xpair<true> only: UCSA_BWD_XPAIR=2; not yet run on a GPU).  A
+// The same run structure on the DPP data path (experimental: UCSA_BWD_XPAIR=2 for
+// the x-pair kernel, UCSA_BWD_DPP=1 for the shipped coarse / packed-bin kernels;
+// verified on the GPU at rel L2 5e-8 against the shuffle ladder, not yet timed).  A
 // __shfl_up is a ds_bpermute_b32 -- an LDS instruction with its latency in a
 // dependent chain -- and run_sum issues two per live step for each of the 16
 // values of a sample; a DPP step is one VALU instruction (wave_ops.h: 3.5 x the scan
@@ -748,10 +749,11 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
 }
 
 // ---------------------------------------------------------------------------
-// x-PAIR records (written at the end of round 5; OFF unless UCSA_BWD_XPAIR=1 and
-// NOT YET RUN ON A GPU -- the round's GPU budget was spent; tests/
-// test_gpu_backward.py::test_xpair_bin_records_match_packed_records is the test
-// to switch on first, docs/DESIGN_NOTEBOOK.md "R6-plan" the reasoning).
+// x-PAIR records (written at the end of round 5; OFF unless UCSA_BWD_XPAIR=1|2.
+// Functionally verified on the GPU -- tests/test_gpu_backward.py::
+// test_xpair_bin_records_match_packed_records, 0.66 of the error bound against
+// the REC_P64 path -- but NOT TIMED: the round's GPU budget was spent;
+// docs/DESIGN_NOTEBOOK.md "R6-plan" has the reasoning).
 //
 // The bin kernel is issue- and LDS-atomic-bound (~82 VALU instructions per
 // record, profiles/r04_train_sq_counters.txt), not byte-bound: what costs is the
@@ -1078,7 +1080,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    MergedSrc mg = MergedSrc{nullptr, nullptr, nullptr, 0u, 0u, 0u}) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
-  // UCSA_BWD_DPP=1 (experimental, not yet run on a GPU): the run plans / run sums
+  // UCSA_BWD_DPP=1 (experimental; verified, not yet timed): the run plans / run sums
   // of the coarse kernel and of the packed bin kernel on the DPP data path
   const char* dpp_env = getenv("UCSA_BWD_DPP");
   const bool dpp_scan = dpp_env && dpp_env[0] == '1';
