@@ -38,10 +38,11 @@ path; a fixed 2e-5 then rejected rays whose explained residual was 2.2e-5 / 2.8e
 the DEPTHS, at least ``window_floor`` = four times the render's median image error (the
 nets' arithmetic moves the weights too; round 5), at most 2 % of the threshold.
 
-A third alternative, used by the whole-view test only (``jitter=True``): ONE fine
+A third alternative, used by the GPU render tests (``jitter=True``): ONE fine
 sample moved by at most 6 x the modelled round-off of its depth, the field
 re-evaluated there (``_moved_fine_sample``) -- a one-parameter family, not a
-decision; it explains the 0-2 semantics-only rays of a 307 200-ray view.
+decision; it explains the 0-2 semantics-only rays of a 307 200-ray view (a 4096-ray
+render may use it for at most 2 rays).
 """
 from __future__ import annotations
 

@@ -57,8 +57,13 @@ def _check(res, ref, fld, rays, T, t, sel=None, tag=""):
     its at-threshold decisions taken the other way (mask bits of the <= 3
     samples whose weight is within fp32 noise of 1e-4; the branch of the <= 2
     fine samples on sample_pdf's ``denom < 1e-5`` step) -- tests/parity_check.py,
-    itself tested by tests/test_parity_check_cpu.py.  No blanket escape."""
-    return pc.check_render(res, ref, fld, rays, AABB4, T, t, sel=sel, tag=tag)
+    itself tested by tests/test_parity_check_cpu.py.  No blanket escape.
+    Since the end of round 5 also: ONE fine sample moved by <= 6 x the modelled
+    round-off of its depth with the field re-evaluated there (the oracle against
+    itself with its cdf summed in another order needs this on 2 of 4096 rays:
+    test_the_oracle_with_its_cdf_summed_in_another_order_is_fully_explained);
+    at most 2 rays of a render may be explained that way."""
+    return pc.check_render(res, ref, fld, rays, AABB4, T, t, sel=sel, tag=tag, jitter=True)
 
 
 def test_cfg1_4096_rays_16_plus_16():
@@ -87,7 +92,7 @@ def test_cfg2_whole_view_f16x2_every_ray_against_the_oracle():
     it (f16x2 nets, one pipelined ucsa_render_view call, depth-ordered fine pass)
     goes against the oracle, in blocks of 32 768 rays (~6 s of CPU each), with the
     same stated tolerance and the same causal explanation of the rays above it
-    (a decision of one of the two step functions, or -- this test only -- one fine
+    (a decision of one of the two step functions, or one fine
     sample moved inside its depth round-off; all but a bounded handful of a view's
     ~550: see the end of the test)."""
     import bench
