@@ -235,6 +235,13 @@ def main_cfg5(args, dev, dist, world, rank, backend):
                        "export_s_not_timed": export_s},
         "stages": stages,
     }
+    try:      # decoded-frame cache of the dataset (round 5): how many PNG decodes it saved
+        from ucsa_neural_rendering_amd.dataset.scannet_ngp_joint import decode_cache
+        dc = decode_cache()
+        result["decode_cache"] = {"hits": dc.hits, "misses": dc.misses, "mb": dc.used / 2 ** 20,
+                                  "budget_mb": dc.budget / 2 ** 20}
+    except Exception as e:      # never let bookkeeping sink a benchmark record
+        result["decode_cache"] = {"error": repr(e)}
     import shutil
     if rank == 0:
         shutil.rmtree(root, ignore_errors=True)
