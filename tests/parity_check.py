@@ -3,7 +3,8 @@ every ray above it (test infrastructure; used by tests/test_gpu_configs.py,
 tested on the CPU by tests/test_parity_check_cpu.py).
 
 Stated tolerance (fp32): image / semantics 1e-4 abs, depth 2e-4 rel -- for at
-least 99.5 % of the rays; every ray within 2e-3 / 5e-3; median <= 5e-6.
+least 99.5 % of the rays (of the view a render samples: the count in a sample is
+held to that fraction at three binomial standard deviations); every ray within 2e-3 / 5e-3; median <= 5e-6.
 
 Why not 100 % at thousands of rays: the reference has two STEP functions in
 this path, and a ray that sits on one is decided by fp32 round-off:
@@ -47,6 +48,7 @@ render may use it for at most 2 rays).
 from __future__ import annotations
 
 import itertools
+import math
 
 import torch
 
@@ -460,7 +462,12 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
                              "reference's two step functions reproduces within "
                              f"{alt[0]:.2g} / {alt[1]:.2g} / {alt[2]:.2g}:\n" + "\n".join(unexplained[:10]))
     # every loose ray is reproduced by a named alternative above; their NUMBER
-    # stays small (0.2 % observed at 4096 rays; 8 allows for the Poisson spread
-    # of a 512-ray sample, where 5 were seen once)
-    assert int(loose.sum()) <= max(8, int(max_loose_frac * n)), int(loose.sum())
+    # stays small: at most 0.5 % of the rays -- of the POPULATION the render samples.
+    # A whole view of a field that leaves haze in empty space has 0.42 % (1295 of
+    # 307 200); 4096 of its rays then hold 17 +- 4, and a fixed 20 would fail one
+    # such sample in five.  So: the count must be consistent with 0.5 % at three
+    # standard deviations of the binomial (4096 rays: 34; 32 768: 202; never below 8:
+    # a 512-ray sample showed 5 once).
+    p_n = max_loose_frac * n
+    assert int(loose.sum()) <= max(8, int(math.ceil(p_n + 3.0 * math.sqrt(p_n)))), int(loose.sum())
     return {"loose": int(loose.sum()), "flagged_frac": frac, "by_jitter": n_jitter}
