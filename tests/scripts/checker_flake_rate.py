@@ -17,7 +17,8 @@ from tests.util import AABB4
 from ucsa_neural_rendering_amd.dataset.synthetic_scene import _slerp_loop_poses
 torch.set_num_threads(8)
 NOISE = float(sys.argv[1]); SEEDS = int(sys.argv[2]); NR = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-C, H, W, T, t = 40, 480, 640, 96, 96
+C, H, W = 40, 480, 640
+T = t = int(os.environ.get("TT", "96"))
 st = torch.load(sys.argv[4] if len(sys.argv) > 4 else "/tmp/oracle_field.pt")
 fld = ofield.OracleField(bound=4.0, num_semantic_classes=C, seed=None)
 fld.grid_params, fld.sigma_params, fld.color_params, fld.sem_params = st["grid"], st["sigma"], st["color"], st["sem"]

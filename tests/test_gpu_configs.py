@@ -61,8 +61,10 @@ def _check(res, ref, fld, rays, T, t, sel=None, tag=""):
     Since the end of round 5 also: ONE fine sample moved by <= 6 x the modelled
     round-off of its depth with the field re-evaluated there (the oracle against
     itself with its cdf summed in another order needs this on 2 of 4096 rays:
-    test_the_oracle_with_its_cdf_summed_in_another_order_is_fully_explained);
-    at most 2 rays of a render may be explained that way."""
+    test_the_oracle_with_its_cdf_summed_in_another_order_is_fully_explained; at
+    16+16 samples, where a bin is 0.4 wide, most loose rays are of this kind:
+    tests/scripts/checker_flake_rate.py with TT=16).  Their number is reported
+    (`by_jitter`); the whole-view test bounds it."""
     return pc.check_render(res, ref, fld, rays, AABB4, T, t, sel=sel, tag=tag, jitter=True)
 
 
