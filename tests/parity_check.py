@@ -3,8 +3,10 @@ every ray above it (test infrastructure; used by tests/test_gpu_configs.py,
 tested on the CPU by tests/test_parity_check_cpu.py).
 
 Stated tolerance (fp32): image / semantics 1e-4 abs, depth 2e-4 rel -- for at
-least 99.5 % of the rays (of the view a render samples: the count in a sample is
-held to that fraction at three binomial standard deviations); every ray within 2e-3 / 5e-3; median <= 5e-6.
+least 99.5 % of the rays; every ray within 2e-3 / 5e-3; median <= 5e-6.  What is
+ENFORCED for the 99.5 %: a hard 0.5 % for a check of >= 32 768 rays (and for the whole
+307 200-ray view); for a smaller SAMPLE of a view, 0.5 % + three binomial standard
+deviations of the sample count (4096 rays: 34 = 0.83 %; never below 8).
 
 Why not 100 % at thousands of rays: the reference has two STEP functions in
 this path, and a ray that sits on one is decided by fp32 round-off:
@@ -399,8 +401,12 @@ def flagged_a_priori(aux, floor=WINDOW_MIN):
     return at_mask, at_denom
 
 
+MAX_BY_JITTER = 2   # rays of ONE check_render call explained by the moved-sample family
+
+
 def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
-                 max_loose_frac=5e-3, collect_unexplained=None, jitter=False):
+                 max_loose_frac=5e-3, collect_unexplained=None, jitter=False,
+                 max_by_jitter=MAX_BY_JITTER):
     """``res``: the outputs under test ([1, N(, C)] tensors, any device);
     ``ref``: ``oracle.renderer.run(..., return_aux=True)`` on ``rays`` = (o, d,
     nrm) [1, n, .] CPU tensors (the rows ``sel`` of what ``res`` rendered).
@@ -409,7 +415,13 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
     no alternative are appended to it as (line, residuals, errors) instead of
     failing here -- the caller bounds their number and size over the whole view
     (one view has ~550 loose rays: a handful of them lie in the tail of the
-    ordinary error distribution the match tolerance is a percentile of)."""
+    ordinary error distribution the match tolerance is a percentile of).
+
+    ``max_by_jitter``: with ``jitter=True`` at most this many rays of the call may be
+    explained by the moved-fine-sample family (ADVICE r5 / VERDICT r5: a one-parameter
+    family, so its use is COUNTED and BOUNDED in every caller -- 2 per render sample
+    here; a whole 307 200-ray view has shown 0-3 and bounds them itself, passing
+    ``None``)."""
     o, d, nrm = rays[0].reshape(-1, 3), rays[1].reshape(-1, 3), rays[2].reshape(-1)
     aux = ref["aux"]
     pick = (lambda x: x[0].cpu()) if sel is None else (lambda x: x[0][sel.to(x.device)].cpu())
@@ -427,6 +439,11 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
         assert float(e.median()) <= 5e-6, (tag, name, float(e.median()))
     loose = (e_img > TOL_ABS) | (e_sem > TOL_ABS) | (rel > TOL_DEPTH_REL)
     floor = window_floor(e_img, loose)
+    # the floor follows the render's own median error, so it is capped by
+    # a CONSTANT (2 % of the threshold, the largest window the rule ever had) and the
+    # median itself is held to 5e-6 above: a regression cannot widen its own excuse
+    # beyond what a healthy render already gets
+    assert WINDOW_MIN <= floor <= WINDOW_MAX, floor
     at_mask, at_denom = flagged_a_priori(aux, floor)
     frac = float((at_mask | at_denom).float().mean())
     print(f"{tag} a-priori candidates (window floor {floor:.1e}): {int(at_mask.sum())} rays with a weight in the mask window, "
@@ -469,6 +486,12 @@ def check_render(res, ref, fld, rays, aabb, T, t, sel=None, tag="", t_rand=None,
     # such sample in five.  So: the count must be consistent with 0.5 % at three
     # standard deviations of the binomial (4096 rays: 34; 32 768: 202; never below 8:
     # a 512-ray sample showed 5 once).
+    # From 32 768 rays on the sample IS a population: 0.5 % is a hard limit there
+    # (ADVICE r5).
     p_n = max_loose_frac * n
-    assert int(loose.sum()) <= max(8, int(math.ceil(p_n + 3.0 * math.sqrt(p_n)))), int(loose.sum())
+    limit = int(p_n) if n >= 32768 else max(8, int(math.ceil(p_n + 3.0 * math.sqrt(p_n))))
+    assert int(loose.sum()) <= limit, (int(loose.sum()), limit)
+    if max_by_jitter is not None:
+        assert n_jitter <= max_by_jitter, (
+            f"{tag}: {n_jitter} rays needed the moved-fine-sample alternative (bound {max_by_jitter})")
     return {"loose": int(loose.sum()), "flagged_frac": frac, "by_jitter": n_jitter}

@@ -169,3 +169,56 @@ def test_bottleneck_of_the_mirror_runs_the_fused_path_and_matches_nchw():
         assert float((pa.grad - pb.grad).abs().max()) <= 1e-3 * max(1e-6, float(pa.grad.abs().max())), n
     for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert float((ba.double() - bb.double()).abs().max()) <= 1e-4, n
+
+
+def test_two_host_threads_on_one_stream_do_not_share_scratch():
+    """the trainer's prefetch thread (`trainer: {prefetch: N}`) issues
+    augmentation / BatchNorm ops on the SAME stream as the training step while
+    ctypes has released the GIL.  Both are multi-launch sequences that pass partial
+    sums through `ops._scratch`; keyed by (device, stream) only, two threads'
+    launches interleave and one op reads the other's partials.  The buffer is now
+    keyed by the thread too: results under contention == the serial results, bit
+    for bit, and the two threads really hold different buffers."""
+    import threading
+
+    from ucsa_neural_rendering_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def case(shape):
+        N, C, H, W = shape
+        x = torch.randn(N, C, H, W, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        w = torch.rand(C, device=dev, generator=g) + 0.5
+        b = torch.rand(C, device=dev, generator=g) - 0.5
+        return x, w, b
+
+    def run(c):
+        x, w, b = c
+        C = x.shape[1]
+        y, m, s = ops.bn_act_fwd(x, None, w, b, torch.zeros(C, device=dev), torch.ones(C, device=dev),
+                                 0.1, 1e-5, True, True)
+        return y, m, s
+
+    cases = [case((8, 64, 30, 40)), case((4, 256, 33, 17))]
+    want = [run(c) for c in cases]
+    torch.cuda.synchronize()
+    got, bufs, errs = [None, None], [None, None], []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(dev)
+            for _ in range(200):
+                got[k] = run(cases[k])
+            bufs[k] = ops._scratch(1, dev).data_ptr()
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert bufs[0] != bufs[1]
+    for k in (0, 1):
+        for a, b in zip(got[k], want[k]):
+            assert torch.equal(a, b), k

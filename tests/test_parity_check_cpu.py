@@ -44,17 +44,21 @@ def test_the_oracle_itself_passes(case):
     assert out["loose"] == 0
 
 
-def test_an_injected_error_off_any_step_fails(case):
+@pytest.mark.parametrize("jitter", [False, True])
+def test_an_injected_error_off_any_step_fails(case, jitter):
+    """``jitter=True`` is how every GPU render test calls the checker:
+    the moved-fine-sample alternative must not explain an injected error either."""
     fld, rays, u, ref = case
     am, ad = pc.flagged_a_priori(ref["aux"])
     clean = torch.nonzero(~(am | ad)).flatten()[:5]
     res = _res(ref)
     res["image"][0, clean, 1] += 3e-4
     with pytest.raises(AssertionError, match="NO alternative"):
-        pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-clean")
+        pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-clean", jitter=jitter)
 
 
-def test_an_injected_error_on_a_flagged_ray_fails_too(case):
+@pytest.mark.parametrize("jitter", [False, True])
+def test_an_injected_error_on_a_flagged_ray_fails_too(case, jitter):
     fld, rays, u, ref = case
     am, _ = pc.flagged_a_priori(ref["aux"])
     flagged = torch.nonzero(am).flatten()[:5]
@@ -66,7 +70,18 @@ def test_an_injected_error_on_a_flagged_ray_fails_too(case):
         else:
             res["semantics"][0, flagged, 3] += 3e-4
         with pytest.raises(AssertionError, match="NO alternative"):
-            pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-flagged-" + key)
+            pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-flagged-" + key,
+                            jitter=jitter)
+    if jitter:      # ... nor one in the image or in the other semantics classes
+        res = _res(ref)
+        res["image"][0, flagged] += 3e-4
+        with pytest.raises(AssertionError, match="NO alternative"):
+            pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-flagged-image", jitter=True)
+        res = _res(ref)
+        res["semantics"][0, flagged, 7] += 1.5e-4
+        res["semantics"][0, flagged, 11] -= 1.2e-4
+        with pytest.raises(AssertionError, match="NO alternative"):
+            pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="inject-flagged-sem2", jitter=True)
 
 
 def _toggle_case(case):
@@ -102,8 +117,9 @@ def test_a_genuine_threshold_flip_passes_and_is_named(case, capsys):
     assert f"'mask_toggled': [{s}]" in capsys.readouterr().out
     # ... and the same ray with an extra 1e-4 on top of the flip does not
     res["image"][0, i, 0] += 1e-4
-    with pytest.raises(AssertionError, match="NO alternative"):
-        pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="flip+error")
+    for jitter in (False, True):
+        with pytest.raises(AssertionError, match="NO alternative"):
+            pc.check_render(res, ref, fld, rays, AABB4, T, t, tag="flip+error", jitter=jitter)
 
 
 def test_a_denom_step_sample_placed_by_the_other_branch_passes(case):
@@ -263,6 +279,10 @@ def test_the_oracle_with_its_cdf_summed_in_another_order_is_fully_explained():
     assert float(moved) > 0.2, "the two summation orders gave the same render"
     out = pc.check_render(_res(alt), ref, fld, rays, AABB4, T2, t2, tag="seq-cdf", jitter=True)
     assert out["loose"] >= 1 and out["by_jitter"] >= 1, out
+    # ... the rays it explains are counted against a bound (here: none allowed)
+    with pytest.raises(AssertionError, match="moved-fine-sample"):
+        pc.check_render(_res(alt), ref, fld, rays, AABB4, T2, t2, tag="seq-cdf-bound", jitter=True,
+                        max_by_jitter=0)
     # ... and without the moved-sample alternative the same render does NOT pass
     with pytest.raises(AssertionError, match="NO alternative"):
         pc.check_render(_res(alt), ref, fld, rays, AABB4, T2, t2, tag="seq-cdf-no-moved-sample")

@@ -37,12 +37,19 @@ def _tick(what):
           flush=True)
 
 
-def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
+def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False,
+                deterministic=None):
     """SURVEY 8d parameter state: tcnn-style init (grid U(-1e-4,1e-4), Xavier
     MLPs, seed 123), then `train_steps` Adam steps (lr 1e-2, the reference's
     NeRF optimizer) on the synthetic box-room scene so that sigma is
     non-trivial and the w > 1e-4 mask is selective.  Runs on the HIP training
-    path; excluded from the timed region."""
+    path; excluded from the timed region.
+
+    ``deterministic=True`` (the parity tests): the 200 steps run
+    with ``net.deterministic`` -- the table gradient through the order-independent
+    fixed-point reduction -- so every box trains the SAME field, bit for bit
+    (``field_checksum`` prints it), and a failing parity test can be replayed.
+    ``None``: as the environment says (``UCSA_DETERMINISTIC``)."""
     from ucsa_neural_rendering_amd import losses as ul
     from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
     from ucsa_neural_rendering_amd.nerf.network_tcnn_semantics import \
@@ -52,6 +59,9 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
     net = SemanticNeRFNetwork(encoding="hashgrid", bound=4, cuda_ray=cuda_ray,
                               density_scale=1, num_semantic_classes=N_CLASSES,
                               seed=seed).to(device).train()
+    env_det = net.deterministic
+    if deterministic is not None:
+        net.deterministic = bool(deterministic)
     ds = SyntheticSceneDataset(0, n_views=16, H=240, W=320,
                                n_classes=N_CLASSES, device=device)
     opt = HipAdam(
@@ -84,7 +94,20 @@ def build_field(device, seed=123, train_steps=200, log=None, cuda_ray=False):
         log["pretrain_steps"] = train_steps
         log["pretrain_s"] = time.perf_counter() - t0
         log["pretrain_final_loss"] = float(loss.detach())
+        log["pretrain_deterministic"] = bool(net.deterministic)
+    net.deterministic = env_det
     return net.eval(), ds
+
+
+def field_checksum(net) -> str:
+    """Order-independent integer checksum of the four parameter tensors' BITS (sum of
+    the int32 views in int64): equal strings = the same field, bit for bit."""
+    parts = []
+    for p in (net.encoder.params, net.sigma_net.params, net.color_net.params,
+              net.semantics_net.params):
+        parts.append("%016x" % (int(p.detach().contiguous().view(torch.int32).to(torch.int64).sum().item())
+                                & 0xFFFFFFFFFFFFFFFF))
+    return "-".join(parts)
 
 
 def masked_fraction(net, o, d, nrm, T, t, rt, ru):

@@ -1377,13 +1377,24 @@ extern "C" int32_t ucsa_hashgrid_bwd_points(const ucsa_grid* grid,
 // w * d_feat -- the same fp32 product the fast kernels form -- is converted to
 // a 64-bit FIXED-POINT number (units of 2^-44) and added with integer atomics:
 // integer addition is associative, so the sum does not depend on the order,
-// and the result is the same bits on every run and every device.  Range +-2^19
-// per entry; a non-finite or out-of-range contribution raises a flag that turns
-// the whole gradient into NaN (found_inf semantics).  ~25 ms for a 4096 x 512
+// and the result is the same bits on every run and every device.  A contribution
+// must be finite and below 2^18 in magnitude (2^62 in fixed point); an entry's
+// running sum must stay inside int64 (+-2^19): every atomic returns the value it
+// added to, so the ONE addition that wraps sees it (signed overflow of old + add)
+// -- exact whatever the order.  Either raises a flag that turns the whole gradient
+// into NaN (found_inf semantics).  ~25 ms for a 4096 x 512
 // step: for `UCSA_DETERMINISTIC=1` runs, not for production.
 //   fix [total_entries * 2 + 1] int64, zeroed by the caller; the last word is the flag.
 // ---------------------------------------------------------------------------
 #define DET_ONE 17592186044416.0   // 2^44
+
+// fix[i] += add; true when THIS addition wrapped int64 (old and add of one sign,
+// the sum of the other)
+__device__ __forceinline__ bool det_add(unsigned long long* p, long long add) {
+  const long long old = (long long)atomicAdd(p, (unsigned long long)add);
+  const long long sum = (long long)((unsigned long long)old + (unsigned long long)add);
+  return ((old ^ sum) & (add ^ sum)) < 0;
+}
 
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd_det(GridDev g, const float* __restrict__ rays_o,
@@ -1420,8 +1431,9 @@ k_hashgrid_bwd_det(GridDev g, const float* __restrict__ rays_o,
     const float vx = w * df.x, vy = w * df.y;
     bad = bad || !(fabsf(vx) < 262144.0f) || !(fabsf(vy) < 262144.0f);   // NaN too
     const uint64_t e = ((uint64_t)g.offset[level] + idx) * 2u;
-    if (vx != 0.f) atomicAdd(&fix[e], (unsigned long long)__double2ll_rn((double)vx * DET_ONE));
-    if (vy != 0.f) atomicAdd(&fix[e + 1], (unsigned long long)__double2ll_rn((double)vy * DET_ONE));
+    if (bad) continue;          // (nothing defined to add; the flag below poisons the result)
+    if (vx != 0.f) bad = det_add(&fix[e], __double2ll_rn((double)vx * DET_ONE)) || bad;
+    if (vy != 0.f) bad = det_add(&fix[e + 1], __double2ll_rn((double)vy * DET_ONE)) || bad;
   }
   if (bad) atomicOr(&fix[flag_at], 1ull);
 }
@@ -1431,7 +1443,7 @@ k_hashgrid_bwd_det_finish(const long long* __restrict__ fix, uint64_t n,
                           float* __restrict__ grad_table) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const bool bad = fix[n] != 0 || fix[i] > (1ll << 62) || fix[i] < -(1ll << 62);
+  const bool bad = fix[n] != 0;      // non-finite / out-of-range contribution or a wrapped sum
   const float v = (float)((double)fix[i] * (1.0 / DET_ONE));
   grad_table[i] = bad ? __builtin_nanf("") : grad_table[i] + v;
 }

@@ -596,6 +596,13 @@ class SemanticNeRFNetwork(SemanticNeRFRenderer):
 
     def _march_render_fn(self):
         def call(net, o, d, nrm, nears, xyzs, deltas, rays, w_min):
+            if net.deterministic and torch.is_grad_enabled():
+                # the marched backward sums the table gradient with float
+                # atomics; silently ignoring the request would defeat its purpose
+                raise _lib.UcsaError("UCSA_DETERMINISTIC=1 / net.deterministic covers the "
+                                     "uniform-sampling training path only; the marched "
+                                     "(cuda_ray=True) backward has no order-independent "
+                                     "table reduction")
             return _MarchRenderFn.apply(net.encoder.params,
                                         net.sigma_net.params,
                                         net.color_net.params,

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -1205,8 +1206,13 @@ _named_ws = {}
 
 
 def _scratch_named(name: str, nbytes: int, device) -> torch.Tensor:
-    """A grow-only scratch buffer of its own (not shared with _scratch's)."""
-    key = (name, device, torch.cuda.current_stream().cuda_stream)
+    """A grow-only scratch buffer of its own (not shared with _scratch's).
+    Keyed by the calling THREAD as well as device and stream: the
+    multi-launch ops (BatchNorm: stats -> finalize -> apply; augmentation: grey
+    sums -> apply) pass intermediates through it, ctypes releases the GIL, and the
+    trainer's prefetch thread issues on the same stream as the training step -- two
+    threads sharing one buffer would overwrite each other's partial sums."""
+    key = (name, device, torch.cuda.current_stream().cuda_stream, threading.get_ident())
     buf = _named_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -1215,7 +1221,7 @@ def _scratch_named(name: str, nbytes: int, device) -> torch.Tensor:
 
 
 def _scratch(nbytes: int, device) -> torch.Tensor:
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, torch.cuda.current_stream().cuda_stream, threading.get_ident())
     buf = _march_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8,
