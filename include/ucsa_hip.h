@@ -17,7 +17,12 @@
  *   - return 0 on success, a negative hipError_t on a launch error, or
  *     UCSA_ERR_ARG (-1000 - k) when argument k (0-based) is invalid;
  *   - buffers are contiguous, fp32 unless stated, 16-byte aligned;
- *   - re-entrant, no global state.
+ *   - re-entrant.  Process-wide state is limited to: (a) the table of tuning
+ *     switches read from the environment ONCE, at the first call that consults
+ *     it (INTEGRATION.md "Environment variables": launch shapes and kernel
+ *     choices, never results); (b) per caller-stream sets of internal streams /
+ *     events created on first use by the calls documented as pipelined
+ *     (ucsa_render_view, the merged grid backward).
  */
 #ifndef UCSA_HIP_H_
 #define UCSA_HIP_H_
@@ -35,6 +40,10 @@ extern "C" {
 int32_t ucsa_version(void);
 /* Human-readable text for a return code (static storage). */
 const char* ucsa_error_string(int32_t code);
+/* Re-read the tuning switches from the environment (lab tools and tests that
+ * flip one inside a process; not for production code, not thread-safe against
+ * concurrent calls into the library). */
+void ucsa_env_reload(void);
 
 /* ---- hash-grid level table -------------------------------------------------
  * Host-side description of tcnn.Encoding("HashGrid") as configured at
@@ -147,28 +156,6 @@ int32_t ucsa_sigma_mlp_fwd(const float* feat, const float* packed_sigma,
                            uint32_t M, uint32_t n_levels, float* h,
                            float* sigma, void* stream);
 
-/* Encode + sigma MLP in ONE kernel for image-ordered rays (the pixels of full
- * rows of an image `image_width` wide): the 32 features of a sample stay in
- * LDS instead of travelling through HBM between ucsa_hashgrid_encode_rays_image
- * and ucsa_sigma_mlp_fwd.  Same outputs, bit for bit: h [N*T,16], sigma [N*T].
- * Replaces density() for a whole sample batch
- * (reference network_tcnn_semantics.py:130-144).  n_levels must be 16. */
-int32_t ucsa_encode_sigma_rays_image(const ucsa_grid* grid, const float* table,
-                                     const float* packed_sigma,
-                                     const float* rays_o, const float* rays_d,
-                                     const float* z, const float* aabb_host,
-                                     uint32_t N, uint32_t T,
-                                     uint32_t image_width, float* h,
-                                     float* sigma, void* stream);
-/* fp16-MFMA form (weights from ucsa_mlp_pack_f16) */
-int32_t ucsa_encode_sigma_rays_image_f16(const ucsa_grid* grid,
-                                         const float* table,
-                                         const void* packed_sigma_half,
-                                         const float* rays_o,
-                                         const float* rays_d, const float* z,
-                                         const float* aabb_host, uint32_t N,
-                                         uint32_t T, uint32_t image_width,
-                                         float* h, float* sigma, void* stream);
 
 /* ---- hierarchical resampling ----------------------------------------------
  * Coarse weights -> pdf over interior bins -> inverse CDF at u.
@@ -339,20 +326,6 @@ int32_t ucsa_sigma_mlp_fwd_scatter(int32_t mode, const void* feat,
                                    const void* packed_sigma, uint32_t M,
                                    uint32_t n_levels, const uint32_t* slot,
                                    float* h, float* sigma, void* stream);
-/* ucsa_hashgrid_encode_sorted + ucsa_sigma_mlp_fwd_scatter as one call in which
- * the sigma MLP ENCODES levels 0-7 itself (their features never go through HBM)
- * and reads levels 8-15 from feat_ws [16][N*T][2] (written here by the per-level
- * depth-ordered encoder): `density()` of the fine samples,
- * network_tcnn_semantics.py:130-144.  mode 2 = bf16x3, 3 = f16x2 packs; 16 levels.
- * Same h / sigma bits as the two separate calls. */
-int32_t ucsa_encode_sigma_sorted(int32_t mode, const ucsa_grid* grid,
-                                 const float* table, const float* rays_o,
-                                 const float* rays_d, const float* z_sorted,
-                                 const uint8_t* pix, const uint32_t* slot,
-                                 const float* aabb_host, uint32_t N, uint32_t T,
-                                 uint32_t image_width, const void* packed_sigma,
-                                 float* feat_ws, float* h, float* sigma,
-                                 void* stream);
 /* ucsa_sigma_mlp_fwd_f16 on fp16 features (same h / sigma) */
 int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
                                  const void* packed_sigma_half, uint32_t M,
@@ -680,7 +653,8 @@ int32_t ucsa_hashgrid_bwd_rays_merged(
  * so two runs of a step give the same bits.  `fix`: int64
  * [ucsa_hashgrid_bwd_det_workspace_bytes / 8], zeroed by the caller, accumulates
  * over any number of _det calls (both density passes); _finish adds it into
- * grad_table (NaN everywhere if a contribution was non-finite or >= 2^18). */
+ * grad_table (NaN everywhere if a contribution was non-finite or >= 2^18, or if
+ * an entry's running sum left int64 -- each addition checks its own overflow). */
 uint64_t ucsa_hashgrid_bwd_det_workspace_bytes(const ucsa_grid* grid);
 int32_t ucsa_hashgrid_bwd_rays_det(const ucsa_grid* grid, const float* rays_o,
                                    const float* rays_d, const float* z,
@@ -689,12 +663,14 @@ int32_t ucsa_hashgrid_bwd_rays_det(const ucsa_grid* grid, const float* rays_o,
 int32_t ucsa_hashgrid_bwd_det_finish(const ucsa_grid* grid, const void* fix,
                                      float* grad_table, void* stream);
 
-/* ucsa_hashgrid_bwd_rays / ucsa_hashgrid_bwd_rays_merged with 8-byte PACKED bin
+/* ucsa_hashgrid_bwd_rays / ucsa_hashgrid_bwd_rays_merged with PACKED bin
  * records: one 64-bit word = entry index inside its bin (L bits) | vx | vy,
  * each value the fp32 rounded to nearest-even to its top min(32, (64 - L) / 2)
  * bits -- 26 bits (2^-18 relative) for the 2^19-entry levels of the
- * reference's grid.  Half the record bytes of both passes; the sums stay fp32;
- * non-finite values stay non-finite.  Meant for training modes whose MLP
+ * reference's grid; since round 6 two such words travel as ONE 16-byte record
+ * per x-pair of corners (the corners x and x + 1 of a cell share a bin: half the
+ * records, counters and staging slots).  Half the record bytes of both passes;
+ * the sums stay fp32; non-finite values stay non-finite.  Meant for training modes whose MLP
  * backward is itself a two-term bf16 split (2^-16): the Python host uses them
  * for bwd_precision "bf16x2".  Same arguments; the workspace is mandatory.
  * (No reference counterpart: tiny-cuda-nn scatters with atomics,

@@ -1,4 +1,4 @@
-"""csrc/hashgrid_bwd.hip's run_plan_dpp / run_sum_dpp in numpy: the segmented wave
+"""csrc/hashgrid_bwd.hip's run_plan / run_sum in numpy: the segmented wave
 scan on the DPP ladder (row_shr 1 / 2 / 4 / 8 inside the four 16-lane rows,
 row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3) must leave the SUM OF
 ITS RUN in the last lane of every run, like the shuffle ladder (__shfl_up by 1, 2,

@@ -609,9 +609,11 @@ def test_merged_grid_backward_equals_the_two_single_pass_calls(ops, N, Tc, Tf):
 
 @pytest.mark.parametrize("case", ["rays", "merged", "overflow", "nonfinite"])
 def test_packed_bin_records_match_fp32_records(ops, case):
-    """ucsa_hashgrid_bwd_rays_p64 / _merged_p64 (8-byte records: entry index |
-    two values rounded to their top 26 bits, fp32 sums) against the 16-byte
-    records on the same inputs.  Every contribution carries a relative error
+    """ucsa_hashgrid_bwd_rays_p64 / _merged_p64 (packed records: entry index |
+    two values rounded to their top 26 bits, fp32 sums; since round 6 ONE 16-byte
+    record per x-pair of corners, k_grid_bwd_bin_xpair -- a pair that straddles two
+    bins goes to the table unrounded) against the 16-byte fp32 records on the same
+    inputs.  Every contribution carries a relative error
     of at most 2^-18, so an entry differs by at most 2^-18 x the sum of the
     MAGNITUDES added to it (+ fp32 summation order) -- checked per entry
     against the gradient of |d_feat|.  `overflow`: all records of a level in
@@ -666,80 +668,6 @@ def test_packed_bin_records_match_fp32_records(ops, case):
           f"rel L2 {float((gpk - g32).norm() / g32.norm()):.2e}")
     assert worst <= 1.0
     assert torch.equal(gpk == 0, g32 == 0) or float(((gpk == 0) != (g32 == 0)).float().mean()) < 1e-5
-
-
-@pytest.mark.parametrize("mode", ["1", "2", "dpp"])
-@pytest.mark.parametrize("case", ["rays", "merged", "overflow", "nonfinite"])
-def test_xpair_bin_records_match_packed_records(ops, case, mode, monkeypatch):
-    """k_grid_bwd_bin_xpair / _accum_xpair (one 16-byte record per x-pair of
-    corners = two REC_P64 words) against the REC_P64 path: the same 26-bit values
-    and fp32 sums, so entries agree up to the order of additions -- except pairs
-    that straddle two bins, which go to the table unrounded (2^-18 per value).
-    mode 2: the run sums on the DPP data path as well (other association);
-    mode dpp: UCSA_BWD_DPP=1 -- the SHIPPED kernels (k_hashgrid_bwd<true>,
-    k_grid_bwd_bin<REC_P64>) with their run plans / run sums as DPP scans.
-    All three are experimental switches, off by default; run once on the GPU in the
-    last seconds of round 5 (gpurun_out/r5/xpair.txt: mode 1 at 0.66 of the bound,
-    rel L2 2e-7; the DPP modes at rel L2 5e-8 but 1.16-1.28 x the ONE-rounding bound:
-    there both sides round differently associated run sums, hence 2 x 2^-18 below);
-    NOT yet timed."""
-    from ucsa_neural_rendering_amd._lib import make_grid
-    dev = torch.device("cuda:0")
-    grid = make_grid(4.0)
-    g = torch.Generator().manual_seed(78)
-    aabb = [-4.0, -4.0, -4.0, 4.0, 4.0, 4.0]
-    if case == "overflow":
-        N, T = 20000, 16
-        o = torch.tensor([0.1, -0.7, 1.3]).repeat(N, 1)
-        d = torch.nn.functional.normalize(torch.tensor([0.3, 0.5, -0.8]), dim=0).repeat(N, 1)
-        z = torch.tensor([0.5, 2.5]).repeat(N, T // 2)
-    else:
-        N, T = 1500, 64
-        o = ((torch.rand(N, 3, generator=g) * 2 - 1) * 2.0)
-        d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
-        z = (torch.rand(N, T, generator=g) * 5 + 0.2).sort(-1).values
-    d_feat = torch.randn(grid.n_levels, N * T, 2, generator=g) * 10.0 ** (
-        torch.rand(grid.n_levels, N * T, 1, generator=g) * 8 - 7)
-    o, d, z, d_feat = [x.to(dev).contiguous() for x in (o, d, z, d_feat)]
-    total = int(grid.total_entries)
-    gpk, gxp, gabs = (torch.zeros(total, 2, device=dev) for _ in range(3))
-
-    def run(out, df, xpair, **kw):
-        monkeypatch.setenv("UCSA_BWD_XPAIR", mode if xpair and mode != "dpp" else "0")
-        monkeypatch.setenv("UCSA_BWD_DPP", "1" if xpair and mode == "dpp" else "0")
-        if case == "merged":
-            ops.hashgrid_bwd_rays_merged(grid, o, d, z, kw["z_f"], kw["src"], aabb, df, kw["d_f"], out, packed=True)
-        else:
-            ops.hashgrid_bwd_rays(grid, o, d, z, aabb, df, out, packed=True)
-
-    kw = {}
-    if case == "merged":
-        Tf = 48
-        kw["z_f"] = (z[:, :1] + 2.0 + 0.05 * torch.rand(N, Tf, generator=g).to(dev)).sort(-1).values.contiguous()
-        kw["d_f"] = (torch.randn(grid.n_levels, N * Tf, 2, generator=g) * 1e-3).to(dev)
-        kw["src"] = torch.sort(torch.cat([z, kw["z_f"]], 1), dim=1, stable=True)[1].to(torch.int32).contiguous()
-    if case == "nonfinite":
-        d_feat[grid.n_levels - 1, 5, 0] = float("inf")
-        d_feat[grid.n_levels - 2, 9, 1] = float("nan")
-    run(gpk, d_feat, False, **kw)
-    run(gxp, d_feat, True, **kw)
-    torch.cuda.synchronize()
-    if case == "nonfinite":
-        assert torch.equal(torch.isfinite(gxp), torch.isfinite(gpk))
-        assert int((~torch.isfinite(gxp)).sum()) >= 2
-        return
-    kw_abs = dict(kw)
-    if case == "merged":
-        kw_abs["d_f"] = kw["d_f"].abs()
-    run(gabs, d_feat.abs(), False, **kw_abs)
-    torch.cuda.synchronize()
-    assert float(gpk.abs().max()) > 0
-    err = (gxp - gpk).abs()
-    bound = gabs * ((1.0 if mode == "1" else 2.0) * 2.0 ** -18 + 2e-6) + 1e-30
-    worst = float((err / bound).max())
-    print(f"x-pair records [{case}]: max err / bound {worst:.3f}, rel L2 {float((gxp - gpk).norm() / gpk.norm()):.2e}")
-    assert worst <= 1.0
-    assert torch.equal(gxp == 0, gpk == 0) or float(((gxp == 0) != (gpk == 0)).float().mean()) < 1e-5
 
 
 @pytest.mark.parametrize("N,T,t,C", [(300, 32, 32, 40), (129, 64, 0, 21), (64, 256, 256, 40)])

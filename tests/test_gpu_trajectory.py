@@ -47,35 +47,42 @@ from tests.util import AABB4, hip_network_from_oracle
 
 pytestmark = pytest.mark.gpu
 
-STEPS, N, T, t, C = 150, 2048, 16, 16, 40
-# quality = mean over the parameter states after these steps (0-based); by
-# step 70 the loss has fallen from 0.545 to ~0.009
-CHECKPOINTS = (69, 79, 89, 99, 109, 119, 129, 139, 149)
+import collections
+
+C = 40
 H, W, VIEWS, HELD = 48, 64, 12, 4   # frames 0..7 train, frames 8..11 held out
 LR, WD = 1e-2, 1e-6
+# quality = mean over the parameter states after `checkpoints` (0-based steps)
+Run = collections.namedtuple("Run", "steps n T t checkpoints seed")
+# round 4: by step 70 the loss has fallen from 0.545 to ~0.009; the semantic head is
+# still in its chance-to-learning transition at step 150
+SHORT = Run(150, 2048, 16, 16, (69, 79, 89, 99, 109, 119, 129, 139, 149), 2024)
+# round 6: a horizon on which the semantic head HAS converged --
+# 600 steps of 4096 rays (the reference's batch, joint_train_lightning_net.py:141),
+# quality = mean over 9 checkpoints of the last 200 steps -- held to north_star's
+# +-0.5 dB / +-0.5 pt
+LONG = Run(600, 4096, 16, 16, tuple(range(399, 600, 25)), 2025)
+STEPS, N, T, t = SHORT.steps, SHORT.n, SHORT.T, SHORT.t      # (the short run's, for the tools)
+CHECKPOINTS = SHORT.checkpoints
 
 
 @pytest.fixture(scope="module")
 def scene():
     """Frames of the synthetic room (GT by analytic ray casting on the GPU),
     and the per-step random tensors, all as CPU tensors."""
-    from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
-    ds = SyntheticSceneDataset(3, n_views=VIEWS, H=H, W=W, n_classes=C, device="cuda")
-    frames = []
-    for i in range(VIEWS):
-        it = ds[i]
-        frames.append(dict(o=it["rays_o"].cpu(), d=it["rays_d"].cpu(),
-                           nrm=it["direction_norms"].cpu(),
-                           rgb=it["img"].reshape(3, -1).t().contiguous().cpu(),
-                           label=it["label"].reshape(-1).cpu(),
-                           depth=it["depth"].float().reshape(-1).cpu()))
-    g = torch.Generator().manual_seed(2024)
+    return (_frames(),) + _draws(SHORT)
+
+
+def _draws(run):
+    """The per-step random tensors of a run (frame, ray indices, rng_t, rng_u) and the
+    uniforms of the evaluation renders, from the run's seed."""
+    g = torch.Generator().manual_seed(run.seed)
     draws = [dict(frame=int(torch.randint(0, VIEWS - HELD, (1,), generator=g)),
-                  inds=torch.randint(0, H * W, (N,), generator=g),
-                  rt=torch.rand(N, T, generator=g), ru=torch.rand(N, t, generator=g))
-             for _ in range(STEPS)]
-    u_eval = torch.rand(VIEWS * H * W, t, generator=g)
-    return frames, draws, u_eval
+                  inds=torch.randint(0, H * W, (run.n,), generator=g),
+                  rt=torch.rand(run.n, run.T, generator=g), ru=torch.rand(run.n, run.t, generator=g))
+             for _ in range(run.steps)]
+    u_eval = torch.rand(VIEWS * H * W, run.t, generator=g)
+    return draws, u_eval
 
 
 def _batch(frames, dr):
@@ -114,7 +121,7 @@ def _mean_quality(quals):
     return out
 
 
-def _train_oracle(frames, draws, u_eval, emulate_tcnn):
+def _train_oracle(frames, draws, u_eval, emulate_tcnn, checkpoints=SHORT.checkpoints):
     fld = ofield.OracleField(bound=4.0, num_semantic_classes=C, seed=123)
     if emulate_tcnn:
         fld.emulate_fp16 = True
@@ -147,12 +154,13 @@ def _train_oracle(frames, draws, u_eval, emulate_tcnn):
                 pn, s["m"], s["v"] = olosses.adam_step(
                     p, p.grad, s["m"], s["v"], k + 1, LR, weight_decay=0.0 if i == 0 else WD)
                 p.copy_(pn)
-        if k in CHECKPOINTS:
+        if k in checkpoints:
             evaluate()
     return _mean_quality(quals), losses, {}
 
 
-def _train_hip(frames, draws, u_eval, precision, deterministic=False, steps=None):
+def _train_hip(frames, draws, u_eval, precision, deterministic=False, steps=None,
+               checkpoints=SHORT.checkpoints):
     from ucsa_neural_rendering_amd import losses as ul
     from ucsa_neural_rendering_amd.nerf.optim import HipAdam
     net = hip_network_from_oracle(ofield.OracleField(bound=4.0, num_semantic_classes=C,
@@ -194,7 +202,7 @@ def _train_hip(frames, draws, u_eval, precision, deterministic=False, steps=None
         scaler.step(opt)
         scaler.update()
         losses.append(loss.detach())
-        if k in CHECKPOINTS:
+        if k in checkpoints:
             evaluate()
     skipped = sum(int(v) for v in opt._skipped.values()) if opt._skipped else 0
     info = {"skipped_steps": skipped, "final_scale": float(scaler.get_scale())}
@@ -215,19 +223,19 @@ def _hip_mean(scene, precision, runs=2):
 
 
 def _oracle_worker(args):
-    frames, draws, u_eval, emulate_tcnn, threads = args
+    frames, draws, u_eval, emulate_tcnn, threads = args[:5]
     torch.set_num_threads(threads)
-    return _train_oracle(frames, draws, u_eval, emulate_tcnn)
+    return _train_oracle(frames, draws, u_eval, emulate_tcnn, *args[5:])
 
 
 @pytest.fixture(scope="module")
 def oracles(scene):
-    """Both oracle trajectories (fp32, fp16-emulating), each in its own CPU
-    worker process with half of the cores, started before the HIP runs: the
+    """Both short oracle trajectories (fp32, fp16-emulating), each in its own CPU
+    worker process with a quarter of the cores, started before the HIP runs: the
     suite's wall clock sees max(.) of them instead of their sum."""
     import multiprocessing as mp
     from tests.conftest import _effective_cores
-    threads = max(1, _effective_cores() // 2)
+    threads = max(1, _effective_cores() // 4)
     ctx = mp.get_context("spawn")      # this process has initialised the GPU: no fork
     pool = ctx.Pool(2)
     jobs = {k: pool.apply_async(_oracle_worker, ((*scene, k == "tcnn", threads),))
@@ -237,14 +245,40 @@ def oracles(scene):
     pool.terminate()
 
 
-@pytest.fixture(scope="module")
-def oracle_fp32(oracles):
-    return oracles["fp32"].get(timeout=1500)
+def _frames():
+    from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
+    ds = SyntheticSceneDataset(3, n_views=VIEWS, H=H, W=W, n_classes=C, device="cuda")
+    frames = []
+    for i in range(VIEWS):
+        it = ds[i]
+        frames.append(dict(o=it["rays_o"].cpu(), d=it["rays_d"].cpu(),
+                           nrm=it["direction_norms"].cpu(),
+                           rgb=it["img"].reshape(3, -1).t().contiguous().cpu(),
+                           label=it["label"].reshape(-1).cpu(),
+                           depth=it["depth"].float().reshape(-1).cpu()))
+    return frames
 
 
-@pytest.fixture(scope="module")
-def oracle_tcnn(oracles):
-    return oracles["tcnn"].get(timeout=1500)
+_LONG = {}
+
+
+def start_long_oracle():
+    """The 600-step fp32 oracle trajectory (~6 min of CPU on half of the box's
+    cores) in a worker process.  tests/conftest.py calls this at the START of a
+    `-m gpu` session that holds the long-horizon test, so that it runs next to the
+    rest of the suite instead of after it; the test itself calls it if nobody has."""
+    if "job" not in _LONG:
+        import multiprocessing as mp
+        from tests.conftest import _effective_cores
+        frames = _frames()
+        draws, u_eval = _draws(LONG)
+        pool = mp.get_context("spawn").Pool(1)
+        _LONG.update(frames=frames, draws=draws, u_eval=u_eval, pool=pool,
+                     job=pool.apply_async(_oracle_worker, ((frames, draws, u_eval, False,
+                                                            max(1, _effective_cores() // 2),
+                                                            LONG.checkpoints),)))
+        pool.close()
+    return _LONG
 
 
 HELD_OUT_DB = 1.5
@@ -293,6 +327,22 @@ def test_trajectory_quality_matches_the_fp32_oracle(scene, oracles, precision):
     lh, lo = _compare(precision, hip, oracle_fp32)
     # before round-off has had time to grow the two runs are the same run
     assert np.abs(lh[:5] - lo[:5]).max() <= 2e-5 * max(1.0, lo[0])
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_long_horizon_quality_within_half_a_db_and_half_a_point(precision):
+    """north_star: ">= 10x ... at matched mIoU / PSNR (+-0.5)".  600 steps of 4096
+    rays -- the reference's batch -- from the same initial state on the same draws;
+    the semantic head has converged by step 400 (the short run above ends inside its
+    chance-to-learning transition, which is why that one is held to +-1.0 pt); the
+    means over the 9 checkpoints of steps 400-600 must agree within 0.5 dB AND 0.5 pt
+    on the training views, for the default training arithmetic (bf16x3 forward, bf16x2
+    backward, packed grid records) and the exact fp32 one."""
+    st = start_long_oracle()
+    hip = _train_hip(st["frames"], st["draws"], st["u_eval"], precision,
+                     checkpoints=LONG.checkpoints)
+    ora = st["job"].get(timeout=2400)
+    _compare(f"long[{precision}]", hip, ora, tol_db=0.5, tol_pt=0.5)
 
 
 def test_trajectory_quality_tcnn_numerics_matches_the_fp16_emulating_oracle(scene, oracles):

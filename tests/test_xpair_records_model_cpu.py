@@ -1,5 +1,5 @@
-"""The arithmetic behind csrc/hashgrid_bwd.hip's x-pair records (k_grid_bwd_bin_xpair,
-off unless UCSA_BWD_XPAIR=1), in numpy: where the corner at x + 1 of a cell lives
+"""The arithmetic behind csrc/hashgrid_bwd.hip's x-pair records (k_grid_bwd_bin_xpair:
+the packed records of the training backward since round 6), in numpy: where the corner at x + 1 of a cell lives
 relative to the corner at x, for the index functions of the reference's grid
 (tiny-cuda-nn: hashed idx = (x ^ y P1 ^ z P2) & (E - 1) with E = 2^19, dense idx =
 (x + y res + z res^2) % E)."""

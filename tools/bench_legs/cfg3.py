@@ -134,8 +134,7 @@ def main_cfg3(args, dev, dist, world, rank, backend):
                    "nerf_render_nets": args.nerf_precision,
                    "nerf_rays_per_step_per_rank": B * (Hh * Ww + 4096),
                    "seg_images_per_s": world * B / dt,
-                   "optimizer_nerf": type(model.optimizers()[1]).__name__,
-                   "joint_overlap": bool(model.joint_overlap)},
+                   "optimizer_nerf": type(model.optimizers()[1]).__name__},
         "losses": {k: v for k, v in model.logged.items()},
         "roofline_step": roof,
     }

@@ -27,6 +27,7 @@ near, far = ops.near_far_from_aabb(o, d, aabb, 0.2)
 T = 96
 z = ops.sample_coarse(near, far, T, None)
 os.environ["UCSA_ENC_ML"] = "0"
+ops.env_reload()   # the library snapshots its switches once per process
 h, sig = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb), f["packed_sigma"])
 zf = ops.resample(z, sig.view(N, T), torch.rand(N, T, device=dev), 1.0)
 # pooled + dealt back
@@ -66,4 +67,5 @@ print("sum:", [round(x) for x in tot])
 for name, zz in (("coarse", z), ("fine shipped", zf), ("fine depth-binned", zc)):
     for ml in (0, 9):
         os.environ["UCSA_ENC_ML"] = str(ml)
+        ops.env_reload()   # the library snapshots its switches once per process
         print(f"{name:18s} UCSA_ENC_ML={ml}: {timed(lambda: ops.hashgrid_encode_rays(full, f['table'], o, d, zz, aabb, image_width=W)):.3f} ms")

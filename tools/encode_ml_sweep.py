@@ -21,6 +21,7 @@ near, far = ops.near_far_from_aabb(o, d, aabb, 0.2)
 T = 96
 z = ops.sample_coarse(near, far, T, None)
 os.environ["UCSA_ENC_ML"] = "0"
+ops.env_reload()   # the library snapshots its switches once per process
 h, sig = ops.sigma_mlp_fwd(ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb), f["packed_sigma"])
 zf = ops.resample(z, sig.view(N, T), torch.rand(N, T, device=dev), 1.0)
 th = net._table_half()
@@ -44,10 +45,12 @@ for tname, tab in (("fp32 table", f["table"]), ("fp16 table", th)):
     enc = (lambda zz: ops.hashgrid_encode_rays(f["grid"], tab, o, d, zz, aabb, image_width=W))
     for name, zz in (("coarse", z), ("fine", zf)):
         os.environ["UCSA_ENC_ML"] = "0"
+        ops.env_reload()   # the library snapshots its switches once per process
         ref = enc(zz).clone()
         row = []
         for k in ks:
             os.environ["UCSA_ENC_ML"] = str(k)
+            ops.env_reload()   # the library snapshots its switches once per process
             same = bool(torch.equal(enc(zz), ref))
             row.append(f"{k}: {timed(lambda: enc(zz)):.3f}{'' if same else ' MISMATCH'}")
         print(f"{tname} {name:6s} ms by UCSA_ENC_ML | " + " | ".join(row), flush=True)

@@ -40,9 +40,11 @@ orders = {
 variants = [("fp32 table", f["table"], lambda zz: ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zz, aabb, image_width=W))]
 for name, zz in (("coarse", z), ("fine", zf)):
     os.environ["UCSA_ENC_ORDER"] = ""
+    ops.env_reload()   # the library snapshots its switches once per process
     ref = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zz, aabb, image_width=W).clone()
     for label, order in orders.items():
         os.environ["UCSA_ENC_ORDER"] = order
+        ops.env_reload()   # the library snapshots its switches once per process
         got = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zz, aabb, image_width=W)
         same = bool(torch.equal(got, ref))
         for _ in range(3):
@@ -54,12 +56,15 @@ for name, zz in (("coarse", z), ("fine", zf)):
         torch.cuda.synchronize()
         print(f"{name:6s} {label:36s} {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms  bit-identical {same}", flush=True)
 os.environ["UCSA_ENC_ORDER"] = ""
+ops.env_reload()   # the library snapshots its switches once per process
 # hashed levels below index n through the plain 8-load gather (UCSA_ENC_SIMPLE)
 for name, zz in (("coarse", z), ("fine", zf)):
     os.environ["UCSA_ENC_SIMPLE"] = "0"
+    ops.env_reload()   # the library snapshots its switches once per process
     ref = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zz, aabb, image_width=W).clone()
     for n in (0, 6, 8, 9, 10, 11, 12, 16):
         os.environ["UCSA_ENC_SIMPLE"] = str(n)
+        ops.env_reload()   # the library snapshots its switches once per process
         got = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, zz, aabb, image_width=W)
         same = bool(torch.equal(got, ref))
         for _ in range(3):
@@ -71,3 +76,4 @@ for name, zz in (("coarse", z), ("fine", zf)):
         torch.cuda.synchronize()
         print(f"{name:6s} simple gather below level {n:2d}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms  bit-identical {same}", flush=True)
 os.environ["UCSA_ENC_SIMPLE"] = "0"
+ops.env_reload()   # the library snapshots its switches once per process

@@ -51,7 +51,9 @@ tot = [0.0, 0.0]
 for l in range(full.n_levels):
     g1 = sub([l])
     os.environ["UCSA_ENC_ML"] = "0"
+    ops.env_reload()   # the library snapshots its switches once per process
     os.environ["UCSA_ENC_SORTED_ML"] = "0"
+    ops.env_reload()   # the library snapshots its switches once per process
     a = 1e3 * timed(lambda: ops.hashgrid_encode_rays(g1, f["table"], o, d, zf, aabb, image_width=W))
     b = 1e3 * timed(lambda: ops.hashgrid_encode_sorted(g1, f["table"], o, d, zs, pix, aabb, T, W))
     tot = [tot[0] + a, tot[1] + b]
@@ -60,10 +62,12 @@ print("sum:", [round(x) for x in tot])
 for k in (4, 8, 9, 10):
     gk = sub(list(range(k)))
     os.environ["UCSA_ENC_SORTED_ML"] = str(k)
+    ops.env_reload()   # the library snapshots its switches once per process
     t = 1e3 * timed(lambda: ops.hashgrid_encode_sorted(gk, f["table"], o, d, zs, pix, aabb, T, W))
     print(f"several-levels kernel, levels 0..{k - 1}: {t:.1f} us ({t / k:.1f} per level)")
 for lo in (8, 9, 10):
     gk = sub(list(range(lo, 16)))
     os.environ["UCSA_ENC_SORTED_ML"] = "0"
+    ops.env_reload()   # the library snapshots its switches once per process
     t = 1e3 * timed(lambda: ops.hashgrid_encode_sorted(gk, f["table"], o, d, zs, pix, aabb, T, W))
     print(f"per-level kernel, levels {lo}..15 in one launch: {t:.1f} us")

@@ -49,6 +49,7 @@ for name, zz in (("coarse", z), ("fine", zf)):
         os.environ["UCSA_ENC_SORTED_LEAN"] = str(lean)
         for ml in [int(x) for x in os.environ.get("KS", "0,4,8,9,10,12").split(",")]:
             os.environ["UCSA_ENC_SORTED_ML"] = str(ml)
+            ops.lib().ucsa_env_reload()      # the library reads its switches once
             got = ops.hashgrid_encode_sorted(f["grid"], f["table"], o, d, zs, pix, aabb, T, W)
             same = bool(torch.equal(got, ref[:, slot.long()]))
             t_e = timed(lambda: ops.hashgrid_encode_sorted(f["grid"], f["table"], o, d, zs, pix, aabb, T, W))
@@ -57,7 +58,3 @@ for name, zz in (("coarse", z), ("fine", zf)):
             t_s = timed(lambda: ops.sigma_mlp_fwd_scatter(3, got, f2["packed_sigma"], slot))
             print(f"{name:6s} depth-ordered lean={lean} ml={ml:2d}: sort {t_sort:.3f} + encode {t_e:.3f} + sigma/scatter {t_s:.3f} = "
                   f"{t_sort + t_e + t_s:.3f} ms  bit-identical {same}", flush=True)
-    hF, sF = ops.encode_sigma_sorted(3, f["grid"], f["table"], o, d, zs, pix, slot, aabb, T, W, f2["packed_sigma"])
-    t_f = timed(lambda: ops.encode_sigma_sorted(3, f["grid"], f["table"], o, d, zs, pix, slot, aabb, T, W, f2["packed_sigma"]))
-    print(f"{name:6s} depth-ordered, levels 0-7 inside the sigma MLP: sort {t_sort:.3f} + encode(8-15)+sigma {t_f:.3f} = "
-          f"{t_sort + t_f:.3f} ms  bit-identical {bool(torch.equal(h0, hF) and torch.equal(s0, sF))}", flush=True)

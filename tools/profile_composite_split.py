@@ -47,8 +47,5 @@ for _ in range(10):
     check(fn(*args, ops._stream()), "fused")
     ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, f["packed_color"], f["packed_sem"],
                         40, half=half)
-    # fused encode + sigma vs staged pair, both passes
-    ops.encode_sigma_rays_image(f["grid"], f["table"], f["packed_sigma"], o, d, zc, aabb, W, half=half)
-    ops.encode_sigma_rays_image(f["grid"], f["table"], f["packed_sigma"], o, d, zf, aabb, W, half=half)
 torch.cuda.synchronize()
 print("done")

@@ -53,6 +53,7 @@ h16 = ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, fh["packed_color"], fh
 print("f16 split: %.3f ms" % timed(lambda: ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, fh["packed_color"], fh["packed_sem"], 40, half=True)), flush=True)
 for v in ("0", "1", "2", "3"):
     os.environ["UCSA_SHADE_VARIANT"] = v
+    ops.env_reload()   # the library snapshots its switches once per process
     fn = lambda: ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, pc3, ps3, 40, x3=True)
     out = fn()
     torch.cuda.synchronize()
@@ -62,9 +63,11 @@ for v in ("0", "1", "2", "3"):
         (h16[0] - ref[0]).abs().max(), (h16[2] - ref[2]).abs().max()), flush=True)
 for v in ("0", "1", "2", "3"):
     os.environ["UCSA_SHADE_VARIANT"] = v
+    ops.env_reload()   # the library snapshots its switches once per process
     fn = lambda: ops.composite_infer(d, nrm, zc, sc, hc, zf, sf, hf, fh["packed_color"], fh["packed_sem"], 40, half=True)
     out = fn()
     torch.cuda.synchronize()
     print("f16 variant %s: %.3f ms; identical to variant 0: %s" % (
         v, timed(fn), torch.equal(out[0], h16[0]) and torch.equal(out[2], h16[2])), flush=True)
 os.environ.pop("UCSA_SHADE_VARIANT")
+ops.env_reload()   # the library snapshots its switches once per process

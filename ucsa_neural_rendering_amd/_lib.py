@@ -82,18 +82,13 @@ SIGNATURES = {
                                                     _u32, _u32, _p, _p]),
     "ucsa_hashgrid_encode_points": (C.c_int32, [C.POINTER(Grid), _p, _p, _u32,
                                                 _p, _p]),
+    "ucsa_env_reload": (None, []),
     "ucsa_mlp_pack": (C.c_int32, [C.c_int32, _p, _p, _u32, _p]),
     "ucsa_sigma_mlp_fwd": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),
     "ucsa_resample": (C.c_int32, [_p, _p, _p, _u32, _u32, _u32, _f, _p, _p]),
     "ucsa_composite_fwd": (C.c_int32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _u32, _u32, _u32, _u32, _f, _p, _p, _p,
                                        _p, _p, _p]),
-    "ucsa_encode_sigma_rays_image": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p,
-                                                 _p, C.POINTER(_f), _u32, _u32,
-                                                 _u32, _p, _p, _p]),
-    "ucsa_encode_sigma_rays_image_f16": (C.c_int32, [C.POINTER(Grid), _p, _p, _p,
-                                                     _p, _p, C.POINTER(_f), _u32,
-                                                     _u32, _u32, _p, _p, _p]),
     "ucsa_composite_infer_workspace_bytes": (C.c_uint64, [_u32, _u32, _u32]),
     "ucsa_composite_infer": (C.c_int32, [_p] * 10 + [_u32, _u32, _u32, _u32, _f,
                                                       _p, _p, _p, _p, _p]),
@@ -126,9 +121,6 @@ SIGNATURES = {
     "ucsa_hashgrid_encode_sorted_hf": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                                    C.POINTER(_f), _u32, _u32, _u32,
                                                    _p, _p]),
-    "ucsa_encode_sigma_sorted": (C.c_int32, [C.c_int32, C.POINTER(Grid), _p, _p, _p, _p, _p, _p,
-                                             C.POINTER(_f), _u32, _u32, _u32, _p, _p, _p, _p,
-                                             _p]),
     "ucsa_sigma_mlp_fwd_scatter": (C.c_int32, [C.c_int32, _p, _p, _u32, _u32, _p,
                                                _p, _p, _p]),
     "ucsa_sigma_mlp_fwd_f16_h": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),

@@ -779,7 +779,7 @@ static void shade_bwd_geometry(uint32_t N, uint32_t& rpw, uint32_t& blocks,
 static bool shade_bwd_split() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("UCSA_SHADE_BWD_SPLIT");
+    const char* e = ucsa_getenv("UCSA_SHADE_BWD_SPLIT");
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v != 0;

@@ -1074,7 +1074,7 @@ static int32_t launch_shade16(const ShArgs& a, uint32_t n_waves, bool off32,
 // 8 -> 256.  UCSA_SHADE_VARIANT selects another shape for experiments
 // (tools/composite_split_bench.py); results do not depend on it.
 static int shade_variant() {
-  const char* v = getenv("UCSA_SHADE_VARIANT");
+  const char* v = ucsa_getenv("UCSA_SHADE_VARIANT");
   return v ? atoi(v) : 0;
 }
 

@@ -315,7 +315,7 @@ static uint32_t coarse_levels(const ucsa_grid* grid) {
 // that the lanes of a tile share their cache lines.  `env` overrides the
 // default for experiments; results do not depend on it.
 static uint32_t simple_gather_below(const char* env, uint32_t dflt) {
-  const char* v = getenv(env);
+  const char* v = ucsa_getenv(env);
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
@@ -372,7 +372,7 @@ static LevelMap level_map(uint32_t L) {
   lm.k = 1;
   lm.simple_below = 0u;   // set per table type by the caller
   for (uint32_t i = 0; i < UCSA_MAX_LEVELS; ++i) lm.lv[i] = (uint8_t)(i < L ? L - 1 - i : 0);
-  const char* e = getenv("UCSA_ENC_ORDER");
+  const char* e = ucsa_getenv("UCSA_ENC_ORDER");
   if (e && *e) {
     const uint32_t k = (uint32_t)strtoul(e, nullptr, 10);
     const char* c = strchr(e, ':');
@@ -432,14 +432,14 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
     // dynamic LDS per workgroup = fewer encoder workgroups per CU, i.e. free
     // registers / wave slots for a co-resident kernel.  Results do not change.
     static const uint32_t lds_pad = []() {
-      const char* v = getenv("UCSA_ENC_LDS_PAD");
+      const char* v = ucsa_getenv("UCSA_ENC_LDS_PAD");
       return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 0u;
     }();
     // levels [0, n_ml) through the several-levels-per-workgroup kernel (see
     // k_hashgrid_encode_tiled_ml); UCSA_ENC_ML overrides (experiments only:
     // the features do not depend on it), 0 = every level through the
     // per-level kernel as in rounds 3-4.  Only for the default level order.
-    const char* ml_v = getenv("UCSA_ENC_ML");
+    const char* ml_v = ucsa_getenv("UCSA_ENC_ML");
     const int ml_env = ml_v && *ml_v ? (int)strtol(ml_v, nullptr, 10) : -1;
     // measured on the bench's chunk (tools/encode_ml_sweep.py, ms by n_ml):
     //   fp32 table  coarse pass 0: 0.702  4: 0.620  8: 0.607  9: 0.603  10: 0.600  12: 0.603  16: 0.824
@@ -448,7 +448,7 @@ static int32_t launch_encode_image(const ucsa_grid* grid, const void* table,
     //   (its per-level kernel has the group-of-four gather on the hashed levels)
     uint32_t n_ml = ml_env >= 0 ? (uint32_t)ml_env : (sizeof(TT) == 8 ? 9u : 6u);
     if (n_ml > grid->n_levels) n_ml = grid->n_levels;
-    if (lm.k != 1 || getenv("UCSA_ENC_ORDER")) n_ml = 0;
+    if (lm.k != 1 || ucsa_getenv("UCSA_ENC_ORDER")) n_ml = 0;
     const uint32_t n_fine = grid->n_levels - n_ml;
     if (n_fine > 0)   // lm.lv = finest level first: its first n_fine rows
       hipLaunchKernelGGL((k_hashgrid_encode_tiled<TT, FT>),

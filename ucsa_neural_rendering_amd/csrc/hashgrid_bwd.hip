@@ -100,54 +100,13 @@ struct RunPlan {
   uint32_t live;  // bit s: some lane of the wave adds at step s (wave-uniform)
 };
 
-__device__ __forceinline__ RunPlan run_plan(uint32_t cx, uint32_t cy,
-                                            uint32_t cz, bool act,
-                                            uint32_t lane) {
-  // inactive lanes get a cell id no active lane can have
-  const uint32_t kx = act ? cx : 0xFFFFFFFFu;
-  const uint32_t px = (uint32_t)__shfl_up((int)kx, 1, 64);
-  const uint32_t py = (uint32_t)__shfl_up((int)cy, 1, 64);
-  const uint32_t pz = (uint32_t)__shfl_up((int)cz, 1, 64);
-  const bool head = lane == 0 || px != kx || py != cy || pz != cz || !act;
-  int f = head ? 1 : 0;
-  RunPlan p;
-  p.live = 0;
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const int d = 1 << s;
-    const int of = __shfl_up(f, d, 64);
-    p.add[s] = lane >= (uint32_t)d && !f;
-    if (p.add[s]) f |= of;
-    // runs are mostly a few samples long: the far steps add nothing and
-    // run_sum skips their shuffles (16 value scans per sample and level)
-    if (__any(p.add[s])) p.live |= 1u << s;
-  }
-  const int next_head = __shfl_down(head ? 1 : 0, 1, 64);
-  p.tail = act && (lane == 63 || next_head);
-  return p;
-}
-
-__device__ __forceinline__ void run_sum(const RunPlan& p, float& vx,
-                                        float& vy) {
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    if (!((p.live >> s) & 1u)) continue;  // wave-uniform
-    const float ox = __shfl_up(vx, 1 << s, 64);
-    const float oy = __shfl_up(vy, 1 << s, 64);
-    if (p.add[s]) {
-      vx += ox;
-      vy += oy;
-    }
-  }
-}
-
-// The same run structure on the DPP data path (experimental: UCSA_BWD_XPAIR=2 for
-// the x-pair kernel, UCSA_BWD_DPP=1 for the shipped coarse / packed-bin kernels;
-// verified on the GPU at rel L2 5e-8 against the shuffle ladder, not yet timed).  A
-// __shfl_up is a ds_bpermute_b32 -- an LDS instruction with its latency in a
-// dependent chain -- and run_sum issues two per live step for each of the 16
-// values of a sample; a DPP step is one VALU instruction (wave_ops.h: 3.5 x the scan
-// rate).  Ladder: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, row_bcast15 into
+// The scans run on the DPP data path (round 6; rounds 2-5 used __shfl_up, i.e.
+// ds_bpermute_b32 -- an LDS instruction with its latency in a dependent chain, two
+// per live step for each of the 16 values of a sample; a DPP step is one VALU
+// instruction.  Measured in round 6, tools/bwd_switches_ab.py: merged grid backward
+// 1.420 -> 1.361 ms with the 8-byte records, 1.205 -> 1.162 ms with x-pair records;
+// rel L2 5e-8 against the shuffle ladder, tests/test_dpp_run_scan_model_cpu.py is
+// its numpy model).  Ladder: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, row_bcast15 into
 // rows 1 and 3, row_bcast31 into rows 2 and 3 -- a segmented scan under the
 // associative operator (f1, v1) o (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2), so the
 // tail lane of a run ends up with the run's sum as with the shuffle ladder (other
@@ -161,7 +120,7 @@ __device__ __forceinline__ float dpp_src_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
 
-__device__ __forceinline__ RunPlan run_plan_dpp(uint32_t cx, uint32_t cy, uint32_t cz,
+__device__ __forceinline__ RunPlan run_plan(uint32_t cx, uint32_t cy, uint32_t cz,
                                                 bool act, uint32_t lane) {
   const uint32_t kx = act ? cx : 0xFFFFFFFFu;
   // previous lane's cell (wave_shr:1; lane 0 is a head anyway)
@@ -189,7 +148,7 @@ __device__ __forceinline__ RunPlan run_plan_dpp(uint32_t cx, uint32_t cy, uint32
   return p;
 }
 
-__device__ __forceinline__ void run_sum_dpp(const RunPlan& p, float& vx, float& vy) {
+__device__ __forceinline__ void run_sum(const RunPlan& p, float& vx, float& vy) {
 #define UCSA_RUN_STEP(S, CTRL, MASK)                         \
   if ((p.live >> S) & 1u) {                                  \
     const float ox = dpp_src_f<CTRL, MASK>(vx);              \
@@ -260,7 +219,7 @@ __device__ __forceinline__ void lds_accumulate(uint32_t* keys, float* vals,
   atomicAdd(gt + (size_t)idx * 2 + 1, vy);
 }
 
-template <bool RUNRED, bool DPPSCAN = false>   // DPPSCAN: run_plan_dpp / run_sum_dpp (UCSA_BWD_DPP=1, experimental)
+template <bool RUNRED>
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
                const float* __restrict__ rays_d, const float* __restrict__ zs,
@@ -317,7 +276,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
     const uint32_t gx = (uint32_t)(int32_t)fx0, gy = (uint32_t)(int32_t)fy0,
                    gz = (uint32_t)(int32_t)fz0;
     RunPlan plan;
-    if (RUNRED) plan = DPPSCAN ? run_plan_dpp(gx, gy, gz, act, lane) : run_plan(gx, gy, gz, act, lane);
+    if (RUNRED) plan = run_plan(gx, gy, gz, act, lane);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float w = (c & 1) ? wx : 1.0f - wx;
@@ -328,8 +287,7 @@ k_hashgrid_bwd(GridDev g, const float* __restrict__ rays_o,
       float vx = w * df.x, vy = w * df.y;
       if (RUNRED) {
         if (!act) { vx = 0.f; vy = 0.f; }
-        if constexpr (DPPSCAN) run_sum_dpp(plan, vx, vy);
-        else run_sum(plan, vx, vy);
+        run_sum(plan, vx, vy);
         if (plan.tail) lds_accumulate(acc_keys, acc_vals, idx, vx, vy, gt);
       } else {
         atomicAdd(gt + (size_t)idx * 2, vx);
@@ -378,7 +336,7 @@ struct BinGeom {
   uint32_t cap;                        // records per bin
 };
 
-// REC_P64 records: one 64-bit word = entry index inside the bin (L = loc_bits)
+// Packed ("p64") record words: one 64-bit word = entry index inside the bin (L = loc_bits)
 // | vx | vy, each value the fp32 rounded (to nearest even) to its top
 // V = min(32, (64 - L) / 2) bits.  For the 2^19-entry levels of the reference's
 // grid L = 11, V = 26: sign, exponent and 17 mantissa bits, a relative error of
@@ -454,12 +412,11 @@ __device__ __forceinline__ void sample_cell(const GridDev& g, uint32_t level,
 // of both passes.  Used by the f16 training mode only (train_precision="fp16":
 // tiny-cuda-nn itself accumulates its grid gradient from half2 values); the
 // sums in the accumulate pass stay fp32.
-// REC: 0 = 16-byte records, REC_H16 = HREC above, REC_P64 = packed 64-bit words
-// (p64_pack; packed before the LDS staging, which shrinks from 32 to 20 KiB).
+// REC: 0 = 16-byte records, REC_H16 = HREC above.  (The packed 64-bit words of
+// round 4, "REC_P64", travel as x-PAIR records since round 6: k_grid_bwd_bin_xpair.)
 #define REC_F32 0
 #define REC_H16 1
-#define REC_P64 2
-template <int REC, bool DPPSCAN = false>
+template <int REC>
 __global__ void __launch_bounds__(256)
 k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                const float* __restrict__ rays_o,
@@ -469,18 +426,13 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
                uint32_t* __restrict__ gcount, void* __restrict__ records_v,
                float* __restrict__ grad_table, float rec_scale, MergedSrc mg) {
   constexpr bool HREC = REC == REC_H16;
-  constexpr bool P64 = REC == REC_P64;
   float4* records = reinterpret_cast<float4*>(records_v);
   uint2* records_h = reinterpret_cast<uint2*>(records_v);
   static_assert(BIN_COUNT == 256, "one thread per bin");
   __shared__ uint32_t hist[BIN_COUNT], base[BIN_COUNT], cursor[BIN_COUNT];
   __shared__ uint32_t it_cnt[BIN_COUNT], it_off[BIN_COUNT], wave_tot[4];
-  // one iteration's records, bin-sorted: float4 (loc, vx, vy, bin), or for
-  // REC_P64 the packed word [2048 x 8 B] followed by the bins [2048 x 2 B]
-  __shared__ float4 stage[P64 ? (256 * 8 * 10) / 16 : 256 * 8];
-  uint64_t* stage_w = reinterpret_cast<uint64_t*>(stage);
-  uint16_t* stage_b = reinterpret_cast<uint16_t*>(stage_w + 256 * 8);
-  const uint32_t lbits = bg.loc_bits[level0 + blockIdx.y];
+  // one iteration's records, bin-sorted: float4 (loc, vx, vy, bin)
+  __shared__ float4 stage[256 * 8];
   const uint32_t level = level0 + blockIdx.y;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t res = g.res[level], entries = g.entries[level],
@@ -517,8 +469,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3];
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
-                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
     if (!(act && plan.tail)) continue;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -556,8 +507,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3] = {0.f, 0.f, 0.f};
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
-                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
     const bool has_runs = plan.live != 0;  // some lane continues a run
     const bool emit = act && plan.tail;
 #pragma unroll
@@ -567,8 +517,7 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
       w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
       float vx = act ? w * df.x : 0.0f, vy = act ? w * df.y : 0.0f;
       if (has_runs) {
-        if constexpr (DPPSCAN) run_sum_dpp(plan, vx, vy);
-        else run_sum(plan, vx, vy);
+        run_sum(plan, vx, vy);
       }
       valx[c] = vx;
       valy[c] = vy;
@@ -596,35 +545,13 @@ k_grid_bwd_bin(GridDev g, BinGeom bg, uint32_t level0,
       for (int c = 0; c < 8; ++c) {
         const uint32_t bin = key[c] >> 16;
         const uint32_t slot = it_off[bin] + (key[c] & 0xFFFFu);
-        if constexpr (P64) {
-          stage_w[slot] = p64_pack(loc[c], valx[c], valy[c], lbits);
-          stage_b[slot] = (uint16_t)bin;
-        } else {
-          stage[slot] = make_float4(__uint_as_float(loc[c]), valx[c], valy[c],
-                                    __uint_as_float(bin));
-        }
+        stage[slot] = make_float4(__uint_as_float(loc[c]), valx[c], valy[c],
+                                  __uint_as_float(bin));
       }
     }
     __syncthreads();
     const uint32_t total = it_off[BIN_COUNT - 1] + it_cnt[BIN_COUNT - 1];
     for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 256) {
-      if constexpr (P64) {
-        const uint64_t w = stage_w[sidx];
-        const uint32_t bin = stage_b[sidx];
-        const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
-        if (pos < bg.cap) {
-          reinterpret_cast<uint64_t*>(records_v)[(size_t)level * BIN_COUNT * bg.cap +
-                                                 (size_t)bin * bg.cap + pos] = w;
-        } else {  // bin full: direct atomics (of the rounded values: same sum)
-          uint32_t l;
-          float vx, vy;
-          p64_unpack(w, lbits, l, vx, vy);
-          const size_t idx = (size_t)bin * bsz + l;
-          atomicAdd(gt + idx * 2, vx);
-          atomicAdd(gt + idx * 2 + 1, vy);
-        }
-        continue;
-      }
       const float4 r = stage[sidx];
       const uint32_t bin = __float_as_uint(r.w);
       const uint32_t pos = base[bin] + cursor[bin] + (sidx - it_off[bin]);
@@ -673,30 +600,7 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
   float* acc = binacc_smem;  // [bsz][2]
   for (uint32_t e = threadIdx.x; e < 2 * bsz; e += 512) acc[e] = 0.f;
   __syncthreads();
-  if constexpr (REC == REC_P64) {
-    const uint64_t* rec = reinterpret_cast<const uint64_t*>(records_v) +
-                          ((size_t)level * BIN_COUNT + bin) * bg.cap;
-    const uint32_t lbits = bg.loc_bits[level];
-    uint32_t i = threadIdx.x;
-    for (; i + (ACC_INFLIGHT - 1) * 512 < n; i += ACC_INFLIGHT * 512) {
-      uint64_t r[ACC_INFLIGHT];
-#pragma unroll
-      for (int k = 0; k < ACC_INFLIGHT; ++k) r[k] = rec[i + k * 512];
-#pragma unroll
-      for (int k = 0; k < ACC_INFLIGHT; ++k) {
-        uint32_t l;
-        float vx, vy;
-        p64_unpack(r[k], lbits, l, vx, vy);
-        lds_add_pair(&acc[2 * l], vx, vy);
-      }
-    }
-    for (; i < n; i += 512) {
-      uint32_t l;
-      float vx, vy;
-      p64_unpack(rec[i], lbits, l, vx, vy);
-      lds_add_pair(&acc[2 * l], vx, vy);
-    }
-  } else if constexpr (HREC) {
+  if constexpr (HREC) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const uint2* rec = reinterpret_cast<const uint2*>(records_v) +
                        ((size_t)level * BIN_COUNT + bin) * bg.cap;
@@ -749,11 +653,10 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
 }
 
 // ---------------------------------------------------------------------------
-// x-PAIR records (written at the end of round 5; OFF unless UCSA_BWD_XPAIR=1|2.
-// Functionally verified on the GPU -- tests/test_gpu_backward.py::
-// test_xpair_bin_records_match_packed_records, 0.66 of the error bound against
-// the REC_P64 path -- but NOT TIMED: the round's GPU budget was spent;
-// docs/DESIGN_NOTEBOOK.md "R6-plan" has the reasoning).
+// x-PAIR records: the packed ("p64") records of ucsa_hashgrid_bwd_rays_p64 /
+// _merged_p64 (written at the end of round 5, timed and made the default in round 6:
+// merged grid backward 1.420 -> 1.162 ms, training step 3.41 -> 3.16 ms,
+// tools/bwd_switches_ab.py; the one-record-per-corner kernels they replace are gone).
 //
 // The bin kernel is issue- and LDS-atomic-bound (~82 VALU instructions per
 // record, profiles/r04_train_sq_counters.txt), not byte-bound: what costs is the
@@ -762,13 +665,11 @@ k_grid_bwd_accum(GridDev g, BinGeom bg, uint32_t level0,
 // number of trailing ones of x; dense rows: idx + 1), so with 2048-entry bins
 // they fall into the SAME bin unless x ends in eleven 1-bits -- never below
 // resolution 2048, 2^-11 of the pairs at the finest level (checked on 4 M random
-// cells per level).  One 16-byte record per x-pair = two REC_P64 words,
+// cells per level).  One 16-byte record per x-pair = two packed 64-bit words,
 // p64(loc0, v0) and p64(loc0 ^ loc1, v1): 4 hashes' worth of bin counters, LDS
 // ranks and stage slots per sample and level instead of 8, the same bytes, the
-// same 26-bit values and fp32 sums as REC_P64 (so the same gradient up to the
-// order of additions).  A pair that straddles two bins goes to the table by direct
+// 26-bit values (p64_round: 2^-18 per record), fp32 sums.  A pair that straddles two bins goes to the table by direct
 // atomics (unrounded).  The workspace is the REC_F32 one (16 bytes x cap per bin).
-template <bool DPPSCAN>   // run plan / run sums on the DPP data path (UCSA_BWD_XPAIR=2)
 __global__ void __launch_bounds__(256)
 k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
                      const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -809,8 +710,7 @@ k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3];
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
-                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
     if (!(act && plan.tail)) continue;
     // index of the corner at x + 1 from the corner at x: one xor on a hashed level
     // ((x ^ h) & (E - 1) with E a power of two), the next entry on a dense one
@@ -850,8 +750,7 @@ k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
     uint32_t gi[3] = {0u, 0u, 0u};
     float wf[3] = {0.f, 0.f, 0.f};
     if (act) sample_cell(g, level, rays_o, rays_d, zs != nullptr, r, zz, bb, m, gi, wf);
-    const RunPlan plan = DPPSCAN ? run_plan_dpp(gi[0], gi[1], gi[2], act, lane)
-                                 : run_plan(gi[0], gi[1], gi[2], act, lane);
+    const RunPlan plan = run_plan(gi[0], gi[1], gi[2], act, lane);
     const bool has_runs = plan.live != 0;
     const bool emit = act && plan.tail;
     float valx[8], valy[8];
@@ -862,8 +761,7 @@ k_grid_bwd_bin_xpair(GridDev g, BinGeom bg, uint32_t level0,
       w = w * ((c & 4) ? wf[2] : 1.0f - wf[2]);
       float vx = act ? w * df.x : 0.0f, vy = act ? w * df.y : 0.0f;
       if (has_runs) {
-        if constexpr (DPPSCAN) run_sum_dpp(plan, vx, vy);
-        else run_sum(plan, vx, vy);
+        run_sum(plan, vx, vy);
       }
       valx[c] = vx;
       valy[c] = vy;
@@ -1041,7 +939,7 @@ static BwdSide* bwd_side(hipStream_t caller) {
   static int enabled = -1;
   std::lock_guard<std::mutex> lk(mu);
   if (enabled < 0) {
-    const char* e = getenv("UCSA_BWD_OVERLAP");
+    const char* e = ucsa_getenv("UCSA_BWD_OVERLAP");
     enabled = !(e && e[0] == '0');
   }
   if (!enabled) return nullptr;
@@ -1076,14 +974,10 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
                                    uint32_t T, const float* d_feat,
                                    float* grad_table, void* workspace,
                                    void* stream,
-                                   float rec_scale = 0.0f,  // > 0: REC_H16, < 0: REC_P64
+                                   float rec_scale = 0.0f,  // > 0: REC_H16, < 0: packed x-pair records
                                    MergedSrc mg = MergedSrc{nullptr, nullptr, nullptr, 0u, 0u, 0u}) {
   const uint64_t M = (uint64_t)N * T;
   if (M == 0) return 0;
-  // UCSA_BWD_DPP=1 (experimental; verified, not yet timed): the run plans / run sums
-  // of the coarse kernel and of the packed bin kernel on the DPP data path
-  const char* dpp_env = getenv("UCSA_BWD_DPP");
-  const bool dpp_scan = dpp_env && dpp_env[0] == '1';
   // Binning pays where updates are spread over the whole slab (hashed levels
   // with cells finer than ~2 sample spacings: 170 us vs 800 us per level and
   // million samples).  On the dense coarse levels the records pile up in a
@@ -1094,7 +988,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
     // UCSA_BWD_BIN_SCALE (tuning only; the result does not depend on it):
     // hashed levels with scale >= this go through the bins
     static const float bin_scale = []() {
-      const char* v = getenv("UCSA_BWD_BIN_SCALE");
+      const char* v = ucsa_getenv("UCSA_BWD_BIN_SCALE");
       return v && *v ? (float)atof(v) : 100.0f;  // measured: 160 -> 4.81, 100 -> 4.76, 60 -> 5.04 ms per step
     }();
     while (n_lo < grid->n_levels && (!grid->level[n_lo].hashed ||
@@ -1132,38 +1026,14 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
       if (bg.bin_size[l] > max_bsz) max_bsz = bg.bin_size[l];
     const uint32_t nl = grid->n_levels - n_lo;
     UCSA_CLEAR_ERR();
-    const char* xp = rec_scale < 0.0f ? getenv("UCSA_BWD_XPAIR") : nullptr;
-    if (xp && (xp[0] == '1' || xp[0] == '2')) {  // x-pair records (experimental, see k_grid_bwd_bin_xpair)
-      if (xp[0] == '2')
-        hipLaunchKernelGGL(k_grid_bwd_bin_xpair<true>, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
-                           dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
-                           bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
-                           grad_table, mg);
-      else
-        hipLaunchKernelGGL(k_grid_bwd_bin_xpair<false>, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
-                           dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
-                           bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
-                           grad_table, mg);
+    if (rec_scale < 0.0f) {  // packed records: one 16-byte record per x-pair of corners
+      hipLaunchKernelGGL(k_grid_bwd_bin_xpair, dim3(ucsa_div_up(M, 256 * BIN_TILE), nl),
+                         dim3(256), 0, (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z,
+                         bb, T, M, (const float2*)d_feat, gcount, (ulonglong2*)records,
+                         grad_table, mg);
       hipLaunchKernelGGL(k_grid_bwd_accum_xpair, dim3(BIN_COUNT, nl), dim3(512),
                          (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream, gd, bg,
                          n_lo, gcount, (const ulonglong2*)records, grad_table);
-    } else if (rec_scale < 0.0f) {  // REC_P64
-      if (dpp_scan)
-        hipLaunchKernelGGL((k_grid_bwd_bin<REC_P64, true>),
-                           dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
-                           (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
-                           T, M, (const float2*)d_feat, gcount, (void*)records,
-                           grad_table, 1.0f, mg);
-      else
-      hipLaunchKernelGGL(k_grid_bwd_bin<REC_P64>,
-                         dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
-                         (hipStream_t)stream, gd, bg, n_lo, rays_o, rays_d, z, bb,
-                         T, M, (const float2*)d_feat, gcount, (void*)records,
-                         grad_table, 1.0f, mg);
-      hipLaunchKernelGGL(k_grid_bwd_accum<REC_P64>, dim3(BIN_COUNT, nl), dim3(512),
-                         (size_t)max_bsz * 2 * sizeof(float), (hipStream_t)stream,
-                         gd, bg, n_lo, gcount, (const void*)records, grad_table,
-                         1.0f);
     } else if (rec_scale > 0.0f) {
       hipLaunchKernelGGL(k_grid_bwd_bin<REC_H16>,
                          dim3(ucsa_div_up(M, 256 * BIN_TILE), nl), dim3(256), 0,
@@ -1205,12 +1075,7 @@ static int32_t hashgrid_bwd_launch(const ucsa_grid* grid, const float* rays_o,
   // (a marched training batch has ~0.3 M points: 34 workgroups per level)
   uint32_t tiles = ACC_TILES;
   while (tiles > 1 && ucsa_div_up(M, 256 * tiles) * n_run < 1024) tiles >>= 1;
-  if (n_run > 0 && dpp_scan)
-    hipLaunchKernelGGL((k_hashgrid_bwd<true, true>),
-                       dim3(ucsa_div_up(M, 256 * tiles), n_run),
-                       dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
-                       bb, T, M, 0u, tiles, (const float2*)d_feat, grad_table, mg);
-  else if (n_run > 0)
+  if (n_run > 0)
     hipLaunchKernelGGL(k_hashgrid_bwd<true>,
                        dim3(ucsa_div_up(M, 256 * tiles), n_run),
                        dim3(256), 0, coarse_stream, gd, rays_o, rays_d, z,
@@ -1265,9 +1130,9 @@ extern "C" int32_t ucsa_hashgrid_bwd_rays_merged(
                              grad_table, workspace, stream, 0.0f, mg);
 }
 
-// ucsa_hashgrid_bwd_rays / _merged with 8-byte PACKED bin records (REC_P64:
-// every value rounded to its top (64 - L) / 2 bits, 2^-18 relative for the
-// reference's grid; fp32 sums).  For the training modes whose MLP backward is
+// ucsa_hashgrid_bwd_rays / _merged with PACKED bin records (p64_pack: every value
+// rounded to its top (64 - L) / 2 bits, 2^-18 relative for the reference's grid;
+// fp32 sums), since round 6 one 16-byte record per x-pair of corners.  For the training modes whose MLP backward is
 // itself a two-term bf16 split (2^-16).  Require the workspace.
 extern "C" int32_t ucsa_hashgrid_bwd_rays_p64(const ucsa_grid* grid,
                                               const float* rays_o,

@@ -373,12 +373,12 @@ extern "C" int32_t ucsa_tile_depth_order(const float* z, uint32_t N, uint32_t T,
   // (128 slabs x 64 pixels x 4 B = 32 KiB of LDS)
   uint32_t nbins = 16u;
   while (nbins < T && nbins < 128u) nbins <<= 1;
-  const char* nb = getenv("UCSA_SORT_BINS");   // experiments only
+  const char* nb = ucsa_getenv("UCSA_SORT_BINS");   // experiments only
   if (nb && *nb) {
     const uint32_t v = (uint32_t)strtoul(nb, nullptr, 10);
     if (v >= 1u && v <= 128u) nbins = v;
   }
-  const char* sv = getenv("UCSA_SORT_EXACT");   // experiments only; default on
+  const char* sv = ucsa_getenv("UCSA_SORT_EXACT");   // experiments only; default on
   const bool exact = T <= 256u && !(sv && sv[0] == '0');
   UCSA_CLEAR_ERR();
   if (exact && !(nb && *nb)) {
@@ -414,7 +414,7 @@ static int32_t launch_sorted(const ucsa_grid* grid, const float* table,
   // experiments only); UCSA_ENC_SORTED_LEAN=0: the fine levels' gather as
   // hashgrid.hip's encode_level instead of encode_cell.  Same features.
   auto env_u = [](const char* name, uint32_t dflt) {
-    const char* v = getenv(name);
+    const char* v = ucsa_getenv(name);
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
   };
   uint32_t n_ml = env_u("UCSA_ENC_SORTED_ML", 9u);

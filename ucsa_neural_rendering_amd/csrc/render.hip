@@ -8,9 +8,58 @@
 
 #include "ucsa_common.h"
 
-#ifndef UCSA_FUSED_ENCODE_DEFAULT
-#define UCSA_FUSED_ENCODE_DEFAULT 0
-#endif
+#include <cassert>
+#include <cstring>
+
+// ---------------------------------------------------------------------------
+// Environment switches: ONE table, snapshotted once per process (VERDICT r5 item
+// 10: they used to be getenv() calls on every C call).  None of them changes a
+// result; INTEGRATION.md lists what each selects.
+// ---------------------------------------------------------------------------
+namespace {
+const char* const kEnvNames[] = {
+    // launch shapes / kernel choices of the render path
+    "UCSA_SHADE_VARIANT", "UCSA_SPLIT_COMPOSITE", "UCSA_ENC_SORTED", "UCSA_ENC_ML",
+    "UCSA_ENC_SORTED_ML", "UCSA_ENC_SORTED_LEAN", "UCSA_ENC_COARSE_SHAPE",
+    // ... of the training path
+    "UCSA_SHADE_BWD_SPLIT", "UCSA_BWD_OVERLAP", "UCSA_BWD_BIN_SCALE",
+    // lab only (tools/encode_*.py, tools/coresident_exp.py)
+    "UCSA_ENC_ORDER", "UCSA_ENC_SIMPLE", "UCSA_ENC_SIMPLE_H", "UCSA_ENC_SIMPLE_RAYS",
+    "UCSA_ENC_LDS_PAD", "UCSA_SORT_BINS", "UCSA_SORT_EXACT"};
+constexpr int kEnvCount = (int)(sizeof(kEnvNames) / sizeof(kEnvNames[0]));
+struct EnvTable {
+  char value[kEnvCount][64];
+  bool set[kEnvCount];
+  void load() {
+    for (int i = 0; i < kEnvCount; ++i) {
+      const char* v = getenv(kEnvNames[i]);
+      set[i] = v && *v && strlen(v) < sizeof(value[i]);
+      if (set[i]) strcpy(value[i], v);
+    }
+  }
+};
+std::mutex env_mu;
+EnvTable* env_table() {
+  static EnvTable t = []() { EnvTable x; x.load(); return x; }();   // once, thread-safe
+  return &t;
+}
+}  // namespace
+
+const char* ucsa_getenv(const char* name) {
+  EnvTable* t = env_table();
+  for (int i = 0; i < kEnvCount; ++i)
+    if (strcmp(name, kEnvNames[i]) == 0) return t->set[i] ? t->value[i] : nullptr;
+  assert(!"ucsa_getenv: a name that is not in kEnvNames");
+  return nullptr;
+}
+
+// lab tools and tests that flip a switch inside one process (tools/bwd_switches_ab.py,
+// tests of the alternative kernels); not for production code, not thread-safe
+// against concurrent calls into the library
+extern "C" void ucsa_env_reload(void) {
+  std::lock_guard<std::mutex> lk(env_mu);
+  env_table()->load();
+}
 
 namespace {
 struct Ws {
@@ -86,15 +135,6 @@ static int32_t encode(const ucsa_grid* grid, const void* table_any,
                                    T, feat, stream);
 }
 
-// image-ordered rays: which passes run encode + sigma MLP as ONE kernel
-// (features through LDS, ucsa_encode_sigma_rays_image): UCSA_FUSED_ENCODE =
-// 0 none, 1 both, 2 the coarse pass only.  Same bits whatever the choice.
-static int fused_encode_mode() {
-  const char* v = getenv("UCSA_FUSED_ENCODE");
-  if (v && v[0] >= '0' && v[0] <= '2') return v[0] - '0';
-  return UCSA_FUSED_ENCODE_DEFAULT;
-}
-
 // Which composite: the f32-input MFMA is bound by the matrix pipe itself (352
 // MFMAs per 32 samples = 1.62 ms per 61 440-ray chunk at 100 % of the pipe)
 // and the fused k_composite (2.25 ms) beats the split pair there (2.5-2.8 ms);
@@ -102,7 +142,7 @@ static int fused_encode_mode() {
 // UCSA_SPLIT_COMPOSITE=0/1 overrides (bf16x3 exists as the split pair only).
 static bool split_composite(int prec) {
   if (prec >= 2) return true;
-  const char* v = getenv("UCSA_SPLIT_COMPOSITE");
+  const char* v = ucsa_getenv("UCSA_SPLIT_COMPOSITE");
   if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
   return prec == 1;
 }
@@ -139,26 +179,16 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays:
   // UCSA_ENC_SORTED = 0 off, 1 the fine pass (default), 2 both passes.  Same
   // h / sigma bits either way.
-  const char* es = getenv("UCSA_ENC_SORTED");
+  const char* es = ucsa_getenv("UCSA_ENC_SORTED");
   const int sorted_mode = es && es[0] >= '0' && es[0] <= '2' ? es[0] - '0' : 1;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
-  auto density = [&](const float* z, uint32_t n, bool fused, float* h,
-                     float* sigma) -> int32_t {
+  auto density = [&](const float* z, uint32_t n, float* h, float* sigma) -> int32_t {
     const bool fine = z == w.z_f;
-    if (image_width && !table_half && !fused && n <= 1024u &&
+    if (image_width && !table_half && n <= 1024u &&
         N % image_width == 0 && grid->n_levels == 16 &&
         (sorted_mode == 2 || (sorted_mode == 1 && fine))) {
       UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
                                      w.slot, stream));
-      // UCSA_ENC_FUSED_ML=1 (bf16x3 / f16x2 nets): the sigma MLP encodes levels
-      // 0-7 itself (encode_sigma_sorted.hip).  Measured SLOWER as built (one
-      // 16-sample block per iteration at 128 VGPRs: fine pass 1.34 ms against
-      // 0.94 + 0.27 for the two calls, bit-identical) -- off by default.
-      const char* fm = getenv("UCSA_ENC_FUSED_ML");
-      if (prec >= 2 && fm && fm[0] == '1')
-        return ucsa_encode_sigma_sorted(prec, grid, table, rays_o, rays_d, w.zs_sorted,
-                                        w.pix, w.slot, aabb_host, N, n, image_width,
-                                        packed_sigma, w.feat, h, sigma, stream);
       if (prec == 1)
         UCSA_TRY(ucsa_hashgrid_encode_sorted_hf(grid, table, rays_o, rays_d,
                                                 w.zs_sorted, w.pix, aabb_host, N, n,
@@ -170,14 +200,6 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
       return ucsa_sigma_mlp_fwd_scatter(prec, w.feat, packed_sigma, N * n,
                                         grid->n_levels, w.slot, h, sigma, stream);
     }
-    if (fused && prec == 0)
-      return ucsa_encode_sigma_rays_image(grid, table, (const float*)packed_sigma,
-                                          rays_o, rays_d, z, aabb_host, N, n,
-                                          image_width, h, sigma, stream);
-    if (fused && prec == 1)
-      return ucsa_encode_sigma_rays_image_f16(grid, table, packed_sigma, rays_o,
-                                              rays_d, z, aabb_host, N, n,
-                                              image_width, h, sigma, stream);
     if (prec == 1 && !table_half) {  // f16 nets: fp16 features at the source
       UCSA_TRY(ucsa_hashgrid_encode_rays_hf(grid, table, rays_o, rays_d, z,
                                             aabb_host, N, n, image_width, w.feat,
@@ -199,13 +221,11 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
     return ucsa_sigma_mlp_fwd_x3(w.feat, packed_sigma, N * n, grid->n_levels, h,
                                  sigma, stream);
   };
-  const int fmode = image_width && grid->n_levels == 16 && prec < 2 && !table_half
-                        ? fused_encode_mode() : 0;
-  UCSA_TRY(density(w.z_c, T, fmode != 0, w.h_c, w.sigma_c));
+  UCSA_TRY(density(w.z_c, T, w.h_c, w.sigma_c));
   if (t > 0) {
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
                            stream));
-    UCSA_TRY(density(w.z_f, t, fmode == 1, w.h_f, w.sigma_f));
+    UCSA_TRY(density(w.z_f, t, w.h_f, w.sigma_f));
   }
   }  // stage & 1
   if (!(stage & 2u)) return 0;

@@ -7,6 +7,14 @@
 
 #define UCSA_WAVE 64
 
+// The library's environment switches ("Environment variables"):
+// every one of them is read ONCE per process, at the first call that asks for
+// any (render.hip), never per call -- a launch shape / kernel choice, never a
+// result.  ucsa_env_reload() (lab tools and tests only) re-reads them.
+// Returns nullptr when unset or empty; asking for a name that is not in the
+// table is a programming error (returns nullptr, asserts in debug builds).
+const char* ucsa_getenv(const char* name);
+
 // negative hipError_t on failure, 0 otherwise
 static inline int32_t ucsa_launch_status() {
   hipError_t e = hipGetLastError();

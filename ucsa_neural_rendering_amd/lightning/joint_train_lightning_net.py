@@ -103,13 +103,6 @@ class JointTrainLightningNet(nn.Module):
         # raise instead of turning into zeros (network_tcnn_semantics.py)
         if "h2_guard" in nerf_cfg:
             self.nerf_model.h2_guard = str(nerf_cfg["h2_guard"])
-        # `nerf: {joint_overlap: true}` / UCSA_JOINT_OVERLAP=1: the joint step's
-        # independent halves on two streams (training_step_joint).  OFF by
-        # default: measured SLOWER (R-101: 177 -> 187 ms) -- every kernel of either
-        # half fills the chip, co-scheduling them only makes them contend
-        self.joint_overlap = bool(nerf_cfg.get(
-            "joint_overlap", os.environ.get("UCSA_JOINT_OVERLAP", "0") == "1"))
-        self._joint_side = None
         # `model: {amp: bf16}` (optional; the reference trains DeepLab in fp32)
         # runs the segmentation network under bf16 autocast in channels_last
         # (MIOpen's fast path on MI355X: 49 -> 34 ms per 8-image train step)
@@ -482,69 +475,41 @@ class JointTrainLightningNet(nn.Module):
     def training_step_joint(self, batch):
         """reference :363-471.
 
-        Round 5: the step's independent halves CAN run on two streams
-        (`nerf: {joint_overlap: true}` / UCSA_JOINT_OVERLAP=1; off by default:
-        measured slower, 177 -> 187 ms on the R-101 step, see __init__).  The
-        reference's data flow (:363-461): the renders of the new-scene frames read
-        the NeRF, the pseudo-label forward reads DeepLab -- independent; the NeRF
-        updates need the pseudo-labels and must follow the renders (they write
-        the parameters the renders read); DeepLab's own step needs the renders
-        only.  So: main stream = renders -> augmentation -> DeepLab forward /
-        backward / step; side stream = pseudo-label forward (next to the renders)
-        -> NeRF updates (next to DeepLab's step), with events at exactly those
-        dependencies.  The host issues the work in the serial order, so every
-        random draw and every BatchNorm statistic update happens in the same
-        order: the step's results are those of the one-stream schedule."""
+        One stream: the renders of the new-scene frames, the pseudo-label forward,
+        the NeRF updates, then DeepLab's own step, in the reference's order.  (A
+        two-stream schedule -- renders || pseudo-label forward, NeRF updates ||
+        DeepLab step -- was built and measured in round 5: 177 -> 187 ms on the
+        R-101 step, every kernel of either half fills the chip; removed in round
+        6, docs/DESIGN_NOTEBOOK.md.)"""
         optimizer_seg, optimizer_nerf = self.optimizers()
         batch_old, batch_new, batch_cl = batch
-        main = side = None
-        if self.joint_overlap and batch_new is not None and batch_new["img"].is_cuda:
-            main = torch.cuda.current_stream(batch_new["img"].device)
-            if self._joint_side is None or self._joint_side.device != main.device:
-                self._joint_side = torch.cuda.Stream(device=main.device)
-            side = self._joint_side
-            side.wait_stream(main)      # the batch and last step's updates are there
-        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         if batch_new is not None:
             with torch.no_grad():
                 self.nerf_model.eval()
                 output_nerf = self.forward_nerf_test(batch_new)
                 self.nerf_model.train()
-            if side is not None:
-                rendered = torch.cuda.Event()
-                rendered.record(main)
         # NeRF updates: one per new-scene frame (reference :381-393).  Under
         # torch.distributed the ranks' samplers mix replayed old-scene frames
         # in, so a rank may hold 0..B new frames: every rank runs
         # max-over-ranks updates, idle ones contribute zero gradients.
         n_new = 0 if (self.fix_nerf or batch_new is None) else int(batch_new["img"].shape[0])
         counts = [0] if self.fix_nerf else self._new_frame_counts(n_new)
-        with on_side():
-            if n_new > 0:
-                self.seg_model.eval()
-                if batch_new["img"].shape[0] > 1:  # BN trains only when B > 1
-                    for m in self.seg_model.modules():
-                        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
-                            m.train()
-                with torch.no_grad():
-                    output_seg = self.forward_seg(batch_new)
-                self.seg_model.train()
-            if side is not None:
-                labelled = torch.cuda.Event()
-                labelled.record(side)
-                # the updates write the parameters the renders are reading
-                side.wait_event(rendered)
-            for bs in range(max(counts)):
-                contributors = sum(1 for c in counts if c > bs)
-                if bs < n_new:
-                    lc, ls, ld = self.forward_nerf_train(batch_new, output_seg, bs)
-                    self._nerf_update(optimizer_nerf, lc, ls, ld, contributors)
-                else:
-                    self._nerf_update_idle(optimizer_nerf, contributors)
-        if side is not None:
-            # DeepLab's own forward (BatchNorm statistics) and step come after
-            # the pseudo-label forward has read the model
-            main.wait_event(labelled)
+        if n_new > 0:
+            self.seg_model.eval()
+            if batch_new["img"].shape[0] > 1:  # BN trains only when B > 1
+                for m in self.seg_model.modules():
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                        m.train()
+            with torch.no_grad():
+                output_seg = self.forward_seg(batch_new)
+            self.seg_model.train()
+        for bs in range(max(counts)):
+            contributors = sum(1 for c in counts if c > bs)
+            if bs < n_new:
+                lc, ls, ld = self.forward_nerf_train(batch_new, output_seg, bs)
+                self._nerf_update(optimizer_nerf, lc, ls, ld, contributors)
+            else:
+                self._nerf_update_idle(optimizer_nerf, contributors)
         with torch.no_grad():
             rgb_seg = label_seg = None
             if batch_new is not None:
@@ -569,8 +534,6 @@ class JointTrainLightningNet(nn.Module):
         self.manual_backward(loss)
         udist.average_grads_(self.seg_model.parameters())
         optimizer_seg.step()
-        if side is not None:
-            main.wait_stream(side)      # the NeRF updates belong to this step
         self.log(f"{self._mode}/loss_seg", loss.detach())
 
     def on_train_epoch_end(self):

@@ -216,43 +216,11 @@ def sigma_mlp_fwd_scatter(mode: int, feat, packed_sigma, slot):
     return h, sigma
 
 
-def encode_sigma_sorted(mode: int, grid: Grid, table, rays_o, rays_d, z_sorted, pix, slot,
-                        aabb, T: int, image_width: int, packed_sigma):
-    """hashgrid_encode_sorted + sigma_mlp_fwd_scatter in one call, levels 0-7
-    encoded inside the sigma MLP (ucsa_encode_sigma_sorted; mode 2 bf16x3, 3
-    f16x2) -> h [N*T,16], sigma [N*T] at the ray-major rows."""
-    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
-    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
-    N = rays_o.shape[0]
-    M = N * int(T)
-    if z_sorted.numel() != M or pix.numel() != M or slot.numel() != M:
-        raise UcsaError("encode_sigma_sorted: z_sorted / pix / slot must hold N*T entries")
-    feat_ws = torch.empty(grid.n_levels, M, 2, device=z_sorted.device)
-    h = torch.empty(M, 16, device=z_sorted.device)
-    sigma = torch.empty(M, device=z_sorted.device)
-    check(lib().ucsa_encode_sigma_sorted(
-        int(mode), C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z_sorted),
-        _ptr(pix), _ptr(slot), fvec(aabb), N, int(T), int(image_width), _ptr(packed_sigma),
-        _ptr(feat_ws), _ptr(h), _ptr(sigma), _stream()), "ucsa_encode_sigma_sorted")
-    return h, sigma
-
-
-def encode_sigma_rays_image(grid: Grid, table, packed_sigma, rays_o, rays_d, z,
-                            aabb, image_width: int, half: bool = False):
-    """hashgrid_encode_rays(image_width=...) + sigma_mlp_fwd in one kernel
-    (features stay in LDS) -> h [N*T,16], sigma [N*T]; bit-identical."""
-    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
-    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
-    z = _f32(z, "z")
-    N, T = z.shape
-    h = torch.empty(N * T, 16, device=z.device)
-    sigma = torch.empty(N * T, device=z.device)
-    fn = (lib().ucsa_encode_sigma_rays_image_f16 if half
-          else lib().ucsa_encode_sigma_rays_image)
-    check(fn(C.byref(grid), _ptr(table), _ptr(packed_sigma), _ptr(rays_o),
-             _ptr(rays_d), _ptr(z), fvec(aabb), N, T, int(image_width), _ptr(h),
-             _ptr(sigma), _stream()), "ucsa_encode_sigma_rays_image")
-    return h, sigma
+def env_reload():
+    """Make the library re-read its UCSA_* tuning switches (it snapshots them once
+    per process: INTEGRATION.md "Environment variables").  Lab tools and tests
+    that flip a switch inside one process call this after changing os.environ."""
+    lib().ucsa_env_reload()
 
 
 def hashgrid_encode_points(grid: Grid, table, x):
