@@ -89,3 +89,35 @@ def test_the_dataset_hands_out_private_copies(tmp_path, monkeypatch):
     before = sj.decode_cache().misses
     assert torch.equal(ds2.preprocess_image(p), ref)
     assert sj.decode_cache().misses == before
+
+
+def test_a_predict_output_rewritten_inside_one_mtime_tick_is_decoded_again(tmp_path):
+    """a pseudo-label PNG rewritten with the same byte size inside the
+    filesystem's mtime granularity looks unchanged to (mtime, size); the predict pass
+    therefore calls ``invalidate()`` -- a generation counter in the key of its output
+    directories -- while the dataset's own frames stay cached."""
+    calls = []
+
+    def decode(p):
+        calls.append(p)
+        return torch.from_numpy(np.asarray(PIL.open(p)).astype(np.int64))
+
+    (tmp_path / "nerf_label").mkdir()
+    (tmp_path / "label_40").mkdir()
+    out, own = str(tmp_path / "nerf_label" / "0.png"), str(tmp_path / "label_40" / "0.png")
+    _png(out, np.full((32, 32), 3, np.uint8))
+    _png(own, np.full((32, 32), 4, np.uint8))
+    c = sj.DecodeCache(budget_mb=4)
+    assert int(c.lookup("label", out, (32, 32), decode)[0, 0]) == 3
+    c.lookup("label", own, (32, 32), decode)
+    st = os.stat(out)
+    _png(out, np.full((32, 32), 7, np.uint8))           # same size ...
+    os.utime(out, ns=(st.st_atime_ns, st.st_mtime_ns))   # ... and the same mtime
+    if os.stat(out).st_size == st.st_size:
+        assert int(c.lookup("label", out, (32, 32), decode)[0, 0]) == 3      # the stale hit
+    c.invalidate()
+    n = len(calls)
+    assert int(c.lookup("label", out, (32, 32), decode)[0, 0]) == 7
+    c.lookup("label", own, (32, 32), decode)                                 # still cached
+    assert len(calls) == n + 1
+    assert not c.pin                                                         # pinning is opt-in

@@ -20,7 +20,7 @@ namespace {
 const char* const kEnvNames[] = {
     // launch shapes / kernel choices of the render path
     "UCSA_SHADE_VARIANT", "UCSA_SPLIT_COMPOSITE", "UCSA_ENC_SORTED", "UCSA_ENC_ML",
-    "UCSA_ENC_SORTED_ML", "UCSA_ENC_SORTED_LEAN", "UCSA_ENC_COARSE_SHAPE",
+    "UCSA_ENC_SORTED_ML", "UCSA_ENC_SORTED_LEAN",
     // ... of the training path
     "UCSA_SHADE_BWD_SPLIT", "UCSA_BWD_OVERLAP", "UCSA_BWD_BIN_SCALE",
     // lab only (tools/encode_*.py, tools/coresident_exp.py)

@@ -57,16 +57,25 @@ class DecodeCache:
     for frames that never change: a stage trains 10 + 2 epochs on the same ~100
     frames, and the next stages replay them.  One process-wide LRU keyed by
     (kind, path, output size, st_mtime_ns, st_size): a file that is rewritten --
-    the pseudo-labels of the predict pass -- misses and is decoded again.  Entries
-    are pinned when a GPU is present (the copy to the device then needs no staging)
-    and are never handed out: ``get`` returns a clone (CPU) or the caller copies to
-    the device.  ``UCSA_DECODE_CACHE_MB`` (default 2048; 0 switches it off) bounds
-    it; 100 frames are ~0.8 GB."""
+    the pseudo-labels of the predict pass -- misses and is decoded again; files
+    rewritten inside the filesystem's mtime granularity with the same byte size
+    would not, so whoever rewrites label files calls ``invalidate()`` (the predict
+    pass does: a generation counter is part of the key).  The entries are the
+    cache's own tensors: callers must not modify them in place (they copy to the
+    device or clone).  ``UCSA_DECODE_CACHE_MB`` (default 2048, DIVIDED by the number
+    of ranks on this node; 0 switches it off) bounds it; 100 frames are ~0.8 GB.
+    Page-locking the entries is opt-in (``UCSA_DECODE_CACHE_PIN=1``): 8 ranks x 2 GB
+    of pinned host memory is not something to take silently."""
 
     def __init__(self, budget_mb=None):
         if budget_mb is None:
             budget_mb = float(os.environ.get("UCSA_DECODE_CACHE_MB", "2048"))
+            local = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+            if local > 1:
+                budget_mb /= local
+        self.pin = os.environ.get("UCSA_DECODE_CACHE_PIN", "0") == "1"
         self.budget = int(budget_mb * (1 << 20))
+        self.generation = 0
         self.used = 0
         self.hits = self.misses = 0
         self._d = OrderedDict()
@@ -77,7 +86,8 @@ class DecodeCache:
         if self.budget <= 0:
             return decode(path)
         st = os.stat(path)
-        key = (kind, os.path.abspath(path), tuple(size), st.st_mtime_ns, st.st_size)
+        key = (kind, os.path.abspath(path), tuple(size), st.st_mtime_ns, st.st_size,
+               self.generation if self._rewritable(path) else 0)
         with self._lock:
             t = self._d.get(key)
             if t is not None:
@@ -85,7 +95,7 @@ class DecodeCache:
                 self.hits += 1
                 return t
         t = decode(path)
-        if torch.cuda.is_available():
+        if self.pin and torch.cuda.is_available():
             try:
                 t = t.pin_memory()
             except RuntimeError:
@@ -100,6 +110,18 @@ class DecodeCache:
                     _, old = self._d.popitem(last=False)
                     self.used -= old.numel() * old.element_size()
         return t
+
+    @staticmethod
+    def _rewritable(path):
+        # the predict pass's outputs (joint_train_lightning_net.predict_step); the
+        # dataset's own frames never change
+        return any(d in path for d in ("nerf_image", "nerf_label", "seg_label"))
+
+    def invalidate(self):
+        """The predict pass has (re)written its PNGs: later look-ups of those files
+        decode again whatever their mtime says."""
+        with self._lock:
+            self.generation += 1
 
     def clear(self):
         with self._lock:

@@ -686,6 +686,11 @@ class JointTrainLightningNet(nn.Module):
         return res
 
     def on_predict_epoch_end(self):
+        if self.predict_to_disk:
+            # the PNGs above may replace files the decode cache has seen (same size,
+            # same mtime tick): ADVICE r5
+            from ..dataset.scannet_ngp_joint import decode_cache
+            decode_cache().invalidate()
         return None
 
     # ---- optimizers (:876-921) ---------------------------------------------------
