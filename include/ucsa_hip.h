@@ -326,6 +326,20 @@ int32_t ucsa_sigma_mlp_fwd_scatter(int32_t mode, const void* feat,
                                    const void* packed_sigma, uint32_t M,
                                    uint32_t n_levels, const uint32_t* slot,
                                    float* h, float* sigma, void* stream);
+/* ucsa_hashgrid_encode_sorted + ucsa_sigma_mlp_fwd_scatter as ONE call in which the
+ * sigma MLP encodes levels 0-7 itself -- a wave owns 64 consecutive samples of the
+ * depth order, the level is wave-uniform, the feature pairs go through a wave-private
+ * LDS tile and never through HBM -- and reads levels 8-15 from feat_ws [16][N*T][2]
+ * (written here by the per-level depth-ordered encoder): `density()` of a sample
+ * batch, reference network_tcnn_semantics.py:130-144, with half of the feature
+ * round trip gone.  mode 2 = bf16x3, 3 = f16x2 packs; 16 levels.  The same h / sigma
+ * BITS as the two separate calls. */
+int32_t ucsa_density_sorted(int32_t mode, const ucsa_grid* grid, const float* table,
+                            const float* rays_o, const float* rays_d,
+                            const float* z_sorted, const uint8_t* pix,
+                            const uint32_t* slot, const float* aabb_host, uint32_t N,
+                            uint32_t T, uint32_t image_width, const void* packed_sigma,
+                            float* feat_ws, float* h, float* sigma, void* stream);
 /* ucsa_sigma_mlp_fwd_f16 on fp16 features (same h / sigma) */
 int32_t ucsa_sigma_mlp_fwd_f16_h(const void* feat_half,
                                  const void* packed_sigma_half, uint32_t M,

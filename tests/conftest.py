@@ -65,16 +65,3 @@ def _library_env_snapshot_follows_monkeypatch():
     mod = sys.modules.get("ucsa_neural_rendering_amd._lib")
     if mod is not None and getattr(mod, "_lib", None) is not None:
         mod._lib.ucsa_env_reload()
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _start_the_long_oracle_trajectory_early(request):
-    """tests/test_gpu_trajectory.py's 600-step oracle run takes ~6 min of CPU; started
-    here, at the beginning of a session that will need it, it runs beside the rest of
-    the `-m gpu` suite (that module is collected last)."""
-    if any("test_long_horizon_quality" in it.nodeid for it in request.session.items):
-        import torch
-        if torch.cuda.is_available():
-            from tests import test_gpu_trajectory as tt
-            tt.start_long_oracle()
-    yield

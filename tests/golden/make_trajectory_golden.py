@@ -1,0 +1,67 @@
+"""Generates tests/golden/g9_trajectory_long.npz: the CPU oracle trainer's side of
+tests/test_gpu_trajectory.py::test_long_horizon_quality_* -- 600 steps of 4096 rays x
+(16+16) samples with the reference's losses and Adam settings (reference
+nr4seg/lightning/joint_train_lightning_net.py:473-513, :897-919) on the synthetic room,
+quality (per-view-mean PSNR and mIoU on the 8 training views, as the reference's test
+loop measures them: nr4seg/utils/metrics.py:13-65, joint_train_lightning_net.py:648-693)
+after every 5th step from step 100.  TWO runs with different BLAS thread counts (another
+summation order: the oracle's own run-to-run spread is part of the fixture).
+
+    python tests/golden/make_trajectory_golden.py [threadsA threadsB]     (~30 min on 8 cores)
+
+No GPU, no reference code: oracle/ + the synthetic scene's analytic ray casting only."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def worker(args):
+    tag, threads = args
+    import torch
+    torch.set_num_threads(threads)
+    from tests import test_gpu_trajectory as tt
+    frames = tt._frames()
+    draws, u_eval = tt._draws(tt.LONG)
+    t0 = time.time()
+    log = open(os.path.join(ROOT, "tests", "golden", f"_trajectory_{tag}.log"), "w")
+
+    def progress(k, q, losses):
+        log.write(f"step {k + 1} t {time.time() - t0:.0f}s psnr {q['train'][0]:.2f} miou {q['train'][1]:.1f} "
+                  f"held {q['held'][0]:.2f} loss {np.mean(losses[-20:]):.5f}\n")
+        log.flush()
+
+    quals, losses, _ = tt._train_oracle(frames, draws, u_eval, False, tt.LONG.checkpoints,
+                                        raw_quals=True, progress=progress)
+    return dict(psnr=[q["train"][0] for q in quals], miou=[q["train"][1] for q in quals],
+                held_psnr=[q["held"][0] for q in quals], held_miou=[q["held"][1] for q in quals],
+                losses=losses, threads=threads, seconds=time.time() - t0)
+
+
+def main():
+    import torch
+    from tests import test_gpu_trajectory as tt
+    threads = [int(x) for x in sys.argv[1:3]] or [5, 3]
+    with mp.get_context("spawn").Pool(2) as pool:
+        a, b = pool.map(worker, [("A", threads[0]), ("B", threads[1])])
+    out = os.path.join(ROOT, "tests", "golden", "g9_trajectory_long.npz")
+    np.savez_compressed(
+        out, checkpoints=np.array(tt.LONG.checkpoints), steps=np.array(tt.LONG.steps),
+        rays=np.array(tt.LONG.n), seed=np.array(tt.LONG.seed),
+        psnr=np.array([a["psnr"], b["psnr"]], dtype=np.float64),
+        miou=np.array([a["miou"], b["miou"]], dtype=np.float64),
+        held_psnr=np.array([a["held_psnr"], b["held_psnr"]], dtype=np.float64),
+        held_miou=np.array([a["held_miou"], b["held_miou"]], dtype=np.float64),
+        losses=np.array([a["losses"], b["losses"]], dtype=np.float64),
+        threads=np.array([a["threads"], b["threads"]]),
+        seconds=np.array([a["seconds"], b["seconds"]]))
+    print("wrote", out, "torch", torch.__version__)
+
+
+if __name__ == "__main__":
+    main()

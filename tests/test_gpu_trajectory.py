@@ -59,9 +59,10 @@ Run = collections.namedtuple("Run", "steps n T t checkpoints seed")
 SHORT = Run(150, 2048, 16, 16, (69, 79, 89, 99, 109, 119, 129, 139, 149), 2024)
 # round 6: a horizon on which the semantic head HAS converged --
 # 600 steps of 4096 rays (the reference's batch, joint_train_lightning_net.py:141),
-# quality = mean over 9 checkpoints of the last 200 steps -- held to north_star's
+# quality at 100 checkpoints (every 5 steps from step 100), the oracle's side a
+# committed fixture (tests/golden/g9_trajectory_long.npz) -- held to north_star's
 # +-0.5 dB / +-0.5 pt
-LONG = Run(600, 4096, 16, 16, tuple(range(399, 600, 25)), 2025)
+LONG = Run(600, 4096, 16, 16, tuple(range(99, 600, 5)), 2025)
 STEPS, N, T, t = SHORT.steps, SHORT.n, SHORT.T, SHORT.t      # (the short run's, for the tools)
 CHECKPOINTS = SHORT.checkpoints
 
@@ -121,7 +122,8 @@ def _mean_quality(quals):
     return out
 
 
-def _train_oracle(frames, draws, u_eval, emulate_tcnn, checkpoints=SHORT.checkpoints):
+def _train_oracle(frames, draws, u_eval, emulate_tcnn, checkpoints=SHORT.checkpoints,
+                  raw_quals=False, progress=None):
     fld = ofield.OracleField(bound=4.0, num_semantic_classes=C, seed=123)
     if emulate_tcnn:
         fld.emulate_fp16 = True
@@ -156,11 +158,13 @@ def _train_oracle(frames, draws, u_eval, emulate_tcnn, checkpoints=SHORT.checkpo
                 p.copy_(pn)
         if k in checkpoints:
             evaluate()
-    return _mean_quality(quals), losses, {}
+            if progress is not None:
+                progress(k, quals[-1], losses)
+    return (quals if raw_quals else _mean_quality(quals)), losses, {}
 
 
 def _train_hip(frames, draws, u_eval, precision, deterministic=False, steps=None,
-               checkpoints=SHORT.checkpoints):
+               checkpoints=SHORT.checkpoints, raw_quals=False):
     from ucsa_neural_rendering_amd import losses as ul
     from ucsa_neural_rendering_amd.nerf.optim import HipAdam
     net = hip_network_from_oracle(ofield.OracleField(bound=4.0, num_semantic_classes=C,
@@ -206,7 +210,7 @@ def _train_hip(frames, draws, u_eval, precision, deterministic=False, steps=None
             evaluate()
     skipped = sum(int(v) for v in opt._skipped.values()) if opt._skipped else 0
     info = {"skipped_steps": skipped, "final_scale": float(scaler.get_scale())}
-    return _mean_quality(quals), [float(x) for x in torch.stack(losses).cpu()], info
+    return (quals if raw_quals else _mean_quality(quals)), [float(x) for x in torch.stack(losses).cpu()], info
 
 
 def _hip_mean(scene, precision, runs=2):
@@ -246,39 +250,24 @@ def oracles(scene):
 
 
 def _frames():
-    from ucsa_neural_rendering_amd.dataset import SyntheticSceneDataset
-    ds = SyntheticSceneDataset(3, n_views=VIEWS, H=H, W=W, n_classes=C, device="cuda")
+    """Frames of the synthetic room as CPU tensors, built WITHOUT the GPU: rays from
+    oracle.rays.pixel_rays (bit-equal to ucsa_get_rays, G1), ground truth by the
+    room's analytic ray casting (plain torch) -- the same frames for the HIP side, the
+    oracle workers and tests/golden/make_trajectory_golden.py."""
+    from oracle.rays import pixel_rays
+    from ucsa_neural_rendering_amd.dataset.synthetic_scene import SyntheticRoom, _slerp_loop_poses
+    room = SyntheticRoom(3, n_classes=C)
+    poses = _slerp_loop_poses(VIEWS, seed=123 + 3)
+    intr = (0.89 * W, 0.89 * W, W / 2.0, H / 2.0)
     frames = []
-    for i in range(VIEWS):
-        it = ds[i]
-        frames.append(dict(o=it["rays_o"].cpu(), d=it["rays_d"].cpu(),
-                           nrm=it["direction_norms"].cpu(),
-                           rgb=it["img"].reshape(3, -1).t().contiguous().cpu(),
-                           label=it["label"].reshape(-1).cpu(),
-                           depth=it["depth"].float().reshape(-1).cpu()))
+    with torch.no_grad():
+        for i in range(VIEWS):
+            o, d, n = pixel_rays(poses[i:i + 1], intr, H, W)
+            t_hit, rgb, label = room.cast(o[0], d[0])
+            depth = (t_hit / n[0, :, 0]).half().float()          # the dataset hands out fp16 depth
+            frames.append(dict(o=o[0].contiguous(), d=d[0].contiguous(), nrm=n[0].contiguous(),
+                               rgb=rgb.contiguous(), label=label.reshape(-1), depth=depth.reshape(-1)))
     return frames
-
-
-_LONG = {}
-
-
-def start_long_oracle():
-    """The 600-step fp32 oracle trajectory (~6 min of CPU on half of the box's
-    cores) in a worker process.  tests/conftest.py calls this at the START of a
-    `-m gpu` session that holds the long-horizon test, so that it runs next to the
-    rest of the suite instead of after it; the test itself calls it if nobody has."""
-    if "job" not in _LONG:
-        import multiprocessing as mp
-        from tests.conftest import _effective_cores
-        frames = _frames()
-        draws, u_eval = _draws(LONG)
-        pool = mp.get_context("spawn").Pool(1)
-        _LONG.update(frames=frames, draws=draws, u_eval=u_eval, pool=pool,
-                     job=pool.apply_async(_oracle_worker, ((frames, draws, u_eval, False,
-                                                            max(1, _effective_cores() // 2),
-                                                            LONG.checkpoints),)))
-        pool.close()
-    return _LONG
 
 
 HELD_OUT_DB = 1.5
@@ -329,20 +318,57 @@ def test_trajectory_quality_matches_the_fp32_oracle(scene, oracles, precision):
     assert np.abs(lh[:5] - lo[:5]).max() <= 2e-5 * max(1.0, lo[0])
 
 
+def long_run_series(quals):
+    """(PSNR, mIoU) per checkpoint on the training views."""
+    return ([q["train"][0] for q in quals], [q["train"][1] for q in quals])
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 def test_long_horizon_quality_within_half_a_db_and_half_a_point(precision):
-    """north_star: ">= 10x ... at matched mIoU / PSNR (+-0.5)".  600 steps of 4096
-    rays -- the reference's batch -- from the same initial state on the same draws;
-    the semantic head has converged by step 400 (the short run above ends inside its
-    chance-to-learning transition, which is why that one is held to +-1.0 pt); the
-    means over the 9 checkpoints of steps 400-600 must agree within 0.5 dB AND 0.5 pt
-    on the training views, for the default training arithmetic (bf16x3 forward, bf16x2
-    backward, packed grid records) and the exact fp32 one."""
-    st = start_long_oracle()
-    hip = _train_hip(st["frames"], st["draws"], st["u_eval"], precision,
-                     checkpoints=LONG.checkpoints)
-    ora = st["job"].get(timeout=2400)
-    _compare(f"long[{precision}]", hip, ora, tol_db=0.5, tol_pt=0.5)
+    """north_star: ">= 10x ... at matched mIoU / PSNR (+-0.5)" -- on a horizon where the
+    semantic head HAS converged: 600 steps of 4096 rays (the
+    reference's batch) from the same initial state on the same draws, quality at 100
+    checkpoints (every 5 steps from step 100).  The oracle's side is a committed
+    fixture, tests/golden/g9_trajectory_long.npz: TWO runs of the CPU oracle trainer
+    with different BLAS thread counts (tests/golden/make_trajectory_golden.py, ~25 min
+    of CPU each -- too long for the suite, and the stored series is the same evidence).
+    With the reference's Adam (lr 1e-2, eps 1e-15, no schedule) single checkpoints of
+    two runs differ by +-2 ... 4 dB from step ~150 on; what is comparable is the MEAN:
+      PSNR  over all 100 checkpoints,
+      mIoU  over the checkpoints from step 425 on (the head converges between steps
+            350 and 400 in every run: ~37 -> ~74 pt),
+    each held to +-0.5 against the mean of the two oracle runs, for the default
+    training arithmetic (bf16x3 forward, bf16x2 backward, x-pair grid records) and the
+    exact fp32 one; the two oracle runs' own difference is printed as the yardstick."""
+    from tests.util import load_golden
+    gold = load_golden("g9_trajectory_long.npz")
+    ck = tuple(int(x) for x in gold["checkpoints"])
+    assert ck == LONG.checkpoints and int(gold["steps"]) == LONG.steps and int(gold["rays"]) == LONG.n
+    frames = _frames()
+    draws, u_eval = _draws(LONG)
+    psnr_h, miou_h = [], []
+    for rep in range(2):        # two HIP runs (float atomics): ~20 s each
+        q, losses, info = _train_hip(frames, draws, u_eval, precision, checkpoints=LONG.checkpoints,
+                                     raw_quals=True)
+        p, m = long_run_series(q)
+        psnr_h.append(p)
+        miou_h.append(m)
+    psnr_h, miou_h = np.array(psnr_h), np.array(miou_h)
+    psnr_o, miou_o = gold["psnr"].numpy(), gold["miou"].numpy()          # [2, 100]
+    late = np.array(ck) >= 424
+    rows = [("oracle run A", psnr_o[0], miou_o[0]), ("oracle run B", psnr_o[1], miou_o[1]),
+            (f"hip {precision} run 1", psnr_h[0], miou_h[0]), (f"hip {precision} run 2", psnr_h[1], miou_h[1])]
+    for name, p, m in rows:
+        print(f"long[{precision}] {name:20s} PSNR mean {p.mean():.3f} dB (late {p[late].mean():.3f}); "
+              f"mIoU late mean {m[late].mean():.2f} pt (at steps 100-420: {m[~late].mean():.2f})")
+    d_psnr = float(psnr_h.mean() - psnr_o.mean())
+    d_miou = float(miou_h[:, late].mean() - miou_o[:, late].mean())
+    print(f"long[{precision}] hip - oracle: PSNR {d_psnr:+.3f} dB, mIoU {d_miou:+.3f} pt; oracle A - B: "
+          f"{psnr_o[0].mean() - psnr_o[1].mean():+.3f} dB, {miou_o[0][late].mean() - miou_o[1][late].mean():+.3f} pt; "
+          f"hip run 1 - run 2: {psnr_h[0].mean() - psnr_h[1].mean():+.3f} dB")
+    assert miou_o[:, late].mean() > 60.0 and psnr_o.mean() > 30.0          # the run means something
+    assert abs(d_psnr) <= 0.5, d_psnr
+    assert abs(d_miou) <= 0.5, d_miou
 
 
 def test_trajectory_quality_tcnn_numerics_matches_the_fp16_emulating_oracle(scene, oracles):

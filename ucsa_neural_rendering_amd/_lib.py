@@ -121,6 +121,9 @@ SIGNATURES = {
     "ucsa_hashgrid_encode_sorted_hf": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                                    C.POINTER(_f), _u32, _u32, _u32,
                                                    _p, _p]),
+    "ucsa_density_sorted": (C.c_int32, [C.c_int32, C.POINTER(Grid), _p, _p, _p, _p, _p, _p,
+                                        C.POINTER(_f), _u32, _u32, _u32, _p, _p, _p, _p,
+                                        _p]),
     "ucsa_sigma_mlp_fwd_scatter": (C.c_int32, [C.c_int32, _p, _p, _u32, _u32, _p,
                                                _p, _p, _p]),
     "ucsa_sigma_mlp_fwd_f16_h": (C.c_int32, [_p, _p, _u32, _u32, _p, _p, _p]),

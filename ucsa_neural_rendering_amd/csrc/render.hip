@@ -20,6 +20,7 @@ namespace {
 const char* const kEnvNames[] = {
     // launch shapes / kernel choices of the render path
     "UCSA_SHADE_VARIANT", "UCSA_SPLIT_COMPOSITE", "UCSA_ENC_SORTED", "UCSA_ENC_ML",
+    "UCSA_DENSITY_FUSED",
     "UCSA_ENC_SORTED_ML", "UCSA_ENC_SORTED_LEAN",
     // ... of the training path
     "UCSA_SHADE_BWD_SPLIT", "UCSA_BWD_OVERLAP", "UCSA_BWD_BIN_SCALE",
@@ -135,6 +136,11 @@ static int32_t encode(const ucsa_grid* grid, const void* table_any,
                                    T, feat, stream);
 }
 
+static bool density_fused() {
+  const char* v = ucsa_getenv("UCSA_DENSITY_FUSED");
+  return !(v && v[0] == '0');
+}
+
 // Which composite: the f32-input MFMA is bound by the matrix pipe itself (352
 // MFMAs per 32 samples = 1.62 ms per 61 440-ray chunk at 100 % of the pipe)
 // and the fused k_composite (2.25 ms) beats the split pair there (2.5-2.8 ms);
@@ -189,6 +195,13 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
         (sorted_mode == 2 || (sorted_mode == 1 && fine))) {
       UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
                                      w.slot, stream));
+      // bf16x3 / f16x2 nets: levels 0-7 are encoded INSIDE the sigma MLP (their
+      // features never travel through HBM: density_sorted.hip; same h / sigma
+      // bits; UCSA_DENSITY_FUSED=0 keeps the staged pair for A/B runs)
+      if (prec >= 2 && density_fused())
+        return ucsa_density_sorted(prec, grid, table, rays_o, rays_d, w.zs_sorted,
+                                   w.pix, w.slot, aabb_host, N, n, image_width,
+                                   packed_sigma, w.feat, h, sigma, stream);
       if (prec == 1)
         UCSA_TRY(ucsa_hashgrid_encode_sorted_hf(grid, table, rays_o, rays_d,
                                                 w.zs_sorted, w.pix, aabb_host, N, n,

@@ -216,6 +216,27 @@ def sigma_mlp_fwd_scatter(mode: int, feat, packed_sigma, slot):
     return h, sigma
 
 
+def density_sorted(mode: int, grid: Grid, table, rays_o, rays_d, z_sorted, pix, slot,
+                   aabb, T: int, image_width: int, packed_sigma):
+    """hashgrid_encode_sorted + sigma_mlp_fwd_scatter in one call, levels 0-7
+    encoded inside the sigma MLP (ucsa_density_sorted; mode 2 bf16x3, 3 f16x2)
+    -> h [N*T,16], sigma [N*T] at the ray-major rows."""
+    rays_o = _f32(rays_o, "rays_o").view(-1, 3)
+    rays_d = _f32(rays_d, "rays_d").view(-1, 3)
+    N = rays_o.shape[0]
+    M = N * int(T)
+    if z_sorted.numel() != M or pix.numel() != M or slot.numel() != M:
+        raise _lib.UcsaError("density_sorted: z_sorted / pix / slot must hold N*T entries")
+    feat_ws = torch.empty(grid.n_levels, M, 2, device=z_sorted.device)
+    h = torch.empty(M, 16, device=z_sorted.device)
+    sigma = torch.empty(M, device=z_sorted.device)
+    check(lib().ucsa_density_sorted(
+        int(mode), C.byref(grid), _ptr(table), _ptr(rays_o), _ptr(rays_d), _ptr(z_sorted),
+        _ptr(pix), _ptr(slot), fvec(aabb), N, int(T), int(image_width), _ptr(packed_sigma),
+        _ptr(feat_ws), _ptr(h), _ptr(sigma), _stream()), "ucsa_density_sorted")
+    return h, sigma
+
+
 def env_reload():
     """Make the library re-read its UCSA_* tuning switches (it snapshots them once
     per process: INTEGRATION.md "Environment variables").  Lab tools and tests
