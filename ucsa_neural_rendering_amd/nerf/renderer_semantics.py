@@ -317,10 +317,18 @@ class SemanticNeRFRenderer(nn.Module):
         if self.precision not in ("fp32", "fp16", "bf16x3", "f16x2"):
             raise ValueError("precision must be fp32, bf16x3, f16x2 or fp16, got "
                              f"{self.precision}")
-        # (the marcher has no bf16x3 / f16x2 kernels: those modes shade in fp32 here)
+        # (the marcher's fused shading kernel has f32-input and f16 nets only: with
+        # bf16x3 / f16x2 the colour / semantics nets shade in fp32 here; the sigma MLP
+        # of the marched points runs on the 16-bit pipe in the selected arithmetic --
+        # round 6: it used to fall back to the f32-input MFMA, 0.33 instead of 0.21 ms
+        # per 5.9 M points)
         half = self.precision == "fp16" and schedule == "segments" and fused_shade
         f = self._field_f16() if half else self._field()
         sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
+        if not half and self.precision in ("bf16x3", "f16x2"):
+            fx = self._field_h2() if self.precision == "f16x2" else self._field_x3()
+            fwd = ops.sigma_mlp_fwd_h2 if self.precision == "f16x2" else ops.sigma_mlp_fwd_x3
+            sigma_mlp = lambda feat, _packed, _fx=fx, _fwd=fwd: _fwd(feat, _fx["packed_sigma"])  # noqa: E731
         ws = torch.zeros(N, device=device)
         depth = torch.zeros(N, device=device)
         image = torch.zeros(N, 3, device=device)
