@@ -269,6 +269,10 @@ ENC_PASS_KERNELS = {
 }
 
 
+# round 6: a density pass of the shipped render path (both passes the same two kernels)
+DENSITY_PASS_KERNELS = ("k_hashgrid_encode_sorted", "k_density_sorted")
+
+
 def encoder_roofline(st, chunk, pretrain_steps):
     """`roofline` of the dominant stage, the hash-grid encoder of one density
     pass: algorithmic gather bytes (L x 8 corners x F x 4 B = 1024 B
@@ -286,20 +290,51 @@ def encoder_roofline(st, chunk, pretrain_steps):
     enc_bytes = samples * 16 * 8 * 2 * 4
     enc_ms = 0.5 * (st["encode_c"] + st["encode_f"])
     enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
-    r = {"kernel": "hash-grid encoder, one density pass = 2 launches: k_hashgrid_encode_tiled + "
-                   "_tiled_ml (coarse) / k_hashgrid_encode_sorted + _sorted_ml (fine, depth-ordered)",
-         "bound": "hbm", "achieved": enc_gbs,
-         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
-         "traffic": None, "launch_ms": enc_ms, "algorithmic_bytes_per_launch": enc_bytes,
-         "pass_ms": {"coarse": st["encode_c"], "fine": st["encode_f"],
-                     "fine_sort": st.get("sort_f", 0.0)},
-         "timing": "HIP events on the launch stream around the two encoder launches of a pass, "
-                   "mean of coarse+fine pass, 5 iterations",
-         "note": "achieved = ALGORITHMIC gather bytes (1024 B/sample) / pass time: a "
-                 "nominal figure against the HBM line, NOT HBM utilisation "
-                 "(hbm_utilisation is: measured traffic / time / peak).  The table slice a "
-                 "launch phase works on is L2/MALL resident; what binds the fine levels is the "
-                 "L2 -> L1 fill of one 128-B line per 8-byte corner pair (binding_resource)"}
+    if "density_c" in st:
+        # round 6: what ships is the DENSITY pass -- k_hashgrid_encode_sorted (levels
+        # 8-15) + k_density_sorted (levels 0-7 encoded inside the sigma MLP): the
+        # encoder of levels 0-7 is no kernel of its own any more.  Algorithmic bytes of
+        # density() per sample: the 1024 B of gathers + 68 B out (h row, sigma) + 4 B in
+        # (depth); the feature round trip between the two launches is not algorithmic.
+        pass_bytes = samples * (1024 + 68 + 4)
+        pass_ms = 0.5 * (st["density_c"] + st["density_f"])
+        pass_gbs = pass_bytes / (pass_ms * 1e-3) / 1e9
+        r = {"kernel": "density pass = 2 launches: k_hashgrid_encode_sorted (hash-grid levels 8-15, one "
+                       "level per grid row) + k_density_sorted (levels 0-7 encoded inside the sigma MLP, "
+                       "wave-private LDS tile); both passes on per-tile depth-ordered samples",
+             "bound": "hbm", "achieved": pass_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": pass_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": pass_ms,
+             "algorithmic_bytes_per_launch": pass_bytes,
+             "algorithmic_bytes_per_sample": {"gathers_16_levels": 1024, "h_row_and_sigma_out": 68,
+                                              "depth_in": 4},
+             "pass_ms": {"coarse": st["density_c"], "fine": st["density_f"],
+                         "coarse_sort": st.get("order_c", 0.0), "fine_sort": st.get("sort_f", 0.0)},
+             "encoder_only_unfused": {
+                 "what": "round 5's figure, kept for continuity: the two encoder launches of a pass "
+                         "(all 16 levels written to HBM) without the sigma MLP, 1024 B per sample",
+                 "launch_ms": enc_ms, "achieved": enc_gbs, "frac": enc_gbs / HBM_PEAK_GBS,
+                 "pass_ms": {"coarse": st["encode_c"], "fine": st["encode_f"]}},
+             "timing": "HIP events on the launch stream around ucsa_density_sorted (its two launches), "
+                       "mean of coarse+fine pass, 5 iterations",
+             "note": "achieved = ALGORITHMIC bytes of density() / pass time: a nominal figure against "
+                     "the HBM line, NOT HBM utilisation.  The table slice a launch phase works on is "
+                     "L2/MALL resident; what binds the levels-8-15 launch is the L2 -> L1 fill of one "
+                     "128-B line per 8-byte corner pair (binding_resource)"}
+    else:
+        r = {"kernel": "hash-grid encoder, one density pass = 2 launches: k_hashgrid_encode_tiled + "
+                       "_tiled_ml (coarse) / k_hashgrid_encode_sorted + _sorted_ml (fine, depth-ordered)",
+             "bound": "hbm", "achieved": enc_gbs,
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
+             "traffic": None, "launch_ms": enc_ms, "algorithmic_bytes_per_launch": enc_bytes,
+             "pass_ms": {"coarse": st["encode_c"], "fine": st["encode_f"],
+                         "fine_sort": st.get("sort_f", 0.0)},
+             "timing": "HIP events on the launch stream around the two encoder launches of a pass, "
+                       "mean of coarse+fine pass, 5 iterations",
+             "note": "achieved = ALGORITHMIC gather bytes (1024 B/sample) / pass time: a "
+                     "nominal figure against the HBM line, NOT HBM utilisation "
+                     "(hbm_utilisation is: measured traffic / time / peak).  The table slice a "
+                     "launch phase works on is L2/MALL resident; what binds the fine levels is the "
+                     "L2 -> L1 fill of one 128-B line per 8-byte corner pair (binding_resource)"}
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_JSON)))
         eb = json.load(open(os.path.join(ROOT, ENC_BINDING_JSON)))
@@ -313,16 +348,22 @@ def encoder_roofline(st, chunk, pretrain_steps):
         raise SystemExit(f"bench.py: {PMC_JSON} / {ENC_BINDING_JSON} malformed: {e!r}")
     # ... on launches of THIS size: 256 threads per 1024 samples and level
     per_level = chunk * T_COARSE // 4
-    names = [k for ks in ENC_PASS_KERNELS.values() for k in ks]
+    shipped = "density_c" in st
+    names = (list(DENSITY_PASS_KERNELS) if shipped
+             else [k for ks in ENC_PASS_KERNELS.values() for k in ks])
     same_launch = all(
         "fetch_bytes" in pmc.get(k, {}) and int(pmc[k].get("grid_threads", -1)) % per_level == 0
         for k in names)
     if int(pmc.get("pretrain_steps", -1)) == int(pretrain_steps) and same_launch:
-        tr = 0.5 * sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in names)
+        # (shipped path: both passes launch the same two kernels at the same size -- the
+        # per-dispatch averages ARE the mean over the passes; round 5's four kernels: half
+        # the sum)
+        tr = (1.0 if shipped else 0.5) * sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"]
+                                             for k in names)
         r["traffic"] = tr
         r["traffic_source"] = PMC_JSON + " (mean over the two passes of the sum of their launches)"
         r["traffic_by_kernel"] = {k: pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in names}
-        r["hbm_utilisation"] = tr / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["hbm_utilisation"] = tr / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     l2 = 0.5 * (eb["coarse"]["l2_request_frac_of_34500"] + eb["fine"]["l2_request_frac_of_34500"])
     keys = ("launch_us", "tcp_accesses_per_clock_per_cu", "l1_hit_rate", "l2_latency_cycles",
             "misses_in_flight_per_tcp", "tcp_pending_stall_frac", "valu_issue_frac",

@@ -310,13 +310,6 @@ int32_t ucsa_hashgrid_encode_rays_hf(const ucsa_grid* grid, const float* table,
 int32_t ucsa_tile_depth_order(const float* z, uint32_t N, uint32_t T,
                               uint32_t image_width, float* z_sorted,
                               uint8_t* pix, uint32_t* slot, void* stream);
-/* The same three arrays for the COARSE samples without a sort: "sample index, then
- * pixel" (sample s of every ray of an 8x8 tile sits at nearly one depth:
- * renderer_semantics.py:154-173), so that the first density() call of run() goes
- * through the depth-ordered kernels as well. */
-int32_t ucsa_tile_index_order(const float* z, uint32_t N, uint32_t T,
-                              uint32_t image_width, float* z_sorted, uint8_t* pix,
-                              uint32_t* slot, void* stream);
 int32_t ucsa_hashgrid_encode_sorted(const ucsa_grid* grid, const float* table,
                                     const float* rays_o, const float* rays_d,
                                     const float* z_sorted, const uint8_t* pix,

@@ -9,6 +9,9 @@ summation order: the oracle's own run-to-run spread is part of the fixture).
 
     python tests/golden/make_trajectory_golden.py [threadsA threadsB]     (~30 min on 8 cores)
 
+The committed fixture holds SIX runs (thread counts 4, 3, 5, 2, 6, 7: three invocations, the
+later ones with APPEND=1, which adds their runs to the existing file).
+
 No GPU, no reference code: oracle/ + the synthetic scene's analytic ray casting only."""
 import multiprocessing as mp
 import os
@@ -29,7 +32,7 @@ def worker(args):
     frames = tt._frames()
     draws, u_eval = tt._draws(tt.LONG)
     t0 = time.time()
-    log = open(os.path.join(ROOT, "tests", "golden", f"_trajectory_{tag}.log"), "w")
+    log = open(os.path.join(ROOT, "tests", "golden", f"_trajectory_{tag}{threads}.log"), "w")
 
     def progress(k, q, losses):
         log.write(f"step {k + 1} t {time.time() - t0:.0f}s psnr {q['train'][0]:.2f} miou {q['train'][1]:.1f} "
@@ -50,16 +53,17 @@ def main():
     with mp.get_context("spawn").Pool(2) as pool:
         a, b = pool.map(worker, [("A", threads[0]), ("B", threads[1])])
     out = os.path.join(ROOT, "tests", "golden", "g9_trajectory_long.npz")
+    new = {k: np.array([a[k], b[k]], dtype=np.float64)
+           for k in ("psnr", "miou", "held_psnr", "held_miou", "losses")}
+    new["threads"] = np.array([a["threads"], b["threads"]])
+    new["seconds"] = np.array([a["seconds"], b["seconds"]])
+    if os.environ.get("APPEND") == "1" and os.path.exists(out):
+        old = np.load(out)
+        assert tuple(old["checkpoints"]) == tuple(tt.LONG.checkpoints)
+        new = {k: np.concatenate([old[k], v], 0) for k, v in new.items()}
     np.savez_compressed(
         out, checkpoints=np.array(tt.LONG.checkpoints), steps=np.array(tt.LONG.steps),
-        rays=np.array(tt.LONG.n), seed=np.array(tt.LONG.seed),
-        psnr=np.array([a["psnr"], b["psnr"]], dtype=np.float64),
-        miou=np.array([a["miou"], b["miou"]], dtype=np.float64),
-        held_psnr=np.array([a["held_psnr"], b["held_psnr"]], dtype=np.float64),
-        held_miou=np.array([a["held_miou"], b["held_miou"]], dtype=np.float64),
-        losses=np.array([a["losses"], b["losses"]], dtype=np.float64),
-        threads=np.array([a["threads"], b["threads"]]),
-        seconds=np.array([a["seconds"], b["seconds"]]))
+        rays=np.array(tt.LONG.n), seed=np.array(tt.LONG.seed), **new)
     print("wrote", out, "torch", torch.__version__)
 
 

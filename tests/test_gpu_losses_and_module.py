@@ -340,62 +340,3 @@ def test_no_valid_depth_pixel_behaves_like_the_reference(ops):
     assert torch.isnan(hd) and float(a[2].grad.abs().max()) == 0.0
     assert torch.isfinite(a[0].grad).all() and torch.isfinite(a[1].grad).all()
     assert maxabs(a[0].grad, c.grad) <= 1e-6 * float(c.grad.abs().max())
-
-
-def test_graphed_deeplab_train_step_equals_the_eager_step(tmp_path):
-    """Round 6 (cfg5 is host-bound at batch 2): the joint step's DeepLab forward +
-    CE-on-softmax + backward as ONE HIP graph per batch shape
-    (`model: {seg_train_graph: true}`, JointTrainLightningNet._seg_train_step_graphed).
-    With the ASPP Dropout switched off, a replayed step leaves the same loss, the same
-    gradients (to the convolutions' run-to-run 1e-5) and the same BatchNorm running
-    statistics as the eager step from the same state; the warm-up iterations of the
-    capture do not move the training state; a shape is captured on its second
-    appearance and an eager step in between does not detach the graph's gradients."""
-    from ucsa_neural_rendering_amd.lightning import JointTrainLightningNet
-    exp = _tiny_exp()
-    torch.manual_seed(3)
-    model = JointTrainLightningNet(exp, {"results": str(tmp_path / "a"), "scannet": str(tmp_path)}).cuda()
-    seg = model.seg_model.train()
-    for m in seg.modules():
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-    g = torch.Generator(device="cuda").manual_seed(1)
-    imgs = [torch.rand(2, 3, 48, 64, device="cuda", generator=g) for _ in range(4)]
-    labs = [torch.randint(-1, 40, (2, 48, 64), device="cuda", generator=g) for _ in range(4)]
-    from ucsa_neural_rendering_amd import losses as ulosses
-    state0 = {k: v.detach().clone() for k, v in seg.state_dict().items()}
-
-    def eager(i):
-        seg.load_state_dict(state0)
-        seg.zero_grad(set_to_none=True)
-        loss = ulosses.seg_loss(model._seg_logits(imgs[i]), labs[i])
-        loss.backward()
-        return (float(loss), [p.grad.detach().clone() for p in seg.parameters()],
-                {k: v.detach().clone() for k, v in seg.state_dict().items() if "running" in k})
-
-    ref = [eager(i) for i in range(4)]
-    seg.load_state_dict(state0)
-    assert model._seg_train_step_graphed(imgs[0], labs[0]) is None            # first sight: eager
-    loss1 = model._seg_train_step_graphed(imgs[1], labs[1])                  # second: captured + replayed
-    assert loss1 is not None and model.seg_train_graph_replays == 1
-    run1 = {k: v.detach().clone() for k, v in seg.state_dict().items() if "running" in k}
-
-    def close(a, b, tol):
-        return float((a.double() - b.double()).abs().max()) <= tol * max(1e-12, float(b.double().abs().max()))
-
-    assert abs(float(loss1) - ref[1][0]) <= 1e-5 * abs(ref[1][0])
-    for p, want in zip(seg.parameters(), ref[1][1]):
-        assert close(p.grad, want, 2e-4)
-    for k, want in ref[1][2].items():      # ONE update of the running statistics, not 1 + warm-ups
-        assert close(run1[k], want, 1e-5), k
-    # an eager step in between (grads set to None), then another replay from state0
-    seg.zero_grad(set_to_none=True)
-    ulosses.seg_loss(model._seg_logits(imgs[2]), labs[2]).backward()
-    seg.load_state_dict(state0)
-    loss3 = model._seg_train_step_graphed(imgs[3], labs[3])
-    assert loss3 is not None and model.seg_train_graph_replays == 2
-    assert abs(float(loss3) - ref[3][0]) <= 1e-5 * abs(ref[3][0])
-    for p, want in zip(seg.parameters(), ref[3][1]):
-        assert close(p.grad, want, 2e-4)
-    # another batch size is another entry (and stays eager on first sight)
-    assert model._seg_train_step_graphed(imgs[0][:1], labs[0][:1]) is None

@@ -242,7 +242,6 @@ def main_cfg5(args, dev, dist, world, rank, backend):
                                   "budget_mb": dc.budget / 2 ** 20}
     except Exception as e:      # never let bookkeeping sink a benchmark record
         result["decode_cache"] = {"error": repr(e)}
-    result["seg_train_graph"] = dict(jl.SEG_TRAIN_GRAPH_STATS)
     import shutil
     if rank == 0:
         shutil.rmtree(root, ignore_errors=True)

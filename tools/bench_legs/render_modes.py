@@ -145,8 +145,9 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
     # the fine pass as ucsa_render_fwd* runs it for image-ordered rays (round 5):
     # depth order per tile, encoder and sigma MLP in that order, h / sigma
     # scattered back (csrc/hashgrid_sorted.hip); UCSA_ENC_SORTED=0: as the coarse pass
-    sorted_f = bool(image_width) and os.environ.get("UCSA_ENC_SORTED", "1") != "0"
+    sorted_f = bool(image_width) and os.environ.get("UCSA_ENC_SORTED", "2") != "0"
     smode = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16x2": 3}[mode]
+    shipped = (sorted_f and (x3 or h2) and os.environ.get("UCSA_DENSITY_FUSED", "1") != "0")
     names = ["near_far+coarse", "encode_c", "sigma_c", "resample", "sort_f", "encode_f",
              "sigma_f", "composite"]
     acc = {k: 0.0 for k in names}
@@ -192,12 +193,31 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
                               sf.view(N, T_FINE), hf, f["packed_color"],
                               f["packed_sem"], N_CLASSES, 1.0)
         marks[8].record()
+        # round 6: the density passes AS SHIPPED for the bf16x3 / f16x2 nets on
+        # image-ordered rays (csrc/render.hip): BOTH passes depth-ordered per tile
+        # (UCSA_ENC_SORTED=2), levels 8-15 through the per-level depth-ordered encoder, levels 0-7 encoded inside the sigma MLP
+        # (ucsa_density_sorted = k_hashgrid_encode_sorted + k_density_sorted); the
+        # stages above keep the unfused pair for the encoder-only figures
+        if shipped:
+            extra = [ev() for _ in range(4)]
+            extra[0].record()
+            zs_c, pix_c, slot_c = ops.tile_depth_order(zc, image_width)
+            extra[1].record()
+            ops.density_sorted(smode, f["grid"], f["table"], o, d, zs_c, pix_c, slot_c, aabb,
+                               T_COARSE, image_width, f["packed_sigma"])
+            extra[2].record()
+            ops.density_sorted(smode, f["grid"], f["table"], o, d, zs, pix, slot, aabb,
+                               T_FINE, image_width, f["packed_sigma"])
+            extra[3].record()
         torch.cuda.synchronize()
         if it == 0:
             rho = float((w > 1e-4).float().mean())
             continue
         for i, k in enumerate(names):
             acc[k] += marks[i].elapsed_time(marks[i + 1]) / iters
+        if shipped:
+            for i, k in enumerate(("order_c", "density_c", "density_f")):
+                acc[k] = acc.get(k, 0.0) + extra[i].elapsed_time(extra[i + 1]) / iters
     return acc, rho
 
 

@@ -68,6 +68,8 @@ def main(d, tag):
                         ("k_hashgrid_encode_sorted", "void k_hashgrid_encode_sorted<"),
                         ("k_hashgrid_encode_sorted_ml", "void k_hashgrid_encode_sorted_ml<"),
                         ("k_tile_depth_order2", "k_tile_depth_order2("),
+                        # round 6: levels 0-7 inside the sigma MLP, both passes depth-ordered
+                        ("k_density_sorted", "void k_density_sorted<3>"),
                         ("k_weights_compact", "k_weights_compact"),
                         ("k_shade16_f16", "void k_shade16<3, 1, 1,"),
                         ("k_shade16_x3", "void k_shade16<3, 1, 2,"),

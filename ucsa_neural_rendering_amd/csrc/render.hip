@@ -137,7 +137,7 @@ static int32_t encode(const ucsa_grid* grid, const void* table_any,
 }
 
 #ifndef UCSA_ENC_SORTED_DEFAULT
-#define UCSA_ENC_SORTED_DEFAULT 1
+#define UCSA_ENC_SORTED_DEFAULT 2
 #endif
 
 static bool density_fused() {
@@ -187,24 +187,23 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
   // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays:
-  // UCSA_ENC_SORTED = 0 off, 1 the fine pass (default), 2 both passes through the
-  // depth sort, 3 the fine pass through the sort and the coarse pass in "sample
-  // index, then pixel" order (no sort: ucsa_tile_index_order).  Same h / sigma
-  // bits whatever the mode.
+  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 2 both passes (default since
+  // round 6: with levels 0-7 encoded inside the sigma MLP the coarse pass gains more
+  // from the fused kernel than its sort costs -- 16.18 / 15.89 / 15.66 ms per cfg2
+  // view for mode 1 unfused / 1 fused / 2 fused; a "sample index, then pixel" order
+  // without the sort measured 15.75: the tile's depth slabs are tighter than its
+  // equal-index sample sets, profiles/r06_density_fused_ab.txt).  Same h / sigma bits
+  // whatever the mode.
   const char* es = ucsa_getenv("UCSA_ENC_SORTED");
-  const int sorted_mode = es && es[0] >= '0' && es[0] <= '3' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
+  const int sorted_mode = es && es[0] >= '0' && es[0] <= '2' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
   auto density = [&](const float* z, uint32_t n, float* h, float* sigma) -> int32_t {
     const bool fine = z == w.z_f;
     if (image_width && !table_half && n <= 1024u &&
         N % image_width == 0 && grid->n_levels == 16 &&
         (sorted_mode >= 2 || (sorted_mode == 1 && fine))) {
-      if (sorted_mode == 3 && !fine)
-        UCSA_TRY(ucsa_tile_index_order(z, N, n, image_width, w.zs_sorted, w.pix,
-                                       w.slot, stream));
-      else
-        UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
-                                       w.slot, stream));
+      UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
+                                     w.slot, stream));
       // bf16x3 / f16x2 nets: levels 0-7 are encoded INSIDE the sigma MLP (their
       // features never travel through HBM: density_sorted.hip; same h / sigma
       // bits; UCSA_DENSITY_FUSED=0 keeps the staged pair for A/B runs)

@@ -41,10 +41,6 @@ from ..network import DeepLabV3
 from ..utils.metrics import SemanticsMeter
 
 
-# process-wide counters of the graphed DeepLab training step (bench.py --mode cfg5 reports them)
-SEG_TRAIN_GRAPH_STATS = {"replays": 0, "captures": 0, "failed_captures": 0}
-
-
 class JointTrainLightningNet(nn.Module):
 
     def __init__(self, exp, env):
@@ -122,14 +118,6 @@ class JointTrainLightningNet(nn.Module):
         # NeRF-only steps replay the frozen segmentation forward as a HIP graph
         self.seg_graph = bool(exp["model"].get("seg_graph", True))
         self._seg_graphs = {}
-        # ... and the joint step's DeepLab forward + loss + backward as ONE HIP graph
-        # per batch shape (`model: {seg_train_graph: true}`; round 6): at the continual
-        # loop's batch sizes (2-4 images) that step is ~300 convolution calls of ~0.4 ms
-        # of library host time each against ~15 ms of GPU work
-        self.seg_train_graph = bool(exp["model"].get(
-            "seg_train_graph", os.environ.get("UCSA_SEG_TRAIN_GRAPH", "1") != "0"))
-        self._seg_train_graphs = {}
-        self.seg_train_graph_replays = 0
         self._nerf_steps = 0
         self._grid_stale = True  # refresh the density grid before evaluating
         self.n_rays_train = int(nerf_cfg.get("n_rays", 4096))
@@ -277,84 +265,6 @@ class JointTrainLightningNet(nn.Module):
         static_in.copy_(image)
         graph.replay()
         return out  # static buffers: consumed before the next replay
-
-    # ---- the DeepLab training step as a HIP graph --------------------------------
-    def _seg_train_step_graphed(self, image, label):
-        """reference :456-461 (forward in train mode, CE-on-softmax, backward) replayed
-        as ONE HIP graph per (batch shape, arithmetic): the gradients land in the
-        parameters' own ``.grad`` tensors (static), BatchNorm's running statistics are
-        updated inside the graph as in the eager step; the optimizer step and the
-        gradient all-reduce stay outside.  Returns the (static) loss tensor, or None
-        when the step must run eagerly (switched off, CPU, capture failed, a shape seen
-        for the first time -- a shape is captured on its SECOND appearance, so that
-        one-off batch sizes cost nothing)."""
-        if not self.seg_train_graph or not image.is_cuda or not self.seg_model.training:
-            return None
-        first = next(self.seg_model.parameters())
-        key = (tuple(image.shape), image.dtype, tuple(label.shape), self.seg_amp,
-               self.seg_channels_last, first.data_ptr())
-        entry = self._seg_train_graphs.get(key)
-        if entry is None:
-            self._seg_train_graphs[key] = "seen"
-            return None
-        if entry == "seen":
-            entry = self._capture_seg_train_graph(image, label)
-            self._seg_train_graphs[key] = entry
-            SEG_TRAIN_GRAPH_STATS["captures" if entry else "failed_captures"] += 1
-        if entry is False:
-            return None
-        graph, static_img, static_lab, static_loss = entry
-        # the graph writes into THESE gradient tensors: an eager step in between
-        # (optimizer.zero_grad() sets .grad to None) must not leave others attached
-        for p, g in self._seg_static_grads:
-            p.grad = g
-        static_img.copy_(image)
-        static_lab.copy_(label)
-        graph.replay()
-        self.seg_train_graph_replays += 1
-        SEG_TRAIN_GRAPH_STATS["replays"] += 1
-        return static_loss
-
-    def _capture_seg_train_graph(self, image, label):
-        model = self.seg_model
-        params = [p for p in model.parameters() if p.requires_grad]
-        # warm-up iterations really run: they must not move the training state
-        buffers = [b.detach().clone() for b in model.buffers()]
-        try:
-            if getattr(self, "_seg_static_grads", None) is None:
-                # one set of gradient tensors for every captured shape, kept alive here
-                self._seg_static_grads = [(p, torch.zeros_like(p)) for p in params]
-            for p, g in self._seg_static_grads:
-                p.grad = g
-            static_img, static_lab = image.clone(), label.clone()
-
-            def step():
-                torch._foreach_zero_([p.grad for p in params])
-                loss = ulosses.seg_loss(self._seg_logits(static_img), static_lab)
-                loss.backward()
-                return loss
-
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):      # MIOpen picks its kernels here
-                for _ in range(2):
-                    step()
-            cur.wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step()
-            return graph, static_img, static_lab, static_loss.detach()
-        except Exception as e:  # noqa: BLE001 -- any capture problem: eager
-            warnings.warn(f"DeepLab training step not captured as a HIP graph "
-                          f"({type(e).__name__}: {e}); running it eagerly")
-            torch.cuda.synchronize()
-            return False
-        finally:
-            with torch.no_grad():
-                for b, saved in zip(model.buffers(), buffers):
-                    b.copy_(saved)
 
     def _forward_seg_eval_eager(self, batch):
         self.seg_model.eval()
@@ -618,12 +528,14 @@ class JointTrainLightningNet(nn.Module):
                 rgb_seg = torch.cat([rgb_seg, rimg.reshape(-1, C, H, W)], 0)
                 label_seg = torch.cat(
                     [label_seg, batch_cl["replay_label"].reshape(-1, H, W)], 0)
-        loss = self._seg_train_step_graphed(rgb_seg, label_seg)
-        if loss is None:
-            logits = self._seg_logits(rgb_seg)
-            loss = ulosses.seg_loss(logits, label_seg)  # CE on softmax (:456-458)
-            optimizer_seg.zero_grad()
-            self.manual_backward(loss)
+        # (round 6: this forward + loss + backward was also captured as ONE HIP graph per
+        # batch shape and measured on the continual loop -- 778 replays, 234.7 s against
+        # 233.8 s eager: the joint step at batch 2 is not paced by DeepLab's launches;
+        # removed again, profiles/r06_cfg5.json)
+        logits = self._seg_logits(rgb_seg)
+        loss = ulosses.seg_loss(logits, label_seg)  # CE on softmax (:456-458)
+        optimizer_seg.zero_grad()
+        self.manual_backward(loss)
         udist.average_grads_(self.seg_model.parameters())
         optimizer_seg.step()
         self.log(f"{self._mode}/loss_seg", loss.detach())
