@@ -206,15 +206,15 @@ def test_the_default_command_prints_the_compact_record(tmp_path):
                               env=env, cwd=ROOT).wait(timeout=900)
     res = _parse(rc, out, err)
     r, c = res["roofline"], res["cpu_baseline"]
-    assert r["bound"] == "hbm" and r["kernel"].startswith("hash-grid encoder, one density pass")
-    for k in ("k_hashgrid_encode_tiled", "_tiled_ml", "k_hashgrid_encode_sorted", "_sorted_ml"):
-        assert k in r["kernel"]            # the four launches the figure covers, by name
+    assert r["bound"] == "hbm" and r["kernel"].startswith("density pass = 2 launches")
+    for k in ("k_hashgrid_encode_sorted", "k_density_sorted"):
+        assert k in r["kernel"]            # the two launches the figure covers, by name
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / r["launch_ms"] / 1e6,
                                           rel=1e-4)
     assert set(r["binding_resource"]) == {"resource", "frac"}
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
-    assert res["speedup_vs_cpu"] == pytest.approx(res["value"] / c["value"], rel=1e-4)
+    assert c["gpu_over_cpu"] == pytest.approx(res["value"] / c["value"], rel=1e-4)
     assert set(res["tuning_tables_matched"]) >= {"miopen", "tunableop"}
     assert res["config"]["workload"].startswith("cfg2") and res["dtype"] == "f32"
     assert "train" in res["_full"] and "stage_ms_per_chunk" in res["_full"]

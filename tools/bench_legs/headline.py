@@ -27,7 +27,7 @@ CONFIG_KEYS = ("workload", "mode", "rays_per_step_per_gpu", "ray_chunk", "timed_
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                  "launch_ms", "algorithmic_bytes_per_launch", "algorithmic_flop_per_launch",
                  "hbm_utilisation", "timing")
-CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "gpu_over_cpu")
 
 
 def _short(s, n):
@@ -67,7 +67,6 @@ def headline(result: dict, text: int = 300) -> dict:
         c = {k: cpu[k] for k in CPU_KEYS if k in cpu}
         c["sample"] = _short(c.get("sample"), 200)
         out["cpu_baseline"] = c
-        out["speedup_vs_cpu"] = result.get("speedup_vs_cpu")
     for k in ("quality", "tuning_tables_matched"):
         if k in result:
             out[k] = result[k]
