@@ -47,7 +47,19 @@ def _parse(rc, out, err):
     parses); everything else a run measured is in the detail file it names."""
     text = out.read_text()
     lines = [l for l in text.splitlines() if l.startswith("{")]
-    assert rc == 0 and len(lines) == 1, (rc, err.read_text()[-2000:])
+    if not (rc == 0 and len(lines) == 1):
+        # keep the ranks' whole stderr where a gpurun call merges it back (the torchrun
+        # summary at its end says only which rank died of which signal)
+        etext = err.read_text()
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_modes_stderr.txt"), "a") as f:
+                f.write(f"=== rc {rc} {out}\n{etext[-60000:]}\n")
+        except OSError:
+            pass
+        first = [l for l in etext.splitlines()
+                 if any(w in l for w in ("Error", "error", "HIP", "hip", "abort", "Abort", "what()", "Assert"))]
+        raise AssertionError((rc, "\n".join(first[:30])[-3000:], etext[-1500:]))
     assert text.strip().splitlines()[-1] == lines[0] and len(lines[0].encode()) <= 4096
     res = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",

@@ -476,10 +476,13 @@ def test_depth_ordered_density_is_bit_identical(H, W, T, exact, monkeypatch):
         h0, s0 = plain(feat_r, packed)
         h1, s1 = ops.sigma_mlp_fwd_scatter(mode, feat_s, packed, slot)
         assert torch.equal(h0, h1) and torch.equal(s0, s1), mode
-        if mode >= 2:   # ... and with levels 0-7 encoded inside the sigma MLP (round 6)
-            h2_, s2_ = ops.density_sorted(mode, f["grid"], f["table"], o, d, zs, pix, slot,
-                                          aabb, T, W, packed)
-            assert torch.equal(h0, h2_) and torch.equal(s0, s2_), ("fused", mode)
+        if mode >= 2:   # ... and with levels 0-7 / 0-11 encoded inside the sigma MLP (round 6)
+            for n_enc in ("8", "12"):
+                monkeypatch.setenv("UCSA_DENSITY_LEVELS", n_enc)
+                ops.env_reload()
+                h2_, s2_ = ops.density_sorted(mode, f["grid"], f["table"], o, d, zs, pix, slot,
+                                              aabb, T, W, packed)
+                assert torch.equal(h0, h2_) and torch.equal(s0, s2_), ("fused", mode, n_enc)
 
 
 @pytest.mark.parametrize("n,H,W,tile", [(1, 5, 7, 16), (700, 37, 50, 16), (4096, 240, 320, 16),

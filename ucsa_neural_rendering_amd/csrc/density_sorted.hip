@@ -29,22 +29,27 @@
 #include "hashgrid_sorted.h"
 #include "mfma_mlp_h2.h"
 
-#define DS_LEVELS 8u          // levels [0, 8) are encoded here
+#define DS_MAX_LEVELS 12u     // levels [0, NENC) are encoded here, NENC = 8 or 12
+#ifndef DS_UNROLL
+#define DS_UNROLL 2           // levels per trip of the encoding loop
+#endif
 #define DS_PITCH 80u          // float2 per LDS row: 64 samples + 16 (rows g, g + 1 of a
                               // half-wave then sit 32 banks apart: conflict-free reads)
 
 // PREC 2: bf16x3 (ucsa_mlp_pack_x3), 3: f16x2 (ucsa_mlp_pack_h2)
-template <int PREC>
+// NENC: 8 (levels g, 4 + g of a lane group from the tile) or 12 (8 + g as well: only
+// levels 12-15 -- the ones bound by line fills -- come from the per-level encoder)
+template <int PREC, uint32_t NENC>
 __global__ void __launch_bounds__(256, 2)
 k_density_sorted(GridDev g, const float2* __restrict__ table,
                  const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                  const float* __restrict__ z_sorted, const uint8_t* __restrict__ pix,
                  Aabb bb, uint32_t T, uint32_t rows, uint32_t W, uint32_t s_blocks,
-                 uint32_t M, const float2* __restrict__ feat,   // levels 8..15 valid
+                 uint32_t M, const float2* __restrict__ feat,   // levels NENC..15 valid
                  const void* __restrict__ packed, const uint32_t* __restrict__ slot,
                  float* __restrict__ h, float* __restrict__ sigma) {
   __shared__ __attribute__((aligned(16))) float ray_s[64][8];
-  __shared__ __attribute__((aligned(16))) float2 ftile[4][DS_LEVELS][DS_PITCH];
+  __shared__ __attribute__((aligned(16))) float2 ftile[4][NENC][DS_PITCH];
   const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
   const TileGeom tg = tile_geom(tile, rows, W, T);
   if (sb * 1024u >= tg.count) return;   // (workgroup-uniform)
@@ -81,13 +86,13 @@ k_density_sorted(GridDev g, const float2* __restrict__ table,
     const uint32_t r0 = sb * 1024u + (it * 4u + wid) * 64u;
     if (r0 >= tg.count) break;            // (wave-uniform; later groups lie further out)
     const uint32_t last = tg.count - 1u;
-    // levels 8 + g, 12 + g of the four column blocks: requested first
+    // levels 8 + g (NENC = 8 only), 12 + g of the four column blocks: requested first
     float2 hi0[4], hi1[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       const uint32_t r = r0 + cb * 16u + j;
       const uint32_t rc = r < last ? r : last;    // clamp loads, predicate stores
-      hi0[cb] = feat_hi0[rc];
+      if constexpr (NENC <= 8u) hi0[cb] = feat_hi0[rc];
       hi1[cb] = feat_hi1[rc];
     }
     {  // levels 0 .. 7 of sample r0 + lane -> the wave's LDS tile
@@ -98,8 +103,8 @@ k_density_sorted(GridDev g, const float2* __restrict__ table,
                     inv, ux, uy, uz);
       // (two levels per trip: 16 gathers in flight per lane; fully unrolled the eight
       // levels' scalars spill out of the SGPR file)
-#pragma unroll 2
-      for (uint32_t level = 0; level < DS_LEVELS; ++level) {
+#pragma unroll DS_UNROLL
+      for (uint32_t level = 0; level < NENC; ++level) {
         const uint32_t res = g.res[level];
         mine[level][lane] = encode_cell(table + g.offset[level], ux, uy, uz, g.scale[level],
                                         res, res * res, g.entries[level], g.hashed[level]);
@@ -113,7 +118,8 @@ k_density_sorted(GridDev g, const float2* __restrict__ table,
       float2 raw[4];
       raw[0] = mine[gq][cb * 16u + j];
       raw[1] = mine[4u + gq][cb * 16u + j];
-      raw[2] = hi0[cb];
+      if constexpr (NENC > 8u) raw[2] = mine[8u + gq][cb * 16u + j];
+      else raw[2] = hi0[cb];
       raw[3] = hi1[cb];
       f32x4 out;
       if constexpr (PREC == 3) {
@@ -155,6 +161,10 @@ int32_t ucsa_hashgrid_encode_sorted_from(const ucsa_grid* grid, const float* tab
                                          uint32_t image_width, uint32_t first_level,
                                          float* feat, void* stream);
 
+#ifndef UCSA_DENSITY_LEVELS_DEFAULT
+#define UCSA_DENSITY_LEVELS_DEFAULT 8
+#endif
+
 extern "C" int32_t ucsa_density_sorted(
     int32_t mode, const ucsa_grid* grid, const float* table, const float* rays_o,
     const float* rays_d, const float* z_sorted, const uint8_t* pix,
@@ -172,24 +182,28 @@ extern "C" int32_t ucsa_density_sorted(
   UCSA_CHECK_ARG(packed_sigma, 12);
   UCSA_CHECK_ARG(feat_ws && h && sigma, 13);
   if (N == 0) return 0;
+  // UCSA_DENSITY_LEVELS (lab switch): 8 or 12 levels inside the sigma MLP
+  const char* lv = ucsa_getenv("UCSA_DENSITY_LEVELS");
+  const uint32_t nenc = (lv ? atoi(lv) : UCSA_DENSITY_LEVELS_DEFAULT) >= 12 ? 12u : 8u;
   const int32_t rc = ucsa_hashgrid_encode_sorted_from(grid, table, rays_o, rays_d, z_sorted,
                                                       pix, aabb_host, N, T, image_width,
-                                                      DS_LEVELS, feat_ws, stream);
+                                                      nenc, feat_ws, stream);
   if (rc != 0) return rc;
   const GridDev gd = ucsa_grid_dev(grid);
   const uint32_t rows = N / image_width;
   const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
   const uint32_t s_blocks = ucsa_div_up(64u * T, 1024u);
   UCSA_CLEAR_ERR();
-  if (mode == 3)
-    hipLaunchKernelGGL(k_density_sorted<3>, dim3(tiles * s_blocks), dim3(256), 0,
-                       (hipStream_t)stream, gd, (const float2*)table, rays_o, rays_d, z_sorted,
-                       pix, ucsa_aabb(aabb_host), T, rows, image_width, s_blocks, N * T,
-                       (const float2*)feat_ws, packed_sigma, slot, h, sigma);
-  else
-    hipLaunchKernelGGL(k_density_sorted<2>, dim3(tiles * s_blocks), dim3(256), 0,
-                       (hipStream_t)stream, gd, (const float2*)table, rays_o, rays_d, z_sorted,
-                       pix, ucsa_aabb(aabb_host), T, rows, image_width, s_blocks, N * T,
-                       (const float2*)feat_ws, packed_sigma, slot, h, sigma);
+#define DS_GO(P, NE)                                                                        \
+  hipLaunchKernelGGL((k_density_sorted<P, NE>), dim3(tiles * s_blocks), dim3(256), 0,          \
+                     (hipStream_t)stream, gd, (const float2*)table, rays_o, rays_d, z_sorted, \
+                     pix, ucsa_aabb(aabb_host), T, rows, image_width, s_blocks, N * T,        \
+                     (const float2*)feat_ws, packed_sigma, slot, h, sigma)
+  if (mode == 3) {
+    if (nenc == 12u) DS_GO(3, 12u); else DS_GO(3, 8u);
+  } else {
+    if (nenc == 12u) DS_GO(2, 12u); else DS_GO(2, 8u);
+  }
+#undef DS_GO
   return ucsa_launch_status();
 }

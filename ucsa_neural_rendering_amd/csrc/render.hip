@@ -20,7 +20,7 @@ namespace {
 const char* const kEnvNames[] = {
     // launch shapes / kernel choices of the render path
     "UCSA_SHADE_VARIANT", "UCSA_SPLIT_COMPOSITE", "UCSA_ENC_SORTED", "UCSA_ENC_ML",
-    "UCSA_DENSITY_FUSED",
+    "UCSA_DENSITY_FUSED", "UCSA_DENSITY_LEVELS",
     "UCSA_ENC_SORTED_ML", "UCSA_ENC_SORTED_LEAN",
     // ... of the training path
     "UCSA_SHADE_BWD_SPLIT", "UCSA_BWD_OVERLAP", "UCSA_BWD_BIN_SCALE",
@@ -187,7 +187,11 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
   // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays:
-  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 2 both passes (default since
+  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 3 both passes always, 2 both passes
+  // when the coarse pass has at most 128 samples per ray -- its sort then costs less
+  // than the fused kernel gains; at the reference's native 256 + 256 samples the
+  // coarse sort (144 KiB of LDS per tile) loses: cfg3's joint step 172.9 ms with the
+  // fine pass only, 178.7 ms with both -- (default since
   // round 6: with levels 0-7 encoded inside the sigma MLP the coarse pass gains more
   // from the fused kernel than its sort costs -- 16.18 / 15.89 / 15.66 ms per cfg2
   // view for mode 1 unfused / 1 fused / 2 fused; a "sample index, then pixel" order
@@ -195,13 +199,13 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   // equal-index sample sets, profiles/r06_density_fused_ab.txt).  Same h / sigma bits
   // whatever the mode.
   const char* es = ucsa_getenv("UCSA_ENC_SORTED");
-  const int sorted_mode = es && es[0] >= '0' && es[0] <= '2' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
+  const int sorted_mode = es && es[0] >= '0' && es[0] <= '3' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
   auto density = [&](const float* z, uint32_t n, float* h, float* sigma) -> int32_t {
     const bool fine = z == w.z_f;
     if (image_width && !table_half && n <= 1024u &&
         N % image_width == 0 && grid->n_levels == 16 &&
-        (sorted_mode >= 2 || (sorted_mode == 1 && fine))) {
+        (fine ? sorted_mode >= 1 : (sorted_mode == 2 && n <= 128u) || sorted_mode == 3)) {
       UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
                                      w.slot, stream));
       // bf16x3 / f16x2 nets: levels 0-7 are encoded INSIDE the sigma MLP (their
