@@ -292,15 +292,15 @@ def encoder_roofline(st, chunk, pretrain_steps):
     enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
     if "density_c" in st:
         # round 6: what ships is the DENSITY pass -- k_hashgrid_encode_sorted (levels
-        # 8-15) + k_density_sorted (levels 0-7 encoded inside the sigma MLP): the
-        # encoder of levels 0-7 is no kernel of its own any more.  Algorithmic bytes of
+        # 12-15) + k_density_sorted (levels 0-11 encoded inside the sigma MLP): the
+        # encoder of levels 0-11 is no kernel of its own any more.  Algorithmic bytes of
         # density() per sample: the 1024 B of gathers + 68 B out (h row, sigma) + 4 B in
         # (depth); the feature round trip between the two launches is not algorithmic.
         pass_bytes = samples * (1024 + 68 + 4)
         pass_ms = 0.5 * (st["density_c"] + st["density_f"])
         pass_gbs = pass_bytes / (pass_ms * 1e-3) / 1e9
-        r = {"kernel": "density pass = 2 launches: k_hashgrid_encode_sorted (hash-grid levels 8-15, one "
-                       "level per grid row) + k_density_sorted (levels 0-7 encoded inside the sigma MLP, "
+        r = {"kernel": "density pass = 2 launches: k_hashgrid_encode_sorted (hash-grid levels 12-15, one "
+                       "level per grid row) + k_density_sorted (levels 0-11 encoded inside the sigma MLP, "
                        "wave-private LDS tile); both passes on per-tile depth-ordered samples",
              "bound": "hbm", "achieved": pass_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": pass_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": pass_ms,
@@ -318,7 +318,7 @@ def encoder_roofline(st, chunk, pretrain_steps):
                        "mean of coarse+fine pass, 5 iterations",
              "note": "achieved = ALGORITHMIC bytes of density() / pass time: a nominal figure against "
                      "the HBM line, NOT HBM utilisation.  The table slice a launch phase works on is "
-                     "L2/MALL resident; what binds the levels-8-15 launch is the L2 -> L1 fill of one "
+                     "L2/MALL resident; what binds the levels-12-15 launch is the L2 -> L1 fill of one "
                      "128-B line per 8-byte corner pair (binding_resource)"}
     else:
         r = {"kernel": "hash-grid encoder, one density pass = 2 launches: k_hashgrid_encode_tiled + "

@@ -327,12 +327,13 @@ int32_t ucsa_sigma_mlp_fwd_scatter(int32_t mode, const void* feat,
                                    uint32_t n_levels, const uint32_t* slot,
                                    float* h, float* sigma, void* stream);
 /* ucsa_hashgrid_encode_sorted + ucsa_sigma_mlp_fwd_scatter as ONE call in which the
- * sigma MLP encodes levels 0-7 itself -- a wave owns 64 consecutive samples of the
- * depth order, the level is wave-uniform, the feature pairs go through a wave-private
- * LDS tile and never through HBM -- and reads levels 8-15 from feat_ws [16][N*T][2]
+ * sigma MLP encodes levels 0-11 itself (0-7 with UCSA_DENSITY_LEVELS=8) -- a wave owns
+ * 64 consecutive samples of the depth order, the level is wave-uniform, the feature pairs
+ * go through a wave-private LDS tile and never through HBM -- and reads the remaining
+ * levels (12-15: the ones bound by L2 -> L1 line fills) from feat_ws [16][N*T][2]
  * (written here by the per-level depth-ordered encoder): `density()` of a sample
- * batch, reference network_tcnn_semantics.py:130-144, with half of the feature
- * round trip gone.  mode 2 = bf16x3, 3 = f16x2 packs; 16 levels.  The same h / sigma
+ * batch, reference network_tcnn_semantics.py:130-144, with three quarters of the
+ * feature round trip gone.  mode 2 = bf16x3, 3 = f16x2 packs; 16 levels.  The same h / sigma
  * BITS as the two separate calls. */
 int32_t ucsa_density_sorted(int32_t mode, const ucsa_grid* grid, const float* table,
                             const float* rays_o, const float* rays_d,

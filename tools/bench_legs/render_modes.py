@@ -195,7 +195,7 @@ def stage_times(net, o, d, nrm, u, iters=5, image_width=0, half=False,
         marks[8].record()
         # round 6: the density passes AS SHIPPED for the bf16x3 / f16x2 nets on
         # image-ordered rays (csrc/render.hip): BOTH passes depth-ordered per tile
-        # (UCSA_ENC_SORTED=2), levels 8-15 through the per-level depth-ordered encoder, levels 0-7 encoded inside the sigma MLP
+        # (UCSA_ENC_SORTED=2), levels 12-15 through the per-level depth-ordered encoder, levels 0-11 encoded inside the sigma MLP
         # (ucsa_density_sorted = k_hashgrid_encode_sorted + k_density_sorted); the
         # stages above keep the unfused pair for the encoder-only figures
         if shipped:

@@ -6,7 +6,8 @@
 // sample and the sigma MLP reads them back: 755 MB out + 755 MB in per 5.9 M samples,
 // the largest HBM stream of a view that is not the table itself.  Levels 0-7 are cheap
 // to compute -- dense, or hashed with cells wider than a depth slab of the tile, so
-// their gathers hit the L1 -- and here the sigma MLP computes them itself:
+// their gathers hit the L1 -- and here the sigma MLP computes them itself (and, by
+// default, levels 8-11 as well: NENC = 12, see ucsa_density_sorted):
 //
 //   * a wave owns 64 consecutive samples of a tile's depth order, lane = sample;
 //   * the LEVEL is wave-uniform: for l = 0 .. 7 every lane gathers its sample at level
@@ -162,7 +163,7 @@ int32_t ucsa_hashgrid_encode_sorted_from(const ucsa_grid* grid, const float* tab
                                          float* feat, void* stream);
 
 #ifndef UCSA_DENSITY_LEVELS_DEFAULT
-#define UCSA_DENSITY_LEVELS_DEFAULT 8
+#define UCSA_DENSITY_LEVELS_DEFAULT 12
 #endif
 
 extern "C" int32_t ucsa_density_sorted(
@@ -182,7 +183,10 @@ extern "C" int32_t ucsa_density_sorted(
   UCSA_CHECK_ARG(packed_sigma, 12);
   UCSA_CHECK_ARG(feat_ws && h && sigma, 13);
   if (N == 0) return 0;
-  // UCSA_DENSITY_LEVELS (lab switch): 8 or 12 levels inside the sigma MLP
+  // UCSA_DENSITY_LEVELS (lab switch): 8 or 12 (default) levels inside the sigma MLP --
+  // measured on the cfg2 view: 15.68 ms with 8, 15.07 ms with 12 (20.4 M rays/s): with
+  // levels 8-11 inside as well only the four levels bound by line fills keep their own
+  // launch, and three quarters of the feature round trip are gone
   const char* lv = ucsa_getenv("UCSA_DENSITY_LEVELS");
   const uint32_t nenc = (lv ? atoi(lv) : UCSA_DENSITY_LEVELS_DEFAULT) >= 12 ? 12u : 8u;
   const int32_t rc = ucsa_hashgrid_encode_sorted_from(grid, table, rays_o, rays_d, z_sorted,
