@@ -30,7 +30,7 @@
 #include "hashgrid_sorted.h"
 #include "mfma_mlp_h2.h"
 
-#define DS_MAX_LEVELS 12u     // levels [0, NENC) are encoded here, NENC = 8 or 12
+#define DS_MAX_LEVELS 16u     // levels [0, NENC) are encoded here, NENC = 8, 12 or 16
 #ifndef DS_UNROLL
 #define DS_UNROLL 2           // levels per trip of the encoding loop
 #endif
@@ -94,7 +94,7 @@ k_density_sorted(GridDev g, const float2* __restrict__ table,
       const uint32_t r = r0 + cb * 16u + j;
       const uint32_t rc = r < last ? r : last;    // clamp loads, predicate stores
       if constexpr (NENC <= 8u) hi0[cb] = feat_hi0[rc];
-      hi1[cb] = feat_hi1[rc];
+      if constexpr (NENC <= 12u) hi1[cb] = feat_hi1[rc];
     }
     {  // levels 0 .. 7 of sample r0 + lane -> the wave's LDS tile
       const uint32_t r = r0 + lane;
@@ -121,7 +121,8 @@ k_density_sorted(GridDev g, const float2* __restrict__ table,
       raw[1] = mine[4u + gq][cb * 16u + j];
       if constexpr (NENC > 8u) raw[2] = mine[8u + gq][cb * 16u + j];
       else raw[2] = hi0[cb];
-      raw[3] = hi1[cb];
+      if constexpr (NENC > 12u) raw[3] = mine[12u + gq][cb * 16u + j];
+      else raw[3] = hi1[cb];
       f32x4 out;
       if constexpr (PREC == 3) {
         H2X xin;
@@ -188,11 +189,14 @@ extern "C" int32_t ucsa_density_sorted(
   // levels 8-11 inside as well only the four levels bound by line fills keep their own
   // launch, and three quarters of the feature round trip are gone
   const char* lv = ucsa_getenv("UCSA_DENSITY_LEVELS");
-  const uint32_t nenc = (lv ? atoi(lv) : UCSA_DENSITY_LEVELS_DEFAULT) >= 12 ? 12u : 8u;
-  const int32_t rc = ucsa_hashgrid_encode_sorted_from(grid, table, rays_o, rays_d, z_sorted,
-                                                      pix, aabb_host, N, T, image_width,
-                                                      nenc, feat_ws, stream);
-  if (rc != 0) return rc;
+  const int lvn = lv ? atoi(lv) : UCSA_DENSITY_LEVELS_DEFAULT;
+  const uint32_t nenc = lvn >= 16 ? 16u : (lvn >= 12 ? 12u : 8u);
+  if (nenc < 16u) {
+    const int32_t rc = ucsa_hashgrid_encode_sorted_from(grid, table, rays_o, rays_d, z_sorted,
+                                                        pix, aabb_host, N, T, image_width,
+                                                        nenc, feat_ws, stream);
+    if (rc != 0) return rc;
+  }
   const GridDev gd = ucsa_grid_dev(grid);
   const uint32_t rows = N / image_width;
   const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
@@ -204,9 +208,9 @@ extern "C" int32_t ucsa_density_sorted(
                      pix, ucsa_aabb(aabb_host), T, rows, image_width, s_blocks, N * T,        \
                      (const float2*)feat_ws, packed_sigma, slot, h, sigma)
   if (mode == 3) {
-    if (nenc == 12u) DS_GO(3, 12u); else DS_GO(3, 8u);
+    if (nenc == 16u) DS_GO(3, 16u); else if (nenc == 12u) DS_GO(3, 12u); else DS_GO(3, 8u);
   } else {
-    if (nenc == 12u) DS_GO(2, 12u); else DS_GO(2, 8u);
+    if (nenc == 16u) DS_GO(2, 16u); else if (nenc == 12u) DS_GO(2, 12u); else DS_GO(2, 8u);
   }
 #undef DS_GO
   return ucsa_launch_status();
