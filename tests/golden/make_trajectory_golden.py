@@ -7,10 +7,10 @@ loop measures them: nr4seg/utils/metrics.py:13-65, joint_train_lightning_net.py:
 after every 5th step from step 100.  TWO runs with different BLAS thread counts (another
 summation order: the oracle's own run-to-run spread is part of the fixture).
 
-    python tests/golden/make_trajectory_golden.py [threadsA threadsB]     (~30 min on 8 cores)
+    python tests/golden/make_trajectory_golden.py [threads ...]     (~30 min per pair on 8 cores)
 
-The committed fixture holds SIX runs (thread counts 4, 3, 5, 2, 6, 7: three invocations, the
-later ones with APPEND=1, which adds their runs to the existing file).
+The committed fixture holds SIX runs (thread counts 4, 3, 5, 2, 7, 8: `... 4 3`, then
+`APPEND=1 ... 5 2`, then `APPEND=1 PAR=1 ... 7 8`; APPEND adds runs to the existing file).
 
 No GPU, no reference code: oracle/ + the synthetic scene's analytic ray casting only."""
 import multiprocessing as mp
@@ -49,14 +49,17 @@ def worker(args):
 def main():
     import torch
     from tests import test_gpu_trajectory as tt
-    threads = [int(x) for x in sys.argv[1:3]] or [5, 3]
-    with mp.get_context("spawn").Pool(2) as pool:
-        a, b = pool.map(worker, [("A", threads[0]), ("B", threads[1])])
+    threads = [int(x) for x in sys.argv[1:]] or [5, 3]
+    # PAR runs at a time: keep the sum of their thread counts at or below the core count
+    # (oversubscribed OpenMP teams spin: two runs with 7 + 6 threads on 8 cores did not
+    # reach step 100 in half an hour)
+    with mp.get_context("spawn").Pool(int(os.environ.get("PAR", "2"))) as pool:
+        runs = pool.map(worker, [("R", t) for t in threads])
     out = os.path.join(ROOT, "tests", "golden", "g9_trajectory_long.npz")
-    new = {k: np.array([a[k], b[k]], dtype=np.float64)
+    new = {k: np.array([r[k] for r in runs], dtype=np.float64)
            for k in ("psnr", "miou", "held_psnr", "held_miou", "losses")}
-    new["threads"] = np.array([a["threads"], b["threads"]])
-    new["seconds"] = np.array([a["seconds"], b["seconds"]])
+    new["threads"] = np.array([r["threads"] for r in runs])
+    new["seconds"] = np.array([r["seconds"] for r in runs])
     if os.environ.get("APPEND") == "1" and os.path.exists(out):
         old = np.load(out)
         assert tuple(old["checkpoints"]) == tuple(tt.LONG.checkpoints)

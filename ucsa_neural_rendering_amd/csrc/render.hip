@@ -186,18 +186,18 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
-  // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays:
-  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 3 both passes always, 2 both passes
-  // when the coarse pass has at most 128 samples per ray -- its sort then costs less
-  // than the fused kernel gains; at the reference's native 256 + 256 samples the
-  // coarse sort (144 KiB of LDS per tile) loses: cfg3's joint step 172.9 ms with the
-  // fine pass only, 178.7 ms with both -- (default since
-  // round 6: with levels 0-7 encoded inside the sigma MLP the coarse pass gains more
-  // from the fused kernel than its sort costs -- 16.18 / 15.89 / 15.66 ms per cfg2
-  // view for mode 1 unfused / 1 fused / 2 fused; a "sample index, then pixel" order
-  // without the sort measured 15.75: the tile's depth slabs are tighter than its
-  // equal-index sample sets, profiles/r06_density_fused_ab.txt).  Same h / sigma bits
-  // whatever the mode.
+  // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays.
+  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 3 both passes always, 2 (default
+  // since round 6) both passes when the coarse pass has at most 128 samples per ray:
+  // with levels 0-11 encoded inside the sigma MLP (density_sorted.hip) the coarse pass
+  // gains more from the fused kernel than its sort costs -- cfg2 view 16.18 ms (fine
+  // pass only, unfused) / 15.89 (fine fused) / 15.66 (both fused, 8 levels inside) /
+  // 15.01 (12 levels inside) -- while at the reference's native 256 + 256 samples the
+  // coarse sort (144 KiB of LDS per tile) costs more than it brings (cfg3's joint step:
+  // 172.9 ms with the fine pass only, 178.7 ms with both).  A "sample index, then
+  // pixel" order without a sort measured slower than sorting (15.75 against 15.66 ms:
+  // a tile's depth slabs are tighter than its equal-index sample sets).  Same h / sigma
+  // bits whatever the mode (profiles/r06_density_fused_ab.txt).
   const char* es = ucsa_getenv("UCSA_ENC_SORTED");
   const int sorted_mode = es && es[0] >= '0' && es[0] <= '3' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
@@ -208,7 +208,7 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
         (fine ? sorted_mode >= 1 : (sorted_mode == 2 && n <= 128u) || sorted_mode == 3)) {
       UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
                                      w.slot, stream));
-      // bf16x3 / f16x2 nets: levels 0-7 are encoded INSIDE the sigma MLP (their
+      // bf16x3 / f16x2 nets: levels 0-11 are encoded INSIDE the sigma MLP (their
       // features never travel through HBM: density_sorted.hip; same h / sigma
       // bits; UCSA_DENSITY_FUSED=0 keeps the staged pair for A/B runs)
       if (prec >= 2 && density_fused())
