@@ -370,8 +370,9 @@ def encoder_roofline(st, chunk, pretrain_steps):
             "l2_request_frac_of_34500")
     fine_top = eb["fine"].get("kernels", {}).get("k_hashgrid_encode_sorted", {})
     r["binding_resource"] = {
-        "resource": "L2 -> L1 line fills of the gathers (128-B lines, ~34.5 TB/s): the levels-9-15 "
-                    "launches; TCP look-ups 1 per clock and CU next",
+        "resource": "L2 -> L1 line fills of the gathers (128-B lines, ~34.5 TB/s): the per-level "
+                    "launch of the finest levels (12-15 since round 6; these counters: round 5's "
+                    "levels-9-15 launches, the same kernel); TCP look-ups 1 per clock and CU next",
         "achieved": l2, "peak": 1.0, "unit": "fraction of the L2 request rate", "frac": l2,
         "fine_levels_kernel": {k: fine_top[k] for k in keys if k in fine_top},
         "fine_pass": {k: eb["fine"][k] for k in keys if k in eb["fine"]},
