@@ -21,7 +21,7 @@ F32_MFMA_PEAK_TF = 157.3  # fp32-input MFMA = fp32 vector peak
 F16_MFMA_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA (SURVEY 8d's MLP roofline)
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 PMC_JSON = "profiles/r06_pmc_traffic.json"
-TRAIN_PMC_JSON = "profiles/r04_train_pmc.json"
+TRAIN_PMC_JSON = "profiles/r06_train_pmc.json"
 SEG_PMC_JSON = "profiles/r03_seg_pmc.json"
 # round 5's encoder kernels (tools/encode_pmc.sh r05 + tools/encode_binding_json.py)
 ENC_BINDING_JSON = "profiles/r05_encoder_binding.json"

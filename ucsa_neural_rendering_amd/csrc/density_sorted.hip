@@ -51,7 +51,8 @@ k_density_sorted(GridDev g, const float2* __restrict__ table,
                  float* __restrict__ h, float* __restrict__ sigma) {
   __shared__ __attribute__((aligned(16))) float ray_s[64][8];
   __shared__ __attribute__((aligned(16))) float2 ftile[4][NENC][DS_PITCH];
-  const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
+  const uint32_t bid = xcd_band(blockIdx.x, gridDim.x);
+  const uint32_t sb = bid % s_blocks, tile = bid / s_blocks;
   const TileGeom tg = tile_geom(tile, rows, W, T);
   if (sb * 1024u >= tg.count) return;   // (workgroup-uniform)
   load_tile_rays(ray_s, tg, W, rays_o, rays_d);

@@ -12,6 +12,27 @@ struct TileGeom {
 };
 }  // namespace
 
+// XCD-aware work distribution (round 6).  The dispatcher hands consecutive workgroup
+// ids to the 8 XCDs in turn, and every XCD has its own 4 MiB L2: with blockIdx ->
+// (tile, sample block) taken literally, each XCD sees every 8th workgroup of the WHOLE
+// chunk and all eight L2s end up caching the same table entries.  Here the blocks of
+// one residue class (= one XCD, within a grid row) get a CONTIGUOUS band of the
+// logical index space -- neighbouring tiles, the same part of the scene -- so that
+// each L2 holds an eighth of the touched table instead of a copy of all of it.  A
+// bijection of [0, n): results do not depend on it.
+#ifndef UCSA_XCD_BAND
+#define UCSA_XCD_BAND 1
+#endif
+__device__ __forceinline__ uint32_t xcd_band(uint32_t bid, uint32_t n) {
+#if UCSA_XCD_BAND
+  const uint32_t per = n >> 3, rem = n & 7u;
+  const uint32_t r = bid & 7u, k = bid >> 3;
+  return r * per + (r < rem ? r : rem) + k;
+#else
+  return bid;
+#endif
+}
+
 // rays = the pixels of `rows` full image rows, W wide; tiles row-major
 __device__ __forceinline__ TileGeom tile_geom(uint32_t tile, uint32_t rows,
                                               uint32_t W, uint32_t T) {

@@ -283,7 +283,8 @@ k_hashgrid_encode_sorted(GridDev g, uint32_t l_top, const TT* __restrict__ table
                          uint32_t M, FT* __restrict__ feat) {
   __shared__ __attribute__((aligned(16))) float ray_s[64][8];
   const uint32_t level = l_top - blockIdx.y;
-  const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
+  const uint32_t bid = xcd_band(blockIdx.x, gridDim.x);
+  const uint32_t sb = bid % s_blocks, tile = bid / s_blocks;
   const TileGeom tg = tile_geom(tile, rows, W, T);
   if (sb * 1024u >= tg.count) return;   // (workgroup-uniform)
   load_tile_rays(ray_s, tg, W, rays_o, rays_d);
@@ -323,7 +324,8 @@ k_hashgrid_encode_sorted_ml(GridDev g, uint32_t l_lo, uint32_t l_hi,
                             uint32_t rows, uint32_t W, uint32_t s_blocks,
                             uint32_t M, FT* __restrict__ feat) {
   __shared__ __attribute__((aligned(16))) float ray_s[64][8];
-  const uint32_t sb = blockIdx.x % s_blocks, tile = blockIdx.x / s_blocks;
+  const uint32_t bid = xcd_band(blockIdx.x, gridDim.x);
+  const uint32_t sb = bid % s_blocks, tile = bid / s_blocks;
   const TileGeom tg = tile_geom(tile, rows, W, T);
   if (sb * 1024u >= tg.count) return;
   load_tile_rays(ray_s, tg, W, rays_o, rays_d);
