@@ -476,7 +476,7 @@ def test_depth_ordered_density_is_bit_identical(H, W, T, exact, monkeypatch):
         h0, s0 = plain(feat_r, packed)
         h1, s1 = ops.sigma_mlp_fwd_scatter(mode, feat_s, packed, slot)
         assert torch.equal(h0, h1) and torch.equal(s0, s1), mode
-        if mode >= 2:   # ... and with levels 0-7 / 0-11 encoded inside the sigma MLP (round 6)
+        if mode >= 2:   # ... and with levels 0-7 / 0-11 / 0-15 encoded inside the sigma MLP (round 6)
             for n_enc in ("8", "12", "16"):
                 monkeypatch.setenv("UCSA_DENSITY_LEVELS", n_enc)
                 ops.env_reload()
