@@ -31,14 +31,32 @@ def _run2(extra, tmp_path, timeout=600, ranks=2):
            "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port",
            str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks)] + extra
     out, err = tmp_path / "out.txt", tmp_path / "err.txt"
-    with open(out, "w") as fo, open(err, "w") as fe:
-        proc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
-                                env=env, cwd=ROOT)
-        try:
-            rc = proc.wait(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            proc.kill()
-            raise AssertionError("bench.py timed out:\n" + err.read_text()[-3000:])
+    for attempt in (1, 2):
+        with open(out, "w") as fo, open(err, "w") as fe:
+            proc = subprocess.Popen(cmd, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                                    env=env, cwd=ROOT)
+            try:
+                rc = proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                raise AssertionError("bench.py timed out:\n" + err.read_text()[-3000:])
+        etext = err.read_text()
+        # EIGHT processes on ONE device is a code-path check, not a supported way to run
+        # (round 6: one such run in seven lost a rank to SIGABRT inside the runtime's
+        # start-up, before any of this repository's code ran -- torchrun's summary named
+        # only the signal).  A rank killed by a signal is retried ONCE, its stderr kept
+        # (gpurun_out/bench_modes_stderr.txt); a second death, or any failure the program
+        # itself reports, fails the test.
+        if attempt == 1 and rc != 0 and ranks >= 8 and "Signal" in etext and "Traceback" not in etext.split("ChildFailedError")[0]:
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "bench_modes_stderr.txt"), "a") as f:
+                    f.write(f"=== attempt 1 of {cmd[-6:]} died of a signal, retrying\n{etext[-20000:]}\n")
+            except OSError:
+                pass
+            cmd[cmd.index("--master-port") + 1] = str(_port())
+            continue
+        break
     return _parse(rc, out, err)
 
 
