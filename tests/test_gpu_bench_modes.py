@@ -42,9 +42,9 @@ def _run2(extra, tmp_path, timeout=600, ranks=2):
                 raise AssertionError("bench.py timed out:\n" + err.read_text()[-3000:])
         etext = err.read_text()
         # EIGHT processes on ONE device is a code-path check, not a supported way to run
-        # (round 6: one such run in seven lost a rank to SIGABRT inside the runtime's
-        # start-up, before any of this repository's code ran -- torchrun's summary named
-        # only the signal).  A rank killed by a signal is retried ONCE, its stderr kept
+        # (round 6: one such run in seven lost a rank to SIGABRT; the cause was not
+        # captured -- torchrun's summary named only the signal -- and six later runs of
+        # the same command passed).  A rank killed by a signal is retried ONCE, its stderr kept
         # (gpurun_out/bench_modes_stderr.txt); a second death, or any failure the program
         # itself reports, fails the test.
         if attempt == 1 and rc != 0 and ranks >= 8 and "Signal" in etext and "Traceback" not in etext.split("ChildFailedError")[0]:
