@@ -150,7 +150,7 @@ def _train_oracle(frames, draws, u_eval, emulate_tcnn, checkpoints=SHORT.checkpo
         for p in fld.parameters():
             p.grad = None
         loss.backward()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         with torch.no_grad():
             for i, (p, s) in enumerate(zip(fld.parameters(), st)):
                 pn, s["m"], s["v"] = olosses.adam_step(
