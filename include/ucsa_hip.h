@@ -310,6 +310,13 @@ int32_t ucsa_hashgrid_encode_rays_hf(const ucsa_grid* grid, const float* table,
 int32_t ucsa_tile_depth_order(const float* z, uint32_t N, uint32_t T,
                               uint32_t image_width, float* z_sorted,
                               uint8_t* pix, uint32_t* slot, void* stream);
+/* The same three arrays for COARSE samples without a sort: "sample index, then
+ * pixel" (sample s of every ray of an 8x8 tile sits at nearly one depth:
+ * renderer_semantics.py:154-173).  The render path uses it for coarse passes of
+ * more than 128 samples per ray, where the depth sort costs more than it brings. */
+int32_t ucsa_tile_index_order(const float* z, uint32_t N, uint32_t T,
+                              uint32_t image_width, float* z_sorted, uint8_t* pix,
+                              uint32_t* slot, void* stream);
 int32_t ucsa_hashgrid_encode_sorted(const ucsa_grid* grid, const float* table,
                                     const float* rays_o, const float* rays_d,
                                     const float* z_sorted, const uint8_t* pix,

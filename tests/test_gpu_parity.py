@@ -485,6 +485,45 @@ def test_depth_ordered_density_is_bit_identical(H, W, T, exact, monkeypatch):
                 assert torch.equal(h0, h2_) and torch.equal(s0, s2_), ("fused", mode, n_enc)
 
 
+@pytest.mark.parametrize("H,W,T", [(24, 40, 16), (17, 23, 8), (8, 8, 1), (16, 320, 256), (9, 16, 70)])
+def test_index_ordered_coarse_density_is_bit_identical(H, W, T):
+    """Round 6: coarse passes of more than 128 samples per ray (the reference's native
+    256) go through the depth-ordered kernels WITHOUT a sort -- ucsa_tile_index_order
+    lays a tile's samples out by (sample index, pixel) -- so that their levels 0-11 are
+    encoded inside the sigma MLP as well (ucsa_density_sorted).  The order is a
+    permutation with the right pixel ids, tiles back to back, sample-major inside a
+    tile; features and h / sigma equal the image-ordered pair's, bit for bit (ragged
+    tiles, T = 1, T not a multiple of 32, T = 256)."""
+    from ucsa_neural_rendering_amd import ops
+    fld = lively_oracle_field()
+    net = hip_network_from_oracle(fld).eval()
+    f, f2, fx = net._field(), net._field_h2(), net._field_x3()
+    N = H * W
+    o, d, _ = make_rays(N, 14)
+    o, d = o.cuda(), d.cuda()
+    aabb = net._aabb_list(False)
+    near, far = ops.near_far_from_aabb(o, d, aabb)
+    z = ops.sample_coarse(near, far, T)
+    zs, pix, slot = ops.tile_index_order(z, W)
+    sl = slot.long()
+    assert torch.equal(torch.sort(sl).values, torch.arange(N * T, device=sl.device))
+    assert torch.equal(zs, z.view(-1)[sl])
+    x, y, smp = (sl // T) % W, (sl // T) // W, sl % T
+    assert torch.equal(pix.long(), (y % 8) * 8 + (x % 8))
+    tile = (y // 8) * ((W + 7) // 8) + x // 8
+    assert bool((tile[1:] >= tile[:-1]).all())
+    same = tile[1:] == tile[:-1]
+    assert bool((smp[1:][same] >= smp[:-1][same]).all())          # sample-major inside a tile
+    ref = ops.hashgrid_encode_rays(f["grid"], f["table"], o, d, z, aabb, image_width=W)
+    got = ops.hashgrid_encode_sorted(f["grid"], f["table"], o, d, zs, pix, aabb, T, W)
+    assert torch.equal(got, ref[:, sl])
+    for mode, packed, plain in ((2, fx["packed_sigma"], ops.sigma_mlp_fwd_x3),
+                                (3, f2["packed_sigma"], ops.sigma_mlp_fwd_h2)):
+        h0, s0 = plain(ref, packed)
+        h1, s1 = ops.density_sorted(mode, f["grid"], f["table"], o, d, zs, pix, slot, aabb, T, W, packed)
+        assert torch.equal(h0, h1) and torch.equal(s0, s1), mode
+
+
 @pytest.mark.parametrize("n,H,W,tile", [(1, 5, 7, 16), (700, 37, 50, 16), (4096, 240, 320, 16),
                                         (4097, 240, 320, 8), (8192, 480, 640, 16), (33, 9, 9, 4)])
 def test_tile_order_kernel_equals_torch_ordering(ops, n, H, W, tile):

@@ -115,6 +115,7 @@ SIGNATURES = {
                                                _u32, _u32, _p, _p, _p]),
     "ucsa_hashgrid_bwd_det_finish": (C.c_int32, [C.POINTER(Grid), _p, _p, _p]),
     "ucsa_tile_depth_order": (C.c_int32, [_p, _u32, _u32, _u32, _p, _p, _p, _p]),
+    "ucsa_tile_index_order": (C.c_int32, [_p, _u32, _u32, _u32, _p, _p, _p, _p]),
     "ucsa_hashgrid_encode_sorted": (C.c_int32, [C.POINTER(Grid), _p, _p, _p, _p, _p,
                                                 C.POINTER(_f), _u32, _u32, _u32,
                                                 _p, _p]),

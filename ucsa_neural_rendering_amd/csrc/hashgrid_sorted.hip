@@ -359,6 +359,65 @@ k_hashgrid_encode_sorted_ml(GridDev g, uint32_t l_lo, uint32_t l_hi,
   }
 }
 
+// The COARSE samples of a tile need no sort: sample s of every ray sits at (nearly)
+// one depth (z = near + (far - near) s / (T - 1), near / far vary slowly over 8x8
+// pixels), so the order "sample index, then pixel" IS the tile's depth order up to
+// that variation -- a wave of the encoders = the tile's pixels at one sample index,
+// as in the image-ordered tiled kernel.  Writes the same three arrays as
+// k_tile_depth_order2 (z_sorted, pix, slot) with a transpose instead of two LDS
+// sorts.  Used for coarse passes of MORE than 128 samples per ray (the reference's
+// native 256): there the sort (144 KiB of LDS per tile) costs more than the fused
+// density kernel gains, while this order gets nearly all of that gain (cfg2, 96
+// samples: 15.75 ms per view against 15.66 with the sort and 15.89 with an
+// image-ordered coarse pass).
+__global__ void __launch_bounds__(256)
+k_tile_index_order(const float* __restrict__ z, uint32_t rows, uint32_t T, uint32_t W,
+                   float* __restrict__ z_sorted, uint8_t* __restrict__ pix,
+                   uint32_t* __restrict__ slot) {
+  __shared__ float zt[64][33];     // 32 samples of the tile's 64 pixels, transposed
+  const TileGeom tg = tile_geom(blockIdx.x, rows, W, T);
+  const uint32_t np = tg.wt * tg.ht;
+  for (uint32_t s0 = 0; s0 < T; s0 += 32u) {
+    const uint32_t ns = T - s0 < 32u ? T - s0 : 32u;
+    // read: consecutive threads = consecutive samples of a ray (coalesced)
+    for (uint32_t e = threadIdx.x; e < 64u * 32u; e += 256u) {
+      const uint32_t k = e >> 5, ds = e & 31u;       // k: valid-pixel index in row-major order
+      if (k < np && ds < ns) {
+        const uint32_t lx = k % tg.wt, ly = k / tg.wt;
+        zt[k][ds] = z[((tg.py0 + ly) * W + tg.px0 + lx) * T + s0 + ds];
+      }
+    }
+    __syncthreads();
+    // write: consecutive threads = consecutive pixels at one sample index
+    for (uint32_t e = threadIdx.x; e < ns * np; e += 256u) {
+      const uint32_t ds = e / np, k = e - ds * np;
+      const uint32_t lx = k % tg.wt, ly = k / tg.wt;
+      const uint32_t q = tg.base + (s0 + ds) * np + k;
+      z_sorted[q] = zt[k][ds];
+      pix[q] = (uint8_t)(ly * 8u + lx);
+      slot[q] = ((tg.py0 + ly) * W + tg.px0 + lx) * T + s0 + ds;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int32_t ucsa_tile_index_order(const float* z, uint32_t N, uint32_t T,
+                                         uint32_t image_width, float* z_sorted,
+                                         uint8_t* pix, uint32_t* slot, void* stream) {
+  UCSA_CHECK_ARG(z, 0);
+  UCSA_CHECK_ARG(T >= 1 && T <= 1024, 2);
+  UCSA_CHECK_ARG(image_width >= 1 && N % image_width == 0, 3);
+  UCSA_CHECK_ARG(z_sorted && pix && slot, 4);
+  UCSA_CHECK_ARG((uint64_t)N * T < 0x80000000ull, 1);
+  if (N == 0) return 0;
+  const uint32_t rows = N / image_width;
+  const uint32_t tiles = ((image_width + 7u) / 8u) * ((rows + 7u) / 8u);
+  UCSA_CLEAR_ERR();
+  hipLaunchKernelGGL(k_tile_index_order, dim3(tiles), dim3(256), 0, (hipStream_t)stream, z,
+                     rows, T, image_width, z_sorted, pix, slot);
+  return ucsa_launch_status();
+}
+
 extern "C" int32_t ucsa_tile_depth_order(const float* z, uint32_t N, uint32_t T,
                                          uint32_t image_width, float* z_sorted,
                                          uint8_t* pix, uint32_t* slot,

@@ -199,15 +199,28 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   // a tile's depth slabs are tighter than its equal-index sample sets).  Same h / sigma
   // bits whatever the mode (profiles/r06_density_fused_ab.txt).
   const char* es = ucsa_getenv("UCSA_ENC_SORTED");
-  const int sorted_mode = es && es[0] >= '0' && es[0] <= '3' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
+  const int sorted_mode = es && es[0] >= '0' && es[0] <= '4' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
   auto density = [&](const float* z, uint32_t n, float* h, float* sigma) -> int32_t {
     const bool fine = z == w.z_f;
+    // a coarse pass of more than 128 samples per ray: "sample index, then pixel" order
+    // instead of the depth sort (mode 2, default); mode 3: always the sort; mode 4:
+    // such a pass stays image-ordered (the rule before ucsa_tile_index_order came back)
+    const bool coarse_long = !fine && n > 128u;
     if (image_width && !table_half && n <= 1024u &&
         N % image_width == 0 && grid->n_levels == 16 &&
-        (fine ? sorted_mode >= 1 : (sorted_mode == 2 && n <= 128u) || sorted_mode == 3)) {
-      UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
-                                     w.slot, stream));
+        (fine ? sorted_mode >= 1
+              // (the coarse pass only where the fused kernel takes it: with the staged
+              // encoder + sigma-MLP pair -- fp32 / fp16 nets -- an ordered coarse pass is
+              // slower than the image-ordered tiled one, 16.70 against 16.18 ms per view)
+              : (sorted_mode == 3 || (sorted_mode >= 2 && prec >= 2 && density_fused()))) &&
+        !(coarse_long && sorted_mode == 4)) {
+      if (coarse_long && sorted_mode == 2)
+        UCSA_TRY(ucsa_tile_index_order(z, N, n, image_width, w.zs_sorted, w.pix,
+                                       w.slot, stream));
+      else
+        UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
+                                       w.slot, stream));
       // bf16x3 / f16x2 nets: levels 0-11 are encoded INSIDE the sigma MLP (their
       // features never travel through HBM: density_sorted.hip; same h / sigma
       // bits; UCSA_DENSITY_FUSED=0 keeps the staged pair for A/B runs)

@@ -182,6 +182,20 @@ def tile_depth_order(z, image_width: int):
     return z_sorted, pix, slot
 
 
+def tile_index_order(z, image_width: int):
+    """The arrays of ``tile_depth_order`` for COARSE samples without a sort: every
+    8x8 tile's samples ordered by (sample index, pixel) (ucsa_tile_index_order)."""
+    z = _f32(z, "z")
+    N, T = z.shape
+    z_sorted = torch.empty(N * T, device=z.device)
+    pix = torch.empty(N * T, dtype=torch.uint8, device=z.device)
+    slot = torch.empty(N * T, dtype=torch.int32, device=z.device)
+    check(lib().ucsa_tile_index_order(_ptr(z), N, T, int(image_width), _ptr(z_sorted),
+                                      _ptr(pix), _ptr(slot), _stream()),
+          "ucsa_tile_index_order")
+    return z_sorted, pix, slot
+
+
 def hashgrid_encode_sorted(grid: Grid, table, rays_o, rays_d, z_sorted, pix, aabb,
                            T: int, image_width: int, half_features: bool = False):
     """-> feat [L, N*T, 2] in the order of ``tile_depth_order`` (fp32 table)."""
