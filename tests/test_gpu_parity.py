@@ -359,12 +359,14 @@ def test_fp16_inference_option_matches_fp16_emulating_oracle(fld):
     assert out["image"].requires_grad
 
 
-@pytest.mark.parametrize("H,W,T,t", [(24, 40, 16, 16), (17, 23, 8, 0), (64, 64, 33, 12)])
+@pytest.mark.parametrize("H,W,T,t", [(24, 40, 16, 16), (17, 23, 8, 0), (64, 64, 33, 12), (16, 24, 160, 40)])
 def test_image_ordered_gather_is_bit_identical(H, W, T, t):
     """image_width > 0 only changes which lanes gather together (8x8 pixel
-    tiles instead of runs along a ray): features, and therefore the whole
-    render, must equal the ray-ordered path bit for bit -- ragged tiles,
-    T not a multiple of 16 and chunking across bands included."""
+    tiles instead of runs along a ray; since rounds 5-6 per-tile depth order, the
+    hash-grid levels 0-11 inside the sigma MLP, and for T > 128 the coarse pass in
+    sample-index order): features, and therefore the whole render, must equal the
+    ray-ordered path bit for bit in every arithmetic -- ragged tiles, T not a
+    multiple of 16 and chunking across bands included."""
     from ucsa_neural_rendering_amd import ops
     fld = lively_oracle_field()
     net = hip_network_from_oracle(fld).eval()
@@ -381,19 +383,22 @@ def test_image_ordered_gather_is_bit_identical(H, W, T, t):
     assert torch.equal(a, b)
     g = torch.Generator().manual_seed(1)
     u = torch.rand(N, max(t, 1), generator=g)[:, :t].cuda()
-    with torch.no_grad():
-        r0 = net.render(o[None], d[None], norms[None], num_steps=T,
-                        upsample_steps=t, rng_u=u if t else None)
-        net.hip_ray_chunk = 8 * W + 5     # -> bands of 8 rows
-        r1 = net.render(o[None], d[None], norms[None], num_steps=T,
-                        upsample_steps=t, rng_u=u if t else None,
-                        image_width=W)
-        net.hip_ray_chunk = 3 * W         # too small for a band: falls back
-        r2 = net.render(o[None], d[None], norms[None], num_steps=T,
-                        upsample_steps=t, rng_u=u if t else None,
-                        image_width=W)
-    for k in ("image", "depth", "semantics"):
-        assert torch.equal(r0[k], r1[k]) and torch.equal(r0[k], r2[k])
+    for precision in ("fp32", "f16x2", "bf16x3", "fp16"):
+        net.precision = precision
+        with torch.no_grad():
+            net.hip_ray_chunk = 65536
+            r0 = net.render(o[None], d[None], norms[None], num_steps=T,
+                            upsample_steps=t, rng_u=u if t else None)
+            net.hip_ray_chunk = 8 * W + 5     # -> bands of 8 rows
+            r1 = net.render(o[None], d[None], norms[None], num_steps=T,
+                            upsample_steps=t, rng_u=u if t else None,
+                            image_width=W)
+            net.hip_ray_chunk = 3 * W         # too small for a band: falls back
+            r2 = net.render(o[None], d[None], norms[None], num_steps=T,
+                            upsample_steps=t, rng_u=u if t else None,
+                            image_width=W)
+        for k in ("image", "depth", "semantics"):
+            assert torch.equal(r0[k], r1[k]) and torch.equal(r0[k], r2[k]), (precision, k)
 
 
 @pytest.mark.parametrize("H,W,T,exact", [(24, 40, 16, True), (17, 23, 8, True), (64, 64, 33, False),
