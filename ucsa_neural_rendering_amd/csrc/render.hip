@@ -187,17 +187,20 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
                                    w.nears, w.fars, stream));
   UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
   // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays.
-  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 3 both passes always, 2 (default
-  // since round 6) both passes when the coarse pass has at most 128 samples per ray:
-  // with levels 0-11 encoded inside the sigma MLP (density_sorted.hip) the coarse pass
-  // gains more from the fused kernel than its sort costs -- cfg2 view 16.18 ms (fine
-  // pass only, unfused) / 15.89 (fine fused) / 15.66 (both fused, 8 levels inside) /
-  // 15.01 (12 levels inside) -- while at the reference's native 256 + 256 samples the
-  // coarse sort (144 KiB of LDS per tile) costs more than it brings (cfg3's joint step:
-  // 172.9 ms with the fine pass only, 178.7 ms with both).  A "sample index, then
-  // pixel" order without a sort measured slower than sorting (15.75 against 15.66 ms:
-  // a tile's depth slabs are tighter than its equal-index sample sets).  Same h / sigma
-  // bits whatever the mode (profiles/r06_density_fused_ab.txt).
+  // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 2 (default since round 6) both
+  // passes -- the coarse one through the per-tile depth sort up to 128 samples per ray
+  // and in "sample index, then pixel" order beyond (ucsa_tile_index_order), and only
+  // where the fused kernel takes it (bf16x3 / f16x2 nets) --, 3 both passes always
+  // through the sort, 4 like 2 with long coarse passes image-ordered.  Measured: with
+  // levels 0-11 encoded inside the sigma MLP (density_sorted.hip) the coarse pass gains
+  // more from the fused kernel than its order costs -- cfg2 view 16.18 ms (fine pass
+  // only, unfused) / 15.89 (fine fused) / 15.66 (both fused, 8 levels inside) / 15.01
+  // (12 levels inside); at 96 samples the index order measured 15.75 against 15.66 with
+  // the sort (a tile's depth slabs are tighter than its equal-index sample sets); at the
+  // reference's native 256 + 256 samples the sort (144 KiB of LDS per tile) costs more
+  // than it brings (cfg3's joint step 178.7 ms sorted) while the index order wins
+  // (171.8 ms with that pass image-ordered -> 168.0).  Same h / sigma bits whatever the
+  // mode (profiles/r06_density_fused_ab.txt).
   const char* es = ucsa_getenv("UCSA_ENC_SORTED");
   const int sorted_mode = es && es[0] >= '0' && es[0] <= '4' ? es[0] - '0' : UCSA_ENC_SORTED_DEFAULT;
   // encode + sigma MLP of one pass (z [N,n] -> h, sigma)
