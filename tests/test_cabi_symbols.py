@@ -124,3 +124,30 @@ def test_ctypes_structures_match_the_header_layout(built_lib, tmp_path):
         assert int(c_layout[cname]) == ctypes.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(c_layout[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
+
+
+def test_every_environment_switch_of_the_library_is_in_its_table_and_documented():
+    """the library reads its UCSA_* switches from ONE table, once
+    per process (csrc/render.hip kEnvNames / ucsa_getenv; an unknown name asserts).
+    Every name the sources look up is in the table, every table entry is looked up,
+    and INTEGRATION.md's "Environment variables" section names each of them."""
+    import glob
+    import re
+    src = os.path.join(ROOT, "ucsa_neural_rendering_amd", "csrc")
+    used = set()
+    for f in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")):
+        text = open(f).read()
+        assert not re.search(r"(?<![_A-Za-z])getenv\(", text.replace("ucsa_getenv(", "")) \
+            or f.endswith("render.hip"), f"{f}: a plain getenv() outside the table"
+        used |= set(re.findall(r'(?:ucsa_getenv|env_u|simple_gather_below)\(\s*"(UCSA_[A-Z0-9_]+)"', text))
+    r = open(os.path.join(src, "render.hip")).read()
+    table = set(re.findall(r'"(UCSA_[A-Z0-9_]+)"',
+                           r[r.index("kEnvNames[] = {"):r.index("constexpr int kEnvCount")]))
+    assert used == table, (used - table, table - used)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("### Environment variables"):doc.index("## 7. Entry-point index")]
+    missing = [n for n in sorted(table) if n not in sec
+               and not any(n.startswith(p.rstrip("*")) for p in re.findall(r"`(UCSA_[A-Z_]+)=", sec) if False)]
+    # (INTEGRATION abbreviates the UCSA_ENC_SIMPLE family as `UCSA_ENC_SIMPLE=n` / `_H` / `_RAYS`)
+    missing = [n for n in missing if not n.startswith("UCSA_ENC_SIMPLE")]
+    assert not missing, missing
