@@ -20,7 +20,7 @@ namespace {
 const char* const kEnvNames[] = {
     // launch shapes / kernel choices of the render path
     "UCSA_SHADE_VARIANT", "UCSA_SPLIT_COMPOSITE", "UCSA_ENC_SORTED", "UCSA_ENC_ML",
-    "UCSA_DENSITY_FUSED", "UCSA_DENSITY_LEVELS", "UCSA_RENDER_SMALL_STREAM",
+    "UCSA_DENSITY_FUSED", "UCSA_DENSITY_LEVELS",
     "UCSA_ENC_SORTED_ML", "UCSA_ENC_SORTED_LEAN",
     // ... of the training path
     "UCSA_SHADE_BWD_SPLIT", "UCSA_BWD_OVERLAP", "UCSA_BWD_BIN_SCALE",
@@ -175,11 +175,7 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
                            uint32_t T, uint32_t t, uint32_t n_classes,
                            float density_scale, uint32_t image_width,
                            float* image, float* depth, float* semantics,
-                           void* ws, void* stream, uint32_t stage = 3u,
-                           hipStream_t small = nullptr, hipEvent_t* hand = nullptr) {
-  // `small` (lab, UCSA_RENDER_SMALL_STREAM=1): the latency-bound little kernels of the
-  // density half (near/far, coarse depths, the per-tile sorts, resampling) on a stream
-  // of their own at high priority, handed to / from `stream` by the three events `hand`
+                           void* ws, void* stream, uint32_t stage = 3u) {
   UCSA_CHECK_ARG(grid, 0);
   UCSA_CHECK_ARG(ws, 21);
   UCSA_CHECK_ARG(t == 0 || u, 11);
@@ -187,26 +183,9 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   const Ws w = carve(ws, N, T, t, grid->n_levels);
   const float* table = table_half ? nullptr : (const float*)table_any;
   if (stage & 1u) {
-  void* lit = small ? (void*)small : stream;   // where the little kernels go
-  int n_hand = 0;
-  // little -> big / big -> little hand-offs (no-ops on one stream)
-  auto to_big = [&]() -> int32_t {
-    if (!small) return 0;
-    if (hipEventRecord(hand[n_hand], small) != hipSuccess ||
-        hipStreamWaitEvent((hipStream_t)stream, hand[n_hand], 0) != hipSuccess) return -1;
-    ++n_hand;
-    return 0;
-  };
-  auto to_small = [&]() -> int32_t {
-    if (!small) return 0;
-    if (hipEventRecord(hand[n_hand], (hipStream_t)stream) != hipSuccess ||
-        hipStreamWaitEvent(small, hand[n_hand], 0) != hipSuccess) return -1;
-    ++n_hand;
-    return 0;
-  };
   UCSA_TRY(ucsa_near_far_from_aabb(rays_o, rays_d, aabb_host, N, min_near,
-                                   w.nears, w.fars, lit));
-  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, lit));
+                                   w.nears, w.fars, stream));
+  UCSA_TRY(ucsa_sample_coarse(w.nears, w.fars, t_rand, N, T, w.z_c, stream));
   // the depth-ordered path (hashgrid_sorted.hip) for image-ordered rays.
   // UCSA_ENC_SORTED = 0 off, 1 the fine pass only, 2 (default since round 6) both
   // passes -- the coarse one through the per-tile depth sort up to 128 samples per ray
@@ -241,11 +220,10 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
         !(coarse_long && sorted_mode == 4)) {
       if (coarse_long && sorted_mode == 2)
         UCSA_TRY(ucsa_tile_index_order(z, N, n, image_width, w.zs_sorted, w.pix,
-                                       w.slot, lit));
+                                       w.slot, stream));
       else
         UCSA_TRY(ucsa_tile_depth_order(z, N, n, image_width, w.zs_sorted, w.pix,
-                                       w.slot, lit));
-      UCSA_TRY(to_big());      // (the sort is the last little kernel before the big ones)
+                                       w.slot, stream));
       // bf16x3 / f16x2 nets: levels 0-11 are encoded INSIDE the sigma MLP (their
       // features never travel through HBM: density_sorted.hip; same h / sigma
       // bits; UCSA_DENSITY_FUSED=0 keeps the staged pair for A/B runs)
@@ -264,7 +242,6 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
       return ucsa_sigma_mlp_fwd_scatter(prec, w.feat, packed_sigma, N * n,
                                         grid->n_levels, w.slot, h, sigma, stream);
     }
-    if (small) return UCSA_ERR_ARG - 99;   // (the little stream is for ordered passes only)
     if (prec == 1 && !table_half) {  // f16 nets: fp16 features at the source
       UCSA_TRY(ucsa_hashgrid_encode_rays_hf(grid, table, rays_o, rays_d, z,
                                             aabb_host, N, n, image_width, w.feat,
@@ -288,9 +265,8 @@ static int32_t render_impl(int prec, const ucsa_grid* grid,
   };
   UCSA_TRY(density(w.z_c, T, w.h_c, w.sigma_c));
   if (t > 0) {
-    UCSA_TRY(to_small());
     UCSA_TRY(ucsa_resample(w.z_c, w.sigma_c, u, N, T, t, density_scale, w.z_f,
-                           lit));
+                           stream));
     UCSA_TRY(density(w.z_f, t, w.h_f, w.sigma_f));
   }
   }  // stage & 1
@@ -406,8 +382,7 @@ namespace {
 struct RenderPipe {
   hipStream_t caller = nullptr;
   int dev = -1;
-  hipStream_t dens = nullptr, shade = nullptr, small = nullptr;
-  hipEvent_t hand[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipStream_t dens = nullptr, shade = nullptr;
   hipEvent_t fork = nullptr, d_done[2] = {nullptr, nullptr},
              s_done[2] = {nullptr, nullptr}, join_d = nullptr, join_s = nullptr;
   bool ok = false, used = false;
@@ -442,10 +417,7 @@ RenderPipe* render_pipe(hipStream_t caller) {
   p.ok = hipStreamCreateWithPriority(&p.dens, hipStreamNonBlocking, least) == hipSuccess &&
          hipStreamCreateWithPriority(&p.shade, hipStreamNonBlocking, greatest) == hipSuccess &&
          ev(&p.fork) && ev(&p.d_done[0]) && ev(&p.d_done[1]) && ev(&p.s_done[0]) &&
-         ev(&p.s_done[1]) && ev(&p.join_d) && ev(&p.join_s) &&
-         hipStreamCreateWithPriority(&p.small, hipStreamNonBlocking, greatest) == hipSuccess &&
-         ev(&p.hand[0][0]) && ev(&p.hand[0][1]) && ev(&p.hand[0][2]) && ev(&p.hand[0][3]) &&
-         ev(&p.hand[1][0]) && ev(&p.hand[1][1]) && ev(&p.hand[1][2]) && ev(&p.hand[1][3]);
+         ev(&p.s_done[1]) && ev(&p.join_d) && ev(&p.join_s);
   if (sw) (void)hipSetDevice(cur);
   return p.ok ? &p : nullptr;
 }
@@ -474,15 +446,14 @@ extern "C" int32_t ucsa_render_view(
   const bool table_half = mode == 3;
   if (image_width && (N % image_width != 0 || chunk % (8 * image_width) != 0))
     image_width = 0;  // not whole 8-row bands: ray-ordered gather (same results)
-  auto part = [&](uint32_t head, uint32_t n, void* ws, void* s, uint32_t stage,
-                  hipStream_t small = nullptr, hipEvent_t* hand = nullptr) {
+  auto part = [&](uint32_t head, uint32_t n, void* ws, void* s, uint32_t stage) {
     return render_impl(prec, grid, table, table_half, packed_sigma, packed_color,
                        packed_sem, rays_o + 3ull * head, rays_d + 3ull * head,
                        norms + head, aabb_host, min_near,
                        t_rand ? t_rand + (uint64_t)head * T : nullptr,
                        u ? u + (uint64_t)head * t : nullptr, n, T, t, n_classes,
                        density_scale, image_width, image + 3ull * head, depth + head,
-                       semantics + (uint64_t)head * n_classes, ws, s, stage, small, hand);
+                       semantics + (uint64_t)head * n_classes, ws, s, stage);
   };
   const uint32_t n_chunks = (N + chunk - 1) / chunk;
   RenderPipe* p = (ws1 && n_chunks >= 2) ? render_pipe((hipStream_t)stream) : nullptr;
@@ -497,23 +468,10 @@ extern "C" int32_t ucsa_render_view(
   UCSA_HIP_TRY(hipStreamWaitEvent(p->shade, p->fork, 0));
   int32_t rc = 0;
   uint32_t k = 0;
-  // LAB (UCSA_RENDER_SMALL_STREAM=1): the little latency-bound kernels of the density
-  // half on a high-priority stream of their own -- only when both passes take the
-  // ordered, fused path (render_impl's density() condition, default modes)
-  const char* rsm = ucsa_getenv("UCSA_RENDER_SMALL_STREAM");
-  const char* esm = ucsa_getenv("UCSA_ENC_SORTED");
-  const bool use_small = rsm && rsm[0] == '1' && !esm && density_fused() && prec >= 2 &&
-                         !table_half && image_width && grid->n_levels == 16 && T <= 1024u &&
-                         t >= 1u && t <= 1024u;
-  if (use_small) UCSA_HIP_TRY(hipStreamWaitEvent(p->small, p->fork, 0));
   for (uint32_t head = 0; head < N && rc == 0; head += chunk, ++k) {
     const uint32_t n = N - head < chunk ? N - head : chunk, b = k & 1u;
     // the shading half of chunk k-2 has finished reading this workspace
     if (k >= 2 && hipStreamWaitEvent(p->dens, p->s_done[b], 0) != hipSuccess) rc = -1;
-    if (use_small && k >= 2 && hipStreamWaitEvent(p->small, p->s_done[b], 0) != hipSuccess) rc = -1;
-    if (rc == 0 && use_small) {
-      rc = part(head, n, ws[b], p->dens, 1u, p->small, p->hand[b]);
-    } else
     if (rc == 0) rc = part(head, n, ws[b], p->dens, 1u);
     if (rc == 0 && hipEventRecord(p->d_done[b], p->dens) != hipSuccess) rc = -1;
     if (rc == 0 && hipStreamWaitEvent(p->shade, p->d_done[b], 0) != hipSuccess) rc = -1;
