@@ -12,6 +12,13 @@ summation order: the oracle's own run-to-run spread is part of the fixture).
 The committed fixture holds SIX runs (thread counts 4, 3, 5, 2, 7, 8: `... 4 3`, then
 `APPEND=1 ... 5 2`, then `APPEND=1 PAR=1 ... 7 8`; APPEND adds runs to the existing file).
 
+    python tests/golden/make_trajectory_golden.py short              (~5 min)
+
+writes tests/golden/g9_trajectory_short.npz instead: the two oracle runs of the SHORT
+horizon (150 steps x 2048 rays; fp32, and the fp16-emulating forward of tiny-cuda-nn's
+numerics) that test_trajectory_quality_* compare the HIP runs with -- until round 6 they
+were trained inside the GPU suite (147 s of its 500).
+
 No GPU, no reference code: oracle/ + the synthetic scene's analytic ray casting only."""
 import multiprocessing as mp
 import os
@@ -46,9 +53,40 @@ def worker(args):
                 losses=losses, threads=threads, seconds=time.time() - t0)
 
 
+def short_worker(args):
+    kind, threads = args
+    import torch
+    torch.set_num_threads(threads)
+    from tests import test_gpu_trajectory as tt
+    frames = tt._frames()
+    draws, u_eval = tt._draws(tt.SHORT)
+    t0 = time.time()
+    quals, losses, _ = tt._train_oracle(frames, draws, u_eval, kind == "tcnn", tt.SHORT.checkpoints,
+                                        raw_quals=True)
+    return kind, dict(psnr=[q["train"][0] for q in quals], miou=[q["train"][1] for q in quals],
+                      held_psnr=[q["held"][0] for q in quals], held_miou=[q["held"][1] for q in quals],
+                      losses=losses, seconds=time.time() - t0)
+
+
+def main_short():
+    import torch
+    from tests import test_gpu_trajectory as tt
+    threads = max(1, (os.cpu_count() or 2) // 2)
+    with mp.get_context("spawn").Pool(2) as pool:
+        runs = dict(pool.map(short_worker, [("fp32", threads), ("tcnn", threads)]))
+    out = os.path.join(ROOT, "tests", "golden", "g9_trajectory_short.npz")
+    arrays = {f"{kind}_{k}": np.array(v, dtype=np.float64) for kind, r in runs.items() for k, v in r.items()}
+    np.savez_compressed(
+        out, checkpoints=np.array(tt.SHORT.checkpoints), steps=np.array(tt.SHORT.steps),
+        rays=np.array(tt.SHORT.n), seed=np.array(tt.SHORT.seed), threads=np.array(threads), **arrays)
+    print("wrote", out, "torch", torch.__version__, {k: round(r["seconds"]) for k, r in runs.items()})
+
+
 def main():
     import torch
     from tests import test_gpu_trajectory as tt
+    if sys.argv[1:2] == ["short"]:
+        return main_short()
     threads = [int(x) for x in sys.argv[1:]] or [5, 3]
     # PAR runs at a time: keep the sum of their thread counts at or below the core count
     # (oversubscribed OpenMP teams spin: two runs with 7 + 6 threads on 8 cores did not

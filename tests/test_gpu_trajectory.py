@@ -1,5 +1,6 @@
 """Trained-quality parity (north_star: "matched mIoU/PSNR +-0.5"): the CPU
-oracle and the HIP path TRAINED side by side -- same initialisation (tcnn
+oracle (its runs: committed fixtures, tests/golden/make_trajectory_golden.py) and
+the HIP path TRAINED on the same schedule -- same initialisation (tcnn
 style, seed 123), same frames, same ray indices, same stratified-sampling
 (``rng_t``) and inverse-CDF (``rng_u``) tensors at every step, the reference's
 loss weights and Adam settings (reference
@@ -226,34 +227,34 @@ def _hip_mean(scene, precision, runs=2):
     return q, outs[0][1], dict(outs[0][2], hip_runs=runs, hip_run_spread_db=round(spread, 3))
 
 
-def _oracle_worker(args):
-    frames, draws, u_eval, emulate_tcnn, threads = args[:5]
-    torch.set_num_threads(threads)
-    return _train_oracle(frames, draws, u_eval, emulate_tcnn, *args[5:])
+def short_oracle(kind):
+    """(mean quality, losses, {}) of the oracle's SHORT run `kind` ("fp32" | "tcnn") from
+    the committed fixture tests/golden/g9_trajectory_short.npz -- what _train_oracle
+    returns for it (tests/golden/make_trajectory_golden.py short;
+    tests/test_trajectory_golden_cpu.py re-runs its first steps)."""
+    from tests.util import load_golden
+    g = load_golden("g9_trajectory_short.npz")
+    assert tuple(int(x) for x in g["checkpoints"]) == SHORT.checkpoints and int(g["steps"]) == SHORT.steps
+    assert int(g["rays"]) == SHORT.n and int(g["seed"]) == SHORT.seed
+    col = lambda k: [float(x) for x in g[f"{kind}_{k}"]]
+    quals = [{"train": (p, m), "held": (hp, hm)} for p, m, hp, hm in
+             zip(col("psnr"), col("miou"), col("held_psnr"), col("held_miou"))]
+    return _mean_quality(quals), col("losses"), {}
 
 
 @pytest.fixture(scope="module")
-def oracles(scene):
-    """Both short oracle trajectories (fp32, fp16-emulating), each in its own CPU
-    worker process with a quarter of the cores, started before the HIP runs: the
-    suite's wall clock sees max(.) of them instead of their sum."""
-    import multiprocessing as mp
-    from tests.conftest import _effective_cores
-    threads = max(1, _effective_cores() // 4)
-    ctx = mp.get_context("spawn")      # this process has initialised the GPU: no fork
-    pool = ctx.Pool(2)
-    jobs = {k: pool.apply_async(_oracle_worker, ((*scene, k == "tcnn", threads),))
-            for k in ("fp32", "tcnn")}
-    pool.close()
-    yield jobs
-    pool.terminate()
+def oracles():
+    """Both short oracle trajectories (fp32, fp16-emulating).  Until round 6 they were
+    trained here, in CPU worker processes beside the HIP runs (147 s of the suite's
+    500); they are a committed fixture now, like the long horizon's."""
+    return {k: short_oracle(k) for k in ("fp32", "tcnn")}
 
 
 def _frames():
     """Frames of the synthetic room as CPU tensors, built WITHOUT the GPU: rays from
     oracle.rays.pixel_rays (bit-equal to ucsa_get_rays, G1), ground truth by the
     room's analytic ray casting (plain torch) -- the same frames for the HIP side, the
-    oracle workers and tests/golden/make_trajectory_golden.py."""
+    oracle trainer and tests/golden/make_trajectory_golden.py."""
     from oracle.rays import pixel_rays
     from ucsa_neural_rendering_amd.dataset.synthetic_scene import SyntheticRoom, _slerp_loop_poses
     room = SyntheticRoom(3, n_classes=C)
@@ -306,7 +307,7 @@ def _compare(tag, hip, ora, tol_db=0.5, tol_pt=1.0):
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_trajectory_quality_matches_the_fp32_oracle(scene, oracles, precision):
     hip = _train_hip(*scene, precision)
-    oracle_fp32 = oracles["fp32"].get(timeout=1500)
+    oracle_fp32 = oracles["fp32"]
     if precision == "fp32":
         # run-to-run spread of the HIP path itself (float atomics in the grid
         # backward: a different round-off every run), for the record
@@ -395,7 +396,7 @@ def test_trajectory_quality_tcnn_numerics_matches_the_fp16_emulating_oracle(scen
     steps on, not after ~100 like two fp32-grade runs (measured: -0.41 / +0.05
     / +0.12 dB over three runs)."""
     hip = _hip_mean(scene, "tcnn")
-    _compare("tcnn", hip, oracles["tcnn"].get(timeout=1500), tol_db=1.0, tol_pt=1.0)
+    _compare("tcnn", hip, oracles["tcnn"], tol_db=1.0, tol_pt=1.0)
 
 
 def test_deterministic_mode_makes_the_trajectory_reproducible(scene):

@@ -1,7 +1,8 @@
 """tests/golden/g9_trajectory_long.npz (the oracle trainer's side of the long-horizon
 quality test, tests/test_gpu_trajectory.py) is what tests/golden/make_trajectory_golden.py
 produces from the committed oracle: its layout, the statistics the GPU test compares
-against, and -- by re-running the first steps of the oracle trainer here -- its losses."""
+against, and -- by re-running the first steps of the oracle trainer here -- its losses.
+The same for the short horizon's two runs (g9_trajectory_short.npz)."""
 import numpy as np
 import torch
 
@@ -43,3 +44,25 @@ def test_the_first_steps_of_the_oracle_trainer_reproduce_the_fixture():
     want = g["losses"].numpy()[:, :3]
     for k in range(3):
         assert abs(losses[k] - want[:, k].mean()) <= 2e-5 * max(1.0, abs(want[:, k].mean())), (k, losses[k], want[:, k])
+
+
+def test_short_fixture_layout_and_what_the_runs_show():
+    for kind in ("fp32", "tcnn"):
+        q, losses, _ = tt.short_oracle(kind)
+        assert len(losses) == tt.SHORT.steps and len(q["per_checkpoint_train_psnr"]) == len(tt.SHORT.checkpoints)
+        losses = np.array(losses)
+        assert losses[-10:].mean() < 0.6 * losses[0] and q["train"][0] > 14.0        # tt._compare's premises
+        assert 0.0 < q["train"][1] <= 100.0 and 0.0 < q["held"][1] <= 100.0
+    a, b = np.array(tt.short_oracle("fp32")[1]), np.array(tt.short_oracle("tcnn")[1])
+    assert abs(a[0] - b[0]) < 1e-2 * a[0] and (a != b).any()                          # same start, other numerics
+
+
+def test_the_first_steps_of_the_short_oracle_runs_reproduce_the_fixture():
+    frames = tt._frames()
+    draws, u_eval = tt._draws(tt.SHORT)
+    for kind in ("fp32", "tcnn"):
+        torch.manual_seed(0)
+        _, losses, _ = tt._train_oracle(frames, draws[:3], u_eval, kind == "tcnn", checkpoints=(), raw_quals=True)
+        want = tt.short_oracle(kind)[1][:3]
+        for k in range(3):
+            assert abs(losses[k] - want[k]) <= 2e-5 * max(1.0, abs(want[k])), (kind, k, losses[k], want[k])
