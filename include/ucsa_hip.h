@@ -1158,6 +1158,17 @@ int32_t ucsa_march_segment_shade_f16(
     float* weights_sum, float* depth, float* image, float* semantics,
     void* stream);
 
+/* Same with the f16x2 nets (packed by ucsa_mlp_pack_h2: two f16 terms per operand,
+ * three MFMA passes per product -- the fp32-grade arithmetic of ucsa_render_fwd_h2;
+ * round 6). */
+int32_t ucsa_march_segment_shade_h2(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const void* packed_color_h2, const void* packed_sem_h2,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth,
+    float* image, float* semantics, void* stream);
+
 /* Stable compaction of the slots with rays_t_old >= 0 into rays_alive/rays_t;
  * n_alive_out[0] (device, != n_alive_dev) = number of survivors. */
 int32_t ucsa_march_segment_compact(uint32_t n_cap, const int32_t* n_alive_dev,

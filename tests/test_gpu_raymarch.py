@@ -450,7 +450,16 @@ def _live_trained_gate(seed):
         net.precision = "fp16"
         p_h, m_h, _ = score(lambda o, d, n: net.run_cuda(o, d, n,
                                                          dt_gamma=1 / 256))
+        # f16x2 (round 6): sigma MLP and the fused shading kernel's nets as two-term f16
+        # operands -- fp32-grade, so the SAME pictures as the f32-input nets up to the
+        # decisions a 1e-7 change of a density can flip (mask w > 1e-4, early stop)
+        net.precision = "f16x2"
+        p_2, m_2, o_2 = score(lambda o, d, n: net.run_cuda(o, d, n, dt_gamma=1 / 256))
         net.precision = "fp32"
+    d2 = {k: float((o_2[k] - o_seg[k]).abs().max()) for k in ("image", "depth", "semantics")}
+    print(f"seed {seed}: f16x2 marcher vs f32-input marcher: max |d| {d2}; PSNR {p_2:.2f} mIoU {m_2:.4f}")
+    assert d2["image"] <= 5e-4 and d2["semantics"] <= 5e-4 and d2["depth"] <= 5e-3
+    assert abs(p_2 - p_seg) <= 0.01 and abs(m_2 - m_seg) <= 0.002
     print(f"seed {seed}: PSNR run {p_run:.2f} march {p_seg:.2f} fp16 {p_h:.2f}; "
           f"mIoU run {m_run:.4f} march {m_seg:.4f} fp16 {m_h:.4f}; "
           f"{pts:.1f} points/ray vs 512")

@@ -30,7 +30,7 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
     res = {"density_grid_update_ms": grid_ms, "mean_density": m.mean_density,
            "dt_gamma": 1 / 128, "march_caps": [32, 96, 1024], "w_min": 1e-4}
     n = min(5, args.steps)
-    for prec in ("fp32", "fp16"):
+    for prec in ("fp32", "f16x2", "fp16"):
         m.precision = prec
         with torch.no_grad():
             for i in range(2):

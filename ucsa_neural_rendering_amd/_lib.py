@@ -276,6 +276,10 @@ SIGNATURES = {
                                                  _p, _p, _f, _p, _p, _p, _p,
                                                  _u32, _f, _p, _p, _p, _p,
                                                  _p]),
+    "ucsa_march_segment_shade_h2": (C.c_int32, [_u32, _p, _u32, _p, _p, _p,
+                                                _p, _p, _f, _p, _p, _p, _p,
+                                                _u32, _f, _p, _p, _p, _p,
+                                                _p]),
     "ucsa_march_segment_compact": (C.c_int32, [_u32, _p, _p, _p, _p, _p, _p,
                                                _p, _p]),
     "ucsa_march_train_fwd": (C.c_int32, [_p, _u32, _u32, _p, _p, _p, _f, _p,

@@ -19,10 +19,12 @@
 // The semantic weights are the same numbers as the colour weights in the
 // forward pass (they differ only in autograd: detached, :270).
 #include "composite_common.h"
+#include "mfma_mlp_h2.h"
 
 #define CMP_MAX_WAVES 12
 #define CMP_CBS 2    // column blocks of 16 samples in flight per wave (fp32)
 #define CMP_CBS_H 2  // fp16 option (4 in flight measured slower: 9.9 vs 11.7 M rays/s)
+#define CMP_H2_WAVES 12  // f16x2 (layer-major: 165 VGPRs, three waves per SIMD)
 
 extern __shared__ __attribute__((aligned(16))) float cmp_smem[];
 
@@ -107,9 +109,14 @@ struct CmpArgs {
 // image / semantics / depth / weights_sum of ray rays_alive[r], and rays_t[r]
 // is set for the next round.  List capacity is 64 + G: survivors are drained
 // after every 64-sample trip.
-template <int NRB_SEM, int CBS, bool HALF, bool MARCH>
-__global__ void __launch_bounds__(64 * CMP_MAX_WAVES)
+// H2 (with HALF, marched mode; round 6): the nets in f16x2 -- two-term operands, three
+// f16 MFMA passes per product (mfma_mlp_h2.h), fp32-grade like the f32-input chain at
+// 72 instead of 160 MFMAs per column block; fragments as ucsa_mlp_pack_h2 writes them.
+template <int NRB_SEM, int CBS, bool HALF, bool MARCH, bool H2 = false>
+__global__ void __launch_bounds__(64 * (H2 ? CMP_H2_WAVES : CMP_MAX_WAVES))
 k_composite(CmpArgs a) {
+  static_assert(!H2 || HALF, "f16x2 is a mode of the 16-bit fragment path");
+  constexpr uint32_t TERMS = H2 ? 2u : 1u;
   constexpr uint32_t G = 16u * CBS;  // survivors shaded per MFMA group
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   const uint32_t nw_block = blockDim.x >> 6;
@@ -119,8 +126,8 @@ k_composite(CmpArgs a) {
 
   // ---- LDS carve ------------------------------------------------------
   // fp32: A fragments as floats; fp16 option: 16-byte half8 fragments
-  constexpr uint32_t WC_FLOATS = HALF ? COLOR_H_FRAGS * 256 : 7168;
-  constexpr uint32_t WS_FLOATS = HALF ? SEM_H_FRAGS(NRB_SEM) * 256
+  constexpr uint32_t WC_FLOATS = HALF ? COLOR_H_FRAGS * 256 * TERMS : 7168;
+  constexpr uint32_t WS_FLOATS = HALF ? SEM_H_FRAGS(NRB_SEM) * 256 * TERMS
                                       : 1024 + NRB_SEM * 1024;
   float* w_color = cmp_smem;
   float* w_sem = w_color + WC_FLOATS;
@@ -336,6 +343,84 @@ k_composite(CmpArgs a) {
       }
     }
 
+    } else if constexpr (H2) {
+      // f16x2: the layer structure of the fp16 branch below with two-term operands,
+      // layer-major as in k_shade16 (composite_split.hip): a weight fragment is read
+      // from LDS once per group and used by all its column blocks.  `wl`: the lane
+      // plus an opaque zero re-made per group, so that the fragment loads stay
+      // inside the group instead of ~190 pinned VGPRs.
+      const H2Sel hsel = h2_selectors();
+      uint32_t zoff = 0;
+      asm volatile("" : "+v"(zoff));
+      const uint32_t wl = lane + zoff;
+      H2X b1[CBS];
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        float sh[4];
+        const float* dd = a.rays_d + (size_t)eray[cb] * 3;
+        sh4_select(dd[0], dd[1], dd[2], g, sh);
+        h2_split_pair(sh[0], sh[1], b1[cb], 0, hsel);
+        h2_split_pair(sh[2], sh[3], b1[cb], 1, hsel);
+        h2_split_pair(geo[cb][0], geo[cb][1], b1[cb], 2, hsel);
+        h2_split_pair(geo[cb][2], geo[cb][3], b1[cb], 3, hsel);
+      }
+      f32x4 a1[CBS][4], a2[CBS][4];
+      H2X h0[CBS], h1[CBS];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const H2W w = h2_frag(w_color, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a1[cb][rb] = h2_mul1(w, b1[cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = h2_chain_relu(a1[cb][0], a1[cb][1], hsel);
+        h1[cb] = h2_chain_relu(a1[cb][2], a1[cb][3], hsel);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const H2W wa = h2_frag(w_color, 4 + 2 * rb, wl), wb = h2_frag(w_color, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) a2[cb][rb] = h2_mul2(wa, h0[cb], wb, h1[cb]);
+      }
+      // semantics L1 reads the h-row slots of b1 (zeros in the SH slots' place)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const H2W w = h2_frag(w_sem, rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          H2X bs;
+#pragma unroll
+          for (int term = 0; term < 2; ++term)
+            bs.t[term] = u32x4{b1[cb].t[term][2], b1[cb].t[term][3], 0u, 0u};
+          a1[cb][rb] = h2_mul1(w, bs);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = h2_chain_relu(a2[cb][0], a2[cb][1], hsel);
+        h1[cb] = h2_chain_relu(a2[cb][2], a2[cb][3], hsel);
+      }
+      {
+        const H2W wa = h2_frag(w_color, 12, wl), wb = h2_frag(w_color, 13, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) {
+          const f32x4 o3 = h2_mul2(wa, h0[cb], wb, h1[cb]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBS; ++cb) {
+        h0[cb] = h2_chain_relu(a1[cb][0], a1[cb][1], hsel);
+        h1[cb] = h2_chain_relu(a1[cb][2], a1[cb][3], hsel);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB_SEM; ++rb) {
+        const H2W wa = h2_frag(w_sem, 4 + 2 * rb, wl), wb = h2_frag(w_sem, 5 + 2 * rb, wl);
+#pragma unroll
+        for (int cb = 0; cb < CBS; ++cb) lg[cb][rb] = h2_mul2(wa, h0[cb], wb, h1[cb]);
+      }
     } else {
       // fp16 option: 24 MFMAs (16x16x32) per column block instead of 160
       const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -799,7 +884,7 @@ extern "C" int32_t ucsa_composite_fwd_f16(
 // rgb / class probabilities never travel through HBM.
 // ---------------------------------------------------------------------------
 static int32_t march_shade_launch(
-    bool half, bool train, uint32_t n_points, float* w_out, float* t_out,
+    int half /* 0 f32-input MFMA, 1 f16, 2 f16x2 */, bool train, uint32_t n_points, float* w_out, float* t_out,
     uint32_t n_cap,
     const int32_t* n_alive_dev, uint32_t cap, const int32_t* rays_alive,
     uint32_t alive_stride, float* rays_t, const int32_t* span,
@@ -824,12 +909,12 @@ static int32_t march_shade_launch(
   const uint32_t nrb = cmp_pad16(n_classes) / 16;
   uint32_t cstride = 3 + n_classes;
   if ((cstride & 1u) == 0) cstride += 1;
-  const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256
+  const size_t w_floats = half ? (size_t)(COLOR_H_FRAGS + SEM_H_FRAGS(nrb)) * 256 * (half == 2 ? 2 : 1)
                                : 7168 + 1024 + (size_t)nrb * 1024;
   const uint32_t cbs = half ? CMP_CBS_H : CMP_CBS;
   const size_t per_wave =
       3 * (size_t)(64 + 16 * cbs) + 16 * cstride + 64 + MARCH_SLOT_FLOATS;
-  const uint32_t waves = CMP_MAX_WAVES;
+  const uint32_t waves = half == 2 ? CMP_H2_WAVES : CMP_MAX_WAVES;
   const size_t smem = (w_floats + waves * per_wave) * 4;
   const uint64_t total_waves = 256ull * waves;
   uint32_t rpw = (uint32_t)((n_cap + total_waves - 1) / total_waves);
@@ -857,7 +942,24 @@ static int32_t march_shade_launch(
     hipLaunchKernelGGL((k_composite<NRB, CB, H, true>), dim3(blocks),         \
                        dim3(64 * waves), smem, s, a);                         \
   } while (0)
-  if (half) {
+#define LAUNCH_M2(NRB)                                                        \
+  do {                                                                        \
+    hipError_t e = hipFuncSetAttribute(                                       \
+        reinterpret_cast<const void*>(&k_composite<NRB, CMP_CBS_H, true, true, true>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
+    if (e != hipSuccess) return -(int32_t)e;                                  \
+    UCSA_CLEAR_ERR();                                                         \
+    hipLaunchKernelGGL((k_composite<NRB, CMP_CBS_H, true, true, true>),       \
+                       dim3(blocks), dim3(64 * waves), smem, s, a);           \
+  } while (0)
+  if (half == 2) {
+    switch (nrb) {
+      case 1: LAUNCH_M2(1); break;
+      case 2: LAUNCH_M2(2); break;
+      case 3: LAUNCH_M2(3); break;
+      default: LAUNCH_M2(4); break;
+    }
+  } else if (half) {
     switch (nrb) {
       case 1: LAUNCH_M(1, true); break;
       case 2: LAUNCH_M(2, true); break;
@@ -872,6 +974,7 @@ static int32_t march_shade_launch(
       default: LAUNCH_M(4, false); break;
     }
   }
+#undef LAUNCH_M2
 #undef LAUNCH_M
   return ucsa_launch_status();
 }
@@ -905,6 +1008,22 @@ extern "C" int32_t ucsa_march_segment_shade_f16(
                             sigma_scale, h, deltas,
                             (const float*)packed_color_half,
                             (const float*)packed_sem_half, n_classes, w_min,
+                            weights_sum, depth, image, semantics, stream);
+}
+
+extern "C" int32_t ucsa_march_segment_shade_h2(
+    uint32_t n_cap, const int32_t* n_alive_dev, uint32_t cap,
+    const int32_t* rays_alive, float* rays_t, const int32_t* span,
+    const float* rays_d, const float* sigmas, float sigma_scale, const float* h,
+    const float* deltas, const void* packed_color_h2, const void* packed_sem_h2,
+    uint32_t n_classes, float w_min, float* weights_sum, float* depth, float* image,
+    float* semantics, void* stream) {
+  return march_shade_launch(2, false, 0u, nullptr, nullptr, n_cap,
+                            n_alive_dev, cap,
+                            rays_alive, 1u, rays_t, span, 2u, rays_d, sigmas,
+                            sigma_scale, h, deltas,
+                            (const float*)packed_color_h2,
+                            (const float*)packed_sem_h2, n_classes, w_min,
                             weights_sum, depth, image, semantics, stream);
 }
 

@@ -317,18 +317,22 @@ class SemanticNeRFRenderer(nn.Module):
         if self.precision not in ("fp32", "fp16", "bf16x3", "f16x2"):
             raise ValueError("precision must be fp32, bf16x3, f16x2 or fp16, got "
                              f"{self.precision}")
-        # (the marcher's fused shading kernel has f32-input and f16 nets only: with
-        # bf16x3 / f16x2 the colour / semantics nets shade in fp32 here; the sigma MLP
+        # (the marcher's fused shading kernel has f32-input, f16 and -- round 6 -- f16x2
+        # nets: with bf16x3 the colour / semantics nets shade in fp32 here; the sigma MLP
         # of the marched points runs on the 16-bit pipe in the selected arithmetic --
         # round 6: it used to fall back to the f32-input MFMA, 0.33 instead of 0.21 ms
         # per 5.9 M points)
-        half = self.precision == "fp16" and schedule == "segments" and fused_shade
+        fused = schedule == "segments" and fused_shade
+        half = self.precision == "fp16" and fused
         f = self._field_f16() if half else self._field()
         sigma_mlp = ops.sigma_mlp_fwd_f16 if half else ops.sigma_mlp_fwd
+        shade_mode, shade_nets = half, f
         if not half and self.precision in ("bf16x3", "f16x2"):
             fx = self._field_h2() if self.precision == "f16x2" else self._field_x3()
             fwd = ops.sigma_mlp_fwd_h2 if self.precision == "f16x2" else ops.sigma_mlp_fwd_x3
             sigma_mlp = lambda feat, _packed, _fx=fx, _fwd=fwd: _fwd(feat, _fx["packed_sigma"])  # noqa: E731
+            if self.precision == "f16x2" and fused:
+                shade_mode, shade_nets = "f16x2", fx
         ws = torch.zeros(N, device=device)
         depth = torch.zeros(N, device=device)
         image = torch.zeros(N, 3, device=device)
@@ -357,8 +361,8 @@ class SemanticNeRFRenderer(nn.Module):
                     if fused_shade:
                         seg.shade(n_alive, cap, sigma,
                                   float(self.density_scale), h, deltas,
-                                  f["packed_color"], f["packed_sem"], C,
-                                  float(w_min), ws, depth, image, sem, half)
+                                  shade_nets["packed_color"], shade_nets["packed_sem"], C,
+                                  float(w_min), ws, depth, image, sem, shade_mode)
                     else:
                         rgbs, probs = ops.point_shade_h(
                             dirs, h, f["packed_color"], f["packed_sem"], C)

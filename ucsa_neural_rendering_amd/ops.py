@@ -1431,8 +1431,11 @@ class MarchSegments:
 
     def shade(self, n_cap: int, cap: int, sigmas, sigma_scale: float, h,
               deltas, packed_color, packed_sem, n_classes: int, w_min: float,
-              weights_sum, depth, image, semantics, half: bool = False):
-        fn = (lib().ucsa_march_segment_shade_f16 if half
+              weights_sum, depth, image, semantics, half=False):
+        """``half``: False -- f32-input MFMA nets (packed by mlp_pack); True / "fp16" --
+        plain f16 nets (mlp_pack_f16); "f16x2" -- two-term f16 nets (mlp_pack_h2)."""
+        fn = (lib().ucsa_march_segment_shade_h2 if half == "f16x2"
+              else lib().ucsa_march_segment_shade_f16 if half
               else lib().ucsa_march_segment_shade)
         check(fn(n_cap, self._n_dev(), cap, _ptr(self.alive[self.cur]),
                  _ptr(self.t[self.cur]), _ptr(self.span), _ptr(self.d),
