@@ -426,6 +426,12 @@ k_composite(CmpArgs a) {
       const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cb = 0; cb < CBS; ++cb) {
+        // (the lane plus an opaque zero per column block: the fragment loads stay
+        // next to their MFMAs instead of being hoisted into pinned VGPRs, which
+        // spilled up to 74 of them)
+        uint32_t zoff = 0;
+        asm volatile("" : "+v"(zoff));
+        const uint32_t wl = lane + zoff;
         float sh[4];
         const float* dd = a.rays_d + (size_t)eray[cb] * 3;
         sh4_select(dd[0], dd[1], dd[2], g, sh);
@@ -439,27 +445,27 @@ k_composite(CmpArgs a) {
         }
         f32x4 a1[4], a2[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, lane), b1, z4);
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_color, rb, wl), b1, z4);
         half8 h0 = chain_relu_h(a1[0], a1[1]), h1 = chain_relu_h(a1[2], a1[3]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, lane), h0, z4);
-          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, lane), h1, a2[rb]);
+          a2[rb] = mfma_h(frag_h(w_color, 4 + 2 * rb, wl), h0, z4);
+          a2[rb] = mfma_h(frag_h(w_color, 5 + 2 * rb, wl), h1, a2[rb]);
         }
         h0 = chain_relu_h(a2[0], a2[1]);
         h1 = chain_relu_h(a2[2], a2[3]);
-        f32x4 o3 = mfma_h(frag_h(w_color, 12, lane), h0, z4);
-        o3 = mfma_h(frag_h(w_color, 13, lane), h1, o3);
+        f32x4 o3 = mfma_h(frag_h(w_color, 12, wl), h0, z4);
+        o3 = mfma_h(frag_h(w_color, 13, wl), h1, o3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[cb][c] = fast_sigmoid(o3[c]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, lane), bs, z4);
+        for (int rb = 0; rb < 4; ++rb) a1[rb] = mfma_h(frag_h(w_sem, rb, wl), bs, z4);
         h0 = chain_relu_h(a1[0], a1[1]);
         h1 = chain_relu_h(a1[2], a1[3]);
 #pragma unroll
         for (int rb = 0; rb < NRB_SEM; ++rb) {
-          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, lane), h0, z4);
-          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, lane), h1, lg[cb][rb]);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 4 + 2 * rb, wl), h0, z4);
+          lg[cb][rb] = mfma_h(frag_h(w_sem, 5 + 2 * rb, wl), h1, lg[cb][rb]);
         }
       }
     }
