@@ -100,16 +100,21 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
         dt_tail = (time.perf_counter() - t_tail) / 100
         t.eval()
         t.update_extra_state()
-        with torch.no_grad():
-            for i in range(2):
-                t.run_cuda(*rays[i], dt_gamma=1 / 256, far_closure=False)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(n):
-                o = t.run_cuda(*rays[n_views - n + i], dt_gamma=1 / 256,
-                               far_closure=False)
-            torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / n
+        by_prec = {}
+        for prec in ("f16x2", "fp16", "fp32"):      # (fp32 last: `o`, `dt` below are its)
+            t.precision = prec
+            with torch.no_grad():
+                for i in range(2):
+                    t.run_cuda(*rays[i], dt_gamma=1 / 256, far_closure=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n):
+                    o = t.run_cuda(*rays[n_views - n + i], dt_gamma=1 / 256,
+                                   far_closure=False)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / n
+            by_prec[prec] = {"render_rays_per_s": H * W / dt, "render_ms_per_view": dt * 1e3,
+                             "psnr_db": float(-10 * torch.log10(torch.mean((o["image"][0] - gt_rgb) ** 2)))}
         meter = SemanticsMeter(N_CLASSES)
         meter.update(o["semantics"][0].argmax(-1), gt_lab)
         res["trained_through_marcher"] = {
@@ -118,6 +123,7 @@ def march_option(net, scene_ds, rays, n_views, out_live, dev, args):
             "train_ms_per_step_last_100": dt_tail * 1e3,
             "train_rays_per_s_last_100": 4096 / dt_tail, "dt_gamma": 1 / 256,
             "render_rays_per_s": H * W / dt, "render_ms_per_view": dt * 1e3,
+            "render_by_arithmetic": by_prec,
             "points_per_ray": t.last_march_points / (H * W),
             "psnr_db": float(-10 * torch.log10(torch.mean((o["image"][0] - gt_rgb) ** 2))),
             "miou": meter.measure()[0],
