@@ -135,10 +135,14 @@ k_reduce_partials(const float* __restrict__ partial, uint32_t n_parts,
 
 // Up to 4 independent reductions in one launch (the three MLP gradients of a
 // training step: three ~50 us launches of 96 / 224 / 128 workgroups each).
+// partial2 / n_parts2 (round 6): a SECOND array of partials added on top of the
+// first one's sum, with the additions of two consecutive k_reduce_partials launches
+// (the second with accumulate = 1) -- the sigma net's coarse and fine passes.
 struct ReduceMulti {
   const float* partial[4];
+  const float* partial2[4];
   float* grad[4];
-  uint32_t n_parts[4], n_params[4], first_block[5];
+  uint32_t n_parts[4], n_parts2[4], n_params[4], first_block[5];
   int accumulate;
 };
 
@@ -154,16 +158,29 @@ k_reduce_partials_multi(ReduceMulti a) {
   const float s = column_sum(partial, n_parts, n_params, p, sy);
   sm[sy][px] = s;
   __syncthreads();
+  float t = 0.0f;
   if (sy == 0 && p < n_params) {
-    float t = a.accumulate ? a.grad[k][p] : 0.0f;
+    t = a.accumulate ? a.grad[k][p] : 0.0f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += sm[q][px];
-    a.grad[k][p] = t;
   }
+  if (a.n_parts2[k] > 0) {   // (workgroup-uniform)
+    __syncthreads();
+    sm[sy][px] = column_sum(a.partial2[k], a.n_parts2[k], n_params, p, sy);
+    __syncthreads();
+    if (sy == 0 && p < n_params) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += sm[q][px];
+    }
+  }
+  if (sy == 0 && p < n_params) a.grad[k][p] = t;
 }
 
-extern "C" int32_t ucsa_reduce_partials_multi(
+// (library-internal: ucsa_render_fused_bwd reduces the three nets' partials in one
+// launch; partials2 / n_parts2 may be NULL)
+int32_t ucsa_reduce_partials_chained(
     uint32_t count, const float* const* partials, const uint32_t* n_parts,
+    const float* const* partials2, const uint32_t* n_parts2,
     const uint32_t* n_params, float* const* grads, int32_t accumulate,
     void* stream) {
   UCSA_CHECK_ARG(count >= 1 && count <= 4, 0);
@@ -176,6 +193,9 @@ extern "C" int32_t ucsa_reduce_partials_multi(
     a.partial[k] = on ? partials[k] : nullptr;
     a.grad[k] = on ? grads[k] : nullptr;
     a.n_parts[k] = on ? n_parts[k] : 0;
+    const bool two = on && partials2 && n_parts2 && partials2[k] && n_parts2[k] > 0;
+    a.partial2[k] = two ? partials2[k] : nullptr;
+    a.n_parts2[k] = two ? n_parts2[k] : 0;
     a.n_params[k] = on ? n_params[k] : 0;
     a.first_block[k] = blocks;
     blocks += on ? ucsa_div_up(n_params[k], 32) : 0;
@@ -187,6 +207,14 @@ extern "C" int32_t ucsa_reduce_partials_multi(
   hipLaunchKernelGGL(k_reduce_partials_multi, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, a);
   return ucsa_launch_status();
+}
+
+extern "C" int32_t ucsa_reduce_partials_multi(
+    uint32_t count, const float* const* partials, const uint32_t* n_parts,
+    const uint32_t* n_params, float* const* grads, int32_t accumulate,
+    void* stream) {
+  return ucsa_reduce_partials_chained(count, partials, n_parts, nullptr, nullptr, n_params,
+                                      grads, accumulate, stream);
 }
 
 extern "C" int32_t ucsa_reduce_partials(const float* partial, uint32_t n_parts,

@@ -24,6 +24,11 @@
     if (rc_ != 0) return rc_;   \
   } while (0)
 
+int32_t ucsa_reduce_partials_chained(
+    uint32_t count, const float* const* partials, const uint32_t* n_parts,
+    const float* const* partials2, const uint32_t* n_parts2,
+    const uint32_t* n_params, float* const* grads, int32_t accumulate, void* stream);
+
 namespace {
 
 inline uint64_t al256(uint64_t b) { return (b + 255ull) & ~255ull; }
@@ -63,7 +68,7 @@ FwdWs fwd_ws(void* base, uint32_t N, uint32_t T, uint32_t t) {
 }
 
 struct BwdWs {
-  float *G, *d_h_c, *d_h_f, *pc, *ps, *d_feat_c, *d_feat_f, *psig;
+  float *G, *d_h_c, *d_h_f, *pc, *ps, *d_feat_c, *d_feat_f, *psig, *psig_f;
   void* bins;
   uint32_t parts_c, parts_sc, parts_sf;
   uint64_t bytes;
@@ -82,7 +87,8 @@ BwdWs bwd_ws(void* base, uint32_t N, uint32_t T, uint32_t t, uint32_t C, uint32_
   w.ps = c.take<float>((uint64_t)w.parts_c * sem_params(C));
   w.d_feat_c = c.take<float>((uint64_t)L * Mc * 2);
   w.d_feat_f = c.take<float>((uint64_t)L * Mf * 2);
-  w.psig = c.take<float>((uint64_t)(w.parts_sc > w.parts_sf ? w.parts_sc : w.parts_sf) * 3072u);
+  w.psig = c.take<float>((uint64_t)w.parts_sc * 3072u);
+  w.psig_f = c.take<float>((uint64_t)w.parts_sf * 3072u);
   w.bins = c.take<char>(ucsa_hashgrid_bwd_workspace_bytes(N, T + t, L));
   w.bytes = c.used;
   return w;
@@ -192,20 +198,28 @@ extern "C" int32_t ucsa_render_fused_bwd(
       saved->weights, packs->color_x3, packs->sem_x3, packs->color_t_x3,
       packs->sem_t_x3, d_image, d_depth, d_sem, N, T, t, n_classes, density_scale,
       w.G, w.d_h_c, t ? w.d_h_f : nullptr, w.pc, w.ps, stream));
-  UCSA_TRY(ucsa_reduce_partials(w.pc, w.parts_c, 7168u, 0, grad_color, stream));
-  UCSA_TRY(ucsa_reduce_partials(w.ps, w.parts_c, sem_params(n_classes), 0, grad_sem,
-                                stream));
   UCSA_TRY(ucsa_sigma_mlp_bwd_x2(saved->feat_c, w.d_h_c, packs->sigma_x3,
                                  packs->sigma_t_x3, N * T, L, w.d_feat_c, w.psig,
                                  stream));
-  UCSA_TRY(ucsa_reduce_partials(w.psig, w.parts_sc, 3072u, 0, grad_sigma, stream));
+  if (t > 0)
+    UCSA_TRY(ucsa_sigma_mlp_bwd_x2(saved->feat_f, w.d_h_f, packs->sigma_x3,
+                                   packs->sigma_t_x3, N * t, L, w.d_feat_f, w.psig_f,
+                                   stream));
+  {
+    // the three nets' partial gradients in ONE launch (they were four of ~18 us):
+    // per parameter the same additions in the same order as
+    // ucsa_reduce_partials(colour), (semantics), (sigma coarse), (sigma fine, accumulate)
+    const float* p1[3] = {w.pc, w.ps, w.psig};
+    const float* p2[3] = {nullptr, nullptr, t ? w.psig_f : nullptr};
+    const uint32_t n1[3] = {w.parts_c, w.parts_c, w.parts_sc};
+    const uint32_t n2[3] = {0u, 0u, w.parts_sf};
+    const uint32_t np[3] = {7168u, sem_params(n_classes), 3072u};
+    float* gr[3] = {grad_color, grad_sem, grad_sigma};
+    UCSA_TRY(ucsa_reduce_partials_chained(3, p1, n1, p2, n2, np, gr, 0, stream));
+  }
   if (t == 0)
     return ucsa_hashgrid_bwd_rays_p64(grid, rays_o, rays_d, saved->z_c, aabb_host, N,
                                       T, w.d_feat_c, grad_table, w.bins, stream);
-  UCSA_TRY(ucsa_sigma_mlp_bwd_x2(saved->feat_f, w.d_h_f, packs->sigma_x3,
-                                 packs->sigma_t_x3, N * t, L, w.d_feat_f, w.psig,
-                                 stream));
-  UCSA_TRY(ucsa_reduce_partials(w.psig, w.parts_sf, 3072u, 1, grad_sigma, stream));
   return ucsa_hashgrid_bwd_rays_merged_p64(
       grid, rays_o, rays_d, saved->z_c, saved->z_f, saved->src, aabb_host, N, T, t,
       w.d_feat_c, w.d_feat_f, grad_table, w.bins, stream);
