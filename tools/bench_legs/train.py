@@ -113,7 +113,7 @@ def train_throughput(net, ds, device, steps=20, n_rays=4096, T=256, t=256,
 
 def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
                  n_rays=4096, T=256, t=256, replicated=False, comm_dtype=None,
-                 eval_view=False, fresh=False):
+                 eval_view=False, fresh=False, train_precision="bf16x3"):
     """The data-parallel NeRF training step north_star describes (reference
     DDP site scripts/train_joint.py:137-142, step
     joint_train_lightning_net.py:497-513): every rank draws ITS OWN `n_rays`
@@ -131,6 +131,10 @@ def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
                                   seed=123).to(dev).train()
     else:
         net = copy.deepcopy(net).train()
+    # the arithmetic JointTrainLightningNet trains with by default (`nerf: {train_precision:
+    # bf16x3}`, lightning/joint_train_lightning_net.py) -- the bare network class defaults to
+    # the f32-input-MFMA path, which this leg ran until round 6 (5.0 instead of 3.2 ms per step)
+    net.train_precision = train_precision
     opt = nerf_optimizer(net, world, replicated, comm_dtype)
     g = torch.Generator(device=dev).manual_seed(7 + rank)      # rank-specific draws
     params = list(net.parameters())
@@ -231,6 +235,7 @@ def dp_train_leg(net, ds, dev, dist, world, rank, backend, steps=20, warmup=3,
                     "samples per rank (own frame, own pixels, tile-ordered), "
                     "fwd+bwd, gradient average over the ranks, Adam",
         "optimizer": type(opt).__name__ + ("" if comm_dtype is None else f"[{comm_dtype}]"),
+        "train_precision": train_precision,
         "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt,
         "rays_per_step_total": world * n_rays, "final_loss": float(loss.detach()),
         "comm_bytes_per_step_per_rank": getattr(opt, "last_comm_bytes", None),
