@@ -6,12 +6,48 @@
 // and sums are wave scans (fp32), so cdf differs from the CPU oracle's
 // sequential double-accumulated cumsum by fp32 round-off; the inverse CDF is
 // continuous, tests state the tolerance.
+#include <type_traits>
+
 #include "ucsa_common.h"
 #include "wave_ops.h"
 
 #define RS_WAVES 4
 
 extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+
+// Bitonic sort of 64 R values held by a wave in registers: element r * 64 + lane in
+// x[r].  Exchanges across lanes by __shfl_xor, across registers in the lane -- no LDS
+// round trip and no fence per stage (the LDS network below costs 28 dependent stages of
+// two reads, two conditional writes and a fence for 128 values; round 6).
+template <int R>
+__device__ __forceinline__ void wave_bitonic_sort(float (&x)[R], uint32_t lane) {
+#pragma unroll
+  for (uint32_t k = 2; k <= 64u * R; k <<= 1) {
+#pragma unroll
+    for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+      if (jj >= 64u) {   // partner in the same lane: registers r and r ^ (jj / 64)
+        const uint32_t dr = jj >> 6;
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)R; ++r) {
+          if (r & dr) continue;
+          const bool up = (((r << 6) | lane) & k) == 0u;
+          const float a = x[r], b = x[r | dr];
+          const float mn = fminf(a, b), mx = fmaxf(a, b);
+          x[r] = up ? mn : mx;
+          x[r | dr] = up ? mx : mn;
+        }
+      } else {           // partner in lane ^ jj, same register
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)R; ++r) {
+          const bool up = (((r << 6) | lane) & k) == 0u;
+          const float a = x[r], b = __shfl_xor(a, (int)jj, 64);
+          const bool keep_min = ((lane & jj) == 0u) == up;
+          x[r] = keep_min ? fminf(a, b) : fmaxf(a, b);
+        }
+      }
+    }
+  }
+}
 
 __global__ void __launch_bounds__(64 * RS_WAVES)
 k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
@@ -77,6 +113,29 @@ k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
   const float* ur = u + (size_t)r * t;
   float* out = new_z + (size_t)r * t;
   float* us = bins + T;  // [tpad]
+  // up to 256 uniforms per ray: sorted in registers (1, 2 or 4 per lane), then handed
+  // to the inversion loop through the same LDS array
+  if (tpad <= 256u) {
+    auto sort_in_regs = [&](auto tag) {
+      constexpr int R = decltype(tag)::value;
+      float x[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t q = (uint32_t)r * 64u + lane;
+        x[r] = q < t ? ur[q] : INFINITY;
+      }
+      wave_bitonic_sort<R>(x, lane);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t q = (uint32_t)r * 64u + lane;
+        if (q < tpad) us[q] = x[r];
+      }
+    };
+    if (tpad <= 64u) sort_in_regs(std::integral_constant<int, 1>{});
+    else if (tpad == 128u) sort_in_regs(std::integral_constant<int, 2>{});
+    else sort_in_regs(std::integral_constant<int, 4>{});
+    __builtin_amdgcn_wave_barrier();
+  } else {
   for (uint32_t q = lane; q < tpad; q += 64) us[q] = q < t ? ur[q] : INFINITY;
   __builtin_amdgcn_wave_barrier();
   for (uint32_t k = 2; k <= tpad; k <<= 1) {
@@ -92,6 +151,7 @@ k_resample(const float* __restrict__ z, const float* __restrict__ sigma,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  }
   }
   for (uint32_t q = lane; q < t; q += 64) {
     const float uu = us[q];
